@@ -1,0 +1,135 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by RUNNING the reference
+(tests/golden/make_golden.py).  CPU-only; this is what makes the oracle trustworthy as the
+checker for the HIP path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import weights as W
+from oracle.step import DistillOracle, synthetic_batch, default_opt
+from oracle.losses import CRDState, crd_loss, distill_kl
+
+
+def _ld(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _close(a, b, tol=1e-5, rel=1e-4):
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach() if isinstance(b, torch.Tensor) else b), dtype=torch.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol + rel * a.abs().max().item(), f"max err {err} (ref max {a.abs().max().item()})"
+
+
+def test_student_forward_backward(golden_dir):
+    g = _ld(golden_dir, "modules_b4_h64.npz")
+    bt = synthetic_batch(int(g["B"]), int(g["H"]), seed=int(g["batch_seed"]))
+    sd = W.make_state_dict(W.student_shapes(), 1)
+    params = {k: v.requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and "running" not in k and "output_" not in k}
+    x = bt["x_path"].clone().requires_grad_(True)
+    f3, feat, hazard, pred, none = oracle.resnet_forward(x, sd)
+    assert none is None
+    _close(g["f3"], f3); _close(g["feat"], feat); _close(g["hazard"], hazard); _close(g["pred"], pred)
+    loss = (feat * torch.linspace(0.5, 1.5, 128)).sum() + (hazard * torch.tensor([1.0, -2.0, 0.5])).sum() \
+        + 0.1 * f3.sum()
+    loss.backward()
+    _close(g["dx"], x.grad, 1e-6, 1e-3)
+    _close(g["g_conv1"], sd["conv1.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_bn1_w"], sd["bn1.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_l1_0_conv1"], sd["layer1.0.conv1.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_l2_0_ds"], sd["layer2.0.downsample.0.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_l4_1_bn2_w"], sd["layer4.1.bn2.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_fc1_w"], sd["fc_new1.0.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_fc2_w"], sd["fc_new2.weight"].grad, 1e-5, 1e-3)
+    _close(g["g_l3_1_conv2_abs"], sd["layer3.1.conv2.weight"].grad.abs().sum(), 1e-4, 1e-3)
+    _close(g["rm_bn1"], sd["bn1.running_mean"]); _close(g["rv_bn1"], sd["bn1.running_var"])
+    _close(g["rm_l4"], sd["layer4.1.bn2.running_mean"]); _close(g["rv_l4"], sd["layer4.1.bn2.running_var"])
+
+
+def test_teacher_forward(golden_dir):
+    g = _ld(golden_dir, "modules_b4_h64.npz")
+    bt = synthetic_batch(int(g["B"]), int(g["H"]), seed=int(g["batch_seed"]))
+    sd = W.make_state_dict(W.teacher_shapes(320), 3)
+    with torch.no_grad():
+        t = oracle.pathomic_forward(bt["x_path"], bt["x_omic"], sd)
+    assert len(t) == 11 and t[8] is None and t[9] is None and t[10] is None
+    _close(g["t_fuse"], t[0]); _close(g["t_path_vec"], t[1]); _close(g["t_omic_vec"], t[2])
+    _close(g["t_f3"], t[3]); _close(g["t_h_path"], t[4][0]); _close(g["t_h_omic"], t[4][1])
+    _close(g["t_h_fuse"], t[4][2]); _close(g["t_pred"], t[5]); _close(g["t_pred_path"], t[6])
+    _close(g["t_pred_omic"], t[7])
+    sd2 = W.make_state_dict(W.teacher_shapes(320), 3)
+    with torch.no_grad():
+        # the golden omic/fusion calls ran after the teacher forward (BN running stats differ, outputs do not)
+        om = oracle.maxnet_forward(bt["x_omic"], sd2, "omic_net.")
+        fo = oracle.bilinear_fusion_forward(torch.as_tensor(g["fus_in1"]), torch.as_tensor(g["fus_in2"]), sd2)
+    _close(g["omic_feat"], om[0]); _close(g["omic_out"], om[1]); _close(g["omic_pred"], om[2])
+    _close(g["fus_out"], fo)
+
+
+def test_distill_kl(golden_dir):
+    g = _ld(golden_dir, "modules_b4_h64.npz")
+    for T in (1, 4):
+        ys = torch.as_tensor(g["kl_ys"]).requires_grad_(True)
+        kl = distill_kl(ys, torch.as_tensor(g["kl_yt"]), float(T))
+        gr, = torch.autograd.grad(kl, ys)
+        _close(g[f"kl_T{T}"], kl, 1e-6); _close(g[f"kl_T{T}_g"], gr, 1e-6)
+
+
+@pytest.mark.parametrize("mode", ["mid", "hard"])
+def test_crd_loss(golden_dir, mode):
+    g = _ld(golden_dir, f"crd_{mode}.npz")
+    st = CRDState(1024, seed=int(g["bank_seed"]),
+                  embed_s=W.make_state_dict(W.embed_shapes(), 10),
+                  embed_t=W.make_state_dict(W.embed_shapes(), 11))
+    for d in (st.embed_s, st.embed_t):
+        for v in d.values():
+            v.requires_grad_(True)
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).requires_grad_(True)
+        ranks = g["ranks"][it] if mode == "mid" else None
+        loss = crd_loss(st, f_s, torch.as_tensor(g[f"f_t{it}"]), torch.as_tensor(g[f"index{it}"]),
+                        torch.as_tensor(g[f"sidx{it}"]), 20, 512, mode, ranks)
+        gs = torch.autograd.grad(loss, [f_s, st.embed_s["linear.weight"], st.embed_t["linear.weight"],
+                                        st.embed_s["linear.bias"]])
+        _close(g[f"loss{it}"], loss, 1e-5, 1e-5)
+        _close(g[f"g_fs{it}"], gs[0], 1e-6, 1e-3); _close(g[f"g_ws{it}"], gs[1], 1e-6, 1e-3)
+        _close(g[f"g_wt{it}"], gs[2], 1e-6, 1e-3); _close(g[f"g_bs{it}"], gs[3], 1e-6, 1e-3)
+        _close(g[f"params{it}"], st.params, 1e-2, 1e-5)
+        idx = torch.as_tensor(g[f"index{it}"])
+        _close(g[f"bank_v1_rows{it}"], st.memory_v1[idx], 1e-6); _close(g[f"bank_v2_rows{it}"], st.memory_v2[idx], 1e-6)
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+def test_full_step_b16_h224(golden_dir, faithful):
+    """Three consecutive steps of train_test_path_multi_distill.py:249-330 vs the reference."""
+    g = _ld(golden_dir, "step_b16_h224.npz")
+    torch.set_num_threads(8)
+    orc = DistillOracle(default_opt(), seed=int(g["seed"]), n_data=int(g["n_data"]))
+    nsteps = 3 if not faithful else 1
+    for it in range(nsteps):
+        bt = synthetic_batch(int(g["B"]), int(g["H"]), seed=100 + it)
+        out = orc.step(bt, mid_ranks=[g["ranks"][2 * it], g["ranks"][2 * it + 1]], faithful=faithful)
+        tol = 2e-5 * (1 + 20 * it)      # trajectories drift apart slowly (Adam amplifies rounding)
+        _close(g[f"logit_path{it}"], out["logit_path"], tol, 1e-4)
+        _close(g[f"ema_logit{it}"], out["ema_logit"], tol, 1e-4)
+        _close(g[f"fuse_logit{it}"], out["fuse_logit"], tol, 1e-4)
+        for k in ("loss_cls", "loss"):
+            _close(g[f"{k}{it}"], out[k], tol * 10, 1e-4)
+        for k in ("loss_div1", "loss_div2", "loss_kd1", "loss_kd2"):
+            _close(g[f"{k}_{it}"], out[k], tol * 10, 1e-4)
+        _close(g[f"scale{it}"], out["scale"], 1e-3 * (1 + 5 * it), 1e-3)
+        if it == 0:
+            _close(g["g0_conv1"], out["grads"]["student.conv1.weight"], 1e-5, 2e-3)
+            _close(g["g0_fc2_w"], out["grads"]["student.fc_new2.weight"], 1e-5, 2e-3)
+            _close(g["g0_embed_s0"], out["grads"]["crd0.embed_s.linear.weight"], 1e-6, 2e-3)
+            _close(g["g0_embed_t1"], out["grads"]["crd1.embed_t.linear.weight"], 1e-6, 2e-3)
+        _close(g[f"p_fc2_{it}"], orc.student["fc_new2.weight"], 2e-4 if it else 2e-5, 0)
+        _close(g[f"ema_fc2_{it}"], orc.ema["fc_new2.weight"], 2e-4, 0)
+        _close(g[f"params0_{it}"], orc.crd[0].params, 1.0, 1e-4)
+        _close(g[f"bank0_v1_rows{it}"], orc.crd[0].memory_v1[bt["index"]], 1e-4)
+        _close(g[f"bank1_v2_rows{it}"], orc.crd[1].memory_v2[bt["index"]], 1e-4)
