@@ -1,0 +1,156 @@
+/* pathomic_hip.h - C-ABI of libpathomic_hip.so (MI355X / gfx950).
+ *
+ * The reference (CityU-AIM-Group/MultiModal-learning) has no FFI layer: its hot path is pure Python on
+ * torch built-ins.  This header is therefore the boundary a maintainer binds
+ * (ctypes stub in INTEGRATION.md) to replace the torch ops under the reference's Python module API;
+ * each entry cites the reference site (path relative to /root/reference/MICCAI-2022) it replaces.
+ *
+ * Conventions: plain pointers to DEVICE memory + sizes, no torch types; every call enqueues work on
+ * `stream` and returns immediately; return 0 on success, negative errno-style code otherwise
+ * (-22 invalid argument, -5 launch failure).  No allocation happens inside: callers pass workspaces.
+ * Thread-compatible (one stream per call), no global mutable state.
+ */
+#ifndef PATHOMIC_HIP_H_
+#define PATHOMIC_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
+
+#define PH_PREC_BF16 0   /* perf mode: bf16 operands + activations, fp32 accumulate/statistics */
+#define PH_PREC_BF16X3 1 /* parity mode: fp32 activations, split-bf16 (3-product) MFMA */
+
+#define PH_ACT_NONE 0
+#define PH_ACT_RELU 1
+#define PH_ACT_ELU 2
+#define PH_ACT_SIGMOID 3
+
+#define PH_EW_RELU 0
+#define PH_EW_GATE 1
+#define PH_EW_RELU_BWD 2
+#define PH_EW_ADD 3
+
+int ph_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ResNet-18 trunk: conv7x7/2-BN-ReLU-maxpool, 8 BasicBlocks, global avg-pool of layer3 and layer4.
+ * Replaces ResNet._forward_impl up to the pooled features (resnets.py:217-236, BasicBlock :58-74) and
+ * its autograd backward.  Train-mode BatchNorm everywhere (train_test_path_multi_distill.py:231-232).
+ *
+ * params: 20 units x 6 pointers [conv weight OIHW f32, bn weight, bn bias, running_mean, running_var,
+ *         num_batches_tracked (int64)] in state_dict order: conv1/bn1, then per block conv1/bn1,
+ *         conv2/bn2, downsample.0/downsample.1 (layer2-4 block 0 only).
+ * grads : 20 units x 3 pointers [d conv weight (OIHW f32), d bn weight, d bn bias] (overwritten).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct PhResnetPlan PhResnetPlan;
+PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec);
+void ph_resnet_plan_destroy(PhResnetPlan* plan);
+size_t ph_resnet_workspace_bytes(const PhResnetPlan* plan);
+size_t ph_resnet_packed_bytes(const PhResnetPlan* plan);
+int ph_resnet_num_units(const PhResnetPlan* plan);
+int ph_resnet_unit_shape(const PhResnetPlan* plan, int unit, int* out4 /* Cout, Cin, KS, stride */);
+/* OIHW fp32 -> MFMA operand layouts (bf16 hi/lo planes, fwd [tap][O][I] and dgrad [tap][I][O]); call after
+ * every optimiser step */
+int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, void* packed, ph_stream_t stream);
+/* x_nchw [B,3,H,W] f32 -> f3 [B,256], f4 [B,512] f32 (either may be NULL).  flags bit0: update running stats */
+int ph_resnet_forward(const PhResnetPlan* plan, const void* const* params, const void* packed, const float* x_nchw,
+                      void* workspace, float* f3, float* f4, int flags, ph_stream_t stream);
+int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
+                       const float* g_f3 /* may be NULL */, const float* g_f4, void* const* grads,
+                       ph_stream_t stream);
+int ph_resnet_tensor_info(const PhResnetPlan* plan, int what, int id, size_t* byte_off, int* dims4);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense fp32 operators of the heads / SNN / fusion (resnets.py:165-169,239-250; networks_new.py:185-251;
+ * fusion.py:36-63).  C[m][n] = act(sum_k A[m*sam+k*sak] * B[k*sbk+n*sbn] + bias[n]) (+C)
+ * ---------------------------------------------------------------------------------------------- */
+int ph_sgemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long sam, long sak,
+             long sbk, long sbn, long ldc, int act, int accumulate, ph_stream_t stream);
+int ph_sgemm_splitk(const float* A, const float* B, const float* bias, float* C, float* part /* nsplit*M*N */,
+                    int nsplit, int M, int N, int K, long sam, long sak, long sbk, long sbn, long ldc, int act,
+                    ph_stream_t stream);
+/* nn.BatchNorm1d training mode (+ReLU) and backward (resnets.py:165-167; fusion.py:29-32) */
+int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
+                float* running_mean, float* running_var, int64_t* num_batches_tracked, int B, int C, float eps,
+                float momentum, int relu, ph_stream_t stream);
+int ph_bn1d_bwd(const float* g, const float* y, const float* x, const float* mean, const float* invstd,
+                const float* gamma, float* dx, float* dgamma, float* dbeta, int B, int C, int relu,
+                ph_stream_t stream);
+/* nn.LogSoftmax(dim=1) (networks_new.py:139-140), F.nll_loss mean (train_test_path_multi_distill.py:262) */
+int ph_log_softmax(const float* x, float* y, int B, int C, ph_stream_t stream);
+int ph_log_softmax_bwd(const float* g, const float* y, float* dx, int B, int C, ph_stream_t stream);
+int ph_nll_fwd(const float* pred, const int64_t* grade, float* loss, int B, int C, float inv_bnorm,
+               ph_stream_t stream);
+int ph_nll_bwd(const float* gscalar, const int64_t* grade, float* dpred, int B, int C, float inv_bnorm,
+               ph_stream_t stream);
+/* DistillKL.forward / backward w.r.t. y_s (KD_loss.py:13-17) */
+int ph_kl_fwd(const float* y_s, const float* y_t, float* loss, int B, int C, float T, float inv_bnorm,
+              ph_stream_t stream);
+int ph_kl_bwd(const float* gscalar, const float* y_s, const float* y_t, float* dy_s, int B, int C, float T,
+              float inv_bnorm, ph_stream_t stream);
+/* Normalize(2) of Embed (CL_utils/CRD_loss.py:263-267,276-279) */
+int ph_l2norm_fwd(const float* x, float* y, float* norm, int B, int D, ph_stream_t stream);
+int ph_l2norm_bwd(const float* g, const float* y, const float* norm, float* dx, int B, int D, ph_stream_t stream);
+int ph_eltwise(const float* a, const float* b, float* out, size_t n, int op, ph_stream_t stream);
+/* o1 (x) o2 with optional appended ones (fusion.py:56-58) / nn.Bilinear operand (fusion.py:43,50) */
+int ph_outer(const float* o1, const float* o2, float* o12, int B, int D1, int D2, int append_one,
+             ph_stream_t stream);
+/* nn.Dropout / nn.AlphaDropout, training mode, counter-based RNG (fusion.py:22-32; networks_new.py:193) */
+int ph_dropout(float* x, size_t n, float p, uint64_t seed, uint64_t offset, int alpha, ph_stream_t stream);
+int ph_sum(const float* x, float* out, int n, float scale, ph_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CRD memory bank (DC-Distill): ContrastMemory_v3.forward (CL_utils/memory_new.py:249-397) and
+ * ContrastLoss_v2 (CL_utils/CRD_loss.py:221-244).  v1 = student embedding, v2 = teacher embedding,
+ * mem1/mem2 = memory_v1/memory_v2 [n_data][128] f32, params = the module's `params` buffer
+ * [K, T, Z_v1, Z_v2, momentum, P].
+ * ---------------------------------------------------------------------------------------------- */
+int ph_crd_score(const float* v1, const float* v2, const int64_t* idx /* [B][P+K] */, const float* mem1,
+                 const float* mem2, float* out1, float* out2, float* diff /* each [B][P+K] */, int B, int PK,
+                 int feat_dim, float T, ph_stream_t stream);
+/* ranks: the P2 host-RNG ranks of memory_new.py:311 (int32, device) or NULL for "hard" (:308) */
+int ph_crd_select(const float* diff, const float* out1, const float* out2, const int* ranks, int* sel /* [B][P2+K2] */,
+                  float* xs, float* xt /* gathered raw scores [B][P2+K2] */, int B, int P, int K, int P2, int K2,
+                  int select_neg, ph_stream_t stream);
+int ph_crd_zsum(const float* xs, const float* xt, float* sums2, int n, ph_stream_t stream);
+int ph_crd_setz(float* params, const float* sums2, float count, float n_data, ph_stream_t stream);
+/* loss partials lossp[B] (sum = s_loss + t_loss) and d loss/d v1, d loss/d v2 [B][128] */
+int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const float* mem1,
+                     const float* mem2, const float* params, float* lossp, float* dv1, float* dv2, int B, int PK,
+                     int P2, int K2, int feat_dim, float n_data, float inv_bnorm, ph_stream_t stream);
+int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
+                  int B, int feat_dim, ph_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GK-Refine (AEKD_loss, train_test_path_multi_distill.py:41-70) and optimiser
+ * (networks_new.py:85 Adam; train_test_path_multi_distill.py:34-38 update_ema_variables)
+ * ---------------------------------------------------------------------------------------------- */
+int ph_gram(const float* G /* [ng][n] */, float* gram /* [ng*ng] */, int ng, int n, ph_stream_t stream);
+int ph_gk_scale(const float* gram, const float* const* losses /* device array of nl device scalars */, int ng, int nl,
+                float mult, float* scale, float* total, ph_stream_t stream);
+int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, size_t n, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int step, double ema_alpha,
+                     ph_stream_t stream);
+int ph_ema_update(float* ema, const float* p, size_t n, float alpha, ph_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fine-grained convolution entry points (unit tests / other callers).  Activations NHWC in the precision
+ * mode's type, weights OIHW f32.  `ws` must hold ph_conv2d_workspace_bytes().
+ * ---------------------------------------------------------------------------------------------- */
+size_t ph_conv2d_workspace_bytes(int B, int Cin, int IH, int IW, int Cout, int KS, int stride, int pad);
+int ph_conv2d_fwd(const void* x, const float* w_oihw, void* y, float* ch_sum /* [Cout] or NULL */,
+                  float* ch_sumsq, int B, int Cin, int IH, int IW, int Cout, int KS, int stride, int pad, int prec,
+                  void* ws, ph_stream_t stream);
+int ph_conv2d_dgrad(const void* dy, const float* w_oihw, void* dx, int B, int Cin, int IH, int IW, int Cout, int KS,
+                    int stride, int pad, int prec, void* ws, ph_stream_t stream);
+int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Cin, int IH, int IW, int Cout, int KS,
+                    int stride, int pad, int prec, void* ws, ph_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHOMIC_HIP_H_ */

@@ -1,0 +1,73 @@
+"""Drop-in for the reference's CL_utils/CRD_loss.py: CRDLoss (:127-175), ContrastLoss_v2 (:212-252),
+Embed (:256-267), Normalize (:270-279)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .memory_new import ContrastMemory_v3
+
+eps = 1e-7
+
+
+class CRDLoss(nn.Module):
+    """CRD loss with DC-Distill pair selection.  forward(epoch, f_s, f_t, idx, contrast_idx) -> 0-d loss,
+    differentiable w.r.t. f_s and both Embed layers; mutates the banks and Z exactly like the reference."""
+
+    def __init__(self, opt, n_data):
+        super().__init__()
+        self.P = opt.nce_p
+        self.P2 = opt.nce_p2
+        self.embed_s = Embed(opt.s_dim, opt.feat_dim)
+        self.embed_t = Embed(opt.t_dim, opt.feat_dim)
+        self.contrast = ContrastMemory_v3(opt.feat_dim, n_data, opt.nce_p, opt.nce_k, opt.nce_t, opt.nce_m,
+                                          opt.select_pos_pairs, opt.nce_p2, opt.select_neg_pairs, opt.nce_k2)
+        if getattr(opt, "sample_KD", "False") != "False":
+            raise NotImplementedError("sample_KD == 'True' is not used by the shipped stage-2 command")
+        self.criterion_t = ContrastLoss_v2(n_data, sample_KD=opt.sample_KD)
+        self.criterion_s = ContrastLoss_v2(n_data, sample_KD=opt.sample_KD)
+        self.select_pos_mode = opt.select_pos_mode
+
+    def forward(self, epoch, f_s, f_t, idx, contrast_idx=None, ranks=None):
+        if contrast_idx is None:
+            raise NotImplementedError("contrast_idx=None (AliasMethod.draw) never happens on the hot path "
+                                      "(memory_new.py:265-267)")
+        f_s = self.embed_s(f_s)
+        f_t = self.embed_t(f_t)
+        return self.contrast.loss(epoch, f_s, f_t, idx, contrast_idx, self.select_pos_mode, ranks)
+
+
+class ContrastLoss_v2(nn.Module):
+    """Kept for API compatibility (attribute of CRDLoss); its arithmetic is fused into ph_crd_loss_grad."""
+
+    def __init__(self, n_data, sample_KD):
+        super().__init__()
+        self.n_data = n_data
+        self.sample_KD = sample_KD
+
+    def forward(self, x, P):
+        raise NotImplementedError("ContrastLoss_v2 is fused into the CRD loss kernel; call CRDLoss.forward")
+
+
+class Embed(nn.Module):
+    """Linear + L2 normalisation (CRD_loss.py:256-267)."""
+
+    def __init__(self, dim_in=1024, dim_out=128):
+        super().__init__()
+        self.linear = nn.Linear(dim_in, dim_out)
+        self.l2norm = Normalize(2)
+
+    def forward(self, x):
+        x = x.view(x.shape[0], -1)
+        x = ops.LinearFn.apply(x, self.linear.weight, self.linear.bias)
+        return self.l2norm(x)
+
+
+class Normalize(nn.Module):
+    def __init__(self, power=2):
+        super().__init__()
+        if power != 2:
+            raise NotImplementedError("only the L2 norm is used (CRD_loss.py:261)")
+        self.power = power
+
+    def forward(self, x):
+        return ops.L2NormFn.apply(x)

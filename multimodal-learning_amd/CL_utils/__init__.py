@@ -1,0 +1,2 @@
+from .CRD_loss import CRDLoss, ContrastLoss_v2, Embed, Normalize   # noqa: F401
+from .memory_new import ContrastMemory_v3                           # noqa: F401

@@ -1,0 +1,133 @@
+"""Drop-in for the reference's CL_utils/memory_new.py ContrastMemory_v3 (:225-397): same buffers
+(`params` [K,T,Z_v1,Z_v2,momentum,P], `memory_v1`, `memory_v2`), same forward semantics
+(score with the PRE-update bank, discrepancy-driven positive/negative selection, first-call Z,
+momentum update).  The forward returns (out_v1, out_v2) like the reference when called directly; inside
+CRDLoss the fused loss+gradient kernel is used instead (nothing [B,P+K,128]-sized is materialised)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import lib, check, ptr, stream, require_cuda
+
+
+class _CRDCoreFn(torch.autograd.Function):
+    """(v1, v2) -> NCE loss (s_loss + t_loss of CRD_loss.py:172-174) with analytic gradients."""
+
+    @staticmethod
+    def forward(ctx, v1, v2, mem, y, idx, ranks):
+        v1, v2 = ops._f32(v1), ops._f32(v2)
+        B, D = v1.shape
+        P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
+        PK, S2 = P + K, P2 + K2
+        dev = v1.device
+        idx = require_cuda(idx).contiguous()
+        y = require_cuda(y).contiguous()
+        if idx.dtype != torch.int64 or y.dtype != torch.int64 or idx.shape != (B, PK):
+            raise RuntimeError("contrast_idx must be int64 [B, nce_p+nce_k] and idx int64 [B]")
+        out1 = torch.empty(B, PK, device=dev, dtype=torch.float32)
+        out2 = torch.empty_like(out1)
+        diff = torch.empty_like(out1)
+        L = lib()
+        st = stream()
+        T = mem.T
+        check(L.ph_crd_score(ptr(v1), ptr(v2), ptr(idx), ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(out1), ptr(out2),
+                             ptr(diff), B, PK, D, T, st), "ph_crd_score")
+        sel = torch.empty(B, S2, device=dev, dtype=torch.int32)
+        xs = torch.empty(B, S2, device=dev, dtype=torch.float32)
+        xt = torch.empty_like(xs)
+        check(L.ph_crd_select(ptr(diff), ptr(out1), ptr(out2), ptr(ranks), ptr(sel), ptr(xs), ptr(xt), B, P, K, P2, K2,
+                              1 if mem.select_neg_pairs == "True" else 0, st), "ph_crd_select")
+        if not mem._z_set:
+            sums = torch.empty(2, device=dev, dtype=torch.float32)
+            check(L.ph_crd_zsum(ptr(xs), ptr(xt), ptr(sums), B * S2, st), "ph_crd_zsum")
+            count = float(B * S2)
+            if mem.sync is not None:
+                count = mem.sync.all_reduce_z(sums, count)
+            check(L.ph_crd_setz(ptr(mem.params), ptr(sums), count, float(mem.nLem), st), "ph_crd_setz")
+            mem._z_set = True
+            if mem.verbose:   # the reference prints Z once (memory_new.py:371,375); costs one host sync
+                z = mem.params[2:4].tolist()
+                print("normalization constant Z_v1 is set to {:.1f}".format(z[0]))
+                print("normalization constant Z_v2 is set to {:.1f}".format(z[1]))
+        lossp = torch.empty(B, device=dev, dtype=torch.float32)
+        dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
+        dv2 = torch.empty_like(dv1)
+        bnorm = float(mem.batch_norm_size or B)
+        check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(mem.memory_v1), ptr(mem.memory_v2),
+                                 ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, PK, P2, K2, D, float(mem.nLem),
+                                 1.0 / bnorm, st), "ph_crd_loss_grad")
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
+        # momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica
+        # applies the update of the whole global batch
+        if mem.sync is not None:
+            yy, vv1, vv2 = mem.sync.all_gather_rows(y, v1.detach(), v2.detach())
+        else:
+            yy, vv1, vv2 = y, v1.detach(), v2.detach()
+        check(L.ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
+                              yy.shape[0], D, st), "ph_crd_update")
+        ctx.save_for_backward(dv1, dv2)
+        mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dv1, dv2 = ctx.saved_tensors
+        return dv1 * g, dv2 * g, None, None, None, None
+
+
+class ContrastMemory_v3(nn.Module):
+    def __init__(self, inputSize, outputSize, P, K, T=0.07, momentum=0.5, select_pos_pairs=True, P2=10,
+                 select_neg_pairs=True, K2=512):
+        super().__init__()
+        self.nLem = outputSize
+        self.P, self.K, self.P2, self.K2 = P, K, P2, K2
+        self.T = T
+        self.select_pos_pairs = select_pos_pairs
+        self.select_neg_pairs = select_neg_pairs
+        if select_pos_pairs is not True or select_neg_pairs not in ("True", "False", True, False):
+            raise NotImplementedError("select_pos_pairs is always on in the reference (options.py:44-45)")
+        if select_neg_pairs in (True, False):
+            self.select_neg_pairs = "True" if select_neg_pairs else "False"
+        if self.select_neg_pairs == "False":
+            self.K2 = K
+        self.register_buffer("params", torch.tensor([K, T, -1, -1, momentum, P], dtype=torch.float32))
+        stdv = 1.0 / math.sqrt(inputSize / 3)
+        self.register_buffer("memory_v1", torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
+        self.register_buffer("memory_v2", torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
+        self._z_set = False
+        self.sync = None               # set by dist.attach() under data parallelism
+        self.batch_norm_size = None    # global batch under data parallelism
+        self.verbose = True
+        self.last = None
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._z_set = bool((self.params[2:4] > 0).all().item())
+
+    def draw_ranks(self, epoch, select_pos_mode):
+        """The host-RNG draw of memory_new.py:311-322 (numpy global RNG, like the reference)."""
+        if select_pos_mode == "hard":
+            return None
+        if select_pos_mode == "mid":
+            r = np.random.choice(np.arange(30, 100, 1), self.P2, replace=False)
+        elif select_pos_mode == "random":
+            r = np.random.randint(0, self.P, self.P2)
+        elif select_pos_mode == "curriculum":
+            interval = 4 - np.ceil(3 * epoch)
+            r = np.random.randint(50 * (interval - 1), 50 * interval, self.P2)
+        else:
+            raise NotImplementedError(select_pos_mode)
+        if r.max() >= self.P:
+            raise RuntimeError("select_pos_mode '%s' needs nce_p > %d" % (select_pos_mode, int(r.max())))
+        return torch.as_tensor(np.asarray(r), dtype=torch.int32)
+
+    def loss(self, epoch, v1, v2, y, idx, select_pos_mode="mid", ranks=None):
+        if ranks is None:
+            ranks = self.draw_ranks(epoch, select_pos_mode)
+        if ranks is not None:
+            ranks = torch.as_tensor(ranks, dtype=torch.int32).to(v1.device, non_blocking=True)
+        return _CRDCoreFn.apply(v1, v2, self, y, idx, ranks)

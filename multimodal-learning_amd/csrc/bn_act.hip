@@ -1,0 +1,455 @@
+// Train-mode BatchNorm, activation, pooling and their backward passes (HBM-bound, 16-B vectorised).
+// Reference semantics: nn.BatchNorm2d in training mode (resnets.py:148 et al.), ReLU, MaxPool2d(3,2,1)
+// (resnets.py:150), AdaptiveAvgPool2d (resnets.py:158,234-236).  Activations are NHWC of type T
+// (bf16 in perf mode, float in parity mode); statistics are always fp32 with fp64 combination.
+#include "ph_common.h"
+#include "ph_kernels.h"
+
+namespace {
+
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ x4, int B, int H, int W) {
+  const size_t npix = (size_t)B * H * W;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const size_t hw = (size_t)H * W;
+  const size_t b = i / hw, r = i - b * hw;
+  const float c0 = x[(b * 3 + 0) * hw + r], c1 = x[(b * 3 + 1) * hw + r], c2 = x[(b * 3 + 2) * hw + r];
+  if constexpr (is_f32<T>::value) {
+    f32x4 v = {c0, c1, c2, 0.f};
+    *reinterpret_cast<f32x4*>(x4 + i * 4) = v;
+  } else {
+    bf16x4 v = {(bf16)c0, (bf16)c1, (bf16)c2, (bf16)0.f};
+    *reinterpret_cast<bf16x4*>(x4 + i * 4) = v;
+  }
+}
+
+// one block per channel: parts[nparts][2][C] -> mean / invstd / scale / shift (+ running stats)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C,
+                                                          double count, float eps, float momentum,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* mean, float* invstd,
+                                                          float* scale, float* shift, float* running_mean,
+                                                          float* running_var, int64_t* nbt) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = tid; p < nparts; p += 256) {
+    s1 += (double)parts[((size_t)p * 2 + 0) * C + c];
+    s2 += (double)parts[((size_t)p * 2 + 1) * C + c];
+  }
+  __shared__ double sh[2][4];
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s1; sh[1][tid >> 6] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    s1 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    s2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m;
+    invstd[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)m * sc;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+      if (c == 0 && nbt) *nbt += 1;
+    }
+  }
+}
+
+// out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] ), 8 channels per thread
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const T* __restrict__ res,
+                                const T* __restrict__ y_r, const float* __restrict__ scale_r,
+                                const float* __restrict__ shift_r, T* __restrict__ out, size_t n8, int C8, int relu) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)(i % C8) * 8;
+  float v[8], r[8];
+  load8(y + i * 8, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = v[k] * scale[c + k] + shift[c + k];
+  if (res) {
+    load8(res + i * 8, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += r[k];
+  } else if (y_r) {
+    load8(y_r + i * 8, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += r[k] * scale_r[c + k] + shift_r[c + k];
+  }
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+  }
+  store8(out + i * 8, v);
+}
+
+// stem: relu(bn(y0)) -> maxpool 3x3/2 pad 1; argmax position code (kh*3+kw, first max wins) saved as u8
+template <typename T>
+__global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, T* __restrict__ out,
+                                       uint8_t* __restrict__ idx, int B, int H, int W, int C8) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;   // floor((H + 2 - 3)/2) + 1
+  const size_t n = (size_t)B * OH * OW * C8;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cg = (int)(i % C8);
+  size_t pix = i / C8;
+  const int ow = (int)(pix % OW); pix /= OW;
+  const int oh = (int)(pix % OH);
+  const int b = (int)(pix / OH);
+  const int c = cg * 8;
+  float sc[8], sh[8], best[8];
+  int bi[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sc[k] = scale[c + k]; sh[k] = shift[c + k]; best[k] = -INFINITY; bi[k] = 0; }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh * 2 - 1 + kh;
+    if (ih < 0 || ih >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow * 2 - 1 + kw;
+      if (iw < 0 || iw >= W) continue;
+      float v[8];
+      load8(y + ((((size_t)b * H + ih) * W + iw) * C8 + cg) * 8, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float a = v[k] * sc[k] + sh[k];
+        a = a > 0.f ? a : 0.f;
+        // activation is *stored* as T before pooling in the unfused formulation: round the same way
+        if constexpr (!is_f32<T>::value) a = (float)(bf16)a;
+        if (a > best[k]) { best[k] = a; bi[k] = kh * 3 + kw; }
+      }
+    }
+  }
+  store8(out + i * 8, best);
+  uint64_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) packed |= (uint64_t)(bi[k] & 0xff) << (8 * k);
+  *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;
+}
+
+// global average pool [B][HW][C] -> [B][C] fp32; block = (b, 64-channel chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, int HW, int C) {
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cg = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 8 channel groups x 32 pixel lanes
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  for (int p = pl; p < HW; p += 32) {
+    float v[8];
+    load8(x + ((size_t)b * HW + p) * C + c0 + cg * 8, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] += v[k];
+  }
+  __shared__ float sh[32][64];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sh[pl][cg * 8 + k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+    for (int q = 0; q < 32; ++q) t += sh[q][threadIdx.x];
+    out[(size_t)b * C + c0 + threadIdx.x] = t / (float)HW;
+  }
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ g, T* __restrict__ dx, size_t n8, int HW, int C8,
+                                   int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int cg = (int)(i % C8);
+  const size_t b = i / ((size_t)C8 * HW);
+  const float inv = 1.f / (float)HW;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = g[b * C8 * 8 + cg * 8 + k] * inv;
+  if (accumulate) {
+    float o[8];
+    load8(dx + i * 8, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += o[k];
+  }
+  store8(dx + i * 8, v);
+}
+
+// ---------------------------------------------------------------- BN backward
+// dz sources: (a) plain block BN: dz = g * (a > 0) ; (b) stem: g scattered through the max-pool argmax.
+template <typename T>
+struct DzPlain {
+  const T* g; const T* a; const T* y;
+  __device__ __forceinline__ void get(size_t i8, float (&dz)[8], float (&yy)[8]) const {
+    load8(g + i8 * 8, dz);
+    load8(y + i8 * 8, yy);
+    if (a) {
+      float m[8];
+      load8(a + i8 * 8, m);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = m[k] > 0.f ? dz[k] : 0.f;
+    }
+  }
+};
+
+template <typename T>
+struct DzStem {
+  const T* dpool; const uint8_t* idx; const T* y; const float* scale; const float* shift;
+  int H, W, C8;
+  __device__ __forceinline__ void get(size_t i8, float (&dz)[8], float (&yy)[8]) const {
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const int cg = (int)(i8 % C8);
+    size_t pix = i8 / C8;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H);
+    const size_t b = pix / H;
+    load8(y + i8 * 8, yy);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dz[k] = 0.f;
+    const int ph0 = h >> 1, ph1 = (h + 1) >> 1, pw0 = w >> 1, pw1 = (w + 1) >> 1;
+    for (int ph = ph0; ph <= ph1; ++ph) {
+      if (ph >= OH) continue;
+      const int kh = h - (2 * ph - 1);
+      for (int pw = pw0; pw <= pw1; ++pw) {
+        if (pw >= OW) continue;
+        const int code = kh * 3 + (w - (2 * pw - 1));
+        const size_t o8 = ((b * OH + ph) * OW + pw) * C8 + cg;
+        const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o8 * 8);
+        float g8[8];
+        load8(dpool + o8 * 8, g8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if ((int)((packed >> (8 * k)) & 0xff) == code) dz[k] += g8[k];
+      }
+    }
+    const int c = cg * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float a = yy[k] * scale[c + k] + shift[c + k];
+      dz[k] = a > 0.f ? dz[k] : 0.f;
+    }
+  }
+};
+
+constexpr int BWD_BLOCKS_MAX = 1024;
+
+template <typename T, typename Src>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd,
+                                                            float* __restrict__ parts, size_t npix, int C) {
+  const int C8 = C >> 3;
+  const int cg = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
+  const int c = cg * 8;
+  float mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mu[k] = mean[c + k]; is[k] = invstd[c + k]; s1[k] = 0.f; s2[k] = 0.f; }
+  const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = (size_t)blockIdx.x * per, p1 = min(npix, p0 + per);
+  for (size_t p = p0 + pl; p < p1; p += npl) {
+    float dz[8], yy[8];
+    src.get(p * C8 + cg, dz, yy);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s1[k] += dz[k];
+      s2[k] += dz[k] * (yy[k] - mu[k]) * is[k];
+    }
+  }
+  __shared__ float sh[2][256][9];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * C; o += 256) {
+    const int which = o / C, ch = o % C;
+    float t = 0.f;
+    for (int q = 0; q < npl; ++q) t += sh[which][q * C8 + (ch >> 3)][ch & 7];
+    parts[((size_t)blockIdx.x * 2 + which) * C + ch] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C,
+                                                              double count, float* dgamma, float* dbeta, float* c1,
+                                                              float* c2) {
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int p = tid; p < nparts; p += 256) {
+    s1 += (double)parts[((size_t)p * 2 + 0) * C + c];
+    s2 += (double)parts[((size_t)p * 2 + 1) * C + c];
+  }
+  __shared__ double sh[2][4];
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s1; sh[1][tid >> 6] = s2; }
+  __syncthreads();
+  if (tid == 0) {
+    s1 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    s2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    c1[c] = (float)(s1 / count);
+    c2[c] = (float)(s2 / count);
+  }
+}
+
+template <typename T, typename Src>
+__global__ void bn_bwd_apply_kernel(Src src, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ c1,
+                                    const float* __restrict__ c2, T* __restrict__ dy, size_t n8, int C8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const int c = (int)(i % C8) * 8;
+  float dz[8], yy[8];
+  src.get(i, dz, yy);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float is = invstd[c + k];
+    const float xh = (yy[k] - mean[c + k]) * is;
+    dz[k] = gamma[c + k] * is * (dz[k] - c1[c + k] - xh * c2[c + k]);
+  }
+  store8(dy + i * 8, dz);
+}
+
+inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+int ph_pack_input_launch(const float* x, void* x4, int B, int H, int W, int prec, hipStream_t st) {
+  const size_t n = (size_t)B * H * W;
+  if (prec == PH_PREC_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, x, (bf16*)x4, B, H, W);
+  else hipLaunchKernelGGL(pack_input_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, x, (float*)x4, B, H, W);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_finalize_launch(const float* parts, int nparts, int C, double count, float eps, float momentum,
+                           const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                           float* shift, float* running_mean, float* running_var, int64_t* nbt, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, eps, momentum, gamma, beta,
+                     mean, invstd, scale, shift, running_mean, running_var, nbt);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
+                       const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,
+                       hipStream_t st) {
+  const size_t n8 = npix * (C / 8);
+  if (prec == PH_PREC_BF16)
+    hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nblk(n8)), dim3(256), 0, st, (const bf16*)y, scale, shift,
+                       (const bf16*)res, (const bf16*)y_r, scale_r, shift_r, (bf16*)out, n8, C / 8, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblk(n8)), dim3(256), 0, st, (const float*)y, scale, shift,
+                       (const float*)res, (const float*)y_r, scale_r, shift_r, (float*)out, n8, C / 8, relu);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int B,
+                              int H, int W, int C, int prec, hipStream_t st) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const size_t n = (size_t)B * OH * OW * (C / 8);
+  if (prec == PH_PREC_BF16)
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)y, scale, shift,
+                       (bf16*)out, idx, B, H, W, C / 8);
+  else
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, (const float*)y, scale, shift,
+                       (float*)out, idx, B, H, W, C / 8);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st) {
+  dim3 grid(C / 64, B);
+  if (prec == PH_PREC_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, out, HW, C);
+  else hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, HW, C);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int accumulate, int prec, hipStream_t st) {
+  const size_t n8 = (size_t)B * HW * (C / 8);
+  if (prec == PH_PREC_BF16)
+    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(nblk(n8)), dim3(256), 0, st, g, (bf16*)dx, n8, HW, C / 8, accumulate);
+  else
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(nblk(n8)), dim3(256), 0, st, g, (float*)dx, n8, HW, C / 8, accumulate);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_bwd_parts(size_t npix) {
+  size_t b = (npix + 255) / 256;
+  return (int)(b < (size_t)BWD_BLOCKS_MAX ? (b ? b : 1) : BWD_BLOCKS_MAX);
+}
+
+int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
+                            float* parts, size_t npix, int C, int prec, hipStream_t st) {
+  const int nb = ph_bn_bwd_parts(npix);
+  if (prec == PH_PREC_BF16) {
+    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y};
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, DzPlain<bf16>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
+  } else {
+    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y};
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, DzPlain<float>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
+                              float* c1, float* c2, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, dgamma, dbeta, c1, c2);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
+                           const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
+                           int prec, hipStream_t st) {
+  const size_t n8 = npix * (C / 8);
+  if (prec == PH_PREC_BF16) {
+    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y};
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, DzPlain<bf16>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (bf16*)dy, n8, C / 8);
+  } else {
+    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y};
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, DzPlain<float>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (float*)dy, n8, C / 8);
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
+                              int W, int C, int prec, hipStream_t st) {
+  const size_t npix = (size_t)B * H * W;
+  const int nb = ph_bn_bwd_parts(npix);
+  if (prec == PH_PREC_BF16) {
+    DzStem<bf16> s{(const bf16*)dpool, idx, (const bf16*)y0, scale, shift, H, W, C / 8};
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, DzStem<bf16>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
+  } else {
+    DzStem<float> s{(const float*)dpool, idx, (const float*)y0, scale, shift, H, W, C / 8};
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, DzStem<float>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_stem_bwd_apply_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, const float* gamma,
+                             const float* c1, const float* c2, void* dy0, int B, int H, int W, int C, int prec,
+                             hipStream_t st) {
+  const size_t n8 = (size_t)B * H * W * (C / 8);
+  if (prec == PH_PREC_BF16) {
+    DzStem<bf16> s{(const bf16*)dpool, idx, (const bf16*)y0, scale, shift, H, W, C / 8};
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, DzStem<bf16>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (bf16*)dy0, n8, C / 8);
+  } else {
+    DzStem<float> s{(const float*)dpool, idx, (const float*)y0, scale, shift, H, W, C / 8};
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, DzStem<float>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (float*)dy0, n8, C / 8);
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}

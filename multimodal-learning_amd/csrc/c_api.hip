@@ -1,0 +1,120 @@
+// Fine-grained convolution entry points of the C-ABI (used by the parity tests to pin each MFMA kernel
+// against the oracle's F.conv2d) + ABI version.
+#include "ph_common.h"
+#include "ph_kernels.h"
+#include "ph_dense.h"
+
+namespace {
+constexpr size_t AL = 256;
+inline size_t up(size_t x) { return (x + AL - 1) / AL * AL; }
+
+__global__ void parts_sum_kernel(const float* __restrict__ parts, int nparts, int C, float* s1, float* s2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int p = 0; p < nparts; ++p) { a += parts[((size_t)p * 2) * C + c]; b += parts[((size_t)p * 2 + 1) * C + c]; }
+  if (s1) s1[c] = (float)a;
+  if (s2) s2[c] = (float)b;
+}
+
+int chunks_for(int B, int OH, int OW, int S, int Cout, int Cin, int* tpc) {
+  const int th = ph_wgrad_tile_h(S);
+  const int ntiles = B * cdiv(OH, th) * cdiv(OW, 16);
+  int want = cdiv(1024, (Cout / 64) * (Cin / 64));
+  if (want > ntiles) want = ntiles;
+  if (want < 1) want = 1;
+  *tpc = cdiv(ntiles, want);
+  return cdiv(ntiles, *tpc);
+}
+}  // namespace
+
+int ph_abi_version(void) { return 1; }
+
+size_t ph_conv2d_workspace_bytes(int B, int Cin, int IH, int IW, int Cout, int KS, int stride, int pad) {
+  const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
+  const size_t wbytes = up((size_t)2 * KS * KS * Cin * Cout * sizeof(bf16));
+  PhTapConv t{}; t.B = B; t.Cout = Cout; t.OHt = OH; t.OWt = OW;
+  const size_t parts = up((size_t)ph_tapconv_stat_parts(&t, stride) * 2 * Cout * sizeof(float));
+  int tpc; const int nc = chunks_for(B, OH, OW, stride, Cout, Cin, &tpc);
+  const size_t slab = up((size_t)nc * KS * KS * Cin * Cout * sizeof(float));
+  return wbytes + (parts > slab ? parts : slab);
+}
+
+int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* ch_sumsq, int B, int Cin, int IH,
+                  int IW, int Cout, int KS, int stride, int pad, int prec, void* ws_, hipStream_t st) {
+  if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(ws_);
+  const size_t plane = (size_t)KS * KS * Cin * Cout;
+  bf16* hi = reinterpret_cast<bf16*>(ws);
+  bf16* lo = hi + plane;
+  int rc = ph_pack_w_fwd_launch(w, hi, lo, Cout, Cin, KS, st);
+  if (rc) return rc;
+  const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
+  PhTapConv t{};
+  t.in = x; t.w_hi = hi; t.w_lo = lo; t.out = y;
+  t.stats = reinterpret_cast<float*>(ws + up(2 * plane * sizeof(bf16)));
+  t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cin; t.Cout = Cout; t.OHt = OH; t.OWt = OW; t.OH = OH; t.OW = OW;
+  t.os = 1; t.iy0 = -pad; t.ix0 = -pad; t.ntaps = KS * KS;
+  for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = k; }
+  if ((rc = ph_tapconv_launch(&t, stride, prec, st))) return rc;
+  if (ch_sum || ch_sumsq) {
+    hipLaunchKernelGGL(parts_sum_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, st, t.stats,
+                       ph_tapconv_stat_parts(&t, stride), Cout, ch_sum, ch_sumsq);
+    PH_LAUNCH_CHECK();
+  }
+  return PH_OK;
+}
+
+int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, int IH, int IW, int Cout, int KS,
+                    int stride, int pad, int prec, void* ws_, hipStream_t st) {
+  if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
+  const size_t plane = (size_t)KS * KS * Cin * Cout;
+  bf16* hi = reinterpret_cast<bf16*>(ws_);
+  bf16* lo = hi + plane;
+  int rc = ph_pack_w_dgrad_launch(w, hi, lo, Cout, Cin, KS, st);
+  if (rc) return rc;
+  const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
+  PhTapConv t{};
+  t.in = dy; t.w_hi = hi; t.w_lo = lo; t.out = dx;
+  t.B = B; t.IH = OH; t.IW = OW; t.Cin = Cout; t.Cout = Cin; t.OH = IH; t.OW = IW;
+  if (stride == 1) {
+    t.OHt = IH; t.OWt = IW; t.os = 1; t.iy0 = -(KS - 1 - pad); t.ix0 = t.iy0; t.ntaps = KS * KS;
+    for (int k = 0; k < t.ntaps; ++k) {
+      t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = (KS - 1 - k / KS) * KS + (KS - 1 - k % KS);
+    }
+    return ph_tapconv_launch(&t, 1, prec, st);
+  }
+  const size_t es = prec == PH_PREC_BF16 ? 2 : 4;
+  if (hipMemsetAsync(dx, 0, (size_t)B * IH * IW * Cin * es, st) != hipSuccess) return PH_ELAUNCH;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      int nk = 0, khs[3], dhs[3], nw = 0, kws[3], dws[3];
+      for (int kh = 0; kh < KS; ++kh)
+        if (((a + pad - kh) & 1) == 0 && a + pad - kh >= 0) { khs[nk] = kh; dhs[nk] = (a + pad - kh) / 2; ++nk; }
+      for (int kw = 0; kw < KS; ++kw)
+        if (((b + pad - kw) & 1) == 0 && b + pad - kw >= 0) { kws[nw] = kw; dws[nw] = (b + pad - kw) / 2; ++nw; }
+      t.OHt = (IH - a + 1) / 2; t.OWt = (IW - b + 1) / 2;
+      t.os = 2; t.oa_h = a; t.oa_w = b; t.iy0 = 0; t.ix0 = 0; t.ntaps = nk * nw;
+      if (t.ntaps == 0 || t.OHt <= 0 || t.OWt <= 0) continue;
+      int q = 0;
+      for (int i = 0; i < nk; ++i)
+        for (int j = 0; j < nw; ++j) { t.dy[q] = dhs[i]; t.dx[q] = dws[j]; t.wtap[q] = khs[i] * KS + kws[j]; ++q; }
+      if ((rc = ph_tapconv_launch(&t, 1, prec, st))) return rc;
+    }
+  return PH_OK;
+}
+
+int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, int IH, int IW, int Cout, int KS,
+                    int stride, int pad, int prec, void* ws_, hipStream_t st) {
+  if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(ws_);
+  const size_t plane = (size_t)KS * KS * Cin * Cout;
+  const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
+  PhWgrad g{};
+  g.x = x; g.dy = dy; g.slab = reinterpret_cast<float*>(ws + up(2 * plane * sizeof(bf16)));
+  g.B = B; g.IH = IH; g.IW = IW; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.S = stride; g.pad = pad; g.KS = KS;
+  g.nchunks = chunks_for(B, OH, OW, stride, Cout, Cin, &g.tiles_per_chunk);
+  int rc = ph_wgrad_launch(&g, prec, st);
+  if (rc) return rc;
+  return ph_wgrad_reduce_launch(g.slab, dw, g.nchunks, KS, Cout, Cin, st);
+}

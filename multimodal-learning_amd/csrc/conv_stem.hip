@@ -1,0 +1,325 @@
+// Stem convolution 7x7 / stride 2 / pad 3, Cin = 3 (reference resnets.py:146-147) on MFMA.
+//
+// The input is repacked NHWC4 (channel 3 = 0) so that one kernel row kh of one output pixel is
+// 8 pixels x 4 channels = 32 contiguous bf16 = exactly two 16-B MFMA A-fragments: K = 7 rows x 32
+// (147 real taps padded to 224).  The halo tile (21 x 38 input pixels for an 8x16 output tile) and ALL
+// weights (28 KB) live in LDS.  Forward: rows = pixels, cols = 64 cout (BN partial sums in the epilogue).
+// wgrad: M = cout, N = (kw,ch) 32 per kh, K = pixels, both operands through ds_read_b64_tr_b16.
+// There is no dgrad (the image needs no gradient on the hot path; dx is produced only on request by a
+// separate small kernel for the parity tests).
+#include "ph_common.h"
+#include "ph_kernels.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16, HPH = (TH - 1) * 2 + 7, HPW = (TW - 1) * 2 + 8;   // 21 x 38
+constexpr int HP = HPH * HPW;
+constexpr int XB = HP * 8;            // bytes of one bf16 halo plane
+constexpr int WB = 7 * 64 * 64;       // bytes of one weight plane [7][64][32] bf16
+
+__device__ __forceinline__ int wsw(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+template <typename T>
+__device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, int iy_base, int ix_base,
+                                           unsigned char* hi, unsigned char* lo, int tid) {
+  for (int i = tid; i < HP; i += 256) {
+    const int hr = i / HPW, hc = i - hr * HPW;
+    const int iy = iy_base + hr, ix = ix_base + hc;
+    const bool ok = iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+    const size_t g = (((size_t)b * IH + iy) * IW + ix) * 4;
+    if constexpr (!is_f32<T>::value) {
+      u32x2 v = {0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x2*>(x4 + g);
+      *reinterpret_cast<u32x2*>(hi + i * 8) = v;
+    } else {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(x4 + g);
+      bf16x4 h4, l4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { bf16 h, l; split_bf16(v[q], h, l); h4[q] = h; l4[q] = l; }
+      *reinterpret_cast<bf16x4*>(hi + i * 8) = h4;
+      *reinterpret_cast<bf16x4*>(lo + i * 8) = l4;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
+  constexpr bool SPLIT = is_f32<T>::value;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsX = smem;
+  unsigned char* ldsW = smem + XB * (SPLIT ? 2 : 1);
+  unsigned char* ldsXlo = smem + XB;
+  unsigned char* ldsWlo = ldsW + WB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_w = (p.OW + TW - 1) / TW;
+  const int tile = blockIdx.x, b = blockIdx.z;
+  const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
+  const T* x4 = reinterpret_cast<const T*>(p.x4);
+
+  stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, ldsXlo, tid);
+  for (int i = tid; i < 7 * 64 * 4; i += 256) {   // 16-B chunks of the weight plane(s)
+    const int ch = i & 3, row = i >> 2;           // row = kh*64 + cout
+    const int off = row * 64 + (wsw(row, ch) << 4);
+    *reinterpret_cast<u32x4*>(ldsW + off) = reinterpret_cast<const u32x4*>(p.w_hi)[i];
+    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(ldsWlo + off) = reinterpret_cast<const u32x4*>(p.w_lo)[i];
+  }
+  __syncthreads();
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+  const int m = wave * 32 + (lane & 31), khalf = lane >> 5;
+  const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int chunk = s * 2 + khalf;
+      const int aoff = (pbase + kh * HPW + 4 * s + 2 * khalf) * 8;
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsX + aoff);
+      bf16x8 bq[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = kh * 64 + j * 32 + (lane & 31);
+        bq[j] = *reinterpret_cast<const bf16x8*>(ldsW + row * 64 + (wsw(row, chunk) << 4));
+      }
+      if constexpr (SPLIT) {
+        bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsXlo + aoff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = kh * 64 + j * 32 + (lane & 31);
+          bf16x8 bl = *reinterpret_cast<const bf16x8*>(ldsWlo + row * 64 + (wsw(row, chunk) << 4));
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[j], acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[j], acc[j], 0, 0, 0);
+    }
+  }
+  // ---- epilogue (as conv_tap.hip): mask, statistics, store
+  T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * 64;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+    const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+    const bool valid = r < p.OH && c < p.OW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float v = valid ? acc[j][q] : 0.f;
+      s1[j] += v; s2[j] += v * v;
+      if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][64]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (khalf == 0) {
+        red[(wave * 2 + 0) * 64 + j * 32 + (lane & 31)] = a1;
+        red[(wave * 2 + 1) * 64 + j * 32 + (lane & 31)] = a2;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, n = tid & 63;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * 64 + n];
+      p.stats[(((size_t)b * gridDim.x + tile) * 2 + which) * 64 + n] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ int sw_piece(int pix, int piece) { return piece ^ (((pix >> 1) & 1) << 1); }
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, int off1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
+  union { s16x4 s[2]; bf16x8 v; } u;
+  u.s[0] = a; u.s[1] = b;
+  return u.v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
+  constexpr bool SPLIT = is_f32<T>::value;
+  constexpr int DB = TH * TW * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsD = smem;
+  unsigned char* ldsX = smem + DB;
+  unsigned char* ldsDlo = smem + DB + XB;
+  unsigned char* ldsXlo = ldsDlo + DB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x;
+  const int tiles_w = (p.OW + TW - 1) / TW, tiles_h = (p.OH + TH - 1) / TH;
+  const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * p.B;
+  const int t_begin = chunk * p.tiles_per_chunk, t_end = min(ntiles, t_begin + p.tiles_per_chunk);
+  const T* X = reinterpret_cast<const T*>(p.x4);
+  const T* DY = reinterpret_cast<const T*>(p.dy);
+  // wave w owns kernel rows kh = w and w+4 (w+4 == 7 does not exist)
+  const int nkh = (wave + 4 < 7) ? 2 : 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][j][q] = 0.f;
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3, colhalf = (lane >> 4) & 1, khalf = lane >> 5;
+
+  for (int tt = t_begin; tt < t_end; ++tt) {
+    const int b = tt / tiles_img, ti = tt - b * tiles_img;
+    const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
+    __syncthreads();
+    for (int i = tid; i < TH * TW * 8; i += 256) {
+      const int pix = i >> 3, ch = i & 7;
+      const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
+      const bool ok = r < p.OH && c < p.OW;
+      const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
+      const T* src = DY + (((size_t)b * p.OH + r) * p.OW + c) * 64 + ch * 8;
+      if constexpr (!SPLIT) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(src);
+        *reinterpret_cast<u32x4*>(ldsD + off) = v;
+      } else {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        if (ok) load8(src, v);
+        bf16x8 h8, l8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bf16 h, l; split_bf16(v[q], h, l); h8[q] = h; l8[q] = l; }
+        *reinterpret_cast<bf16x8*>(ldsD + off) = h8;
+        *reinterpret_cast<bf16x8*>(ldsDlo + off) = l8;
+      }
+    }
+    stage_halo<T>(X, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, ldsXlo, tid);
+    __syncthreads();
+#pragma unroll 2
+    for (int kk = 0; kk < TH * TW / 16; ++kk) {
+      const int t0 = kk * 16 + 8 * khalf + q4, t1 = t0 + 4;
+      bf16x8 a[2], al[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int piece = j * 2 + colhalf;
+        const int o0 = t0 * 128 + sw_piece(t0, piece) * 32 + p4 * 8;
+        const int o1 = t1 * 128 + sw_piece(t1, piece) * 32 + p4 * 8;
+        a[j] = tr_pair(ldsD, o0, o1);
+        if constexpr (SPLIT) al[j] = tr_pair(ldsDlo, o0, o1);
+      }
+      const int kw = 4 * colhalf + p4;
+      const int hb0 = ((t0 >> 4) * 2) * HPW + (t0 & 15) * 2 + kw;
+      const int hb1 = ((t1 >> 4) * 2) * HPW + (t1 & 15) * 2 + kw;
+#pragma unroll
+      for (int ai = 0; ai < 2; ++ai) {
+        if (ai < nkh) {
+          const int kh = wave + 4 * ai;
+          const int o0 = (hb0 + kh * HPW) * 8, o1 = (hb1 + kh * HPW) * 8;
+          bf16x8 bq = tr_pair(ldsX, o0, o1);
+          if constexpr (SPLIT) {
+            bf16x8 bl = tr_pair(ldsXlo, o0, o1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], bq, acc[ai][j], 0, 0, 0);
+              acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bl, acc[ai][j], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq, acc[ai][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* slab = p.slab + (size_t)chunk * 7 * 64 * 32;
+#pragma unroll
+  for (int ai = 0; ai < 2; ++ai) {
+    if (ai < nkh) {
+      const int kh = wave + 4 * ai;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+          slab[((size_t)kh * 64 + row) * 32 + (lane & 31)] = acc[ai][j][q];
+        }
+    }
+  }
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunks) {
+  // dw [64][3][7][7] <- sum_chunks slab[chunk][kh][co][kw*4+ch]
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 3 * 49) return;
+  const int kw = i % 7, kh = (i / 7) % 7, ch = (i / 49) % 3, co = i / 147;
+  const size_t e = ((size_t)kh * 64 + co) * 32 + kw * 4 + ch;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += slab[(size_t)c * 7 * 64 * 32 + e];
+  dw[i] = s;
+}
+
+template <typename K>
+int set_lds(K kern, int bytes, bool& done) {
+  if (!done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) !=
+        hipSuccess)
+      return PH_ELAUNCH;
+    done = true;
+  }
+  return PH_OK;
+}
+
+}  // namespace
+
+int ph_stem_stat_parts(int B, int OH, int OW) { return B * cdiv(OH, TH) * cdiv(OW, TW); }
+
+int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
+  dim3 grid(cdiv(p->OH, TH) * cdiv(p->OW, TW), 1, p->B);
+  if (prec == PH_PREC_BF16) {
+    static bool done = false;
+    const int lds = XB + WB;
+    if (set_lds(stem_fwd_kernel<bf16>, lds, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, *p);
+  } else if (prec == PH_PREC_BF16X3) {
+    static bool done = false;
+    const int lds = 2 * (XB + WB);
+    if (set_lds(stem_fwd_kernel<float>, lds, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, *p);
+  } else {
+    return PH_EINVAL;
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
+  dim3 grid(p->nchunks);
+  const int base = TH * TW * 128 + XB;
+  if (prec == PH_PREC_BF16) {
+    static bool done = false;
+    if (set_lds(stem_wgrad_kernel<bf16>, base, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_wgrad_kernel<bf16>, grid, dim3(256), base, st, *p);
+  } else if (prec == PH_PREC_BF16X3) {
+    static bool done = false;
+    if (set_lds(stem_wgrad_kernel<float>, 2 * base, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), 2 * base, st, *p);
+  } else {
+    return PH_EINVAL;
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_stem_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, hipStream_t st) {
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 147 + 255) / 256), dim3(256), 0, st, slab, dw, nchunks);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}

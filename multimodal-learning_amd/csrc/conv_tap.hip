@@ -1,0 +1,259 @@
+// Tap-convolution implicit GEMM on MFMA (gfx950): ONE kernel family serves
+//   * forward 3x3 / 1x1 convolutions, stride 1 or 2   (reference resnets.py:26-34,50-74)
+//   * data-gradient (dgrad) of the same convolutions: stride-1 dgrad = conv with transposed weights;
+//     stride-2 dgrad = 4 output-parity classes, each a stride-1 tap-conv with 1/2/4 taps.
+//
+// GEMM view: C[pixel][cout] = sum_{tap,cin} A[pixel+tap][cin] * W[tap][cout][cin]
+//   A: NHWC activations.  A spatial halo tile ((TH-1)*S+3) x ((TW-1)*S+3) x 64 channels is staged in LDS
+//      ONCE per 64-channel slice and re-read by all taps ("LDS-staged im2col": nothing im2col-shaped
+//      ever exists in HBM).  16-B chunks are XOR-swizzled by pixel index against bank conflicts.
+//   W: packed [tap][Cout][Cin] bf16 (cin contiguous = the MFMA K direction), staged per tap group.
+//   MFMA: v_mfma_f32_32x32x16_bf16; rows = pixels, cols = cout, so per-channel BatchNorm partial sums
+//      are plain in-register sums over the accumulator registers (cout lives on the lane).
+// Precision: T = bf16 -> perf mode (1 MFMA / k-step).  T = float -> parity mode: fp32 activations are
+//   split hi/lo bf16 while staging, weights come as hi/lo planes, 3 MFMAs / k-step (bf16x3).
+#include "ph_common.h"
+#include "ph_kernels.h"
+
+namespace {
+
+template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
+struct TapCfg {
+  static constexpr bool SPLIT = is_f32<T>::value;
+  static constexpr int TW = 16;
+  static constexpr int HPH = (TH - 1) * S + 3;
+  static constexpr int HPW = (TW - 1) * S + 3;
+  static constexpr int HP = HPH * HPW;
+  static constexpr int A_BYTES = HP * 128;
+  static constexpr int B_BYTES = TG * BNT * 128;
+  static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) * (SPLIT ? 2 : 1);
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(WM * FM * 32 == TH * TW, "M tiling");
+  static_assert(WN * FN * 32 == BNT, "N tiling");
+};
+
+template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
+__global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
+  using C = TapCfg<T, S, TH, BNT, WM, WN, FM, FN, TG>;
+  constexpr bool SPLIT = C::SPLIT;
+  constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsA = smem;
+  unsigned char* ldsAlo = smem + C::A_BYTES;
+  unsigned char* ldsB = smem + C::A_BYTES * (SPLIT ? 2 : 1);
+  unsigned char* ldsBlo = ldsB + C::B_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_w = (p.OWt + TW - 1) / TW;
+  const int tile = blockIdx.x;
+  const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
+  const int n0 = blockIdx.y * BNT;
+  const int b = blockIdx.z;
+  const T* in = reinterpret_cast<const T*>(p.in) + (size_t)b * p.IH * p.IW * p.Cin;
+  const bf16* whi = reinterpret_cast<const bf16*>(p.w_hi);
+  const bf16* wlo = reinterpret_cast<const bf16*>(p.w_lo);
+  const int iy_base = r0 * S + p.iy0, ix_base = c0 * S + p.ix0;
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+
+  // per-lane constant pieces of the fragment addresses
+  int prow[FM];   // (r*S)*HPW + c*S of this lane's pixel row, per M fragment
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int m = (wm * FM + i) * 32 + (lane & 31);
+    prow[i] = ((m >> 4) * S) * HPW + (m & 15) * S;
+  }
+  int nrow[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) nrow[j] = (wn * FN + j) * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  const int nslices = p.Cin >> 6;
+  for (int sl = 0; sl < nslices; ++sl) {
+    const int k0 = sl << 6;
+    __syncthreads();   // previous slice's MFMA reads of ldsA are done
+    // ---- stage the halo tile of this 64-channel slice
+    for (int i = tid; i < HP * 8; i += 256) {
+      const int pix = i >> 3, ch = i & 7;
+      const int hr = pix / HPW, hc = pix - hr * HPW;
+      const int iy = iy_base + hr, ix = ix_base + hc;
+      const bool ok = (iy >= 0) && (iy < p.IH) && (ix >= 0) && (ix < p.IW);
+      const int off = pix * 128 + ((ch ^ (pix & 7)) << 4);
+      if constexpr (!SPLIT) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8);
+        *reinterpret_cast<u32x4*>(ldsA + off) = v;
+      } else {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        if (ok) load8(in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8, v);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { bf16 h, l; split_bf16(v[q], h, l); hi[q] = h; lo[q] = l; }
+        *reinterpret_cast<bf16x8*>(ldsA + off) = hi;
+        *reinterpret_cast<bf16x8*>(ldsAlo + off) = lo;
+      }
+    }
+    for (int tg0 = 0; tg0 < p.ntaps; tg0 += TG) {
+      const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
+      if (tg0 > 0) __syncthreads();   // previous group's reads of ldsB are done
+      // ---- stage weights of this tap group: [gcount][BNT][64] bf16
+      for (int i = tid; i < gcount * BNT * 8; i += 256) {
+        const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
+        const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
+        const int off = (t * BNT + row) * 128 + ((ch ^ (row & 7)) << 4);
+        *reinterpret_cast<u32x4*>(ldsB + off) = *reinterpret_cast<const u32x4*>(whi + g);
+        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(ldsBlo + off) = *reinterpret_cast<const u32x4*>(wlo + g);
+      }
+      __syncthreads();
+      // ---- MFMA over the group's taps x 4 k16-steps
+      for (int t = 0; t < gcount; ++t) {
+        const int toff = p.dy[tg0 + t] * HPW + p.dx[tg0 + t];
+        int hp[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) hp[i] = prow[i] + toff;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int chunk = ks * 2 + khalf;
+          bf16x8 a[FM], bq[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            a[i] = *reinterpret_cast<const bf16x8*>(ldsA + hp[i] * 128 + ((chunk ^ (hp[i] & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            bq[j] = *reinterpret_cast<const bf16x8*>(ldsB + (t * BNT + nrow[j]) * 128 + ((chunk ^ (nrow[j] & 7)) << 4));
+          if constexpr (SPLIT) {
+            bf16x8 al[FM], bl[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+              al[i] = *reinterpret_cast<const bf16x8*>(ldsAlo + hp[i] * 128 + ((chunk ^ (hp[i] & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              bl[j] = *reinterpret_cast<const bf16x8*>(ldsBlo + (t * BNT + nrow[j]) * 128 + ((chunk ^ (nrow[j] & 7)) << 4));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+              for (int j = 0; j < FN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bq[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+              }
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---------------- epilogue: mask, BN partial statistics, (residual), store
+  // accumulator register q of fragment (i,j): pixel m = (wm*FM+i)*32 + (q&3) + 8*(q>>2) + 4*khalf,
+  // channel n0 + nrow[j].
+  const bool full = (r0 + TH <= p.OHt) && (c0 + TW <= p.OWt);
+  T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * p.Cout;
+  const T* resg = p.res_g ? reinterpret_cast<const T*>(p.res_g) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
+  const T* resa = p.res_a ? reinterpret_cast<const T*>(p.res_a) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
+  float s1[FN], s2[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = (wm * FM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+      const int r = r0 + (m >> 4), c = c0 + (m & 15);
+      const bool valid = full || (r < p.OHt && c < p.OWt);
+      const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float v = valid ? acc[i][j][q] : 0.f;
+        s1[j] += v;
+        s2[j] += v * v;
+        if (valid) {
+          if (resg) {
+            float g = ldf(resg + o + nrow[j]);
+            if (resa) g = (ldf(resa + o + nrow[j]) > 0.f) ? g : 0.f;
+            v += g;
+          }
+          stf(out + o + nrow[j], v);
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();   // all MFMA reads of LDS done; reuse smem as float[WM][2][BNT]
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (khalf == 0) {
+        red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
+        red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BNT) {
+      const int which = tid / BNT, n = tid % BNT;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BNT + n];
+      const size_t part = (size_t)b * gridDim.x + tile;
+      p.stats[(part * 2 + which) * p.Cout + n0 + n] = v;
+    }
+  }
+}
+
+template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
+int launch_cfg(const PhTapConv& p, hipStream_t st) {
+  using C = TapCfg<T, S, TH, BNT, WM, WN, FM, FN, TG>;
+  auto kern = tapconv_kernel<T, S, TH, BNT, WM, WN, FM, FN, TG>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess)
+      return PH_ELAUNCH;
+    attr_done = true;
+  }
+  dim3 grid(cdiv(p.OHt, TH) * cdiv(p.OWt, 16), p.Cout / BNT, p.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+template <typename T>
+int launch_T(const PhTapConv& p, int S, hipStream_t st) {
+  constexpr bool SPLIT = is_f32<T>::value;
+  if (S == 1) {
+    if (p.Cout % 128 == 0) return launch_cfg<T, 1, 8, 128, 2, 2, 2, 2, 3>(p, st);
+    return launch_cfg<T, 1, 16, 64, 4, 1, 2, 2, 3>(p, st);
+  } else {
+    if (p.Cout % 128 == 0) return launch_cfg<T, 2, 4, 128, 1, 4, 2, 1, SPLIT ? 1 : 3>(p, st);
+    return launch_cfg<T, 2, 4, 64, 2, 2, 1, 1, SPLIT ? 1 : 3>(p, st);
+  }
+}
+
+}  // namespace
+
+// number of statistic partial rows a launch writes: B * tiles
+int ph_tapconv_stat_parts(const PhTapConv* p, int S) {
+  int TH = (S == 1) ? ((p->Cout % 128 == 0) ? 8 : 16) : 4;
+  return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
+}
+
+int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
+  if (p->Cin % 64 || p->Cout % 64 || p->ntaps < 1 || p->ntaps > 9 || (S != 1 && S != 2)) return PH_EINVAL;
+  if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
+  if (prec == PH_PREC_BF16X3) return launch_T<float>(*p, S, st);
+  return PH_EINVAL;
+}

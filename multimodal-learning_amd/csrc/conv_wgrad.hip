@@ -1,0 +1,260 @@
+// Weight-gradient (wgrad) of the 3x3 / 1x1 convolutions on MFMA, plus weight packing kernels.
+//
+//   dW[tap][cout][cin] = sum_{b,r,c} dY[b,r,c,cout] * X[b, r*S + kh - pad, c*S + kw - pad, cin]
+// GEMM view: M = cout, N = cin, K = pixels (huge).  Both operands are K-major in HBM (NHWC: pixel is the
+// slow index), so both MFMA fragments are fetched from LDS with the CDNA4 transposing read
+// ds_read_b64_tr_b16 - the tiles are staged exactly as they lie in HBM (coalesced 16-B rows), no
+// transposed copy is ever made.  One workgroup owns a 64x64 (cout x cin) block for ALL taps and walks a
+// chunk of spatial tiles, keeping 9 x 32x32 accumulators per wave in registers (144 VGPRs); the X halo
+// tile is staged once per spatial tile and re-read by all 9 taps.  Partial sums go to a slab
+// [chunk][tap][cout][cin] and are combined in fixed order by a reduce kernel (bitwise reproducible,
+// no float atomics).
+#include "ph_common.h"
+#include "ph_kernels.h"
+
+namespace {
+
+// 32-B piece swizzle of a [pixel][64 ch] bf16 image (128-B rows): makes the 4-row tr-reads conflict-free
+__device__ __forceinline__ int sw_piece(int pix, int piece) { return piece ^ (((pix >> 1) & 1) << 1); }
+
+template <typename T, int S, int TH, int KS>
+struct WgCfg {
+  static constexpr bool SPLIT = is_f32<T>::value;
+  static constexpr int TW = 16, BM = TH * TW;
+  static constexpr int HPH = (TH - 1) * S + KS, HPW = (TW - 1) * S + KS, HP = HPH * HPW;
+  static constexpr int D_BYTES = BM * 128, X_BYTES = HP * 128;
+  static constexpr int LDS_BYTES = (D_BYTES + X_BYTES) * (SPLIT ? 2 : 1);
+  static constexpr int NT = KS * KS;
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_row(const T* src, bool ok, unsigned char* hi, unsigned char* lo, int off) {
+  if constexpr (!is_f32<T>::value) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ok) v = *reinterpret_cast<const u32x4*>(src);
+    *reinterpret_cast<u32x4*>(hi + off) = v;
+  } else {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    if (ok) load8(src, v);
+    bf16x8 h8, l8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { bf16 h, l; split_bf16(v[q], h, l); h8[q] = h; l8[q] = l; }
+    *reinterpret_cast<bf16x8*>(hi + off) = h8;
+    *reinterpret_cast<bf16x8*>(lo + off) = l8;
+  }
+}
+
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, int off1) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off0));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off1));
+  union { s16x4 s[2]; bf16x8 v; } u;
+  u.s[0] = a; u.s[1] = b;
+  return u.v;
+}
+
+template <typename T, int S, int TH, int KS>
+__global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
+  using C = WgCfg<T, S, TH, KS>;
+  constexpr bool SPLIT = C::SPLIT;
+  constexpr int TW = C::TW, BM = C::BM, HPW = C::HPW, HP = C::HP, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsD = smem;
+  unsigned char* ldsX = smem + C::D_BYTES;
+  unsigned char* ldsDlo = smem + C::D_BYTES + C::X_BYTES;
+  unsigned char* ldsXlo = ldsDlo + C::D_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cf = wave >> 1, kf = wave & 1;     // 32-wide cout / cin fragment of this wave
+  const int cin_blocks = p.Cin >> 6;
+  const int co0 = (blockIdx.x / cin_blocks) << 6, ci0 = (blockIdx.x % cin_blocks) << 6;
+  const int chunk = blockIdx.y;
+  const int tiles_w = (p.OW + TW - 1) / TW, tiles_h = (p.OH + TH - 1) / TH;
+  const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * p.B;
+  const int t_begin = chunk * p.tiles_per_chunk;
+  const int t_end = min(ntiles, t_begin + p.tiles_per_chunk);
+  const T* X = reinterpret_cast<const T*>(p.x);
+  const T* DY = reinterpret_cast<const T*>(p.dy);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  // tr-read lane roles: within each 16-lane group, lane 4q+p supplies row q, columns 4p..4p+3
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3, colhalf = (lane >> 4) & 1, khalf = lane >> 5;
+  const int pieceA = cf * 2 + colhalf, pieceB = kf * 2 + colhalf;
+
+  for (int tt = t_begin; tt < t_end; ++tt) {
+    const int b = tt / tiles_img, ti = tt - b * tiles_img;
+    const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
+    __syncthreads();
+    // ---- stage dY tile [BM pix][64 cout] and X halo [HP pix][64 cin]
+    for (int i = tid; i < BM * 8; i += 256) {
+      const int pix = i >> 3, ch = i & 7;
+      const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
+      const bool ok = r < p.OH && c < p.OW;
+      const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
+      stage_row<T>(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8, ok, ldsD, ldsDlo, off);
+    }
+    const int iy_base = r0 * S - p.pad, ix_base = c0 * S - p.pad;
+    for (int i = tid; i < HP * 8; i += 256) {
+      const int pix = i >> 3, ch = i & 7;
+      const int hr = pix / HPW, hc = pix - hr * HPW;
+      const int iy = iy_base + hr, ix = ix_base + hc;
+      const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
+      stage_row<T>(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8, ok, ldsX, ldsXlo, off);
+    }
+    __syncthreads();
+    // ---- K loop over the tile's pixels, 16 per MFMA
+#pragma unroll 2
+    for (int kk = 0; kk < BM / 16; ++kk) {
+      // the two 4-pixel row groups this lane's tr-reads address
+      const int t0 = kk * 16 + 8 * khalf + q4, t1 = t0 + 4;
+      const int offA0 = t0 * 128 + sw_piece(t0, pieceA) * 32 + p4 * 8;
+      const int offA1 = t1 * 128 + sw_piece(t1, pieceA) * 32 + p4 * 8;
+      bf16x8 a = tr_pair(ldsD, offA0, offA1);
+      bf16x8 al;
+      if constexpr (SPLIT) al = tr_pair(ldsDlo, offA0, offA1);
+      const int hb0 = ((t0 >> 4) * S) * HPW + (t0 & 15) * S;
+      const int hb1 = ((t1 >> 4) * S) * HPW + (t1 & 15) * S;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int toff = (t / KS) * HPW + (t % KS);
+        const int h0 = hb0 + toff, h1 = hb1 + toff;
+        const int offB0 = h0 * 128 + sw_piece(h0, pieceB) * 32 + p4 * 8;
+        const int offB1 = h1 * 128 + sw_piece(h1, pieceB) * 32 + p4 * 8;
+        bf16x8 bq = tr_pair(ldsX, offB0, offB1);
+        if constexpr (SPLIT) {
+          bf16x8 bl = tr_pair(ldsXlo, offB0, offB1);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[t], 0, 0, 0);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // ---- partial slab: acc[t][q] -> row (cout) = (q&3)+8*(q>>2)+4*khalf, col (cin) = lane&31
+  float* slab = p.slab + (size_t)chunk * NT * p.Cout * p.Cin;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = co0 + cf * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+      const int col = ci0 + kf * 32 + (lane & 31);
+      slab[((size_t)t * p.Cout + row) * p.Cin + col] = acc[t][q];
+    }
+}
+
+template <typename T, int S, int TH, int KS>
+int launch_wg(const PhWgrad& p, hipStream_t st) {
+  using C = WgCfg<T, S, TH, KS>;
+  auto kern = wgrad_kernel<T, S, TH, KS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess)
+      return PH_ELAUNCH;
+    attr_done = true;
+  }
+  dim3 grid((p.Cout / 64) * (p.Cin / 64), p.nchunks);
+  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+template <typename T>
+int launch_wg_T(const PhWgrad& p, hipStream_t st) {
+  if (p.S == 1 && p.KS == 3) return launch_wg<T, 1, 8, 3>(p, st);
+  if (p.S == 2 && p.KS == 3) return launch_wg<T, 2, 4, 3>(p, st);
+  if (p.S == 2 && p.KS == 1) return launch_wg<T, 2, 4, 1>(p, st);
+  if (p.S == 1 && p.KS == 1) return launch_wg<T, 1, 8, 1>(p, st);
+  return PH_EINVAL;
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunks, int NT,
+                                    int Cout, int Cin) {
+  // one thread per (tap, cout, cin); writes OIHW: dw[((co*Cin + ci)*NT) + tap]
+  const size_t n = (size_t)NT * Cout * Cin;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ci = i % Cin;
+  const int co = (i / Cin) % Cout;
+  const int t = i / ((size_t)Cin * Cout);
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += slab[(size_t)c * n + i];
+  dw[((size_t)co * Cin + ci) * NT + t] = s;
+}
+
+__global__ void pack_w_kernel(const float* __restrict__ w, bf16* __restrict__ hi, bf16* __restrict__ lo, int O, int I,
+                              int NT, int dgrad) {
+  // w OIHW [O][I][NT].  fwd layout [tap][O][I]; dgrad layout [tap][I][O]
+  const size_t n = (size_t)NT * O * I;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int t, o, ii;
+  if (!dgrad) { ii = i % I; o = (i / I) % O; t = i / ((size_t)I * O); }
+  else        { o = i % O; ii = (i / O) % I; t = i / ((size_t)I * O); }
+  const float v = w[((size_t)o * I + ii) * NT + t];
+  bf16 h, l;
+  split_bf16(v, h, l);
+  hi[i] = h;
+  if (lo) lo[i] = l;
+}
+
+__global__ void pack_w_stem_kernel(const float* __restrict__ w, bf16* __restrict__ hi, bf16* __restrict__ lo) {
+  // w [64][3][7][7] -> [kh 7][cout 64][kw 8 x ch 4], zero padded
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 7 * 64 * 32) return;
+  const int k = i & 31, co = (i >> 5) & 63, kh = i >> 11;
+  const int kw = k >> 2, ch = k & 3;
+  float v = 0.f;
+  if (kw < 7 && ch < 3) v = w[((co * 3 + ch) * 7 + kh) * 7 + kw];
+  bf16 h, l;
+  split_bf16(v, h, l);
+  hi[i] = h;
+  if (lo) lo[i] = l;
+}
+
+}  // namespace
+
+int ph_wgrad_tile_h(int S) { return S == 1 ? 8 : 4; }
+
+int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
+  if (p->Cin % 64 || p->Cout % 64 || p->nchunks < 1) return PH_EINVAL;
+  if (prec == PH_PREC_BF16) return launch_wg_T<bf16>(*p, st);
+  if (prec == PH_PREC_BF16X3) return launch_wg_T<float>(*p, st);
+  return PH_EINVAL;
+}
+
+int ph_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, int KS, int Cout, int Cin, hipStream_t st) {
+  const size_t n = (size_t)KS * KS * Cout * Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dw, nchunks,
+                     KS * KS, Cout, Cin);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_pack_w_fwd_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st) {
+  const size_t n = (size_t)KS * KS * O * I;
+  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (bf16*)hi, (bf16*)lo, O, I,
+                     KS * KS, 0);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_pack_w_dgrad_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st) {
+  const size_t n = (size_t)KS * KS * O * I;
+  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (bf16*)hi, (bf16*)lo, O, I,
+                     KS * KS, 1);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_pack_w_stem_launch(const float* w, void* hi, void* lo, hipStream_t st) {
+  hipLaunchKernelGGL(pack_w_stem_kernel, dim3((7 * 64 * 32 + 255) / 256), dim3(256), 0, st, w, (bf16*)hi, (bf16*)lo);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}

@@ -1,0 +1,260 @@
+// CRD memory-bank contrastive loss (DC-Distill): reference CL_utils/memory_new.py:249-397
+// (ContrastMemory_v3.forward) + CL_utils/CRD_loss.py:221-244 (ContrastLoss_v2), fused so that nothing
+// [B, P+K, 128]-sized is ever written:
+//   crd_score   : one coalesced 512-B read per bank row, 4 dot products + 2 norms in registers,
+//                 half-wave (32-lane) reductions -> exp scores (both directions) + cosine discrepancy
+//   crd_select  : per-sample rank-by-counting in LDS (replaces two full torch.sort calls): P2 positives at the
+//                 requested ranks of (student-sim - teacher-sim) descending, slot 0 forced to the exact
+//                 positive; K2 negatives with the smallest discrepancy (ascending order kept)
+//   crd_zsum/crd_setz : first-call normalisation constants Z (memory_new.py:368-375)
+//   crd_loss_grad: NCE loss + analytic d loss / d (v1, v2) as a weighted gather-sum of the *pre-update*
+//                 bank rows (the bank is momentum-updated right after, as in the reference)
+//   crd_update  : momentum update + re-normalisation of the rows mem[y] (memory_new.py:382-395)
+// All bank traffic is row-granular 512-B coalesced reads; the bank (n_data x 128 fp32 x 2) is L2/MALL
+// resident for the reference's dataset sizes.
+#include "ph_common.h"
+#include "ph_dense.h"
+
+namespace {
+
+constexpr int D = 128;   // feat_dim (options.py:83); asserted by the launcher
+
+__device__ __forceinline__ float half_sum(float v) {   // reduce within each 32-lane half of the wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// grid (ceil(PK/64), B), block 256 = 8 half-waves, each half-wave walks 8 of the block's 64 columns
+__global__ __launch_bounds__(256) void crd_score_kernel(const float* __restrict__ v1, const float* __restrict__ v2,
+                                                        const int64_t* __restrict__ idx,
+                                                        const float* __restrict__ mem1,
+                                                        const float* __restrict__ mem2, float* __restrict__ out1,
+                                                        float* __restrict__ out2, float* __restrict__ diff, int PK,
+                                                        float invT) {
+  const int b = blockIdx.y;
+  const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const f32x4 a1 = *reinterpret_cast<const f32x4*>(v1 + (size_t)b * D + l * 4);
+  const f32x4 a2 = *reinterpret_cast<const f32x4*>(v2 + (size_t)b * D + l * 4);
+  const float n1 = sqrtf(half_sum(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2] + a1[3] * a1[3]));
+  const float n2 = sqrtf(half_sum(a2[0] * a2[0] + a2[1] * a2[1] + a2[2] * a2[2] + a2[3] * a2[3]));
+  const int j0 = blockIdx.x * 64 + hw * 8;
+#pragma unroll 4
+  for (int jj = 0; jj < 8; ++jj) {
+    const int j = j0 + jj;
+    if (j >= PK) break;
+    const int64_t row = idx[(size_t)b * PK + j];
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(mem1 + row * D + l * 4);
+    const f32x4 m2 = *reinterpret_cast<const f32x4*>(mem2 + row * D + l * 4);
+    float d12 = 0.f, d21 = 0.f, d11 = 0.f, d22 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d12 += m1[k] * a2[k];   // memory_v1 . v2  -> out_v2   (:270-273)
+      d21 += m2[k] * a1[k];   // memory_v2 . v1  -> out_v1   (:275-278)
+      d11 += m1[k] * a1[k];   // "t_relation" = student bank x student query (:288-289, names swapped)
+      d22 += m2[k] * a2[k];   // "s_relation" = teacher bank x teacher query (:291-292)
+      q1 += m1[k] * m1[k];
+      q2 += m2[k] * m2[k];
+    }
+    d12 = half_sum(d12); d21 = half_sum(d21); d11 = half_sum(d11); d22 = half_sum(d22);
+    q1 = half_sum(q1); q2 = half_sum(q2);
+    if (l == 0) {
+      out2[(size_t)b * PK + j] = expf(d12 * invT);
+      out1[(size_t)b * PK + j] = expf(d21 * invT);
+      diff[(size_t)b * PK + j] = d11 / (sqrtf(q1) * n1) - d22 / (sqrtf(q2) * n2);
+    }
+  }
+}
+
+// one block per sample.  sel[b][0..P2) = positive columns, sel[b][P2..P2+K2) = negative columns (absolute
+// column numbers in [0, P+K)); xs/xt = gathered raw exp scores.
+__global__ __launch_bounds__(256) void crd_select_kernel(const float* __restrict__ diff,
+                                                         const float* __restrict__ out1,
+                                                         const float* __restrict__ out2,
+                                                         const int* __restrict__ ranks, int* __restrict__ sel,
+                                                         float* __restrict__ xs, float* __restrict__ xt, int P, int K,
+                                                         int P2, int K2, int select_neg) {
+  extern __shared__ float sd[];   // [P+K] discrepancies, then int rank_to_col[P]
+  const int b = blockIdx.x, PK = P + K, S2 = P2 + K2;
+  int* r2c = reinterpret_cast<int*>(sd + PK);
+  for (int i = threadIdx.x; i < PK; i += blockDim.x) sd[i] = diff[(size_t)b * PK + i];
+  __syncthreads();
+  // positives: rank in DEscending order of diff[0..P)  (memory_new.py:303)
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    const float v = sd[i];
+    int r = 0;
+    for (int q = 0; q < P; ++q) { const float w = sd[q]; r += (w > v) || (w == v && q < i); }
+    r2c[r] = i;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < P2; t += blockDim.x) {
+    int col = r2c[ranks ? ranks[t] : t];   // "hard": ranks 0..P2-1 (:308); "mid"/"random": host-drawn ranks (:311-318)
+    if (t == 0) col = 0;                    // slot 0 := exact positive (:325)
+    sel[(size_t)b * S2 + t] = col;
+    xs[(size_t)b * S2 + t] = out1[(size_t)b * PK + col];
+    xt[(size_t)b * S2 + t] = out2[(size_t)b * PK + col];
+  }
+  // negatives: the K2 smallest of diff[P..P+K) in AScending order (:342-345)
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    int r;
+    if (select_neg) {
+      const float v = sd[P + i];
+      r = 0;
+      for (int q = 0; q < K; ++q) { const float w = sd[P + q]; r += (w < v) || (w == v && q < i); }
+    } else {
+      r = i;
+    }
+    if (r < K2) {
+      sel[(size_t)b * S2 + P2 + r] = P + i;
+      xs[(size_t)b * S2 + P2 + r] = out1[(size_t)b * PK + P + i];
+      xt[(size_t)b * S2 + P2 + r] = out2[(size_t)b * PK + P + i];
+    }
+  }
+}
+
+// sums[0] = sum(xs), sums[1] = sum(xt) over n elements (single block, deterministic)
+__global__ __launch_bounds__(1024) void crd_zsum_kernel(const float* __restrict__ xs, const float* __restrict__ xt,
+                                                        float* sums, int n) {
+  __shared__ double sh[2][16];
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { s1 += xs[i]; s2 += xt[i]; }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, c = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += sh[0][i]; c += sh[1][i]; }
+    sums[0] = (float)a; sums[1] = (float)c;
+  }
+}
+// params = [K, T, Z_v1, Z_v2, momentum, P] (memory_new.py:244); Z set only while negative (:368-375)
+__global__ void crd_setz_kernel(float* params, const float* sums, float count, float n_data) {
+  if (threadIdx.x == 0) {
+    if (params[2] < 0.f) params[2] = sums[0] / count * n_data;
+    if (params[3] < 0.f) params[3] = sums[1] / count * n_data;
+  }
+}
+
+// one block per sample: NCE loss terms + coefficient-weighted gather-sum of bank rows
+//   loss_s = -(1/Bn) [ sum_p log(x/(x+c)) / P2 + sum_n log(mPn/(x+c)) ],  x = xs/Z_v1, c = K2/n_data + eps
+//   d loss_s / d dot_j = -(1/(Bn P2)) (c/(x+c))/T  (positives) ;  +(1/Bn) (x/(x+c))/T  (negatives)
+//   dv1[b] = sum_j coef_s[j] mem2[idx[b][sel_j]] ; dv2[b] = sum_j coef_t[j] mem1[idx[b][sel_j]]
+__global__ __launch_bounds__(256) void crd_loss_grad_kernel(const float* __restrict__ xs,
+                                                            const float* __restrict__ xt,
+                                                            const int* __restrict__ sel,
+                                                            const int64_t* __restrict__ idx,
+                                                            const float* __restrict__ mem1,
+                                                            const float* __restrict__ mem2,
+                                                            const float* __restrict__ params,
+                                                            float* __restrict__ lossp, float* __restrict__ dv1,
+                                                            float* __restrict__ dv2, int PK, int P2, int K2,
+                                                            float n_data, float inv_bnorm) {
+  const int b = blockIdx.x, S2 = P2 + K2;
+  const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const float invT = 1.f / params[1], Z1 = params[2], Z2 = params[3];
+  const float mPn = (float)K2 / n_data, c = mPn + 1e-7f;
+  f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
+  float ls = 0.f;
+  for (int j = hw; j < S2; j += 8) {
+    const float x1 = xs[(size_t)b * S2 + j] / Z1, x2 = xt[(size_t)b * S2 + j] / Z2;
+    float c1, c2;
+    if (j < P2) {
+      ls += (logf(x1 / (x1 + c)) + logf(x2 / (x2 + c))) / (float)P2;
+      c1 = -(c / (x1 + c)) * invT * inv_bnorm / (float)P2;
+      c2 = -(c / (x2 + c)) * invT * inv_bnorm / (float)P2;
+    } else {
+      ls += logf(mPn / (x1 + c)) + logf(mPn / (x2 + c));
+      c1 = (x1 / (x1 + c)) * invT * inv_bnorm;
+      c2 = (x2 / (x2 + c)) * invT * inv_bnorm;
+    }
+    const int64_t row = idx[(size_t)b * PK + sel[(size_t)b * S2 + j]];
+    const f32x4 m2 = *reinterpret_cast<const f32x4*>(mem2 + row * D + l * 4);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(mem1 + row * D + l * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { g1[k] += c1 * m2[k]; g2[k] += c2 * m1[k]; }
+  }
+  __shared__ float sh[8][2][D];
+  __shared__ float shl[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sh[hw][0][l * 4 + k] = g1[k]; sh[hw][1][l * 4 + k] = g2[k]; }
+  if (l == 0) shl[hw] = ls;
+  __syncthreads();
+  {
+    const int which = threadIdx.x >> 7, d = threadIdx.x & 127;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sh[q][which][d];
+    (which ? dv2 : dv1)[(size_t)b * D + d] = t;
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int q = 0; q < 8; ++q) t += shl[q];
+    lossp[b] = -t * inv_bnorm;
+  }
+}
+
+// mem[y[b]] = normalize(momentum * mem[y[b]] + (1 - momentum) * v[b]); one wave per (sample, bank)
+__global__ __launch_bounds__(256) void crd_update_kernel(float* __restrict__ mem1, float* __restrict__ mem2,
+                                                         const float* __restrict__ v1, const float* __restrict__ v2,
+                                                         const int64_t* __restrict__ y, const float* params, int B) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= 2 * B) return;
+  const int b = w >> 1;
+  float* mem = (w & 1) ? mem2 : mem1;
+  const float* v = (w & 1) ? v2 : v1;
+  const float mom = params[4];
+  const int64_t row = y[b];
+  float a0 = mem[row * D + lane] * mom + v[(size_t)b * D + lane] * (1.f - mom);
+  float a1 = mem[row * D + 64 + lane] * mom + v[(size_t)b * D + 64 + lane] * (1.f - mom);
+  const float n = sqrtf(wave_sum(a0 * a0 + a1 * a1));
+  mem[row * D + lane] = a0 / n;
+  mem[row * D + 64 + lane] = a1 / n;
+}
+
+}  // namespace
+
+int ph_crd_score(const float* v1, const float* v2, const int64_t* idx, const float* mem1, const float* mem2,
+                 float* out1, float* out2, float* diff, int B, int PK, int feat_dim, float T, hipStream_t st) {
+  if (feat_dim != D) return PH_EINVAL;
+  hipLaunchKernelGGL(crd_score_kernel, dim3(cdiv(PK, 64), B), dim3(256), 0, st, v1, v2, idx, mem1, mem2, out1, out2,
+                     diff, PK, 1.f / T);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_crd_select(const float* diff, const float* out1, const float* out2, const int* ranks, int* sel, float* xs,
+                  float* xt, int B, int P, int K, int P2, int K2, int select_neg, hipStream_t st) {
+  if (P2 > P || K2 > K) return PH_EINVAL;
+  const size_t lds = (size_t)(P + K) * 4 + (size_t)P * 4;
+  hipLaunchKernelGGL(crd_select_kernel, dim3(B), dim3(256), lds, st, diff, out1, out2, ranks, sel, xs, xt, P, K, P2,
+                     K2, select_neg);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_crd_zsum(const float* xs, const float* xt, float* sums, int n, hipStream_t st) {
+  hipLaunchKernelGGL(crd_zsum_kernel, dim3(1), dim3(1024), 0, st, xs, xt, sums, n);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_crd_setz(float* params, const float* sums, float count, float n_data, hipStream_t st) {
+  hipLaunchKernelGGL(crd_setz_kernel, dim3(1), dim3(64), 0, st, params, sums, count, n_data);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const float* mem1,
+                     const float* mem2, const float* params, float* lossp, float* dv1, float* dv2, int B, int PK,
+                     int P2, int K2, int feat_dim, float n_data, float inv_bnorm, hipStream_t st) {
+  if (feat_dim != D) return PH_EINVAL;
+  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B), dim3(256), 0, st, xs, xt, sel, idx, mem1, mem2, params, lossp, dv1,
+                     dv2, PK, P2, K2, n_data, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
+                  int B, int feat_dim, hipStream_t st) {
+  if (feat_dim != D) return PH_EINVAL;
+  hipLaunchKernelGGL(crd_update_kernel, dim3(cdiv(2 * B, 4)), dim3(256), 0, st, mem1, mem2, v1, v2, y, params, B);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}

@@ -1,0 +1,467 @@
+// Small dense fp32 operators of the heads / SNN / fusion / losses (a2-a7, a12 of SURVEY.md section 8).
+// These carry < 0.02 % of the step's FLOPs; they are plain LDS-tiled fp32 VALU kernels written for
+// correctness and low launch count, not MFMA.
+#include "ph_common.h"
+#include "ph_dense.h"
+
+namespace {
+
+// ------------------------------------------------------------------ generic strided SGEMM
+// C[m][n] (ldc) = act( sum_k A(m,k) * B(k,n) + bias[n] ) (+ C if accumulate)
+//   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
+constexpr int GT = 64, GK = 16;
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                    const float* __restrict__ bias, float* __restrict__ Cm, int M,
+                                                    int N, int K, long sam, long sak, long sbk, long sbn, long ldc,
+                                                    int act, int accumulate) {
+  __shared__ float As[GK][GT + 1];
+  __shared__ float Bs[GK][GT + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  // loader mapping: pick the unit-stride direction of each operand as the fast thread index
+  const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
+  for (int k0 = 0; k0 < K; k0 += GK) {
+#pragma unroll
+    for (int e = tid; e < GT * GK; e += 256) {
+      int m, k;
+      if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
+      int n, kk;
+      if (b_nfast) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
+      const int gn = n0 + n, gk2 = k0 + kk;
+      Bs[kk][n] = (gn < N && gk2 < K) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + ty * 4 + i;
+    if (gm >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + tx * 4 + j;
+      if (gn >= N) continue;
+      float v = acc[i][j] + (bias ? bias[gn] : 0.f);
+      if (act == PH_ACT_RELU) v = v > 0.f ? v : 0.f;
+      else if (act == PH_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+      else if (act == PH_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+      if (accumulate) v += Cm[gm * ldc + gn];
+      Cm[gm * ldc + gn] = v;
+    }
+  }
+}
+
+// split-K variant for skinny problems (M,N small, K huge: the 16641-wide fusion encoder, bilinear gates)
+__global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                           float* __restrict__ part, int M, int N, int K, long sam,
+                                                           long sak, long sbk, long sbn, int kchunk) {
+  __shared__ float As[GK][GT + 1];
+  __shared__ float Bs[GK][GT + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int kb = blockIdx.z * kchunk, ke = min(K, kb + kchunk);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
+  for (int k0 = kb; k0 < ke; k0 += GK) {
+#pragma unroll
+    for (int e = tid; e < GT * GK; e += 256) {
+      int m, k;
+      if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < M && gk < ke) ? A[gm * sam + gk * sak] : 0.f;
+      int n, kk;
+      if (b_nfast) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
+      const int gn = n0 + n, gk2 = k0 + kk;
+      Bs[kk][n] = (gn < N && gk2 < ke) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  float* P = part + (size_t)blockIdx.z * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gm = m0 + ty * 4 + i;
+    if (gm >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + tx * 4 + j;
+      if (gn < N) P[(size_t)gm * N + gn] = acc[i][j];
+    }
+  }
+}
+
+__global__ void splitk_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                     float* __restrict__ Cm, int M, int N, long ldc, int nsplit, int act) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int m = i / N, n = i % N;
+  float v = bias ? bias[n] : 0.f;
+  for (int s = 0; s < nsplit; ++s) v += part[(size_t)s * M * N + i];
+  if (act == PH_ACT_RELU) v = v > 0.f ? v : 0.f;
+  else if (act == PH_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+  else if (act == PH_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+  Cm[m * ldc + n] = v;
+}
+
+// ------------------------------------------------------------------ BatchNorm1d (train mode), thread per channel
+__global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, float* mean, float* invstd,
+                                float* running_mean, float* running_var, int64_t* nbt, int B, int C, float eps,
+                                float momentum, int relu) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) { const double v = x[(size_t)b * C + c]; s1 += v; s2 += v * v; }
+  const double m = s1 / B;
+  double var = s2 / B - m * m;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m; invstd[c] = is;
+  const float sc = gamma[c] * is, sh = beta[c] - (float)m * sc;
+  for (int b = 0; b < B; ++b) {
+    float v = x[(size_t)b * C + c] * sc + sh;
+    if (relu) v = v > 0.f ? v : 0.f;
+    y[(size_t)b * C + c] = v;
+  }
+  if (running_mean) {
+    const double unb = B > 1 ? var * B / (B - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    if (c == 0 && nbt) *nbt += 1;
+  }
+}
+
+// g: grad wrt the (relu'd) output y; dz = g * (y > 0) when relu
+__global__ void bn1d_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
+                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, float* __restrict__ dx, float* dgamma, float* dbeta,
+                                int B, int C, int relu) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], is = invstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    float dz = g[(size_t)b * C + c];
+    if (relu && !(y[(size_t)b * C + c] > 0.f)) dz = 0.f;
+    s1 += dz;
+    s2 += (double)dz * ((x[(size_t)b * C + c] - mu) * is);
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  const float c1 = (float)(s1 / B), c2 = (float)(s2 / B), sc = gamma[c] * is;
+  for (int b = 0; b < B; ++b) {
+    float dz = g[(size_t)b * C + c];
+    if (relu && !(y[(size_t)b * C + c] > 0.f)) dz = 0.f;
+    const float xh = (x[(size_t)b * C + c] - mu) * is;
+    dx[(size_t)b * C + c] = sc * (dz - c1 - xh * c2);
+  }
+}
+
+// ------------------------------------------------------------------ row ops on [B][C<=64]
+__global__ void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[b * C + c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(x[b * C + c] - mx);
+  const float l = mx + logf(s);
+  for (int c = 0; c < C; ++c) y[b * C + c] = x[b * C + c] - l;
+}
+__global__ void log_softmax_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                       float* __restrict__ dx, int B, int C) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += g[b * C + c];
+  for (int c = 0; c < C; ++c) dx[b * C + c] = g[b * C + c] - expf(y[b * C + c]) * s;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  __syncthreads();
+  return t;
+}
+
+// loss = -(1/Bnorm) sum_b pred[b][grade[b]]
+__global__ void nll_fwd_kernel(const float* __restrict__ pred, const int64_t* __restrict__ grade, float* loss, int B,
+                               int C, float inv_bnorm) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) s -= pred[b * C + (int)grade[b]];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *loss = s * inv_bnorm;
+}
+__global__ void nll_bwd_kernel(const float* __restrict__ gs, const int64_t* __restrict__ grade, float* dpred, int B,
+                               int C, float inv_bnorm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  dpred[i] = (c == (int)grade[b]) ? -(*gs) * inv_bnorm : 0.f;
+}
+
+// DistillKL (KD_loss.py:13-17): T^2/Bnorm * sum p_t (log p_t - log_softmax(y_s/T))
+__global__ void kl_fwd_kernel(const float* __restrict__ ys, const float* __restrict__ yt, float* loss, int B, int C,
+                              float T, float inv_bnorm) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float ms = -INFINITY, mt = -INFINITY;
+    for (int c = 0; c < C; ++c) { ms = fmaxf(ms, ys[b * C + c] / T); mt = fmaxf(mt, yt[b * C + c] / T); }
+    float ss = 0.f, st = 0.f;
+    for (int c = 0; c < C; ++c) { ss += expf(ys[b * C + c] / T - ms); st += expf(yt[b * C + c] / T - mt); }
+    const float ls = ms + logf(ss), lt = mt + logf(st);
+    for (int c = 0; c < C; ++c) {
+      const float lpt = yt[b * C + c] / T - lt, lps = ys[b * C + c] / T - ls;
+      const float pt = expf(lpt);
+      if (pt > 0.f) s += pt * (lpt - lps);
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *loss = s * T * T * inv_bnorm;
+}
+// d loss / d ys = gs * T/Bnorm * (softmax(ys/T) - softmax(yt/T))
+__global__ void kl_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ ys,
+                              const float* __restrict__ yt, float* __restrict__ dys, int B, int C, float T,
+                              float inv_bnorm) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int c = 0; c < C; ++c) { ms = fmaxf(ms, ys[b * C + c] / T); mt = fmaxf(mt, yt[b * C + c] / T); }
+  float ss = 0.f, st = 0.f;
+  for (int c = 0; c < C; ++c) { ss += expf(ys[b * C + c] / T - ms); st += expf(yt[b * C + c] / T - mt); }
+  const float k = (*gs) * T * inv_bnorm;
+  for (int c = 0; c < C; ++c)
+    dys[b * C + c] = k * (expf(ys[b * C + c] / T - ms) / ss - expf(yt[b * C + c] / T - mt) / st);
+}
+
+// ------------------------------------------------------------------ L2 normalise rows (Normalize, CRD_loss.py:276-279)
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm, int B,
+                                  int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = x[(size_t)row * D + d]; s += v * v; }
+  s = wave_sum(s);
+  const float n = sqrtf(s);
+  for (int d = lane; d < D; d += 64) y[(size_t)row * D + d] = x[(size_t)row * D + d] / n;
+  if (lane == 0) nrm[row] = n;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                  const float* __restrict__ nrm, float* __restrict__ dx, int B, int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += g[(size_t)row * D + d] * y[(size_t)row * D + d];
+  s = wave_sum(s);
+  const float inv = 1.f / nrm[row];
+  for (int d = lane; d < D; d += 64)
+    dx[(size_t)row * D + d] = (g[(size_t)row * D + d] - y[(size_t)row * D + d] * s) * inv;
+}
+
+// ------------------------------------------------------------------ elementwise helpers
+__global__ void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+                               size_t n, int op) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v;
+  switch (op) {
+    case PH_EW_RELU: v = a[i] > 0.f ? a[i] : 0.f; break;
+    case PH_EW_GATE: v = (1.f / (1.f + expf(-a[i]))) * b[i]; break;   // sigmoid(z) * h
+    case PH_EW_RELU_BWD: v = b[i] > 0.f ? a[i] : 0.f; break;          // g * (y > 0)
+    case PH_EW_ADD: v = a[i] + b[i]; break;
+    default: v = a[i];
+  }
+  o[i] = v;
+}
+
+// o12[b][i*(D2+1)+j] = o1e[b][i] * o2e[b][j] with an implicit trailing 1 on both (fusion.py:56-58) when
+// append_one, plain outer product otherwise (the nn.Bilinear operand, fusion.py:43,50)
+__global__ void outer_kernel(const float* __restrict__ o1, const float* __restrict__ o2, float* __restrict__ o12,
+                             int B, int D1, int D2, int append_one) {
+  const int E1 = D1 + append_one, E2 = D2 + append_one;
+  const size_t n = (size_t)B * E1 * E2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int j = (int)(i % E2);
+  const int ii = (int)((i / E2) % E1);
+  const int b = (int)(i / ((size_t)E1 * E2));
+  const float a = ii < D1 ? o1[(size_t)b * D1 + ii] : 1.f;
+  const float c = j < D2 ? o2[(size_t)b * D2 + j] : 1.f;
+  o12[i] = a * c;
+}
+
+// counter-based RNG: one 32-bit draw per element from (seed, offset + index); splitmix64 finaliser
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+// nn.Dropout / nn.AlphaDropout in training mode (fusion.py:22-32, networks_new.py:193-211)
+__global__ void dropout_kernel(float* __restrict__ x, size_t n, float p, uint64_t seed, uint64_t offset, int alpha) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool keep = u01(seed, offset + i) >= p;
+  if (!alpha) {
+    x[i] = keep ? x[i] / (1.f - p) : 0.f;
+  } else {
+    const float ap = -1.7580993408473766f;
+    const float a = rsqrtf((1.f - p) * (1.f + p * ap * ap));
+    const float b = -a * ap * p;
+    x[i] = a * (keep ? x[i] : ap) + b;
+  }
+}
+
+__global__ void sum_kernel(const float* __restrict__ x, float* out, int n, float scale) {
+  __shared__ float sh[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) *out = s * scale;
+}
+
+inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+int ph_sgemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long sam, long sak,
+             long sbk, long sbn, long ldc, int act, int accumulate, hipStream_t st) {
+  dim3 grid(cdiv(N, GT), cdiv(M, GT));
+  hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, st, A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, act,
+                     accumulate);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_sgemm_splitk(const float* A, const float* B, const float* bias, float* C, float* part, int nsplit, int M, int N,
+                    int K, long sam, long sak, long sbk, long sbn, long ldc, int act, hipStream_t st) {
+  int kchunk = cdiv(cdiv(K, nsplit), GK) * GK;
+  nsplit = cdiv(K, kchunk);
+  dim3 grid(cdiv(N, GT), cdiv(M, GT), nsplit);
+  hipLaunchKernelGGL(sgemm_splitk_kernel, grid, dim3(256), 0, st, A, B, part, M, N, K, sam, sak, sbk, sbn, kchunk);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk((size_t)M * N)), dim3(256), 0, st, part, bias, C, M, N, ldc,
+                     nsplit, act);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
+                float* running_mean, float* running_var, int64_t* nbt, int B, int C, float eps, float momentum,
+                int relu, hipStream_t st) {
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, x, gamma, beta, y, mean, invstd,
+                     running_mean, running_var, nbt, B, C, eps, momentum, relu);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_bn1d_bwd(const float* g, const float* y, const float* x, const float* mean, const float* invstd,
+                const float* gamma, float* dx, float* dgamma, float* dbeta, int B, int C, int relu, hipStream_t st) {
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, g, y, x, mean, invstd, gamma, dx, dgamma,
+                     dbeta, B, C, relu);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_log_softmax(const float* x, float* y, int B, int C, hipStream_t st) {
+  hipLaunchKernelGGL(log_softmax_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, x, y, B, C);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_log_softmax_bwd(const float* g, const float* y, float* dx, int B, int C, hipStream_t st) {
+  hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, g, y, dx, B, C);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_nll_fwd(const float* pred, const int64_t* grade, float* loss, int B, int C, float inv_bnorm, hipStream_t st) {
+  hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(256), 0, st, pred, grade, loss, B, C, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_nll_bwd(const float* gs, const int64_t* grade, float* dpred, int B, int C, float inv_bnorm, hipStream_t st) {
+  hipLaunchKernelGGL(nll_bwd_kernel, dim3(nblk((size_t)B * C)), dim3(256), 0, st, gs, grade, dpred, B, C, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_kl_fwd(const float* ys, const float* yt, float* loss, int B, int C, float T, float inv_bnorm, hipStream_t st) {
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, st, ys, yt, loss, B, C, T, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_kl_bwd(const float* gs, const float* ys, const float* yt, float* dys, int B, int C, float T, float inv_bnorm,
+              hipStream_t st) {
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, gs, ys, yt, dys, B, C, T, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_l2norm_fwd(const float* x, float* y, float* nrm, int B, int D, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, y, nrm, B, D);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_l2norm_bwd(const float* g, const float* y, const float* nrm, float* dx, int B, int D, hipStream_t st) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, g, y, nrm, dx, B, D);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_eltwise(const float* a, const float* b, float* o, size_t n, int op, hipStream_t st) {
+  hipLaunchKernelGGL(eltwise_kernel, dim3(nblk(n)), dim3(256), 0, st, a, b, o, n, op);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_outer(const float* o1, const float* o2, float* o12, int B, int D1, int D2, int append_one, hipStream_t st) {
+  const size_t n = (size_t)B * (D1 + append_one) * (D2 + append_one);
+  hipLaunchKernelGGL(outer_kernel, dim3(nblk(n)), dim3(256), 0, st, o1, o2, o12, B, D1, D2, append_one);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_dropout(float* x, size_t n, float p, uint64_t seed, uint64_t offset, int alpha, hipStream_t st) {
+  if (p <= 0.f) return PH_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n)), dim3(256), 0, st, x, n, p, seed, offset, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_sum(const float* x, float* out, int n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, x, out, n, scale);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}

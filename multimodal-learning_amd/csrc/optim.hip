@@ -1,0 +1,141 @@
+// GK-Refine gradient-agreement weights (reference train_test_path_multi_distill.py:41-70) and the fused
+// multi-tensor Adam + EMA update (networks_new.py:85 torch.optim.Adam with L2-in-grad weight decay;
+// train_test_path_multi_distill.py:34-38 update_ema_variables).  HBM-bound streaming kernels.
+#include "ph_common.h"
+#include "ph_dense.h"
+
+namespace {
+
+// G[NG][n] row-major -> gram[NG*NG] = G G^T (single block, fixed summation order: deterministic)
+template <int NG>
+__global__ __launch_bounds__(1024) void gram_kernel(const float* __restrict__ G, float* __restrict__ gram, int n) {
+  float acc[NG * (NG + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < NG * (NG + 1) / 2; ++i) acc[i] = 0.f;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    float v[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) v[i] = G[(size_t)i * n + e];
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+      for (int j = i; j < NG; ++j) acc[q++] += v[i] * v[j];
+  }
+  __shared__ float sh[16][NG * (NG + 1) / 2];
+#pragma unroll
+  for (int q = 0; q < NG * (NG + 1) / 2; ++q) {
+    const float s = wave_sum(acc[q]);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int q = 0;
+    for (int i = 0; i < NG; ++i)
+      for (int j = i; j < NG; ++j) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w][q];
+        gram[i * NG + j] = s;
+        gram[j * NG + i] = s;
+        ++q;
+      }
+  }
+}
+
+// scale_i = sum_j gram_ij * mult / (sqrt(gram_ii) sqrt(gram_jj));  total = sum_{i<nl} scale_i * losses_i
+// (AEKD_loss :59-68: mult = len(loss_t_list); scale[:-1] . losses)
+__global__ void gk_scale_kernel(const float* __restrict__ gram, const float* const* __restrict__ losses, int ng,
+                                int nl, float mult, float* __restrict__ scale, float* total) {
+  if (threadIdx.x != 0) return;
+  float t = 0.f;
+  for (int i = 0; i < ng; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < ng; ++j) s += gram[i * ng + j] * mult / (sqrtf(gram[i * ng + i]) * sqrtf(gram[j * ng + j]));
+    scale[i] = s;
+    if (i < nl) t += s * (*losses[i]);
+  }
+  if (total) *total = t;
+}
+
+// Adam (torch.optim.Adam semantics) + optional EMA of the parameters, 4 elements per thread.
+//   g' = g + wd*p ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+//   ema = alpha*ema + (1-alpha)*p_new
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, float* __restrict__ ema, size_t n, float lr, float b1, float b2,
+                                float eps, float wd, float bc1, float bc2_sqrt, float ema_alpha) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float step = lr / bc1;
+  if (i + 4 <= n) {
+    f32x4 P = *reinterpret_cast<f32x4*>(p + i), Gr = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 M = *reinterpret_cast<f32x4*>(m + i), V = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = Gr[k] + wd * P[k];
+      M[k] = b1 * M[k] + (1.f - b1) * gg;
+      V[k] = b2 * V[k] + (1.f - b2) * gg * gg;
+      P[k] -= step * M[k] / (sqrtf(V[k]) / bc2_sqrt + eps);
+    }
+    *reinterpret_cast<f32x4*>(p + i) = P;
+    *reinterpret_cast<f32x4*>(m + i) = M;
+    *reinterpret_cast<f32x4*>(v + i) = V;
+    if (ema) {
+      f32x4 E = *reinterpret_cast<f32x4*>(ema + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) E[k] = ema_alpha * E[k] + (1.f - ema_alpha) * P[k];
+      *reinterpret_cast<f32x4*>(ema + i) = E;
+    }
+  } else {
+    for (size_t e = i; e < n; ++e) {
+      const float gg = g[e] + wd * p[e];
+      m[e] = b1 * m[e] + (1.f - b1) * gg;
+      v[e] = b2 * v[e] + (1.f - b2) * gg * gg;
+      p[e] -= step * m[e] / (sqrtf(v[e]) / bc2_sqrt + eps);
+      if (ema) ema[e] = ema_alpha * ema[e] + (1.f - ema_alpha) * p[e];
+    }
+  }
+}
+
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n, float alpha) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ema[i] = alpha * ema[i] + (1.f - alpha) * p[i];
+}
+
+}  // namespace
+
+int ph_gram(const float* G, float* gram, int ng, int n, hipStream_t st) {
+  switch (ng) {
+    case 2: hipLaunchKernelGGL(gram_kernel<2>, dim3(1), dim3(1024), 0, st, G, gram, n); break;
+    case 3: hipLaunchKernelGGL(gram_kernel<3>, dim3(1), dim3(1024), 0, st, G, gram, n); break;
+    case 4: hipLaunchKernelGGL(gram_kernel<4>, dim3(1), dim3(1024), 0, st, G, gram, n); break;
+    case 5: hipLaunchKernelGGL(gram_kernel<5>, dim3(1), dim3(1024), 0, st, G, gram, n); break;
+    default: return PH_EINVAL;
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_gk_scale(const float* gram, const float* const* losses, int ng, int nl, float mult, float* scale, float* total,
+                hipStream_t st) {
+  hipLaunchKernelGGL(gk_scale_kernel, dim3(1), dim3(64), 0, st, gram, losses, ng, nl, mult, scale, total);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, int step, double ema_alpha, hipStream_t st) {
+  // bias corrections in double, exactly like torch.optim.Adam's Python-side scalars
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
+  const size_t nt = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, m, v, ema, n, (float)lr,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1, bc2s, (float)ema_alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_ema_update(float* ema, const float* p, size_t n, float alpha, hipStream_t st) {
+  hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ema, p, n, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}

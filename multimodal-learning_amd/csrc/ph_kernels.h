@@ -1,0 +1,98 @@
+// Internal launcher prototypes shared by the .hip translation units (not part of the public C-ABI;
+// the public boundary is include/pathomic_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct PhTapConv {
+  const void* in;        // [B][IH][IW][Cin]   activation type T of the precision mode
+  const void* w_hi;      // [nslabs][Cout][Cin] bf16
+  const void* w_lo;      // idem (parity mode only)
+  void* out;             // [B][OH][OW][Cout]
+  float* stats;          // [B*tiles][2][Cout] per-workgroup sum / sum-of-squares partials, or null
+  const void* res_g;     // optional: out += res_g * (res_a > 0 | 1)   (dgrad residual fusion)
+  const void* res_a;
+  int B, IH, IW, Cin, Cout;
+  int OHt, OWt;          // extent of the (r,c) output-position space this launch covers
+  int OH, OW;            // full output tensor dims; output pixel = (r*os+oa_h, c*os+oa_w)
+  int os, oa_h, oa_w;
+  int iy0, ix0;          // input pixel of tap t for position (r,c) = (r*S + dy[t] + iy0, c*S + dx[t] + ix0)
+  int ntaps;
+  int dy[9], dx[9];      // 0..2
+  int wtap[9];           // weight slab index of each tap
+};
+int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
+int ph_tapconv_stat_parts(const PhTapConv* p, int S);
+
+struct PhWgrad {
+  const void* x;         // [B][IH][IW][Cin]
+  const void* dy;        // [B][OH][OW][Cout]
+  float* slab;           // [nchunks][KS*KS][Cout][Cin] fp32 partial sums
+  int B, IH, IW, Cin, OH, OW, Cout;
+  int S, pad, KS;
+  int nchunks, tiles_per_chunk;
+};
+int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st);
+int ph_wgrad_tile_h(int S);
+// slab -> OIHW fp32 gradient
+int ph_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, int KS, int Cout, int Cin, hipStream_t st);
+
+struct PhStem {
+  const void* x4;        // [B][IH][IW][4]
+  const void* w_hi;      // [7][64][32] bf16: k = kw*4 + ch, kw==7 and ch==3 are zero
+  const void* w_lo;
+  void* out;             // [B][OH][OW][64]
+  float* stats;          // [B*tiles][2][64]
+  int B, IH, IW, OH, OW;
+};
+int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st);
+int ph_stem_stat_parts(int B, int OH, int OW);
+
+struct PhStemWgrad {
+  const void* x4; const void* dy; float* slab;   // slab [nchunks][7][64][32]
+  int B, IH, IW, OH, OW;
+  int nchunks, tiles_per_chunk;
+};
+int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st);
+int ph_stem_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, hipStream_t st);
+
+// weight packing (OIHW fp32 -> MFMA-friendly bf16 hi/lo planes)
+int ph_pack_w_fwd_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st);   // [tap][O][I]
+int ph_pack_w_dgrad_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st); // [tap][I][O]
+int ph_pack_w_stem_launch(const float* w, void* hi, void* lo, hipStream_t st);                        // [7][64][32]
+
+// ---- BatchNorm / elementwise (bn_act.hip).  `prec` selects the activation type (bf16 | float).
+int ph_pack_input_launch(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st);
+// partial slab [nparts][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
+// (+ running stats update when running_mean != null)
+int ph_bn_finalize_launch(const float* parts, int nparts, int C, double count, float eps, float momentum,
+                          const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                          float* shift, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                          hipStream_t st);
+// out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] )
+int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
+                       const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,
+                       hipStream_t st);
+int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int B,
+                              int H, int W, int C, int prec, hipStream_t st);
+int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st);
+// d_x (+)= g / HW  broadcast
+int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int accumulate, int prec, hipStream_t st);
+// BN backward: dz = g * (a > 0 ? 1 : 0) (a may be null).  reduce -> parts [nparts][2][C] (sum dz, sum dz*xhat)
+int ph_bn_bwd_parts(size_t npix);
+int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
+                            float* parts, size_t npix, int C, int prec, hipStream_t st);
+// parts -> dgamma, dbeta, c1 = mean(dz), c2 = mean(dz*xhat)
+int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
+                              float* c1, float* c2, hipStream_t st);
+int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
+                           const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
+                           int prec, hipStream_t st);
+// stem: da0 = scatter of d_pool through the saved argmax, dz = da0 * (bn(y0) > 0)
+int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
+                              const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
+                              int W, int C, int prec, hipStream_t st);
+int ph_stem_bwd_apply_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
+                             const float* invstd, const float* scale, const float* shift, const float* gamma,
+                             const float* c1, const float* c2, void* dy0, int B, int H, int W, int C, int prec,
+                             hipStream_t st);

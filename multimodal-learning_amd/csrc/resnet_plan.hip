@@ -1,0 +1,436 @@
+// Host-side runtime for the ResNet-18 trunk (reference resnets.py:126-236, BasicBlock :37-74):
+// a static plan (layer table + workspace layout in one HBM arena, no allocation at run time) and the
+// forward / backward launch sequences over the kernels in conv_*.hip and bn_act.hip.
+//
+// Data layout in HBM: activations NHWC of the precision mode's type T; every conv
+// writes its RAW output y plus per-workgroup BN partial sums; BN is finalised per channel (fp64
+// combine) into scale/shift; the consumer-side elementwise kernel applies BN(+residual)+ReLU.
+// Saved for backward per BasicBlock: x_in, y1, a1, y2, (y_ds), out.
+#include <new>
+#include <vector>
+#include "ph_common.h"
+#include "ph_kernels.h"
+#include "ph_dense.h"
+
+namespace {
+
+struct Unit {
+  int Cin, Cout, KS, S, pad;
+  int IH, IW, OH, OW;
+  size_t wf_off, wd_off;   // element offsets (bf16) of the fwd / dgrad hi planes in the packed buffer
+  size_t wplane;           // elements per plane (lo plane follows hi)
+  size_t y_off;            // byte offset of raw conv output in ws
+  size_t st_off;           // byte offset of [mean, invstd, scale, shift] (4*C floats)
+};
+struct Block {
+  int u1, u2, uds;
+  size_t in_off, a1_off, out_off;   // byte offsets of the block input / post-bn1-relu / output activations
+  int IH, IW, OH, OW, Cin, Cout;
+};
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+}  // namespace
+
+struct PhResnetPlan {
+  int B, H, W, prec, es;
+  std::vector<Unit> units;
+  std::vector<Block> blocks;
+  size_t x4_off, p0_off, idx_off, parts_off, parts_bytes;
+  size_t g0_off, g1_off, dy_off, da_off, slab_off, slab_bytes, bparts_off, cc_off;
+  size_t ws_bytes, packed_bytes;
+  int PH0, PW0;   // pooled dims
+  size_t act_max;   // max block-level activation bytes
+};
+
+namespace {
+
+int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
+  const int th = ph_wgrad_tile_h(u.S);
+  const int ntiles = B * cdiv(u.OH, th) * cdiv(u.OW, 16);
+  const int blocks = (u.Cout / 64) * (u.Cin / 64);
+  int want = cdiv(1024, blocks);           // aim for ~1024 workgroups
+  if (want > ntiles) want = ntiles;
+  if (want < 1) want = 1;
+  int tpc = cdiv(ntiles, want);
+  *tiles_per_chunk = tpc;
+  return cdiv(ntiles, tpc);
+}
+int stem_chunks(int B, int OH, int OW, int* tpc) {
+  const int ntiles = B * cdiv(OH, 8) * cdiv(OW, 16);
+  int want = ntiles < 1024 ? ntiles : 1024;
+  *tpc = cdiv(ntiles, want);
+  return cdiv(ntiles, *tpc);
+}
+
+}  // namespace
+
+extern "C" {
+
+PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
+  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X3)) return nullptr;
+  PhResnetPlan* P = new (std::nothrow) PhResnetPlan();
+  if (!P) return nullptr;
+  P->B = B; P->H = H; P->W = W; P->prec = prec; P->es = prec == PH_PREC_BF16 ? 2 : 4;
+  const size_t es = P->es;
+  size_t off = 0, woff = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = up(off + bytes); return o; };
+  P->x4_off = take((size_t)B * H * W * 4 * es);
+  // stem
+  Unit s{};
+  s.Cin = 3; s.Cout = 64; s.KS = 7; s.S = 2; s.pad = 3; s.IH = H; s.IW = W;
+  s.OH = (H + 6 - 7) / 2 + 1; s.OW = (W + 6 - 7) / 2 + 1;
+  s.wplane = 7 * 64 * 32; s.wf_off = woff; woff += 2 * s.wplane; s.wd_off = 0;
+  s.y_off = take((size_t)B * s.OH * s.OW * 64 * es);
+  s.st_off = take(4 * 64 * sizeof(float));
+  P->units.push_back(s);
+  P->PH0 = (s.OH + 1) / 2; P->PW0 = (s.OW + 1) / 2;
+  P->p0_off = take((size_t)B * P->PH0 * P->PW0 * 64 * es);
+  P->idx_off = take((size_t)B * P->PH0 * P->PW0 * 64);
+  size_t parts_max = (size_t)ph_stem_stat_parts(B, s.OH, s.OW) * 2 * 64 * sizeof(float);
+  size_t slab_max = 0;
+  { int tpc; int nc = stem_chunks(B, s.OH, s.OW, &tpc); slab_max = (size_t)nc * 7 * 64 * 32 * sizeof(float); }
+  size_t act_max = (size_t)B * P->PH0 * P->PW0 * 64 * es;
+  int ih = P->PH0, iw = P->PW0, inpl = 64;
+  size_t in_off = P->p0_off;
+  const int planes[4] = {64, 128, 256, 512};
+  for (int li = 0; li < 4; ++li)
+    for (int bi = 0; bi < 2; ++bi) {
+      const int stride = (li > 0 && bi == 0) ? 2 : 1;
+      const int pl = planes[li];
+      Block b{};
+      b.IH = ih; b.IW = iw; b.Cin = inpl; b.Cout = pl;
+      b.OH = (ih + 2 - 3) / stride + 1; b.OW = (iw + 2 - 3) / stride + 1;
+      auto mk = [&](int cin, int cout, int ks, int st, int pad, int uih, int uiw) {
+        Unit u{};
+        u.Cin = cin; u.Cout = cout; u.KS = ks; u.S = st; u.pad = pad; u.IH = uih; u.IW = uiw;
+        u.OH = (uih + 2 * pad - ks) / st + 1; u.OW = (uiw + 2 * pad - ks) / st + 1;
+        u.wplane = (size_t)ks * ks * cin * cout;
+        u.wf_off = woff; woff += 2 * u.wplane;
+        u.wd_off = woff; woff += 2 * u.wplane;
+        u.y_off = take((size_t)B * u.OH * u.OW * cout * es);
+        u.st_off = take(4 * (size_t)cout * sizeof(float));
+        PhTapConv tc{}; tc.B = B; tc.Cout = cout; tc.OHt = u.OH; tc.OWt = u.OW;
+        parts_max = std::max(parts_max, (size_t)ph_tapconv_stat_parts(&tc, st) * 2 * cout * sizeof(float));
+        int tpc; int nc = wgrad_chunks(u, B, &tpc);
+        slab_max = std::max(slab_max, (size_t)nc * ks * ks * cin * cout * sizeof(float));
+        P->units.push_back(u);
+        return (int)P->units.size() - 1;
+      };
+      b.u1 = mk(inpl, pl, 3, stride, 1, ih, iw);
+      b.u2 = mk(pl, pl, 3, 1, 1, b.OH, b.OW);
+      b.uds = (stride != 1 || inpl != pl) ? mk(inpl, pl, 1, stride, 0, ih, iw) : -1;
+      b.in_off = in_off;
+      b.a1_off = take((size_t)B * b.OH * b.OW * pl * es);
+      b.out_off = take((size_t)B * b.OH * b.OW * pl * es);
+      act_max = std::max(act_max, (size_t)B * b.OH * b.OW * pl * es);
+      P->blocks.push_back(b);
+      in_off = b.out_off; ih = b.OH; iw = b.OW; inpl = pl;
+    }
+  P->act_max = act_max;
+  P->parts_bytes = parts_max;
+  P->parts_off = take(parts_max);
+  // backward scratch
+  P->g0_off = take(act_max);
+  P->g1_off = take(act_max);
+  P->da_off = take(act_max);
+  P->dy_off = take((size_t)B * s.OH * s.OW * 64 * es);
+  P->slab_bytes = slab_max;
+  P->slab_off = take(slab_max);
+  P->bparts_off = take((size_t)ph_bn_bwd_parts((size_t)B * s.OH * s.OW) * 2 * 512 * sizeof(float));
+  P->cc_off = take(2 * 512 * sizeof(float));
+  P->ws_bytes = off;
+  P->packed_bytes = woff * sizeof(bf16);
+  return P;
+}
+
+void ph_resnet_plan_destroy(PhResnetPlan* P) { delete P; }
+size_t ph_resnet_workspace_bytes(const PhResnetPlan* P) { return P ? P->ws_bytes : 0; }
+size_t ph_resnet_packed_bytes(const PhResnetPlan* P) { return P ? P->packed_bytes : 0; }
+int ph_resnet_num_units(const PhResnetPlan* P) { return P ? (int)P->units.size() : 0; }
+// shape of unit u's conv weight: out[0..3] = Cout, Cin, KS, has_downsample_role(0)
+int ph_resnet_unit_shape(const PhResnetPlan* P, int u, int* out4) {
+  if (!P || u < 0 || u >= (int)P->units.size()) return PH_EINVAL;
+  out4[0] = P->units[u].Cout; out4[1] = P->units[u].Cin; out4[2] = P->units[u].KS; out4[3] = P->units[u].S;
+  return PH_OK;
+}
+
+// params: per unit 6 pointers [w (OIHW f32), gamma, beta, running_mean, running_var, num_batches_tracked(i64)]
+int ph_resnet_pack_weights(const PhResnetPlan* P, const void* const* params, void* packed, hipStream_t st) {
+  if (!P || !params || !packed) return PH_EINVAL;
+  bf16* pk = reinterpret_cast<bf16*>(packed);
+  for (size_t i = 0; i < P->units.size(); ++i) {
+    const Unit& u = P->units[i];
+    const float* w = reinterpret_cast<const float*>(params[i * 6 + 0]);
+    int rc;
+    if (i == 0) {
+      rc = ph_pack_w_stem_launch(w, pk + u.wf_off, pk + u.wf_off + u.wplane, st);
+    } else {
+      rc = ph_pack_w_fwd_launch(w, pk + u.wf_off, pk + u.wf_off + u.wplane, u.Cout, u.Cin, u.KS, st);
+      if (rc) return rc;
+      rc = ph_pack_w_dgrad_launch(w, pk + u.wd_off, pk + u.wd_off + u.wplane, u.Cout, u.Cin, u.KS, st);
+    }
+    if (rc) return rc;
+  }
+  return PH_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Ctx {
+  const PhResnetPlan* P;
+  const void* const* params;
+  const bf16* pk;
+  unsigned char* ws;
+  hipStream_t st;
+  int update_running;
+  float* stat(const Unit& u, int which) const {
+    return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
+  }
+};
+
+int conv_fwd(const Ctx& c, int ui, const void* in) {
+  const PhResnetPlan* P = c.P;
+  const Unit& u = P->units[ui];
+  PhTapConv t{};
+  t.in = in; t.w_hi = c.pk + u.wf_off; t.w_lo = c.pk + u.wf_off + u.wplane;
+  t.out = c.ws + u.y_off; t.stats = reinterpret_cast<float*>(c.ws + P->parts_off);
+  t.B = P->B; t.IH = u.IH; t.IW = u.IW; t.Cin = u.Cin; t.Cout = u.Cout;
+  t.OHt = u.OH; t.OWt = u.OW; t.OH = u.OH; t.OW = u.OW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
+  t.iy0 = -u.pad; t.ix0 = -u.pad; t.ntaps = u.KS * u.KS;
+  for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / u.KS; t.dx[k] = k % u.KS; t.wtap[k] = k; }
+  int rc = ph_tapconv_launch(&t, u.S, P->prec, c.st);
+  if (rc) return rc;
+  const int nparts = ph_tapconv_stat_parts(&t, u.S);
+  float* rm = c.update_running ? (float*)c.params[ui * 6 + 3] : nullptr;
+  return ph_bn_finalize_launch(t.stats, nparts, u.Cout, (double)P->B * u.OH * u.OW, 1e-5f, 0.1f,
+                               (const float*)c.params[ui * 6 + 1], (const float*)c.params[ui * 6 + 2], c.stat(u, 0),
+                               c.stat(u, 1), c.stat(u, 2), c.stat(u, 3), rm, (float*)c.params[ui * 6 + 4],
+                               (int64_t*)c.params[ui * 6 + 5], c.st);
+}
+
+// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual)
+int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a) {
+  const PhResnetPlan* P = c.P;
+  const Unit& u = P->units[ui];
+  PhTapConv t{};
+  t.in = dy; t.w_hi = c.pk + u.wd_off; t.w_lo = c.pk + u.wd_off + u.wplane;
+  t.out = dx; t.stats = nullptr; t.res_g = res_g; t.res_a = res_a;
+  t.B = P->B; t.IH = u.OH; t.IW = u.OW; t.Cin = u.Cout; t.Cout = u.Cin;
+  t.OH = u.IH; t.OW = u.IW;
+  if (u.S == 1) {
+    t.OHt = u.IH; t.OWt = u.IW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
+    t.iy0 = -(u.KS - 1 - u.pad); t.ix0 = t.iy0; t.ntaps = u.KS * u.KS;
+    for (int k = 0; k < t.ntaps; ++k) {
+      const int dyy = k / u.KS, dxx = k % u.KS;
+      t.dy[k] = dyy; t.dx[k] = dxx; t.wtap[k] = (u.KS - 1 - dyy) * u.KS + (u.KS - 1 - dxx);
+    }
+    return ph_tapconv_launch(&t, 1, P->prec, c.st);
+  }
+  // stride 2: one launch per output parity class (a,b); x row 2i+a receives kh with (a + pad - kh) even
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      int nk = 0, khs[3], dhs[3], nw = 0, kws[3], dws[3];
+      for (int kh = 0; kh < u.KS; ++kh)
+        if (((a + u.pad - kh) & 1) == 0) { khs[nk] = kh; dhs[nk] = (a + u.pad - kh) / 2; ++nk; }
+      for (int kw = 0; kw < u.KS; ++kw)
+        if (((b + u.pad - kw) & 1) == 0) { kws[nw] = kw; dws[nw] = (b + u.pad - kw) / 2; ++nw; }
+      t.OHt = (u.IH - a + 1) / 2; t.OWt = (u.IW - b + 1) / 2;
+      if (t.OHt <= 0 || t.OWt <= 0) continue;
+      t.os = 2; t.oa_h = a; t.oa_w = b; t.iy0 = 0; t.ix0 = 0;
+      t.ntaps = nk * nw;
+      if (t.ntaps == 0) {
+        // no tap reaches this class (1x1 stride-2): gradient is zero there; with an in-place residual
+        // (res_g == dx) the existing values already are the result, otherwise the caller pre-zeroed dx.
+        continue;
+      }
+      int q = 0;
+      for (int i = 0; i < nk; ++i)
+        for (int j = 0; j < nw; ++j) {
+          if (dhs[i] < 0 || dws[j] < 0 || dhs[i] > 2 || dws[j] > 2) return PH_EINVAL;
+          t.dy[q] = dhs[i]; t.dx[q] = dws[j]; t.wtap[q] = khs[i] * u.KS + kws[j]; ++q;
+        }
+      int rc = ph_tapconv_launch(&t, 1, P->prec, c.st);
+      if (rc) return rc;
+    }
+  return PH_OK;
+}
+
+int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
+  const PhResnetPlan* P = c.P;
+  const Unit& u = P->units[ui];
+  PhWgrad w{};
+  w.x = x; w.dy = dy; w.slab = reinterpret_cast<float*>(c.ws + P->slab_off);
+  w.B = P->B; w.IH = u.IH; w.IW = u.IW; w.Cin = u.Cin; w.OH = u.OH; w.OW = u.OW; w.Cout = u.Cout;
+  w.S = u.S; w.pad = u.pad; w.KS = u.KS;
+  w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk);
+  int rc = ph_wgrad_launch(&w, P->prec, c.st);
+  if (rc) return rc;
+  return ph_wgrad_reduce_launch(w.slab, dw, w.nchunks, u.KS, u.Cout, u.Cin, c.st);
+}
+
+// BN backward of unit ui: dz = g * (a > 0) -> dgamma/dbeta, dy (into ws dy buffer)
+int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta) {
+  const PhResnetPlan* P = c.P;
+  const Unit& u = P->units[ui];
+  const size_t npix = (size_t)P->B * u.OH * u.OW;
+  float* parts = reinterpret_cast<float*>(c.ws + P->bparts_off);
+  float* c1 = reinterpret_cast<float*>(c.ws + P->cc_off);
+  float* c2 = c1 + 512;
+  const void* y = c.ws + u.y_off;
+  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, c.st);
+  if (rc) return rc;
+  rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix), u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
+  if (rc) return rc;
+  return ph_bn_bwd_apply_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), (const float*)c.params[ui * 6 + 1], c1, c2, dy, npix,
+                                u.Cout, P->prec, c.st);
+}
+
+}  // namespace
+
+extern "C" {
+
+// flags: bit0 = update BN running statistics
+int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const void* packed, const float* x_nchw,
+                      void* ws_, float* f3, float* f4, int flags, hipStream_t st) {
+  if (!P || !params || !packed || !x_nchw || !ws_) return PH_EINVAL;
+  Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, flags & 1};
+  unsigned char* ws = c.ws;
+  int rc = ph_pack_input_launch(x_nchw, ws + P->x4_off, P->B, P->H, P->W, P->prec, st);
+  if (rc) return rc;
+  {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
+    const Unit& u = P->units[0];
+    PhStem s{};
+    s.x4 = ws + P->x4_off; s.w_hi = c.pk + u.wf_off; s.w_lo = c.pk + u.wf_off + u.wplane;
+    s.out = ws + u.y_off; s.stats = reinterpret_cast<float*>(ws + P->parts_off);
+    s.B = P->B; s.IH = P->H; s.IW = P->W; s.OH = u.OH; s.OW = u.OW;
+    if ((rc = ph_stem_fwd_launch(&s, P->prec, st))) return rc;
+    float* rm = c.update_running ? (float*)params[3] : nullptr;
+    if ((rc = ph_bn_finalize_launch(s.stats, ph_stem_stat_parts(P->B, u.OH, u.OW), 64, (double)P->B * u.OH * u.OW,
+                                    1e-5f, 0.1f, (const float*)params[1], (const float*)params[2], c.stat(u, 0),
+                                    c.stat(u, 1), c.stat(u, 2), c.stat(u, 3), rm, (float*)params[4],
+                                    (int64_t*)params[5], st)))
+      return rc;
+    if ((rc = ph_bn_relu_maxpool_launch(ws + u.y_off, c.stat(u, 2), c.stat(u, 3), ws + P->p0_off, ws + P->idx_off,
+                                        P->B, u.OH, u.OW, 64, P->prec, st)))
+      return rc;
+  }
+  for (size_t bi = 0; bi < P->blocks.size(); ++bi) {
+    const Block& b = P->blocks[bi];
+    const Unit& u1 = P->units[b.u1];
+    const Unit& u2 = P->units[b.u2];
+    const size_t npix = (size_t)P->B * b.OH * b.OW;
+    if ((rc = conv_fwd(c, b.u1, ws + b.in_off))) return rc;
+    if ((rc = ph_bn_apply_launch(ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3), nullptr, nullptr, nullptr, nullptr,
+                                 ws + b.a1_off, npix, b.Cout, 1, P->prec, st)))
+      return rc;
+    if ((rc = conv_fwd(c, b.u2, ws + b.a1_off))) return rc;
+    if (b.uds >= 0) {
+      const Unit& ud = P->units[b.uds];
+      if ((rc = conv_fwd(c, b.uds, ws + b.in_off))) return rc;
+      rc = ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + ud.y_off, c.stat(ud, 2),
+                              c.stat(ud, 3), ws + b.out_off, npix, b.Cout, 1, P->prec, st);
+    } else {
+      rc = ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), ws + b.in_off, nullptr, nullptr, nullptr,
+                              ws + b.out_off, npix, b.Cout, 1, P->prec, st);
+    }
+    if (rc) return rc;
+    if (bi == 5 && f3) { if ((rc = ph_avgpool_launch(ws + b.out_off, f3, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
+    if (bi == 7 && f4) { if ((rc = ph_avgpool_launch(ws + b.out_off, f4, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
+  }
+  return PH_OK;
+}
+
+// grads: per unit 3 pointers [dw (OIHW f32), dgamma, dbeta]; g_f3 may be null.  Needs the activations the
+// matching ph_resnet_forward left in `ws`.
+int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
+                       const float* g_f3, const float* g_f4, void* const* grads, hipStream_t st) {
+  if (!P || !params || !packed || !ws_ || !g_f4 || !grads) return PH_EINVAL;
+  Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0};
+  unsigned char* ws = c.ws;
+  unsigned char* gcur = ws + P->g0_off;
+  unsigned char* gnext = ws + P->g1_off;
+  unsigned char* dyb = ws + P->dy_off;
+  unsigned char* dab = ws + P->da_off;
+  int rc;
+  {
+    const Block& b = P->blocks[7];
+    if ((rc = ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st))) return rc;
+  }
+  for (int bi = 7; bi >= 0; --bi) {
+    const Block& b = P->blocks[bi];
+    if (bi == 5 && g_f3)
+      if ((rc = ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st))) return rc;
+    const void* out = ws + b.out_off;
+    const void* a1 = ws + b.a1_off;
+    const void* xin = ws + b.in_off;
+    // bn2 <- d_out * (out > 0)
+    if ((rc = bn_bwd(c, b.u2, gcur, out, dyb, (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]))) return rc;
+    if ((rc = conv_wgrad(c, b.u2, a1, dyb, (float*)grads[b.u2 * 3 + 0]))) return rc;
+    if ((rc = conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr))) return rc;
+    // bn1 <- d_a1 * (a1 > 0)
+    if ((rc = bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2]))) return rc;
+    if ((rc = conv_wgrad(c, b.u1, xin, dyb, (float*)grads[b.u1 * 3 + 0]))) return rc;
+    if (b.uds < 0) {
+      // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
+      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, gcur, out))) return rc;
+    } else {
+      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, nullptr, nullptr))) return rc;
+      if ((rc = bn_bwd(c, b.uds, gcur, out, dyb, (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]))) return rc;
+      if ((rc = conv_wgrad(c, b.uds, xin, dyb, (float*)grads[b.uds * 3 + 0]))) return rc;
+      if ((rc = conv_dgrad(c, b.uds, dyb, gnext, gnext, nullptr))) return rc;   // in-place accumulate
+    }
+    unsigned char* t = gcur; gcur = gnext; gnext = t;
+  }
+  {  // stem: d_pool -> (maxpool, relu, bn) backward -> wgrad.  No dgrad: the image needs no gradient.
+    const Unit& u = P->units[0];
+    const size_t npix = (size_t)P->B * u.OH * u.OW;
+    float* parts = reinterpret_cast<float*>(ws + P->bparts_off);
+    float* c1 = reinterpret_cast<float*>(ws + P->cc_off);
+    float* c2 = c1 + 512;
+    if ((rc = ph_stem_bwd_reduce_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
+                                        c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, st)))
+      return rc;
+    if ((rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix), 64, (double)npix, (float*)grads[1],
+                                        (float*)grads[2], c1, c2, st)))
+      return rc;
+    if ((rc = ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
+                                       c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64,
+                                       P->prec, st)))
+      return rc;
+    PhStemWgrad w{};
+    w.x4 = ws + P->x4_off; w.dy = dyb; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
+    w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
+    w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
+    if ((rc = ph_stem_wgrad_launch(&w, P->prec, st))) return rc;
+    if ((rc = ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, st))) return rc;
+  }
+  return PH_OK;
+}
+
+// debug / test access: byte offset + dims of an intermediate activation in the workspace
+//   what: 0 = unit raw output y (id = unit), 1 = block output (id = block), 2 = block a1, 3 = pooled stem
+int ph_resnet_tensor_info(const PhResnetPlan* P, int what, int id, size_t* byte_off, int* dims4) {
+  if (!P) return PH_EINVAL;
+  if (what == 0 && id >= 0 && id < (int)P->units.size()) {
+    const Unit& u = P->units[id];
+    *byte_off = u.y_off; dims4[0] = P->B; dims4[1] = u.OH; dims4[2] = u.OW; dims4[3] = u.Cout;
+    return PH_OK;
+  }
+  if ((what == 1 || what == 2) && id >= 0 && id < (int)P->blocks.size()) {
+    const Block& b = P->blocks[id];
+    *byte_off = what == 1 ? b.out_off : b.a1_off;
+    dims4[0] = P->B; dims4[1] = b.OH; dims4[2] = b.OW; dims4[3] = b.Cout;
+    return PH_OK;
+  }
+  if (what == 3) {
+    *byte_off = P->p0_off; dims4[0] = P->B; dims4[1] = P->PH0; dims4[2] = P->PW0; dims4[3] = 64;
+    return PH_OK;
+  }
+  return PH_EINVAL;
+}
+
+}  // extern "C"

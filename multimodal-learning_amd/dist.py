@@ -1,0 +1,81 @@
+"""Data parallelism for the distill step: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  The reference uses single-process nn.DataParallel which
+re-broadcasts three networks every step (utils.py:257-260); here parameters stay resident and per step
+there are exactly four exchanges:
+  1. all-reduce (sum) of the flat gradient buffer, in buckets so RCCL pipelines over all xGMI links
+  2. all-gather of (index, embed_s(f_s), embed_t(f_t)) rows -> identical CRD bank updates on every replica
+  3. all-reduce of the 5x5 GK-Refine Gram matrix (global-batch gradient cosine)
+  4. one-off all-reduce of the CRD normalisation sums (first batch only)
+BatchNorm keeps per-replica statistics - that IS the DataParallel semantics of the reference.
+Loss normalisers use the GLOBAL batch so summed gradients equal the single-process result."""
+import torch
+import torch.distributed as dist
+
+
+class ReplicaSync:
+    def __init__(self, group=None, bucket_bytes=32 << 20):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bucket_elems = max(1, bucket_bytes // 4)
+
+    # 1 -------------------------------------------------------------------------------------------------
+    def all_reduce_grads(self, flat):
+        g = flat.grad if hasattr(flat, "grad") else flat
+        n = g.numel()
+        works = []
+        for s in range(0, n, self.bucket_elems):
+            works.append(dist.all_reduce(g[s:min(n, s + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True))
+        for w in works:
+            w.wait()
+        return g
+
+    # 2 -------------------------------------------------------------------------------------------------
+    def all_gather_rows(self, y, v1, v2):
+        W = self.world_size
+        ys = [torch.empty_like(y) for _ in range(W)]
+        dist.all_gather(ys, y.contiguous(), group=self.group)
+        packed = torch.cat([v1, v2], dim=1).contiguous()
+        ps = [torch.empty_like(packed) for _ in range(W)]
+        dist.all_gather(ps, packed, group=self.group)
+        allp = torch.cat(ps, dim=0)
+        D = v1.shape[1]
+        return torch.cat(ys, dim=0), allp[:, :D].contiguous(), allp[:, D:].contiguous()
+
+    # 3 -------------------------------------------------------------------------------------------------
+    def all_reduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    # 4 -------------------------------------------------------------------------------------------------
+    def all_reduce_z(self, sums, count):
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        return count * self.world_size
+
+    def attach(self, step):
+        """Wire the CRD memories of a DistillStep to this group and make every replica start identical."""
+        for crd in (step.criterion_kd, step.criterion_kd_path):
+            crd.contrast.sync = self
+            for b in (crd.contrast.memory_v1, crd.contrast.memory_v2, crd.contrast.params):
+                dist.broadcast(b, src=0, group=self.group)
+        for t in (step.optimizer.flat.flat, step.ema_flat.flat):
+            dist.broadcast(t, src=0, group=self.group)
+        for m in (step.fix_model, step.model, step.ema_model):
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+
+
+def shard_batch(batch, rank, world_size):
+    """Split a loader batch tuple (data_loaders_MT.py:256 layout) into this rank's contiguous shard."""
+    (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
+    B = x_path.shape[0]
+    if B % world_size:
+        raise ValueError("global batch must divide by the world size")
+    n = B // world_size
+    s = slice(rank * n, (rank + 1) * n)
+    f = lambda t: t[s] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == B else t
+    return ((f(x_path), f(ema_x_path)), f(x_grph), f(x_omic), f(censor), f(survtime), f(grade), f(index),
+            f(sample_idx))

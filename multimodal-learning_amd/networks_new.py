@@ -1,0 +1,194 @@
+"""Drop-in for the reference's MICCAI-2022/networks_new.py: define_net / define_optimizer /
+define_scheduler / define_reg / define_act_layer / define_bifusion, MaxNet, PathomicNet, get_resnet.
+Same factories, constructor arguments, tuple returns and state_dict keys; compute through the C-ABI."""
+import torch
+import torch.nn as nn
+import torch.optim.lr_scheduler as lr_scheduler
+from torch.nn import Parameter
+
+from . import ops
+from .fusion import BilinearFusion
+from .resnets import ResNet18
+from .utils import init_net, init_max_weights
+
+
+def define_net(opt, k, path_only=False, omic_only=False):
+    """networks_new.py:53-77"""
+    net = None
+    act = define_act_layer(act_type=opt.act_type)
+    init_max = True if opt.init_type == "max" else False
+    if opt.mode == "path":
+        net = get_resnet(path_dim=opt.path_dim, act=act, label_dim=opt.label_dim)
+    elif opt.mode == "omic":
+        net = MaxNet(input_dim=opt.input_size_omic, omic_dim=opt.omic_dim, dropout_rate=opt.dropout_rate, act=act,
+                     label_dim=opt.label_dim, init_max=init_max)
+    elif opt.mode == "pathomic":
+        if not path_only and not omic_only:
+            if opt.fusion_type == "mmdynamics":
+                raise NotImplementedError("PathomicNet_dynamics needs the reference's absent MMDynamic module "
+                                          "(networks_new.py:372-402): out of scope")
+            net = PathomicNet(opt=opt, act=act, k=k)
+        if path_only:
+            net = get_resnet(path_dim=opt.path_dim, act=act, label_dim=opt.label_dim)
+        if omic_only:
+            net = MaxNet(input_dim=opt.input_size_omic, omic_dim=opt.omic_dim, dropout_rate=opt.dropout_rate,
+                         act=act, label_dim=opt.label_dim, init_max=init_max)
+    else:
+        raise NotImplementedError("model [%s] is not implemented" % opt.mode)
+    return init_net(net, opt.init_type, opt.init_gain, opt.gpu_ids)
+
+
+def define_optimizer(opt, model):
+    """networks_new.py:80-90.  'adam' returns the fused multi-tensor HIP Adam (same update rule and
+    state_dict surface as torch.optim.Adam with L2-in-grad weight decay)."""
+    from .train_step import FusedAdam
+    if opt.optimizer_type == "adam":
+        return FusedAdam(model.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2), weight_decay=opt.weight_decay)
+    raise NotImplementedError("optimizer [%s]: the shipped commands use adam (options.py:126)" % opt.optimizer_type)
+
+
+def define_reg(opt, model):
+    """networks_new.py:93-108; the stage-2 command uses --reg_type none."""
+    if opt.reg_type == "none":
+        return 0
+    raise NotImplementedError("reg_type [%s]: stage-2 hot path uses 'none' (README.md:30-33)" % opt.reg_type)
+
+
+def define_scheduler(opt, optimizer):
+    """networks_new.py:111-129"""
+    if opt.lr_policy == "linear":
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + opt.epoch_count - opt.niter) / float(opt.niter_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    elif opt.lr_policy == "exp":
+        return lr_scheduler.ExponentialLR(optimizer, 0.1, last_epoch=-1)
+    elif opt.lr_policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    elif opt.lr_policy == "cosine":
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.niter, eta_min=0)
+    raise NotImplementedError("learning rate policy [%s] is not implemented" % opt.lr_policy)
+
+
+def define_act_layer(act_type="Tanh"):
+    """networks_new.py:132-145"""
+    if act_type == "Tanh":
+        return nn.Tanh()
+    if act_type == "ReLU":
+        return nn.ReLU()
+    if act_type == "Sigmoid":
+        return nn.Sigmoid()
+    if act_type == "LSM":
+        return nn.LogSoftmax(dim=1)
+    if act_type == "none":
+        return None
+    raise NotImplementedError("activation layer [%s] is not found" % act_type)
+
+
+def define_bifusion(fusion_type, skip=1, use_bilinear=1, gate1=1, gate2=1, dim1=32, dim2=32, scale_dim1=1,
+                    scale_dim2=1, mmhid=32, dropout_rate=0.25):
+    """networks_new.py:148-154"""
+    if fusion_type == "pofusion":
+        return BilinearFusion(skip=skip, use_bilinear=use_bilinear, gate1=gate1, gate2=gate2, dim1=dim1, dim2=dim2,
+                              scale_dim1=scale_dim1, scale_dim2=scale_dim2, mmhid=mmhid, dropout_rate=dropout_rate)
+    raise NotImplementedError("fusion type [%s] is not found" % fusion_type)
+
+
+class MaxNet(nn.Module):
+    """Genomic SNN (networks_new.py:182-251): 4 x (Linear-ELU-AlphaDropout), ReLU, Linear, act.
+    forward(**kwargs) -> (features, out, pred, None).  Forward only on the stage-2 hot path."""
+
+    def __init__(self, input_dim=80, omic_dim=32, return_grad="False", dropout_rate=0.25, act=None, label_dim=1,
+                 init_max=True):
+        super().__init__()
+        hidden = [64, 48, 32, 32]
+        self.act = act
+        self.return_grad = return_grad
+        dims = [input_dim, hidden[0], hidden[1], hidden[2], omic_dim]
+        self.encoder = nn.Sequential(*[
+            nn.Sequential(nn.Linear(dims[i], dims[i + 1]), nn.ELU(), nn.AlphaDropout(p=dropout_rate, inplace=False))
+            for i in range(4)])
+        self.relu = nn.ReLU(inplace=False)
+        self.classifier = nn.Sequential(nn.Linear(omic_dim, label_dim))
+        if init_max:
+            init_max_weights(self)
+        self.output_range = Parameter(torch.FloatTensor([6]), requires_grad=False)
+        self.output_shift = Parameter(torch.FloatTensor([-3]), requires_grad=False)
+        self.dropout_rate = dropout_rate
+        self.rng_seed = 0xA11CE
+        self._rng_offset = 0
+
+    def forward(self, **kwargs):
+        x = kwargs["x_omic"]
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("MaxNet backward (stage-1 teacher training) is the 'next' row f-1")
+        if self.return_grad == "True":
+            raise NotImplementedError("return_grad needs the reference's absent my_utils.compute_gradients")
+        h = x
+        for i in range(4):
+            lin = self.encoder[i][0]
+            h = ops.linear_fwd(h, lin.weight, lin.bias, ops.ACT_ELU)
+            if self.training and self.dropout_rate > 0:
+                ops.dropout_(h, self.dropout_rate, self.rng_seed, self._rng_offset, alpha=True)
+                self._rng_offset += h.numel()
+        features = ops.eltwise(h, None, ops.EW_RELU)
+        out = ops.linear_fwd(features, self.classifier[0].weight, self.classifier[0].bias)
+        pred = None
+        if self.act is not None:
+            if not isinstance(self.act, nn.LogSoftmax):
+                raise NotImplementedError("only act_type 'LSM' is on the hot path")
+            pred = ops.LogSoftmaxFn.apply(out)
+        return features, out, pred, None
+
+
+def get_resnet(path_dim=32, act=None, label_dim=1, **kwargs):
+    """networks_new.py:258-259"""
+    return ResNet18(path_dim=path_dim, act=act, num_classes=label_dim, **kwargs)
+
+
+class PathomicNet(nn.Module):
+    """Multi-modal teacher (networks_new.py:267-353): path_net + omic_net + fusion + classifier; forward
+    returns the reference's 11-tuple."""
+
+    def __init__(self, opt, act, k):
+        super().__init__()
+        init_max = True if opt.init_type == "max" else False
+        self.path_net = get_resnet(path_dim=opt.path_dim, act=act, label_dim=opt.label_dim, return_grad=opt.return_grad)
+        self.omic_net = MaxNet(input_dim=opt.input_size_omic, omic_dim=opt.omic_dim, return_grad=opt.return_grad,
+                               dropout_rate=opt.dropout_rate, act=act, label_dim=opt.label_dim, init_max=init_max)
+        self.bilinear_dim = 20
+        self.task = opt.task
+        self.fusion = define_bifusion(fusion_type=opt.fusion_type, skip=opt.skip, use_bilinear=opt.use_bilinear,
+                                      gate1=opt.path_gate, gate2=opt.omic_gate, dim1=opt.path_dim, dim2=opt.omic_dim,
+                                      scale_dim1=opt.path_scale, scale_dim2=opt.omic_scale, mmhid=opt.mmhid,
+                                      dropout_rate=opt.dropout_rate)
+        self.classifier = nn.Sequential(nn.Linear(opt.mmhid, opt.label_dim))
+        self.act = act
+        self.return_grad = opt.return_grad
+        self.cut_fuse_grad = opt.cut_fuse_grad
+        self.fusion_type = opt.fusion_type
+        self.output_range = Parameter(torch.FloatTensor([6]), requires_grad=False)
+        self.output_shift = Parameter(torch.FloatTensor([-3]), requires_grad=False)
+
+    def forward(self, **kwargs):
+        path_vec_f3, path_vec, hazard_path, pred_path, path_grads = self.path_net(x_path=kwargs["x_path"])
+        omic_vec, hazard_omic, pred_omic, omic_grads = self.omic_net(x_omic=kwargs["x_omic"])
+        if self.fusion_type == "concat":
+            raise NotImplementedError("fusion_type concat is not on the hot path (default pofusion)")
+        if self.cut_fuse_grad:
+            features = self.fusion(path_vec.clone().detach(), omic_vec.clone().detach())   # :302-306
+        else:
+            features = self.fusion(path_vec, omic_vec)
+        hazard = ops.LinearFn.apply(features, self.classifier[0].weight, self.classifier[0].bias)
+        pred = None
+        if self.act is not None:
+            if not isinstance(self.act, nn.LogSoftmax):
+                raise NotImplementedError("only act_type 'LSM' is on the hot path")
+            pred = ops.LogSoftmaxFn.apply(hazard)
+        logits = [hazard_path, hazard_omic, hazard]
+        return features, path_vec, omic_vec, path_vec_f3, logits, pred, pred_path, pred_omic, None, path_grads, omic_grads
+
+    def __hasattr__(self, name):   # networks_new.py:356-369
+        for d in ("_parameters", "_buffers", "_modules"):
+            if d in self.__dict__ and name in self.__dict__[d]:
+                return True
+        return False

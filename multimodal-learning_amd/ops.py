@@ -1,0 +1,245 @@
+"""torch.autograd glue over the C-ABI: every Function's forward/backward is a call into
+libpathomic_hip.so on raw device pointers + the current HIP stream.  torch supplies memory and the
+autograd tape only; there is no eager-PyTorch compute fallback."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream, require_cuda
+
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD = 0, 1, 2, 3
+PREC_BF16, PREC_BF16X3 = 0, 1
+
+_precision = PREC_BF16
+_weight_epoch = 0
+
+
+def bump_weight_epoch():
+    """Call after parameters were modified through raw device pointers (fused Adam / EMA kernels), so that
+    cached MFMA weight packings are refreshed."""
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+def weight_epoch():
+    return _weight_epoch
+
+
+def set_precision(mode):
+    """'bf16' (perf mode) or 'bf16x3' (parity mode: fp32 activations, split-bf16 3-product MFMA)."""
+    global _precision
+    _precision = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, PREC_BF16: PREC_BF16, PREC_BF16X3: PREC_BF16X3}[mode]
+
+
+def get_precision():
+    return _precision
+
+
+def _f32(t):
+    t = require_cuda(t)
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected float32 tensor")
+    return t.contiguous()
+
+
+_ones_cache = {}
+
+
+def _ones(n, device):
+    key = (n, device)
+    if key not in _ones_cache:
+        _ones_cache[key] = torch.ones(n, device=device, dtype=torch.float32)
+    return _ones_cache[key]
+
+
+def sgemm(A, Bm, bias, out, M, N, K, sam, sak, sbk, sbn, act=ACT_NONE, accumulate=False):
+    check(lib().ph_sgemm(ptr(A), ptr(Bm), ptr(bias), ptr(out), M, N, K, sam, sak, sbk, sbn, N, act,
+                         int(accumulate), stream()), "ph_sgemm")
+    return out
+
+
+def linear_fwd(x, w, b, act=ACT_NONE):
+    """y[B,N] = act(x[B,K] @ w[N,K]^T + b)   (nn.Linear)"""
+    x, w = _f32(x), _f32(w)
+    Bn, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(Bn, N, device=x.device, dtype=torch.float32)
+    if K >= 4096 and Bn * N <= 256 * 256:
+        nsplit = 32
+        part = torch.empty(nsplit * Bn * N, device=x.device, dtype=torch.float32)
+        check(lib().ph_sgemm_splitk(ptr(x), ptr(w), ptr(b), ptr(y), ptr(part), nsplit, Bn, N, K, K, 1, 1, K, N, act,
+                                    stream()), "ph_sgemm_splitk")
+        return y
+    return sgemm(x, w, b, y, Bn, N, K, K, 1, 1, K, act)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return linear_fwd(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _f32(g)
+        Bn, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            sgemm(g, w, None, dx, Bn, K, N, N, 1, K, 1)              # dX = dY @ W
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            sgemm(g, x, None, dw, N, K, Bn, 1, N, K, 1)              # dW = dY^T @ X
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, device=g.device, dtype=torch.float32)
+            sgemm(_ones(Bn, g.device), g, None, db, 1, N, Bn, 0, 1, N, 1)   # db = 1^T dY
+        return dx, dw, db
+
+
+class BN1dFn(torch.autograd.Function):
+    """nn.BatchNorm1d (training statistics) optionally fused with ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, relu, update_running):
+        x = _f32(x)
+        Bn, Cn = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(Cn, device=x.device, dtype=torch.float32)
+        invstd = torch.empty_like(mean)
+        check(lib().ph_bn1d_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(invstd),
+                                ptr(rm) if update_running else None, ptr(rv), ptr(nbt), Bn, Cn, 1e-5, 0.1, int(relu),
+                                stream()), "ph_bn1d_fwd")
+        ctx.save_for_backward(x, y, mean, invstd, gamma)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mean, invstd, gamma = ctx.saved_tensors
+        g = _f32(g)
+        Bn, Cn = x.shape
+        dx = torch.empty_like(x)
+        dg = torch.empty_like(gamma)
+        db = torch.empty_like(gamma)
+        check(lib().ph_bn1d_bwd(ptr(g), ptr(y), ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(dx), ptr(dg), ptr(db),
+                                Bn, Cn, int(ctx.relu), stream()), "ph_bn1d_bwd")
+        return dx, dg, db, None, None, None, None, None
+
+
+class LogSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        check(lib().ph_log_softmax(ptr(x), ptr(y), x.shape[0], x.shape[1], stream()), "ph_log_softmax")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        g = _f32(g)
+        dx = torch.empty_like(y)
+        check(lib().ph_log_softmax_bwd(ptr(g), ptr(y), ptr(dx), y.shape[0], y.shape[1], stream()), "ph_log_softmax_bwd")
+        return dx
+
+
+class NLLFn(torch.autograd.Function):
+    """F.nll_loss(pred, grade) with mean reduction over `bnorm` samples (the global batch under DDP)."""
+
+    @staticmethod
+    def forward(ctx, pred, grade, bnorm):
+        pred = _f32(pred)
+        grade = require_cuda(grade).contiguous()
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        check(lib().ph_nll_fwd(ptr(pred), ptr(grade), ptr(loss), pred.shape[0], pred.shape[1], 1.0 / bnorm, stream()),
+              "ph_nll_fwd")
+        ctx.save_for_backward(grade)
+        ctx.shape = tuple(pred.shape)
+        ctx.bnorm = bnorm
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grade, = ctx.saved_tensors
+        g = _f32(g)
+        d = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        check(lib().ph_nll_bwd(ptr(g), ptr(grade), ptr(d), ctx.shape[0], ctx.shape[1], 1.0 / ctx.bnorm, stream()),
+              "ph_nll_bwd")
+        return d, None, None
+
+
+class KLFn(torch.autograd.Function):
+    """DistillKL (reference KD_loss.py:13-17); gradient w.r.t. y_s only (y_t is detached on the hot path)."""
+
+    @staticmethod
+    def forward(ctx, y_s, y_t, T, bnorm):
+        y_s, y_t = _f32(y_s), _f32(y_t)
+        loss = torch.empty((), device=y_s.device, dtype=torch.float32)
+        check(lib().ph_kl_fwd(ptr(y_s), ptr(y_t), ptr(loss), y_s.shape[0], y_s.shape[1], T, 1.0 / bnorm, stream()),
+              "ph_kl_fwd")
+        ctx.save_for_backward(y_s, y_t)
+        ctx.T, ctx.bnorm = T, bnorm
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        y_s, y_t = ctx.saved_tensors
+        g = _f32(g)
+        d = torch.empty_like(y_s)
+        check(lib().ph_kl_bwd(ptr(g), ptr(y_s), ptr(y_t), ptr(d), y_s.shape[0], y_s.shape[1], ctx.T, 1.0 / ctx.bnorm,
+                              stream()), "ph_kl_bwd")
+        return d, None, None, None
+
+
+class L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        nrm = torch.empty(x.shape[0], device=x.device, dtype=torch.float32)
+        check(lib().ph_l2norm_fwd(ptr(x), ptr(y), ptr(nrm), x.shape[0], x.shape[1], stream()), "ph_l2norm_fwd")
+        ctx.save_for_backward(y, nrm)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, nrm = ctx.saved_tensors
+        g = _f32(g)
+        dx = torch.empty_like(y)
+        check(lib().ph_l2norm_bwd(ptr(g), ptr(y), ptr(nrm), ptr(dx), y.shape[0], y.shape[1], stream()), "ph_l2norm_bwd")
+        return dx
+
+
+def eltwise(a, b, op):
+    a = _f32(a)
+    out = torch.empty_like(a)
+    check(lib().ph_eltwise(ptr(a), ptr(b), ptr(out), a.numel(), op, stream()), "ph_eltwise")
+    return out
+
+
+def dropout_(x, p, seed, offset, alpha=False):
+    if p > 0:
+        check(lib().ph_dropout(ptr(x), x.numel(), p, seed, offset, int(alpha), stream()), "ph_dropout")
+    return x
+
+
+def outer(o1, o2, append_one):
+    o1, o2 = _f32(o1), _f32(o2)
+    Bn, D1 = o1.shape
+    D2 = o2.shape[1]
+    out = torch.empty(Bn, (D1 + append_one) * (D2 + append_one), device=o1.device, dtype=torch.float32)
+    check(lib().ph_outer(ptr(o1), ptr(o2), ptr(out), Bn, D1, D2, int(append_one), stream()), "ph_outer")
+    return out
+
+
+def void_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

@@ -1,0 +1,259 @@
+"""Drop-in for the reference's MICCAI-2022/resnets.py (ResNet / BasicBlock / ResNet18): same module tree,
+same ``state_dict`` keys (OIHW fp32 at the boundary), same ``forward(**kwargs)`` 5-tuple
+(resnets.py:267-272) - but the trunk forward AND backward run as hand-written HIP kernels through
+``ph_resnet_forward`` / ``ph_resnet_backward`` (include/pathomic_hip.h).
+
+The torch sub-modules (nn.Conv2d, nn.BatchNorm2d, ...) are used ONLY as parameter containers so that
+checkpoints round-trip; their ``forward`` is never called.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from . import ops
+from ._lib import lib, check, ptr, stream, require_cuda
+
+__all__ = ["ResNet", "ResNet18", "BasicBlock"]
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """Parameter container with the reference layout (resnets.py:37-56)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):   # pragma: no cover
+        raise RuntimeError("BasicBlock is executed by the fused HIP trunk, not standalone")
+
+
+class _Plan:
+    """RAII wrapper of a PhResnetPlan."""
+
+    def __init__(self, B, H, W, prec):
+        self.h = lib().ph_resnet_plan_create(B, H, W, prec)
+        if not self.h:
+            raise RuntimeError(f"ph_resnet_plan_create({B},{H},{W},{prec}) failed")
+        self.ws_bytes = lib().ph_resnet_workspace_bytes(self.h)
+        self.packed_bytes = lib().ph_resnet_packed_bytes(self.h)
+        self.key = (B, H, W, prec)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().ph_resnet_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _TrunkFn(torch.autograd.Function):
+    """x [B,3,H,W] f32 -> (f3 [B,256], f4 [B,512]); backward fills every trunk parameter's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        x = require_cuda(x, "x_path")
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        if Cc != 3:
+            raise RuntimeError("x_path must be [B,3,H,W]")
+        plan = net._get_plan(B, H, W)
+        packed = net._get_packed(plan)
+        table = net._param_table()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        ws = net._get_workspace(plan, persistent=need_grad)
+        f3 = torch.empty(B, 256, device=x.device, dtype=torch.float32)
+        f4 = torch.empty(B, 512, device=x.device, dtype=torch.float32)
+        check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4),
+                                      1 if net.training else 0, stream()), "ph_resnet_forward")
+        ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table
+        ctx.set_materialize_grads(False)
+        ctx.nparams = len(params)
+        return f3, f4
+
+    @staticmethod
+    def backward(ctx, g3, g4):
+        net, plan = ctx.net, ctx.plan
+        dev = ctx.ws.device
+        if g4 is None:
+            g4 = torch.zeros(plan.key[0], 512, device=dev, dtype=torch.float32)
+        g4 = g4.contiguous().float()
+        g3 = g3.contiguous().float() if g3 is not None else None
+        grads, gptrs = net._alloc_trunk_grads()
+        check(lib().ph_resnet_backward(plan.h, ctx.table, ptr(ctx.packed), ptr(ctx.ws), ptr(g3), ptr(g4),
+                                       ops.void_array(gptrs), stream()), "ph_resnet_backward")
+        ctx.ws = None
+        return (None, None) + tuple(grads)
+
+
+class ResNet(nn.Module):
+    """Same constructor / attributes / state_dict as the reference ResNet (resnets.py:126-191)."""
+
+    def __init__(self, block, layers, path_dim=32, act=None, num_classes=7, return_grad="False",
+                 zero_init_residual=False):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc_new1 = nn.Sequential(nn.Linear(512 * block.expansion, path_dim), nn.BatchNorm1d(path_dim),
+                                     nn.ReLU(inplace=True))
+        self.fc_new2 = nn.Linear(path_dim, num_classes)
+        self.act = act
+        self.return_grad = return_grad
+        self.output_range = Parameter(torch.FloatTensor([6]), requires_grad=False)
+        self.output_shift = Parameter(torch.FloatTensor([-3]), requires_grad=False)
+        for m in self.modules():   # resnets.py:176-181
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
+        if list(layers) != [2, 2, 2, 2] or block is not BasicBlock:
+            raise NotImplementedError("only ResNet-18 (BasicBlock, [2,2,2,2]) is on the hot path; the reference's "
+                                      "ResNet34/50 factories are dead code (SURVEY.md section 2.1 row 3)")
+        self._plans = {}
+        self._packed = None
+        self._packed_versions = None
+        self._packed_key = None
+        self._ws_cache = {}
+        self._table = None
+        self._table_key = None
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------ runtime plumbing
+    def _units(self):
+        """(conv, bn) pairs in the C-ABI unit order (include/pathomic_hip.h)."""
+        u = [(self.conv1, self.bn1)]
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                u.append((blk.conv1, blk.bn1))
+                u.append((blk.conv2, blk.bn2))
+                if blk.downsample is not None:
+                    u.append((blk.downsample[0], blk.downsample[1]))
+        return u
+
+    def _trunk_params(self):
+        out = []
+        for conv, bn in self._units():
+            out += [conv.weight, bn.weight, bn.bias]
+        return out
+
+    def _param_table(self):
+        ptrs = []
+        for conv, bn in self._units():
+            ptrs += [conv.weight.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                     bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()]
+        key = tuple(ptrs)
+        if key != self._table_key:
+            self._table = ops.void_array(ptrs)
+            self._table_key = key
+        return self._table
+
+    def _get_plan(self, B, H, W):
+        key = (B, H, W, ops.get_precision())
+        if key not in self._plans:
+            self._plans[key] = _Plan(*key)
+        return self._plans[key]
+
+    def _get_packed(self, plan):
+        vers = (ops.weight_epoch(),) + tuple((c.weight._version, c.weight.data_ptr()) for c, _ in self._units())
+        if self._packed is None or self._packed_versions != vers or self._packed.numel() != plan.packed_bytes:
+            dev = self.conv1.weight.device
+            if self._packed is None or self._packed.numel() != plan.packed_bytes:
+                self._packed = torch.empty(plan.packed_bytes, device=dev, dtype=torch.uint8)
+            check(lib().ph_resnet_pack_weights(plan.h, self._param_table(), ptr(self._packed), stream()),
+                  "ph_resnet_pack_weights")
+            self._packed_versions = vers
+        return self._packed
+
+    def _get_workspace(self, plan, persistent):
+        dev = self.conv1.weight.device
+        if persistent:
+            return torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
+        key = plan.key
+        if key not in self._ws_cache:
+            self._ws_cache.clear()
+            self._ws_cache[key] = torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
+        return self._ws_cache[key]
+
+    def _alloc_trunk_grads(self):
+        grads, gptrs = [], []
+        for p in self._trunk_params():
+            g = torch.empty_like(p)
+            grads.append(g)
+            gptrs.append(g.data_ptr())
+        return grads, gptrs
+
+    # ------------------------------------------------------------------ reference API
+    def _forward_impl(self, x):
+        if not self.training:
+            raise NotImplementedError("eval-mode (running-statistics) forward is the 'next' row f-3 of SURVEY.md "
+                                      "section 8; the hot loop runs all three networks in train mode "
+                                      "(train_test_path_multi_distill.py:231-232)")
+        f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())
+        lin, bn = self.fc_new1[0], self.fc_new1[1]
+        h = ops.LinearFn.apply(f4, lin.weight, lin.bias)
+        features = ops.BN1dFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                    True, True)
+        hazard = ops.LinearFn.apply(features, self.fc_new2.weight, self.fc_new2.bias)
+        pred = None
+        if self.act is not None:
+            if isinstance(self.act, nn.LogSoftmax):
+                pred = ops.LogSoftmaxFn.apply(hazard)
+            else:
+                raise NotImplementedError("only act_type 'LSM' (grading task) is on the hot path")
+        return f3, features, hazard, pred, None
+
+    def forward(self, **kwargs):
+        return self._forward_impl(kwargs["x_path"])
+
+
+def ResNet18(pretrained=True, progress=True, path_dim=32, act=None, num_classes=1, **kwargs):
+    """resnets.py:287-295.  The reference loads ImageNet weights from a hard-coded relative path
+    (resnets.py:278-282, strict=False); here `pretrained` loads the same file only if it exists."""
+    model = ResNet(BasicBlock, [2, 2, 2, 2], path_dim, act, num_classes, **kwargs)
+    if pretrained:
+        import os
+        path = "../pathomic_fusion_20211126/pretrained_resnet/resnet18-5c106cde.pth"
+        if os.path.exists(path):
+            model.load_state_dict(torch.load(path), strict=False)
+    return model

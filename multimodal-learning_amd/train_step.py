@@ -1,0 +1,260 @@
+"""Drop-in for the hot-loop functions of the reference's MICCAI-2022/train_test_path_multi_distill.py:
+``update_ema_variables`` (:34-38), ``AEKD_loss`` (:41-70) and the batch body of ``train()`` (:242-330,
+here ``DistillStep``), plus the fused optimiser behind ``define_optimizer`` (networks_new.py:80-90)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import lib, check, ptr, stream
+
+
+# ----------------------------------------------------------------------------------------- flat storage
+class FlatParams:
+    """Re-homes a list of tensors into ONE contiguous fp32 buffer (each tensor 16-B aligned) so that the
+    optimiser / EMA / gradient all-reduce are single streaming kernels instead of ~70 small launches."""
+
+    def __init__(self, tensors, with_grad=False):
+        tensors = list(tensors)
+        dev = tensors[0].device
+        offs, off = [], 0
+        for t in tensors:
+            offs.append(off)
+            off += (t.numel() + 3) // 4 * 4
+        self.numel = off
+        self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32) if with_grad else None
+        self.offsets = offs
+        self.tensors = tensors
+        for t, o in zip(tensors, offs):
+            n = t.numel()
+            self.flat[o:o + n].copy_(t.detach().reshape(-1))
+            t.data = self.flat[o:o + n].view(t.shape)
+            if with_grad and t.requires_grad:
+                t.grad = self.grad[o:o + n].view(t.shape)
+
+    def segments(self, pred):
+        """Maximal [start, end) runs of consecutive tensors for which pred(t) holds."""
+        segs, cur = [], None
+        for t, o in zip(self.tensors, self.offsets):
+            e = o + (t.numel() + 3) // 4 * 4
+            if pred(t):
+                if cur is not None and cur[1] == o:
+                    cur[1] = e
+                else:
+                    cur = [o, e]
+                    segs.append(cur)
+            else:
+                cur = None
+        return [tuple(s) for s in segs]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2-in-grad weight decay, bias correction, eps outside the sqrt) as one
+    HIP kernel over flat parameter / gradient / state buffers (ph_adam_ema_step)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("one parameter group (the reference passes model.parameters())")
+        self._flat = None
+        self._step = 0
+        self.ema_flat = None      # optional FlatParams of the EMA model to update in the same kernel
+        self.ema_alpha = None
+        self.ema_range = None
+
+    def _ensure_flat(self):
+        if self._flat is None:
+            ps = self.param_groups[0]["params"]
+            if not ps[0].is_cuda:
+                raise RuntimeError("FusedAdam needs parameters on the GPU (no CPU fallback)")
+            self._flat = FlatParams(ps, with_grad=True)
+            self._m = torch.zeros_like(self._flat.flat)
+            self._v = torch.zeros_like(self._flat.flat)
+            self._segs = self._flat.segments(lambda t: t.requires_grad)
+            ops.bump_weight_epoch()
+        return self._flat
+
+    @property
+    def flat(self):
+        return self._ensure_flat()
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients are views of one flat buffer: zeroing is a single memset and the views persist."""
+        f = self._ensure_flat()
+        f.grad.zero_()
+        for t, o in zip(f.tensors, f.offsets):
+            if t.requires_grad and (t.grad is None or t.grad.data_ptr() != f.grad.data_ptr() + 4 * o):
+                t.grad = f.grad[o:o + t.numel()].view(t.shape)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        f = self._ensure_flat()
+        # a gradient tensor torch re-allocated (e.g. after zero_grad(set_to_none=True)) is copied back
+        for t, o in zip(f.tensors, f.offsets):
+            if t.requires_grad and t.grad is not None and t.grad.data_ptr() != f.grad.data_ptr() + 4 * o:
+                f.grad[o:o + t.numel()].copy_(t.grad.reshape(-1))
+                t.grad = f.grad[o:o + t.numel()].view(t.shape)
+        g = self.param_groups[0]
+        self._step += 1
+        segs = []
+        for (s, e) in self._segs:      # split at the EMA boundary (student params | embed params)
+            if self.ema_flat is not None and self.ema_range is not None and s < self.ema_range[1] < e:
+                segs += [(s, self.ema_range[1]), (self.ema_range[1], e)]
+            else:
+                segs.append((s, e))
+        for (s, e) in segs:
+            ema = None
+            alpha = 0.0
+            if self.ema_flat is not None and self.ema_range is not None and s >= self.ema_range[0] and e <= self.ema_range[1]:
+                ema = self.ema_flat.flat[s:e]
+                alpha = self.ema_alpha
+            check(lib().ph_adam_ema_step(ptr(f.flat[s:e]), ptr(f.grad[s:e]), ptr(self._m[s:e]), ptr(self._v[s:e]),
+                                         ptr(ema), e - s, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                         g["weight_decay"], self._step, alpha, stream()), "ph_adam_ema_step")
+        ops.bump_weight_epoch()
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = dict(step=self._step, exp_avg=None if self._flat is None else self._m.clone(),
+                           exp_avg_sq=None if self._flat is None else self._v.clone())
+        return sd
+
+    def load_state_dict(self, sd):
+        fused = sd.pop("fused", None)
+        super().load_state_dict(sd)
+        if fused is not None and fused["exp_avg"] is not None:
+            self._ensure_flat()
+            self._step = fused["step"]
+            self._m.copy_(fused["exp_avg"])
+            self._v.copy_(fused["exp_avg_sq"])
+
+
+def update_ema_variables(model, ema_model, alpha, global_step):
+    """train_test_path_multi_distill.py:34-38 - parameters only, BN buffers untouched."""
+    alpha = min(1 - 1 / (global_step + 1), alpha)
+    with torch.no_grad():
+        for ema_param, param in zip(ema_model.parameters(), model.parameters()):
+            check(lib().ph_ema_update(ptr(ema_param.data), ptr(param.data), param.numel(), alpha, stream()),
+                  "ph_ema_update")
+    ops.bump_weight_epoch()
+
+
+def AEKD_loss(opt, optimizer, main_loss, feat_s, loss_t_list, sync=None):
+    """GK-Refine (train_test_path_multi_distill.py:41-70): weights = row sums of the (x len(loss_t_list))
+    cosine Gram matrix of d loss_i / d feat_s.  The reference obtains each gradient by a FULL backward pass
+    (5 ResNet-18 backward passes thrown away except the hook value, :49-56); the identical values are the
+    VJPs stopped at feat_s, so this costs a few [B,128]-sized kernels.  Returns (scale[5], total_KD_loss)."""
+    losses = list(loss_t_list) + ([main_loss] if opt.CE_grads else [])
+    grads = [torch.autograd.grad(l, feat_s, retain_graph=True)[0] for l in losses]
+    ng = len(grads)
+    G = torch.stack([g.reshape(-1) for g in grads]).contiguous()
+    gram = torch.empty(ng * ng, device=G.device, dtype=torch.float32)
+    check(lib().ph_gram(ptr(G), ptr(gram), ng, G.shape[1], stream()), "ph_gram")
+    if sync is not None:
+        sync.all_reduce_sum(gram)        # global-batch cosine under data parallelism
+    scale = torch.empty(ng, device=G.device, dtype=torch.float32)
+    check(lib().ph_gk_scale(ptr(gram), None, ng, 0, float(len(loss_t_list)), ptr(scale), None, stream()), "ph_gk_scale")
+    losses_div_tensor = torch.stack(list(loss_t_list))
+    total_KD_loss = torch.dot(scale[:-1], losses_div_tensor)      # :68 (mirrors the slicing as written)
+    return scale, total_KD_loss
+
+
+# ----------------------------------------------------------------------------------------- the hot loop
+class DistillStep:
+    """The batch body of train() (train_test_path_multi_distill.py:242-330) over the drop-in modules:
+    student fwd, EMA fwd, teacher fwd, CE + 2xKL + 2xCRD, GK-Refine, backward, fused Adam + EMA.
+
+    No host synchronisation inside `step` (the reference does >= 7 `.item()` syncs); losses are returned
+    as device scalars."""
+
+    def __init__(self, opt, n_data, device="cuda", k=1, sync=None, models=None):
+        from .networks_new import define_net, define_optimizer, define_scheduler
+        from .kd_loss import DistillKL
+        from .CL_utils import CRDLoss
+        self.opt = opt
+        self.device = torch.device(device)
+        self.sync = sync
+        if models is None:
+            self.fix_model = define_net(opt, k).to(self.device)
+            self.model = define_net(opt, k, path_only=True).to(self.device)
+            self.ema_model = define_net(opt, k, path_only=True).to(self.device)
+        else:
+            self.fix_model, self.model, self.ema_model = models
+        for p in self.fix_model.parameters():
+            p.detach_(); p.requires_grad = False                                   # :170-173
+        for p in self.ema_model.parameters():
+            p.detach_()                                                            # :178-180
+        self.criterion_div = DistillKL(opt.kd_T)                                   # :197
+        self.criterion_kd = CRDLoss(opt, n_data).to(self.device)                   # :202
+        self.criterion_kd_path = CRDLoss(opt, n_data).to(self.device)              # :206
+        self.module_list = nn.ModuleList([self.model, self.criterion_kd.embed_s, self.criterion_kd.embed_t,
+                                          self.criterion_kd_path.embed_s, self.criterion_kd_path.embed_t])
+        self.optimizer = define_optimizer(opt, self.module_list)                   # :211
+        self.scheduler = define_scheduler(opt, self.optimizer)                     # :212
+        self.iter_num = opt.global_step
+        self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
+        # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
+        flat = self.optimizer.flat
+        n_student = len(list(self.model.parameters()))
+        self.ema_flat = FlatParams(list(self.ema_model.parameters()))
+        end = flat.offsets[n_student] if n_student < len(flat.offsets) else flat.numel
+        self.optimizer.ema_flat = self.ema_flat
+        self.optimizer.ema_range = (0, end)
+        if sync is not None:
+            sync.attach(self)
+
+    def step(self, batch, epoch=0, ranks=None):
+        opt = self.opt
+        (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
+        dev = self.device
+        x_path = x_path.to(dev, non_blocking=True)                                 # ONE H2D copy (reference: three)
+        ema_x_path = ema_x_path.to(dev, non_blocking=True)
+        x_omic = x_omic.to(dev, non_blocking=True)
+        grade = grade.to(dev, non_blocking=True)
+        index = index.to(dev, non_blocking=True)
+        sample_idx = sample_idx.to(dev, non_blocking=True)
+        bnorm = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))
+        self.criterion_div.batch_norm_size = bnorm
+        self.criterion_kd.contrast.batch_norm_size = bnorm
+        self.criterion_kd_path.contrast.batch_norm_size = bnorm
+
+        _, path_feat, logit_path, pred_path, _ = self.model(x_path=x_path, x_grph=x_grph, x_omic=x_omic)   # :249
+        with torch.no_grad():
+            _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                      # :254
+            fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
+        loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
+        if opt.num_teachers != 2 or opt.distill != "crd":
+            raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd)")
+        loss_div1 = self.criterion_div(logit_path, logits[-1].detach())                                     # :264
+        loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
+        r1 = r2 = None
+        if ranks is not None:
+            r1, r2 = ranks
+        e = epoch / opt.niter_decay
+        loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx, ranks=r1)         # :278
+        loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx, ranks=r2)  # :279
+        loss_div1 = opt.alpha * loss_div1; loss_div2 = opt.alpha * loss_div2                                # :293-294
+        loss_kd1 = opt.beta * loss_kd1; loss_kd2 = opt.beta * loss_kd2                                      # :296-297
+        KD_loss_list = [loss_div1, loss_div2, loss_kd1, loss_kd2]
+        if opt.assign_weights == "True":
+            scale, loss_KD = AEKD_loss(opt, self.optimizer, loss_cls, path_feat, KD_loss_list, self.sync)   # :304
+        else:
+            scale = None
+            loss_KD = loss_div1 + loss_div2 + loss_kd1 + loss_kd2                                           # :309
+        loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :313
+        self.optimizer.zero_grad()                                                                          # :326
+        loss.backward()                                                                                     # :327
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self.optimizer.flat)
+        self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)                          # :36
+        self.optimizer.step()                                                                               # :328 (+ :329 fused)
+        self.iter_num += 1
+        return dict(loss=loss.detach(), loss_cls=loss_cls.detach(), loss_div1=loss_div1.detach(),
+                    loss_div2=loss_div2.detach(), loss_kd1=loss_kd1.detach(), loss_kd2=loss_kd2.detach(),
+                    scale=scale, logit_path=logit_path.detach(), pred_path=pred_path.detach(),
+                    path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
+                    fuse_feat=fuse_feat, ema_feat=ema_path_feat)

@@ -1,0 +1,65 @@
+"""Parity of the MFMA convolution kernels (forward / dgrad / wgrad) against the oracle's F.conv2d, through
+the fine-grained C-ABI entry points ph_conv2d_*.  Bit-level expectations:
+  * parity mode (bf16x3): |err| <= 2e-4 * max|ref|   (split-bf16 drops only the lo*lo term, 2^-16 relative)
+  * perf mode  (bf16)   : inputs pre-rounded to bf16 on both sides; fp32 accumulate; the only differences are
+    summation order and the final bf16 store (<= 2^-8 relative per element)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # Cin, Cout, H, KS, stride, pad, B
+    (64, 64, 32, 3, 1, 1, 2),
+    (64, 128, 32, 3, 2, 1, 2),
+    (128, 128, 20, 3, 1, 1, 3),      # ragged: 20 is not a multiple of the 8x16 tile
+    (64, 128, 32, 1, 2, 0, 2),
+    (256, 512, 14, 3, 2, 1, 2),      # 14 -> 7 (the 224^2 layer4 case)
+    (512, 512, 7, 3, 1, 1, 2),
+    (128, 256, 9, 3, 2, 1, 1),       # odd input size
+]
+
+
+def _setup():
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd._lib import lib, ptr, stream, check
+    return m, lib(), ptr, stream, check
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case, prec):
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, KS, S, pad, B = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) * (2.0 / (Cin * KS * KS)) ** 0.5
+    OH = (H + 2 * pad - KS) // S + 1
+    dy = torch.randn(B, Cout, OH, OH, generator=g)
+    dt = torch.float32 if prec == 1 else torch.bfloat16
+    if prec == 0:   # like-for-like operand rounding
+        x = x.bfloat16().float(); w_r = w.bfloat16().float(); dy = dy.bfloat16().float()
+    else:
+        w_r = w
+    xr = x.clone().requires_grad_(True); wr = w_r.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, S, pad)
+    y_ref.backward(dy)
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, KS, S, pad), device="cuda", dtype=torch.uint8)
+    xd = nhwc(x, dt); wd = w.cuda(); dyd = nhwc(dy, dt)
+    y = torch.empty(B, OH, OH, Cout, device="cuda", dtype=dt)
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, KS, S, pad, prec, ptr(ws),
+                          stream()), "fwd")
+    tol = 2e-4 if prec == 1 else 1.0 / 128
+    assert_close(y_ref.detach(), nchw_cpu(y), 1e-6, tol, "conv fwd")
+    assert_close(y_ref.detach().sum(dim=(0, 2, 3)), s1.cpu(), 1e-3, 2e-4, "channel sum")
+    assert_close((y_ref.detach() ** 2).sum(dim=(0, 2, 3)), s2.cpu(), 1e-3, 2e-4, "channel sumsq")
+    dx = torch.full((B, H, H, Cin), float("nan"), device="cuda", dtype=dt)
+    check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx), B, Cin, H, H, Cout, KS, S, pad, prec, ptr(ws), stream()), "dgrad")
+    assert_close(xr.grad, nchw_cpu(dx), 1e-6, tol, "conv dgrad")
+    dw = torch.empty_like(wd)
+    check(L.ph_conv2d_wgrad(ptr(xd), ptr(dyd), ptr(dw), B, Cin, H, H, Cout, KS, S, pad, prec, ptr(ws), stream()), "wgrad")
+    assert_close(wr.grad, dw.cpu(), 1e-6, 2e-4 if prec == 1 else 2e-3, "conv wgrad")
