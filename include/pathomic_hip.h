@@ -22,7 +22,7 @@ extern "C" {
 typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
 
 #define PH_PREC_BF16 0   /* perf mode: bf16 operands + activations, fp32 accumulate/statistics */
-#define PH_PREC_BF16X3 1 /* parity mode: fp32 activations, split-bf16 (3-product) MFMA */
+#define PH_PREC_BF16X6 1 /* parity mode: fp32 activations, 3-plane split-bf16 (6-product, fp32-equivalent) MFMA */
 
 #define PH_ACT_NONE 0
 #define PH_ACT_RELU 1

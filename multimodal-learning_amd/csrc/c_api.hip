@@ -32,9 +32,9 @@ int ph_abi_version(void) { return 1; }
 
 size_t ph_conv2d_workspace_bytes(int B, int Cin, int IH, int IW, int Cout, int KS, int stride, int pad) {
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
-  const size_t wbytes = up((size_t)2 * KS * KS * Cin * Cout * sizeof(bf16));
+  const size_t wbytes = up((size_t)PH_NPLANES * KS * KS * Cin * Cout * sizeof(bf16));
   PhTapConv t{}; t.B = B; t.Cout = Cout; t.OHt = OH; t.OWt = OW;
-  const size_t parts = up((size_t)ph_tapconv_stat_parts(&t, stride) * 2 * Cout * sizeof(float));
+  const size_t parts = up((size_t)ph_tapconv_stat_parts(&t, stride, PH_PREC_BF16X6) * 2 * Cout * sizeof(float));
   int tpc; const int nc = chunks_for(B, OH, OW, stride, Cout, Cin, &tpc);
   const size_t slab = up((size_t)nc * KS * KS * Cin * Cout * sizeof(float));
   return wbytes + (parts > slab ? parts : slab);
@@ -46,20 +46,19 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
   unsigned char* ws = reinterpret_cast<unsigned char*>(ws_);
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws);
-  bf16* lo = hi + plane;
-  int rc = ph_pack_w_fwd_launch(w, hi, lo, Cout, Cin, KS, st);
+  int rc = ph_pack_w_fwd_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
-  t.in = x; t.w_hi = hi; t.w_lo = lo; t.out = y;
-  t.stats = reinterpret_cast<float*>(ws + up(2 * plane * sizeof(bf16)));
+  t.in = x; t.w = hi; t.wplane = plane; t.out = y;
+  t.stats = reinterpret_cast<float*>(ws + up(PH_NPLANES * plane * sizeof(bf16)));
   t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cin; t.Cout = Cout; t.OHt = OH; t.OWt = OW; t.OH = OH; t.OW = OW;
   t.os = 1; t.iy0 = -pad; t.ix0 = -pad; t.ntaps = KS * KS;
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = k; }
   if ((rc = ph_tapconv_launch(&t, stride, prec, st))) return rc;
   if (ch_sum || ch_sumsq) {
     hipLaunchKernelGGL(parts_sum_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, st, t.stats,
-                       ph_tapconv_stat_parts(&t, stride), Cout, ch_sum, ch_sumsq);
+                       ph_tapconv_stat_parts(&t, stride, prec), Cout, ch_sum, ch_sumsq);
     PH_LAUNCH_CHECK();
   }
   return PH_OK;
@@ -70,12 +69,11 @@ int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, in
   if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws_);
-  bf16* lo = hi + plane;
-  int rc = ph_pack_w_dgrad_launch(w, hi, lo, Cout, Cin, KS, st);
+  int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
-  t.in = dy; t.w_hi = hi; t.w_lo = lo; t.out = dx;
+  t.in = dy; t.w = hi; t.wplane = plane; t.out = dx;
   t.B = B; t.IH = OH; t.IW = OW; t.Cin = Cout; t.Cout = Cin; t.OH = IH; t.OW = IW;
   if (stride == 1) {
     t.OHt = IH; t.OWt = IW; t.os = 1; t.iy0 = -(KS - 1 - pad); t.ix0 = t.iy0; t.ntaps = KS * KS;
@@ -111,7 +109,7 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, in
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhWgrad g{};
-  g.x = x; g.dy = dy; g.slab = reinterpret_cast<float*>(ws + up(2 * plane * sizeof(bf16)));
+  g.x = x; g.dy = dy; g.slab = reinterpret_cast<float*>(ws + up(PH_NPLANES * plane * sizeof(bf16)));
   g.B = B; g.IH = IH; g.IW = IW; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.S = stride; g.pad = pad; g.KS = KS;
   g.nchunks = chunks_for(B, OH, OW, stride, Cout, Cin, &g.tiles_per_chunk);
   int rc = ph_wgrad_launch(&g, prec, st);

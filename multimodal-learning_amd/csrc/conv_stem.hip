@@ -21,7 +21,7 @@ __device__ __forceinline__ int wsw(int row, int chunk) { return chunk ^ ((row >>
 
 template <typename T>
 __device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, int iy_base, int ix_base,
-                                           unsigned char* hi, unsigned char* lo, int tid) {
+                                           unsigned char* hi, int tid) {
   for (int i = tid; i < HP; i += 256) {
     const int hr = i / HPW, hc = i - hr * HPW;
     const int iy = iy_base + hr, ix = ix_base + hc;
@@ -34,11 +34,12 @@ __device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, i
     } else {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) v = *reinterpret_cast<const f32x4*>(x4 + g);
-      bf16x4 h4, l4;
+      bf16x4 p0, p1, p2;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { bf16 h, l; split_bf16(v[q], h, l); h4[q] = h; l4[q] = l; }
-      *reinterpret_cast<bf16x4*>(hi + i * 8) = h4;
-      *reinterpret_cast<bf16x4*>(lo + i * 8) = l4;
+      for (int q = 0; q < 4; ++q) { bf16 a, b2, c2; split3_bf16(v[q], a, b2, c2); p0[q] = a; p1[q] = b2; p2[q] = c2; }
+      *reinterpret_cast<bf16x4*>(hi + i * 8) = p0;
+      *reinterpret_cast<bf16x4*>(hi + XB + i * 8) = p1;
+      *reinterpret_cast<bf16x4*>(hi + 2 * XB + i * 8) = p2;
     }
   }
 }
@@ -46,23 +47,24 @@ __device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, i
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   constexpr bool SPLIT = is_f32<T>::value;
+  constexpr int NP = SPLIT ? PH_NPLANES : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsX = smem;
-  unsigned char* ldsW = smem + XB * (SPLIT ? 2 : 1);
-  unsigned char* ldsXlo = smem + XB;
-  unsigned char* ldsWlo = ldsW + WB;
+  unsigned char* ldsX = smem;               // NP planes of XB
+  unsigned char* ldsW = smem + XB * NP;     // NP planes of WB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_w = (p.OW + TW - 1) / TW;
   const int tile = blockIdx.x, b = blockIdx.z;
   const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
   const T* x4 = reinterpret_cast<const T*>(p.x4);
 
-  stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, ldsXlo, tid);
+  stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
   for (int i = tid; i < 7 * 64 * 4; i += 256) {   // 16-B chunks of the weight plane(s)
     const int ch = i & 3, row = i >> 2;           // row = kh*64 + cout
     const int off = row * 64 + (wsw(row, ch) << 4);
-    *reinterpret_cast<u32x4*>(ldsW + off) = reinterpret_cast<const u32x4*>(p.w_hi)[i];
-    if constexpr (SPLIT) *reinterpret_cast<u32x4*>(ldsWlo + off) = reinterpret_cast<const u32x4*>(p.w_lo)[i];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+      *reinterpret_cast<u32x4*>(ldsW + pl * WB + off) =
+          reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(p.w) + (size_t)pl * p.wplane)[i];
   }
   __syncthreads();
 
@@ -79,25 +81,26 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     for (int s = 0; s < 2; ++s) {
       const int chunk = s * 2 + khalf;
       const int aoff = (pbase + kh * HPW + 4 * s + 2 * khalf) * 8;
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsX + aoff);
-      bf16x8 bq[2];
+      bf16x8 a[NP], bq[NP][2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = kh * 64 + j * 32 + (lane & 31);
-        bq[j] = *reinterpret_cast<const bf16x8*>(ldsW + row * 64 + (wsw(row, chunk) << 4));
-      }
-      if constexpr (SPLIT) {
-        bf16x8 al = *reinterpret_cast<const bf16x8*>(ldsXlo + aoff);
+      for (int pl = 0; pl < NP; ++pl) {
+        a[pl] = *reinterpret_cast<const bf16x8*>(ldsX + pl * XB + aoff);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int row = kh * 64 + j * 32 + (lane & 31);
-          bf16x8 bl = *reinterpret_cast<const bf16x8*>(ldsWlo + row * 64 + (wsw(row, chunk) << 4));
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq[j], acc[j], 0, 0, 0);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[j], 0, 0, 0);
+          bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsW + pl * WB + row * 64 + (wsw(row, chunk) << 4));
         }
       }
+      if constexpr (SPLIT) {
+#define PH_MM(PI, PJ)                                                                               \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ][j], acc[j], 0, 0, 0);
+        PH_SPLIT_PAIRS(PH_MM)
+#undef PH_MM
+      } else {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0][j], acc[j], 0, 0, 0);
+      }
     }
   }
   // ---- epilogue (as conv_tap.hip): mask, statistics, store
@@ -152,12 +155,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, i
 template <typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
   constexpr bool SPLIT = is_f32<T>::value;
+  constexpr int NP = SPLIT ? PH_NPLANES : 1;
   constexpr int DB = TH * TW * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsD = smem;
-  unsigned char* ldsX = smem + DB;
-  unsigned char* ldsDlo = smem + DB + XB;
-  unsigned char* ldsXlo = ldsDlo + DB;
+  unsigned char* ldsD = smem;               // NP planes of DB
+  unsigned char* ldsX = smem + DB * NP;     // NP planes of XB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int chunk = blockIdx.x;
   const int tiles_w = (p.OW + TW - 1) / TW, tiles_h = (p.OH + TH - 1) / TH;
@@ -195,26 +197,27 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
         if (ok) load8(src, v);
-        bf16x8 h8, l8;
+        bf16x8 p0, p1, p2;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { bf16 h, l; split_bf16(v[q], h, l); h8[q] = h; l8[q] = l; }
-        *reinterpret_cast<bf16x8*>(ldsD + off) = h8;
-        *reinterpret_cast<bf16x8*>(ldsDlo + off) = l8;
+        for (int q = 0; q < 8; ++q) { bf16 a, b2, c2; split3_bf16(v[q], a, b2, c2); p0[q] = a; p1[q] = b2; p2[q] = c2; }
+        *reinterpret_cast<bf16x8*>(ldsD + off) = p0;
+        *reinterpret_cast<bf16x8*>(ldsD + DB + off) = p1;
+        *reinterpret_cast<bf16x8*>(ldsD + 2 * DB + off) = p2;
       }
     }
-    stage_halo<T>(X, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, ldsXlo, tid);
+    stage_halo<T>(X, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
     __syncthreads();
 #pragma unroll 2
     for (int kk = 0; kk < TH * TW / 16; ++kk) {
       const int t0 = kk * 16 + 8 * khalf + q4, t1 = t0 + 4;
-      bf16x8 a[2], al[2];
+      bf16x8 a[NP][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int piece = j * 2 + colhalf;
         const int o0 = t0 * 128 + sw_piece(t0, piece) * 32 + p4 * 8;
         const int o1 = t1 * 128 + sw_piece(t1, piece) * 32 + p4 * 8;
-        a[j] = tr_pair(ldsD, o0, o1);
-        if constexpr (SPLIT) al[j] = tr_pair(ldsDlo, o0, o1);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) a[pl][j] = tr_pair(ldsD + pl * DB, o0, o1);
       }
       const int kw = 4 * colhalf + p4;
       const int hb0 = ((t0 >> 4) * 2) * HPW + (t0 & 15) * 2 + kw;
@@ -224,17 +227,20 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
         if (ai < nkh) {
           const int kh = wave + 4 * ai;
           const int o0 = (hb0 + kh * HPW) * 8, o1 = (hb1 + kh * HPW) * 8;
-          bf16x8 bq = tr_pair(ldsX, o0, o1);
+          bf16x8 bq[NP];
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) bq[pl] = tr_pair(ldsX + pl * XB, o0, o1);
           if constexpr (SPLIT) {
-            bf16x8 bl = tr_pair(ldsXlo, o0, o1);
+#define PH_MM(PI, PJ)                                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+      acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI][j], bq[PJ], acc[ai][j], 0, 0, 0);
+            PH_SPLIT_PAIRS(PH_MM)
+#undef PH_MM
+          } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], bq, acc[ai][j], 0, 0, 0);
-              acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bl, acc[ai][j], 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j)
+              acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][j], bq[0], acc[ai][j], 0, 0, 0);
           }
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq, acc[ai][j], 0, 0, 0);
         }
       }
     }
@@ -288,9 +294,9 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     const int lds = XB + WB;
     if (set_lds(stem_fwd_kernel<bf16>, lds, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, *p);
-  } else if (prec == PH_PREC_BF16X3) {
+  } else if (prec == PH_PREC_BF16X6) {
     static bool done = false;
-    const int lds = 2 * (XB + WB);
+    const int lds = PH_NPLANES * (XB + WB);
     if (set_lds(stem_fwd_kernel<float>, lds, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, *p);
   } else {
@@ -307,10 +313,10 @@ int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
     static bool done = false;
     if (set_lds(stem_wgrad_kernel<bf16>, base, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_wgrad_kernel<bf16>, grid, dim3(256), base, st, *p);
-  } else if (prec == PH_PREC_BF16X3) {
+  } else if (prec == PH_PREC_BF16X6) {
     static bool done = false;
-    if (set_lds(stem_wgrad_kernel<float>, 2 * base, done)) return PH_ELAUNCH;
-    hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), 2 * base, st, *p);
+    if (set_lds(stem_wgrad_kernel<float>, PH_NPLANES * base, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), PH_NPLANES * base, st, *p);
   } else {
     return PH_EINVAL;
   }

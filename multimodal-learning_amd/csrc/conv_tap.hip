@@ -10,8 +10,9 @@
 //   W: packed [tap][Cout][Cin] bf16 (cin contiguous = the MFMA K direction), staged per tap group.
 //   MFMA: v_mfma_f32_32x32x16_bf16; rows = pixels, cols = cout, so per-channel BatchNorm partial sums
 //      are plain in-register sums over the accumulator registers (cout lives on the lane).
-// Precision: T = bf16 -> perf mode (1 MFMA / k-step).  T = float -> parity mode: fp32 activations are
-//   split hi/lo bf16 while staging, weights come as hi/lo planes, 3 MFMAs / k-step (bf16x3).
+// Precision: T = bf16 -> perf mode (1 MFMA / k-step).  T = float -> parity mode "bf16x6": fp32 activations are
+//   split into 3 bf16 planes while staging, weights come as 3 planes, 6 MFMAs / k-step reproduce the fp32
+//   products to ~2^-24 (fp32 accumulate as in the reference).
 #include "ph_common.h"
 #include "ph_kernels.h"
 
@@ -26,7 +27,8 @@ struct TapCfg {
   static constexpr int HP = HPH * HPW;
   static constexpr int A_BYTES = HP * 128;
   static constexpr int B_BYTES = TG * BNT * 128;
-  static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) * (SPLIT ? 2 : 1);
+  static constexpr int NP = SPLIT ? PH_NPLANES : 1;
+  static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) * NP;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(WM * FM * 32 == TH * TW, "M tiling");
   static_assert(WN * FN * 32 == BNT, "N tiling");
@@ -36,12 +38,10 @@ template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, in
 __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   using C = TapCfg<T, S, TH, BNT, WM, WN, FM, FN, TG>;
   constexpr bool SPLIT = C::SPLIT;
-  constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP;
+  constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP, NP = C::NP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsA = smem;
-  unsigned char* ldsAlo = smem + C::A_BYTES;
-  unsigned char* ldsB = smem + C::A_BYTES * (SPLIT ? 2 : 1);
-  unsigned char* ldsBlo = ldsB + C::B_BYTES;
+  unsigned char* ldsA = smem;                      // NP planes of A_BYTES
+  unsigned char* ldsB = smem + C::A_BYTES * NP;    // NP planes of B_BYTES
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -51,8 +51,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   const int n0 = blockIdx.y * BNT;
   const int b = blockIdx.z;
   const T* in = reinterpret_cast<const T*>(p.in) + (size_t)b * p.IH * p.IW * p.Cin;
-  const bf16* whi = reinterpret_cast<const bf16*>(p.w_hi);
-  const bf16* wlo = reinterpret_cast<const bf16*>(p.w_lo);
+  const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
   const int iy_base = r0 * S + p.iy0, ix_base = c0 * S + p.ix0;
 
   f32x16 acc[FM][FN];
@@ -95,11 +94,12 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
         if (ok) load8(in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8, v);
-        bf16x8 hi, lo;
+        bf16x8 p0, p1, p2;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { bf16 h, l; split_bf16(v[q], h, l); hi[q] = h; lo[q] = l; }
-        *reinterpret_cast<bf16x8*>(ldsA + off) = hi;
-        *reinterpret_cast<bf16x8*>(ldsAlo + off) = lo;
+        for (int q = 0; q < 8; ++q) { bf16 a, b2, c2; split3_bf16(v[q], a, b2, c2); p0[q] = a; p1[q] = b2; p2[q] = c2; }
+        *reinterpret_cast<bf16x8*>(ldsA + off) = p0;
+        *reinterpret_cast<bf16x8*>(ldsA + C::A_BYTES + off) = p1;
+        *reinterpret_cast<bf16x8*>(ldsA + 2 * C::A_BYTES + off) = p2;
       }
     }
     for (int tg0 = 0; tg0 < p.ntaps; tg0 += TG) {
@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
         const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
         const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
         const int off = (t * BNT + row) * 128 + ((ch ^ (row & 7)) << 4);
-        *reinterpret_cast<u32x4*>(ldsB + off) = *reinterpret_cast<const u32x4*>(whi + g);
-        if constexpr (SPLIT) *reinterpret_cast<u32x4*>(ldsBlo + off) = *reinterpret_cast<const u32x4*>(wlo + g);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          *reinterpret_cast<u32x4*>(ldsB + pl * C::B_BYTES + off) =
+              *reinterpret_cast<const u32x4*>(wbase + (size_t)pl * p.wplane + g);
       }
       __syncthreads();
       // ---- MFMA over the group's taps x 4 k16-steps
@@ -123,34 +125,31 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int chunk = ks * 2 + khalf;
-          bf16x8 a[FM], bq[FN];
+          bf16x8 a[NP][FM], bq[NP][FN];
 #pragma unroll
-          for (int i = 0; i < FM; ++i)
-            a[i] = *reinterpret_cast<const bf16x8*>(ldsA + hp[i] * 128 + ((chunk ^ (hp[i] & 7)) << 4));
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            bq[j] = *reinterpret_cast<const bf16x8*>(ldsB + (t * BNT + nrow[j]) * 128 + ((chunk ^ (nrow[j] & 7)) << 4));
-          if constexpr (SPLIT) {
-            bf16x8 al[FM], bl[FN];
+          for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
-              al[i] = *reinterpret_cast<const bf16x8*>(ldsAlo + hp[i] * 128 + ((chunk ^ (hp[i] & 7)) << 4));
+              a[pl][i] = *reinterpret_cast<const bf16x8*>(ldsA + pl * C::A_BYTES + hp[i] * 128 +
+                                                          ((chunk ^ (hp[i] & 7)) << 4));
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-              bl[j] = *reinterpret_cast<const bf16x8*>(ldsBlo + (t * BNT + nrow[j]) * 128 + ((chunk ^ (nrow[j] & 7)) << 4));
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-              for (int j = 0; j < FN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bq[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
-              }
+              bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsB + pl * C::B_BYTES + (t * BNT + nrow[j]) * 128 +
+                                                           ((chunk ^ (nrow[j] & 7)) << 4));
           }
+          if constexpr (SPLIT) {
+#define PH_MM(PI, PJ)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < FN; ++j)          \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI][i], bq[PJ][j], acc[i][j], 0, 0, 0);
+            PH_SPLIT_PAIRS(PH_MM)
+#undef PH_MM
+          } else {
 #pragma unroll
-          for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], bq[0][j], acc[i][j], 0, 0, 0);
+          }
         }
       }
     }
@@ -234,26 +233,28 @@ int launch_cfg(const PhTapConv& p, hipStream_t st) {
 template <typename T>
 int launch_T(const PhTapConv& p, int S, hipStream_t st) {
   constexpr bool SPLIT = is_f32<T>::value;
+  constexpr int TG = SPLIT ? 1 : 3;   // parity mode stages one tap at a time (3 planes must fit 160 KB LDS)
   if (S == 1) {
-    if (p.Cout % 128 == 0) return launch_cfg<T, 1, 8, 128, 2, 2, 2, 2, 3>(p, st);
-    return launch_cfg<T, 1, 16, 64, 4, 1, 2, 2, 3>(p, st);
+    if (p.Cout % 128 == 0) return launch_cfg<T, 1, 8, 128, 2, 2, 2, 2, TG>(p, st);
+    return launch_cfg<T, 1, 16, 64, 4, 1, 2, 2, TG>(p, st);
   } else {
-    if (p.Cout % 128 == 0) return launch_cfg<T, 2, 4, 128, 1, 4, 2, 1, SPLIT ? 1 : 3>(p, st);
-    return launch_cfg<T, 2, 4, 64, 2, 2, 1, 1, SPLIT ? 1 : 3>(p, st);
+    if (p.Cout % 128) return PH_EINVAL;   // stride-2 forward convs of ResNet-18 all have Cout >= 128
+    if constexpr (SPLIT) return launch_cfg<T, 2, 2, 128, 1, 4, 1, 1, 1>(p, st);
+    else return launch_cfg<T, 2, 4, 128, 1, 4, 2, 1, 3>(p, st);
   }
 }
 
 }  // namespace
 
 // number of statistic partial rows a launch writes: B * tiles
-int ph_tapconv_stat_parts(const PhTapConv* p, int S) {
-  int TH = (S == 1) ? ((p->Cout % 128 == 0) ? 8 : 16) : 4;
+int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
+  const int TH = (S == 1) ? ((p->Cout % 128 == 0) ? 8 : 16) : (prec == PH_PREC_BF16 ? 4 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
 }
 
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->ntaps < 1 || p->ntaps > 9 || (S != 1 && S != 2)) return PH_EINVAL;
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
-  if (prec == PH_PREC_BF16X3) return launch_T<float>(*p, S, st);
+  if (prec == PH_PREC_BF16X6) return launch_T<float>(*p, S, st);
   return PH_EINVAL;
 }

@@ -23,26 +23,29 @@ struct WgCfg {
   static constexpr int TW = 16, BM = TH * TW;
   static constexpr int HPH = (TH - 1) * S + KS, HPW = (TW - 1) * S + KS, HP = HPH * HPW;
   static constexpr int D_BYTES = BM * 128, X_BYTES = HP * 128;
-  static constexpr int LDS_BYTES = (D_BYTES + X_BYTES) * (SPLIT ? 2 : 1);
+  static constexpr int NP = SPLIT ? PH_NPLANES : 1;
+  static constexpr int LDS_BYTES = (D_BYTES + X_BYTES) * NP;
   static constexpr int NT = KS * KS;
 };
 
+// stage 8 channels of one pixel into plane 0 (bf16) or into the 3 split planes (fp32 source)
 template <typename T>
-__device__ __forceinline__ void stage_row(const T* src, bool ok, unsigned char* hi, unsigned char* lo, int off) {
+__device__ __forceinline__ void stage_row(const T* src, bool ok, unsigned char* base, int plane_bytes, int off) {
   if constexpr (!is_f32<T>::value) {
     u32x4 v = {0u, 0u, 0u, 0u};
     if (ok) v = *reinterpret_cast<const u32x4*>(src);
-    *reinterpret_cast<u32x4*>(hi + off) = v;
+    *reinterpret_cast<u32x4*>(base + off) = v;
   } else {
     float v[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = 0.f;
     if (ok) load8(src, v);
-    bf16x8 h8, l8;
+    bf16x8 p0, p1, p2;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { bf16 h, l; split_bf16(v[q], h, l); h8[q] = h; l8[q] = l; }
-    *reinterpret_cast<bf16x8*>(hi + off) = h8;
-    *reinterpret_cast<bf16x8*>(lo + off) = l8;
+    for (int q = 0; q < 8; ++q) { bf16 a, b, c; split3_bf16(v[q], a, b, c); p0[q] = a; p1[q] = b; p2[q] = c; }
+    *reinterpret_cast<bf16x8*>(base + off) = p0;
+    *reinterpret_cast<bf16x8*>(base + plane_bytes + off) = p1;
+    *reinterpret_cast<bf16x8*>(base + 2 * plane_bytes + off) = p2;
   }
 }
 
@@ -59,12 +62,10 @@ template <typename T, int S, int TH, int KS>
 __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   using C = WgCfg<T, S, TH, KS>;
   constexpr bool SPLIT = C::SPLIT;
-  constexpr int TW = C::TW, BM = C::BM, HPW = C::HPW, HP = C::HP, NT = C::NT;
+  constexpr int TW = C::TW, BM = C::BM, HPW = C::HPW, HP = C::HP, NT = C::NT, NP = C::NP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsD = smem;
-  unsigned char* ldsX = smem + C::D_BYTES;
-  unsigned char* ldsDlo = smem + C::D_BYTES + C::X_BYTES;
-  unsigned char* ldsXlo = ldsDlo + C::D_BYTES;
+  unsigned char* ldsD = smem;                      // NP planes of D_BYTES
+  unsigned char* ldsX = smem + C::D_BYTES * NP;    // NP planes of X_BYTES
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cf = wave >> 1, kf = wave & 1;     // 32-wide cout / cin fragment of this wave
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
       const bool ok = r < p.OH && c < p.OW;
       const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
-      stage_row<T>(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8, ok, ldsD, ldsDlo, off);
+      stage_row<T>(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8, ok, ldsD, C::D_BYTES, off);
     }
     const int iy_base = r0 * S - p.pad, ix_base = c0 * S - p.pad;
     for (int i = tid; i < HP * 8; i += 256) {
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       const int iy = iy_base + hr, ix = ix_base + hc;
       const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
       const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
-      stage_row<T>(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8, ok, ldsX, ldsXlo, off);
+      stage_row<T>(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8, ok, ldsX, C::X_BYTES, off);
     }
     __syncthreads();
     // ---- K loop over the tile's pixels, 16 per MFMA
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       const int t0 = kk * 16 + 8 * khalf + q4, t1 = t0 + 4;
       const int offA0 = t0 * 128 + sw_piece(t0, pieceA) * 32 + p4 * 8;
       const int offA1 = t1 * 128 + sw_piece(t1, pieceA) * 32 + p4 * 8;
-      bf16x8 a = tr_pair(ldsD, offA0, offA1);
-      bf16x8 al;
-      if constexpr (SPLIT) al = tr_pair(ldsDlo, offA0, offA1);
+      bf16x8 a[NP];
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) a[pl] = tr_pair(ldsD + pl * C::D_BYTES, offA0, offA1);
       const int hb0 = ((t0 >> 4) * S) * HPW + (t0 & 15) * S;
       const int hb1 = ((t1 >> 4) * S) * HPW + (t1 & 15) * S;
 #pragma unroll
@@ -128,13 +129,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int h0 = hb0 + toff, h1 = hb1 + toff;
         const int offB0 = h0 * 128 + sw_piece(h0, pieceB) * 32 + p4 * 8;
         const int offB1 = h1 * 128 + sw_piece(h1, pieceB) * 32 + p4 * 8;
-        bf16x8 bq = tr_pair(ldsX, offB0, offB1);
+        bf16x8 bq[NP];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) bq[pl] = tr_pair(ldsX + pl * C::X_BYTES, offB0, offB1);
         if constexpr (SPLIT) {
-          bf16x8 bl = tr_pair(ldsXlo, offB0, offB1);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bq, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[t], 0, 0, 0);
+#define PH_MM(PI, PJ) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ], acc[t], 0, 0, 0);
+          PH_SPLIT_PAIRS(PH_MM)
+#undef PH_MM
+        } else {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[t], 0, 0, 0);
         }
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[t], 0, 0, 0);
       }
     }
   }
@@ -190,8 +194,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   dw[((size_t)co * Cin + ci) * NT + t] = s;
 }
 
-__global__ void pack_w_kernel(const float* __restrict__ w, bf16* __restrict__ hi, bf16* __restrict__ lo, int O, int I,
-                              int NT, int dgrad) {
+__global__ void pack_w_kernel(const float* __restrict__ w, bf16* __restrict__ planes, int O, int I, int NT,
+                              int dgrad) {
   // w OIHW [O][I][NT].  fwd layout [tap][O][I]; dgrad layout [tap][I][O]
   const size_t n = (size_t)NT * O * I;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,13 +204,12 @@ __global__ void pack_w_kernel(const float* __restrict__ w, bf16* __restrict__ hi
   if (!dgrad) { ii = i % I; o = (i / I) % O; t = i / ((size_t)I * O); }
   else        { o = i % O; ii = (i / O) % I; t = i / ((size_t)I * O); }
   const float v = w[((size_t)o * I + ii) * NT + t];
-  bf16 h, l;
-  split_bf16(v, h, l);
-  hi[i] = h;
-  if (lo) lo[i] = l;
+  bf16 a, b, c;
+  split3_bf16(v, a, b, c);
+  planes[i] = a; planes[n + i] = b; planes[2 * n + i] = c;
 }
 
-__global__ void pack_w_stem_kernel(const float* __restrict__ w, bf16* __restrict__ hi, bf16* __restrict__ lo) {
+__global__ void pack_w_stem_kernel(const float* __restrict__ w, bf16* __restrict__ planes) {
   // w [64][3][7][7] -> [kh 7][cout 64][kw 8 x ch 4], zero padded
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 7 * 64 * 32) return;
@@ -214,10 +217,9 @@ __global__ void pack_w_stem_kernel(const float* __restrict__ w, bf16* __restrict
   const int kw = k >> 2, ch = k & 3;
   float v = 0.f;
   if (kw < 7 && ch < 3) v = w[((co * 3 + ch) * 7 + kh) * 7 + kw];
-  bf16 h, l;
-  split_bf16(v, h, l);
-  hi[i] = h;
-  if (lo) lo[i] = l;
+  bf16 a, b, c;
+  split3_bf16(v, a, b, c);
+  planes[i] = a; planes[7 * 64 * 32 + i] = b; planes[2 * 7 * 64 * 32 + i] = c;
 }
 
 }  // namespace
@@ -227,7 +229,7 @@ int ph_wgrad_tile_h(int S) { return S == 1 ? 8 : 4; }
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->nchunks < 1) return PH_EINVAL;
   if (prec == PH_PREC_BF16) return launch_wg_T<bf16>(*p, st);
-  if (prec == PH_PREC_BF16X3) return launch_wg_T<float>(*p, st);
+  if (prec == PH_PREC_BF16X6) return launch_wg_T<float>(*p, st);
   return PH_EINVAL;
 }
 
@@ -239,22 +241,22 @@ int ph_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, int KS, in
   return PH_OK;
 }
 
-int ph_pack_w_fwd_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st) {
+int ph_pack_w_fwd_launch(const float* w, void* planes, int O, int I, int KS, hipStream_t st) {
   const size_t n = (size_t)KS * KS * O * I;
-  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (bf16*)hi, (bf16*)lo, O, I,
+  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (bf16*)planes, O, I,
                      KS * KS, 0);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
-int ph_pack_w_dgrad_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st) {
+int ph_pack_w_dgrad_launch(const float* w, void* planes, int O, int I, int KS, hipStream_t st) {
   const size_t n = (size_t)KS * KS * O * I;
-  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (bf16*)hi, (bf16*)lo, O, I,
+  hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, (bf16*)planes, O, I,
                      KS * KS, 1);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
-int ph_pack_w_stem_launch(const float* w, void* hi, void* lo, hipStream_t st) {
-  hipLaunchKernelGGL(pack_w_stem_kernel, dim3((7 * 64 * 32 + 255) / 256), dim3(256), 0, st, w, (bf16*)hi, (bf16*)lo);
+int ph_pack_w_stem_launch(const float* w, void* planes, hipStream_t st) {
+  hipLaunchKernelGGL(pack_w_stem_kernel, dim3((7 * 64 * 32 + 255) / 256), dim3(256), 0, st, w, (bf16*)planes);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

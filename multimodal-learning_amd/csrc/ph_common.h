@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // precision modes of the C-ABI (activation storage type follows the mode)
 #define PH_PREC_BF16 0    // perf mode: bf16 operands+activations, fp32 accumulate / statistics
-#define PH_PREC_BF16X3 1  // parity mode: fp32 activations, operands split hi/lo bf16, 3 MFMA products
+#define PH_PREC_BF16X6 1  // parity mode: fp32 activations, operands split into 3 bf16 planes, 6 MFMA products
 
 #define PH_LAUNCH_CHECK()                                  \
   do {                                                     \
@@ -64,11 +64,18 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
-// hi/lo bf16 split of an fp32 value (bf16x3 parity mode): x ~= hi + lo, |x - hi - lo| <= 2^-17 |x|
-__device__ __forceinline__ void split_bf16(float x, bf16& hi, bf16& lo) {
-  hi = (bf16)x;
-  lo = (bf16)(x - (float)hi);
+// 3-way bf16 split of an fp32 value (parity mode "bf16x6"): x = p0 + p1 + p2 exactly (3 x 8 significant
+// bits = the fp32 mantissa).  Products p_i*q_j with i+j <= 2 (6 MFMAs) reproduce the fp32 product to
+// ~2^-24 relative; accumulation is fp32 as in the reference.
+__device__ __forceinline__ void split3_bf16(float x, bf16& p0, bf16& p1, bf16& p2) {
+  p0 = (bf16)x;
+  const float r1 = x - (float)p0;
+  p1 = (bf16)r1;
+  p2 = (bf16)(r1 - (float)p1);
 }
+constexpr int PH_NPLANES = 3;
+// the (i, j) plane pairs, least significant first
+#define PH_SPLIT_PAIRS(X) X(2, 0) X(0, 2) X(1, 1) X(1, 0) X(0, 1) X(0, 0)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

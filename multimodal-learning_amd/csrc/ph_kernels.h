@@ -6,8 +6,8 @@
 
 struct PhTapConv {
   const void* in;        // [B][IH][IW][Cin]   activation type T of the precision mode
-  const void* w_hi;      // [nslabs][Cout][Cin] bf16
-  const void* w_lo;      // idem (parity mode only)
+  const void* w;         // [nplanes][nslabs][Cout][Cin] bf16 (1 plane in perf mode, 3 in parity mode)
+  size_t wplane;         // elements per plane
   void* out;             // [B][OH][OW][Cout]
   float* stats;          // [B*tiles][2][Cout] per-workgroup sum / sum-of-squares partials, or null
   const void* res_g;     // optional: out += res_g * (res_a > 0 | 1)   (dgrad residual fusion)
@@ -22,7 +22,7 @@ struct PhTapConv {
   int wtap[9];           // weight slab index of each tap
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
-int ph_tapconv_stat_parts(const PhTapConv* p, int S);
+int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec);
 
 struct PhWgrad {
   const void* x;         // [B][IH][IW][Cin]
@@ -39,8 +39,8 @@ int ph_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, int K
 
 struct PhStem {
   const void* x4;        // [B][IH][IW][4]
-  const void* w_hi;      // [7][64][32] bf16: k = kw*4 + ch, kw==7 and ch==3 are zero
-  const void* w_lo;
+  const void* w;         // [nplanes][7][64][32] bf16: k = kw*4 + ch, kw==7 and ch==3 are zero
+  size_t wplane;
   void* out;             // [B][OH][OW][64]
   float* stats;          // [B*tiles][2][64]
   int B, IH, IW, OH, OW;
@@ -56,10 +56,10 @@ struct PhStemWgrad {
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st);
 int ph_stem_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, hipStream_t st);
 
-// weight packing (OIHW fp32 -> MFMA-friendly bf16 hi/lo planes)
-int ph_pack_w_fwd_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st);   // [tap][O][I]
-int ph_pack_w_dgrad_launch(const float* w, void* hi, void* lo, int O, int I, int KS, hipStream_t st); // [tap][I][O]
-int ph_pack_w_stem_launch(const float* w, void* hi, void* lo, hipStream_t st);                        // [7][64][32]
+// weight packing (OIHW fp32 -> MFMA-friendly bf16, 3 split planes of `plane` elements each)
+int ph_pack_w_fwd_launch(const float* w, void* planes, int O, int I, int KS, hipStream_t st);   // [tap][O][I]
+int ph_pack_w_dgrad_launch(const float* w, void* planes, int O, int I, int KS, hipStream_t st); // [tap][I][O]
+int ph_pack_w_stem_launch(const float* w, void* planes, hipStream_t st);                        // [7][64][32]
 
 // ---- BatchNorm / elementwise (bn_act.hip).  `prec` selects the activation type (bf16 | float).
 int ph_pack_input_launch(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st);

@@ -69,7 +69,7 @@ int stem_chunks(int B, int OH, int OW, int* tpc) {
 extern "C" {
 
 PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
-  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X3)) return nullptr;
+  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X6)) return nullptr;
   PhResnetPlan* P = new (std::nothrow) PhResnetPlan();
   if (!P) return nullptr;
   P->B = B; P->H = H; P->W = W; P->prec = prec; P->es = prec == PH_PREC_BF16 ? 2 : 4;
@@ -81,7 +81,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   Unit s{};
   s.Cin = 3; s.Cout = 64; s.KS = 7; s.S = 2; s.pad = 3; s.IH = H; s.IW = W;
   s.OH = (H + 6 - 7) / 2 + 1; s.OW = (W + 6 - 7) / 2 + 1;
-  s.wplane = 7 * 64 * 32; s.wf_off = woff; woff += 2 * s.wplane; s.wd_off = 0;
+  s.wplane = 7 * 64 * 32; s.wf_off = woff; woff += PH_NPLANES * s.wplane; s.wd_off = 0;
   s.y_off = take((size_t)B * s.OH * s.OW * 64 * es);
   s.st_off = take(4 * 64 * sizeof(float));
   P->units.push_back(s);
@@ -107,12 +107,12 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
         u.Cin = cin; u.Cout = cout; u.KS = ks; u.S = st; u.pad = pad; u.IH = uih; u.IW = uiw;
         u.OH = (uih + 2 * pad - ks) / st + 1; u.OW = (uiw + 2 * pad - ks) / st + 1;
         u.wplane = (size_t)ks * ks * cin * cout;
-        u.wf_off = woff; woff += 2 * u.wplane;
-        u.wd_off = woff; woff += 2 * u.wplane;
+        u.wf_off = woff; woff += PH_NPLANES * u.wplane;
+        u.wd_off = woff; woff += PH_NPLANES * u.wplane;
         u.y_off = take((size_t)B * u.OH * u.OW * cout * es);
         u.st_off = take(4 * (size_t)cout * sizeof(float));
         PhTapConv tc{}; tc.B = B; tc.Cout = cout; tc.OHt = u.OH; tc.OWt = u.OW;
-        parts_max = std::max(parts_max, (size_t)ph_tapconv_stat_parts(&tc, st) * 2 * cout * sizeof(float));
+        parts_max = std::max(parts_max, (size_t)ph_tapconv_stat_parts(&tc, st, prec) * 2 * cout * sizeof(float));
         int tpc; int nc = wgrad_chunks(u, B, &tpc);
         slab_max = std::max(slab_max, (size_t)nc * ks * ks * cin * cout * sizeof(float));
         P->units.push_back(u);
@@ -165,11 +165,11 @@ int ph_resnet_pack_weights(const PhResnetPlan* P, const void* const* params, voi
     const float* w = reinterpret_cast<const float*>(params[i * 6 + 0]);
     int rc;
     if (i == 0) {
-      rc = ph_pack_w_stem_launch(w, pk + u.wf_off, pk + u.wf_off + u.wplane, st);
+      rc = ph_pack_w_stem_launch(w, pk + u.wf_off, st);
     } else {
-      rc = ph_pack_w_fwd_launch(w, pk + u.wf_off, pk + u.wf_off + u.wplane, u.Cout, u.Cin, u.KS, st);
+      rc = ph_pack_w_fwd_launch(w, pk + u.wf_off, u.Cout, u.Cin, u.KS, st);
       if (rc) return rc;
-      rc = ph_pack_w_dgrad_launch(w, pk + u.wd_off, pk + u.wd_off + u.wplane, u.Cout, u.Cin, u.KS, st);
+      rc = ph_pack_w_dgrad_launch(w, pk + u.wd_off, u.Cout, u.Cin, u.KS, st);
     }
     if (rc) return rc;
   }
@@ -196,7 +196,7 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhTapConv t{};
-  t.in = in; t.w_hi = c.pk + u.wf_off; t.w_lo = c.pk + u.wf_off + u.wplane;
+  t.in = in; t.w = c.pk + u.wf_off; t.wplane = u.wplane;
   t.out = c.ws + u.y_off; t.stats = reinterpret_cast<float*>(c.ws + P->parts_off);
   t.B = P->B; t.IH = u.IH; t.IW = u.IW; t.Cin = u.Cin; t.Cout = u.Cout;
   t.OHt = u.OH; t.OWt = u.OW; t.OH = u.OH; t.OW = u.OW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
@@ -204,7 +204,7 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / u.KS; t.dx[k] = k % u.KS; t.wtap[k] = k; }
   int rc = ph_tapconv_launch(&t, u.S, P->prec, c.st);
   if (rc) return rc;
-  const int nparts = ph_tapconv_stat_parts(&t, u.S);
+  const int nparts = ph_tapconv_stat_parts(&t, u.S, P->prec);
   float* rm = c.update_running ? (float*)c.params[ui * 6 + 3] : nullptr;
   return ph_bn_finalize_launch(t.stats, nparts, u.Cout, (double)P->B * u.OH * u.OW, 1e-5f, 0.1f,
                                (const float*)c.params[ui * 6 + 1], (const float*)c.params[ui * 6 + 2], c.stat(u, 0),
@@ -217,7 +217,7 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhTapConv t{};
-  t.in = dy; t.w_hi = c.pk + u.wd_off; t.w_lo = c.pk + u.wd_off + u.wplane;
+  t.in = dy; t.w = c.pk + u.wd_off; t.wplane = u.wplane;
   t.out = dx; t.stats = nullptr; t.res_g = res_g; t.res_a = res_a;
   t.B = P->B; t.IH = u.OH; t.IW = u.OW; t.Cin = u.Cout; t.Cout = u.Cin;
   t.OH = u.IH; t.OW = u.IW;
@@ -304,7 +304,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
     const Unit& u = P->units[0];
     PhStem s{};
-    s.x4 = ws + P->x4_off; s.w_hi = c.pk + u.wf_off; s.w_lo = c.pk + u.wf_off + u.wplane;
+    s.x4 = ws + P->x4_off; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
     s.out = ws + u.y_off; s.stats = reinterpret_cast<float*>(ws + P->parts_off);
     s.B = P->B; s.IH = P->H; s.IW = P->W; s.OH = u.OH; s.OW = u.OW;
     if ((rc = ph_stem_fwd_launch(&s, P->prec, st))) return rc;

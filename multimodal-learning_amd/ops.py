@@ -10,7 +10,7 @@ from ._lib import lib, check, ptr, stream, require_cuda
 
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD = 0, 1, 2, 3
-PREC_BF16, PREC_BF16X3 = 0, 1
+PREC_BF16, PREC_BF16X6 = 0, 1
 
 _precision = PREC_BF16
 _weight_epoch = 0
@@ -28,9 +28,9 @@ def weight_epoch():
 
 
 def set_precision(mode):
-    """'bf16' (perf mode) or 'bf16x3' (parity mode: fp32 activations, split-bf16 3-product MFMA)."""
+    """'bf16' (perf mode) or 'bf16x6' (parity mode: fp32 activations, 3-plane split-bf16 6-product MFMA, fp32-equivalent)."""
     global _precision
-    _precision = {"bf16": PREC_BF16, "bf16x3": PREC_BF16X3, PREC_BF16: PREC_BF16, PREC_BF16X3: PREC_BF16X3}[mode]
+    _precision = {"bf16": PREC_BF16, "bf16x6": PREC_BF16X6, PREC_BF16: PREC_BF16, PREC_BF16X6: PREC_BF16X6}[mode]
 
 
 def get_precision():

@@ -13,9 +13,14 @@ def nchw_cpu(y):
     return y.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
+def _d(a):
+    if torch.is_tensor(a):
+        return a.detach().double().cpu()
+    return torch.as_tensor(np.asarray(a)).double()
+
+
 def maxerr(a, b):
-    a = torch.as_tensor(np.asarray(a)).double() if not torch.is_tensor(a) else a.detach().double().cpu()
-    b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().double().cpu()
+    a, b = _d(a), _d(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     return (a - b).abs().max().item(), a.abs().max().item()
 
@@ -24,3 +29,26 @@ def assert_close(ref, got, atol, rtol=0.0, what=""):
     err, mx = maxerr(ref, got)
     assert err <= atol + rtol * mx, f"{what}: max|err| {err:.3e} > {atol:.1e} + {rtol:.1e}*{mx:.3e}"
     return err
+
+
+class Report:
+    """Collects every comparison of a test, prints the whole table, fails at the end if any exceeded its
+    tolerance (one GPU round trip shows all errors instead of the first)."""
+
+    def __init__(self, title):
+        self.title, self.rows = title, []
+
+    def close(self, ref, got, atol, rtol=0.0, what=""):
+        err, mx = maxerr(ref, got)
+        self.rows.append((what, err, mx, atol + rtol * mx))
+        return err
+
+    def finish(self):
+        print(f"\n== {self.title}")
+        bad = []
+        for what, err, mx, tol in self.rows:
+            flag = "" if err <= tol else "   <-- FAIL"
+            print(f"   {what:<34s} max|err| {err:9.3e}   max|ref| {mx:9.3e}   tol {tol:9.3e}{flag}")
+            if err > tol:
+                bad.append(what)
+        assert not bad, f"{self.title}: out of tolerance: {bad}"
