@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ROI-tiles/sec of one full teacher+student distillation step
+(reference MICCAI-2022/train_test_path_multi_distill.py:242-330: student fwd+bwd, EMA fwd, teacher fwd,
+2x KL, 2x CRD with DC-Distill selection, GK-Refine, Adam, EMA) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json configs[1]): per-GPU batch 64 synthetic 512x512 ROI tiles + 320-d genomic vectors,
+bf16 perf mode, README stage-2 flags, dropout 0.1 (the reference default: teacher Dropout/AlphaDropout live),
+n_data = 1024 CRD bank rows.  Weak scaling: 64 tiles per GPU at every N.  Inputs are resident in HBM
+before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+CLS_NAMES = ["tapconv_kernel<bf16,S=1,TH=16,BNT=64> (Cout=64 fwd+dgrad)",
+             "tapconv_kernel<bf16,S=1,TH=8,BNT=128> (Cout>=128 fwd+dgrad)",
+             "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
+             "stem_wgrad_kernel<bf16>"]
+
+
+def make_batch(B, H, n_data, opt, device, seed):
+    import torch
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1234 + seed)
+    x_path = torch.rand(B, 3, H, H, generator=g) * 2 - 1
+    ema_x_path = x_path + 0.01 * torch.randn(B, 3, H, H, generator=g)
+    x_omic = torch.randn(B, opt.input_size_omic, generator=g)
+    grade = torch.randint(0, 3, (B,), generator=g)
+    index = torch.randperm(n_data, generator=g)[:B]
+    sample_idx = torch.randint(0, n_data, (B, opt.nce_p + opt.nce_k), generator=g)
+    sample_idx[:, 0] = index
+    z = torch.zeros(B)
+    d = lambda t: t.to(device)
+    return ((d(x_path), d(ema_x_path)), d(z), d(x_omic), d(z), d(z), d(grade), d(index), d(sample_idx))
+
+
+def cpu_baseline(nsteps=2):
+    """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/test_oracle_golden.py) timed on
+    this host for BASELINE config 1 (B=16, 224x224), 3 fwd + 1 bwd ("minimal") mode.  Threads are capped at 16:
+    at B=16 torch's CPU kernels stop scaling there (with all 256 host threads of the GPU box the same step takes
+    ~80x longer from oversubscription; the reference's own driver caps at 4, train_cv_path_multi_MT.py:2-4)."""
+    import torch
+    from oracle.step import DistillOracle, default_opt, synthetic_batch
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    orc = DistillOracle(default_opt(), seed=0, n_data=1024)
+    bt = synthetic_batch(16, 224, seed=0)
+    orc.step(bt)   # warm-up
+    t0 = time.time()
+    for i in range(nsteps):
+        orc.step(synthetic_batch(16, 224, seed=1 + i))
+    dt = (time.time() - t0) / nsteps
+    return {"value": round(16.0 / dt, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps} distill steps of BASELINE config 1 (B=16, 224x224, 320-d omic, fp32, 3 fwd + 1 bwd), "
+                      f"{dt:.2f} s/step after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import multimodal_learning_amd as m
+    sync = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+        sync = m.dist.ReplicaSync()
+    m.set_precision("bf16")
+    opt = m.stage2_opt(dropout_rate=0.1, batch_size=args.batch)
+    n_data = 1024
+    torch.manual_seed(0)
+    np.random.seed(2019 + rank)
+    step = m.DistillStep(opt, n_data, device=device, sync=sync)
+    for crd in (step.criterion_kd, step.criterion_kd_path):
+        crd.contrast.verbose = False
+    batches = [make_batch(args.batch, args.size, n_data, opt, device, seed=rank * 100 + i) for i in range(2)]
+    if sync is not None:
+        np.random.seed(2019)   # the 'mid' rank draw is host RNG state shared by all replicas
+
+    L = m.lib()
+    for i in range(args.warmup):
+        step.step(batches[i % 2], epoch=1)
+    if not args.no_kernel_timer:
+        L.ph_prof_reset(); L.ph_prof_enable(1)
+    if sync is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step.step(batches[i % 2], epoch=1)
+    torch.cuda.synchronize()
+    if sync is not None:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    L.ph_prof_enable(0)
+    if sync is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    loss = out["loss"].item()
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss in benchmark: %r" % loss)
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        res = {"metric": "ROI-tiles/sec (teacher+student distill step)", "value": round(tiles / dt, 2),
+               "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: teacher+student distill step, bf16, batch 64 per GPU, "
+                                      "512x512 tiles, 320-d omic, CRD P=300/K=700->P2=20/K2=512, n_data=1024, "
+                                      "GK-Refine on, Adam+EMA, dropout 0.1",
+                          "tiles_per_gpu": args.batch, "tile": args.size, "global_batch": args.batch * world,
+                          "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4)}}
+        # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region)
+        if not args.no_kernel_timer:
+            buf = (ctypes.c_double * 18)()
+            L.ph_prof_summary(buf, 6)
+            rows = [(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c in range(6)]
+            dom = max(range(6), key=lambda c: buf[3 * c + 1])
+            n, ms, fl = buf[3 * dom], buf[3 * dom + 1], buf[3 * dom + 2]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(str(dom))
+                except Exception:
+                    traffic = None
+            res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "kernel": CLS_NAMES[dom], "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
+                               "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                               "all_kernels": [{"kernel": k, "launches": int(a), "total_ms": round(b, 3),
+                                                "tflops": round(c / (b * 1e-3) / 1e12, 2) if b > 0 else 0.0}
+                                               for (k, a, b, c) in rows],
+                               "mfma_kernel_ms_per_step": round(sum(r[2] for r in rows) / args.steps, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,6 +150,15 @@ int ph_conv2d_dgrad(const void* dy, const float* w_oihw, void* dx, int B, int Ci
 int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Cin, int IH, int IW, int Cout, int KS,
                     int stride, int pad, int prec, void* ws, ph_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * In-library kernel timer for bench.py's `roofline` object: HIP events around every MFMA kernel launch on the
+ * launch stream.  Classes: 0 tap-conv Cout=64, 1 tap-conv Cout>=128 stride 1, 2 tap-conv stride 2,
+ * 3 wgrad, 4 stem forward, 5 stem wgrad.  out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic FLOPs}.
+ * ---------------------------------------------------------------------------------------------- */
+int ph_prof_enable(int on);
+int ph_prof_reset(void);
+int ph_prof_summary(double* out, int nclasses);
+
 #ifdef __cplusplus
 }
 #endif

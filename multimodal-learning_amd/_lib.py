@@ -52,6 +52,9 @@ SIGNATURES = {
     "ph_gk_scale": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),
     "ph_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, f64, vp]),
     "ph_ema_update": (i32, [vp, vp, sz, f32, vp]),
+    "ph_prof_enable": (i32, [i32]),
+    "ph_prof_reset": (i32, []),
+    "ph_prof_summary": (i32, [vp, i32]),
     "ph_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "ph_conv2d_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ph_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),

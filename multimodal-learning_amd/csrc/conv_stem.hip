@@ -289,6 +289,9 @@ int ph_stem_stat_parts(int B, int OH, int OW) { return B * cdiv(OH, TH) * cdiv(O
 
 int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
   dim3 grid(cdiv(p->OH, TH) * cdiv(p->OW, TW), 1, p->B);
+  void* tok = nullptr;
+  if (ph_prof_on()) ph_prof_begin(PH_CLS_STEM_FWD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0, st, &tok);
+  struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
   if (prec == PH_PREC_BF16) {
     static bool done = false;
     const int lds = XB + WB;
@@ -308,6 +311,9 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
 
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
   dim3 grid(p->nchunks);
+  void* tok = nullptr;
+  if (ph_prof_on()) ph_prof_begin(PH_CLS_STEM_WGRAD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0, st, &tok);
+  struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
   const int base = TH * TW * 128 + XB;
   if (prec == PH_PREC_BF16) {
     static bool done = false;

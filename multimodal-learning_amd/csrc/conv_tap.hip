@@ -225,7 +225,12 @@ int launch_cfg(const PhTapConv& p, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(cdiv(p.OHt, TH) * cdiv(p.OWt, 16), p.Cout / BNT, p.B);
+  void* tok = nullptr;
+  if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
+    ph_prof_begin(S == 2 ? PH_CLS_TAPCONV_S2 : (BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128),
+                  2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -166,7 +166,11 @@ int launch_wg(const PhWgrad& p, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid((p.Cout / 64) * (p.Cin / 64), p.nchunks);
+  void* tok = nullptr;
+  if (ph_prof_on())
+    ph_prof_begin(PH_CLS_WGRAD, 2.0 * p.B * p.OH * p.OW * (double)p.Cout * p.KS * p.KS * p.Cin, st, &tok);
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -4,6 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// in-library kernel timer (prof.hip); classes are indices of ph_prof_summary()
+#define PH_CLS_TAPCONV_N64 0    // tapconv_kernel<.., S=1, TH=16, BNT=64 ..>   (Cout = 64 layers)
+#define PH_CLS_TAPCONV_N128 1   // tapconv_kernel<.., S=1, TH=8, BNT=128 ..>   (Cout >= 128, stride 1)
+#define PH_CLS_TAPCONV_S2 2     // tapconv_kernel<.., S=2 ..>
+#define PH_CLS_WGRAD 3
+#define PH_CLS_STEM_FWD 4
+#define PH_CLS_STEM_WGRAD 5
+#define PH_NUM_CLS 6
+bool ph_prof_on();
+void ph_prof_begin(int cls, double work, hipStream_t st, void** token);
+void ph_prof_end(void* token, hipStream_t st);
+
 struct PhTapConv {
   const void* in;        // [B][IH][IW][Cin]   activation type T of the precision mode
   const void* w;         // [nplanes][nslabs][Cout][Cin] bf16 (1 plane in perf mode, 3 in parity mode)
