@@ -34,11 +34,28 @@ struct TapCfg {
   static_assert(WN * FN * 32 == BNT, "N tiling");
 };
 
+// LDS image addressing shared by the A (halo pixels) and B (weight rows) tiles: 128-B rows (64 bf16), two rows
+// per 256-B bank row, 16-B chunk slot XOR-swizzled with 4 bits of the row-pair index.  With the lane->pixel
+// permutation below every 16-lane ds_read_b128 group touches 16 distinct slots (no bank conflicts); the
+// previous 3-bit swizzle measured 38-54 % conflict cycles (profiles/r01_pmc_before.txt).
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return (row >> 1) * 256 + (((((row & 1) << 3) | chunk) ^ ((row >> 1) & 15)) << 4);
+}
+// MFMA A-fragment row i (0..31) -> pixel (fr, c) inside a 2 x 16 patch such that the hardware's
+// ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each read 16 CONSECUTIVE pixels of one row
+__device__ __forceinline__ void frag_row_to_pixel(int i, int& fr, int& c) {
+  const int k = i >> 2;
+  fr = __popc(k) & 1;
+  c = ((k >> 1) << 2) | (i & 3);
+}
+
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
 __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   using C = TapCfg<T, S, TH, BNT, WM, WN, FM, FN, TG>;
   constexpr bool SPLIT = C::SPLIT;
   constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP, NP = C::NP;
+  constexpr int HCH = (HP * 8 + 255) / 256;          // halo 16-B chunks per thread
+  constexpr int WCH = (TG * BNT * 8 + 255) / 256;    // weight 16-B chunks per thread (full tap group)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;                      // NP planes of A_BYTES
   unsigned char* ldsB = smem + C::A_BYTES * NP;    // NP planes of B_BYTES
@@ -63,11 +80,12 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
       for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
 
   // per-lane constant pieces of the fragment addresses
-  int prow[FM];   // (r*S)*HPW + c*S of this lane's pixel row, per M fragment
+  int prow[FM];   // (r*S)*HPW + c*S of this lane's pixel, per M fragment (fragment f covers tile rows 2f, 2f+1)
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    int m = (wm * FM + i) * 32 + (lane & 31);
-    prow[i] = ((m >> 4) * S) * HPW + (m & 15) * S;
+    int fr, c;
+    frag_row_to_pixel(lane & 31, fr, c);
+    prow[i] = (((wm * FM + i) * 2 + fr) * S) * HPW + c * S;
   }
   int nrow[FN];
 #pragma unroll
@@ -75,89 +93,177 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   const int khalf = lane >> 5;
 
   const int nslices = p.Cin >> 6;
-  for (int sl = 0; sl < nslices; ++sl) {
-    const int k0 = sl << 6;
-    __syncthreads();   // previous slice's MFMA reads of ldsA are done
-    // ---- stage the halo tile of this 64-channel slice
+  const int ngroups = (p.ntaps + TG - 1) / TG;
+  const int nstages = nslices * ngroups;
+
+  // ---- staging helpers ------------------------------------------------------------------------------
+  auto halo_src = [&](int i, int k0, bool& ok) -> const T* {
+    const int pix = i >> 3, ch = i & 7;
+    const int hr = pix / HPW, hc = pix - hr * HPW;
+    const int iy = iy_base + hr, ix = ix_base + hc;
+    ok = (i < HP * 8) && (iy >= 0) && (iy < p.IH) && (ix >= 0) && (ix < p.IW);
+    return in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8;
+  };
+  auto stage_halo_sync = [&](int k0) {   // parity mode: load, split into 3 planes, store
     for (int i = tid; i < HP * 8; i += 256) {
-      const int pix = i >> 3, ch = i & 7;
-      const int hr = pix / HPW, hc = pix - hr * HPW;
-      const int iy = iy_base + hr, ix = ix_base + hc;
-      const bool ok = (iy >= 0) && (iy < p.IH) && (ix >= 0) && (ix < p.IW);
-      const int off = pix * 128 + ((ch ^ (pix & 7)) << 4);
-      if constexpr (!SPLIT) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *reinterpret_cast<const u32x4*>(in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8);
-        *reinterpret_cast<u32x4*>(ldsA + off) = v;
-      } else {
+      bool ok;
+      const T* src = halo_src(i, k0, ok);
+      const int off = lds_off(i >> 3, i & 7);
+      if constexpr (SPLIT) {
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = 0.f;
-        if (ok) load8(in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8, v);
+        if (ok) load8(src, v);
         bf16x8 p0, p1, p2;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { bf16 a, b2, c2; split3_bf16(v[q], a, b2, c2); p0[q] = a; p1[q] = b2; p2[q] = c2; }
         *reinterpret_cast<bf16x8*>(ldsA + off) = p0;
         *reinterpret_cast<bf16x8*>(ldsA + C::A_BYTES + off) = p1;
         *reinterpret_cast<bf16x8*>(ldsA + 2 * C::A_BYTES + off) = p2;
+      } else {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u32x4*>(src);
+        *reinterpret_cast<u32x4*>(ldsA + off) = v;
       }
     }
-    for (int tg0 = 0; tg0 < p.ntaps; tg0 += TG) {
-      const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
-      if (tg0 > 0) __syncthreads();   // previous group's reads of ldsB are done
-      // ---- stage weights of this tap group: [gcount][BNT][64] bf16
-      for (int i = tid; i < gcount * BNT * 8; i += 256) {
+  };
+  auto stage_w_sync = [&](int k0, int tg0, int gcount) {
+    for (int i = tid; i < gcount * BNT * 8; i += 256) {
+      const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
+      const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
+      const int off = t * BNT * 128 + lds_off(row, ch);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<u32x4*>(ldsB + pl * C::B_BYTES + off) =
+            *reinterpret_cast<const u32x4*>(wbase + (size_t)pl * p.wplane + g);
+    }
+  };
+  // perf mode: register prefetch (issue the global loads before the MFMA block, write LDS after it)
+  u32x4 hreg[SPLIT ? 1 : HCH], wreg[SPLIT ? 1 : WCH];
+  auto load_halo_regs = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < HCH; ++e) {
+      const int i = tid + e * 256;
+      bool ok;
+      const T* src = halo_src(i, k0, ok);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *reinterpret_cast<const u32x4*>(src);
+      hreg[e] = v;
+    }
+  };
+  auto store_halo_regs = [&]() {
+#pragma unroll
+    for (int e = 0; e < HCH; ++e) {
+      const int i = tid + e * 256;
+      if (i < HP * 8) *reinterpret_cast<u32x4*>(ldsA + lds_off(i >> 3, i & 7)) = hreg[e];
+    }
+  };
+  auto load_w_regs = [&](int k0, int tg0, int gcount) {
+#pragma unroll
+    for (int e = 0; e < WCH; ++e) {
+      const int i = tid + e * 256;
+      if (i < gcount * BNT * 8) {
         const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
         const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
-        const int off = (t * BNT + row) * 128 + ((ch ^ (row & 7)) << 4);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-          *reinterpret_cast<u32x4*>(ldsB + pl * C::B_BYTES + off) =
-              *reinterpret_cast<const u32x4*>(wbase + (size_t)pl * p.wplane + g);
+        wreg[e] = *reinterpret_cast<const u32x4*>(wbase + g);
       }
-      __syncthreads();
-      // ---- MFMA over the group's taps x 4 k16-steps
-      for (int t = 0; t < gcount; ++t) {
-        const int toff = p.dy[tg0 + t] * HPW + p.dx[tg0 + t];
-        int hp[FM];
+    }
+  };
+  auto store_w_regs = [&](int gcount) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) hp[i] = prow[i] + toff;
+    for (int e = 0; e < WCH; ++e) {
+      const int i = tid + e * 256;
+      if (i < gcount * BNT * 8) {
+        const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
+        *reinterpret_cast<u32x4*>(ldsB + t * BNT * 128 + lds_off(row, ch)) = wreg[e];
+      }
+    }
+  };
+  // ---- MFMA over one staged tap group -----------------------------------------------------------------
+  auto compute = [&](int tg0, int gcount) {
+    for (int t = 0; t < gcount; ++t) {
+      const int toff = p.dy[tg0 + t] * HPW + p.dx[tg0 + t];
+      int hp[FM];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int chunk = ks * 2 + khalf;
-          bf16x8 a[NP][FM], bq[NP][FN];
+      for (int i = 0; i < FM; ++i) hp[i] = prow[i] + toff;
 #pragma unroll
-          for (int pl = 0; pl < NP; ++pl) {
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = ks * 2 + khalf;
+        bf16x8 a[NP][FM], bq[NP][FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-              a[pl][i] = *reinterpret_cast<const bf16x8*>(ldsA + pl * C::A_BYTES + hp[i] * 128 +
-                                                          ((chunk ^ (hp[i] & 7)) << 4));
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-              bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsB + pl * C::B_BYTES + (t * BNT + nrow[j]) * 128 +
-                                                           ((chunk ^ (nrow[j] & 7)) << 4));
-          }
-          if constexpr (SPLIT) {
+          for (int i = 0; i < FM; ++i)
+            a[pl][i] = *reinterpret_cast<const bf16x8*>(ldsA + pl * C::A_BYTES + lds_off(hp[i], chunk));
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsB + pl * C::B_BYTES + t * BNT * 128 + lds_off(nrow[j], chunk));
+        }
+        if constexpr (SPLIT) {
 #define PH_MM(PI, PJ)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < FN; ++j)          \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI][i], bq[PJ][j], acc[i][j], 0, 0, 0);
-            PH_SPLIT_PAIRS(PH_MM)
+          PH_SPLIT_PAIRS(PH_MM)
 #undef PH_MM
-          } else {
+        } else {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+          for (int i = 0; i < FM; ++i)
 #pragma unroll
-              for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], bq[0][j], acc[i][j], 0, 0, 0);
-          }
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], bq[0][j], acc[i][j], 0, 0, 0);
         }
       }
+    }
+  };
+
+  if constexpr (SPLIT) {
+    // parity mode: simple synchronous staging (throughput is irrelevant here, LDS holds 3 planes)
+    for (int sl = 0; sl < nslices; ++sl) {
+      const int k0 = sl << 6;
+      __syncthreads();
+      stage_halo_sync(k0);
+      for (int tg0 = 0; tg0 < p.ntaps; tg0 += TG) {
+        const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
+        if (tg0 > 0) __syncthreads();
+        stage_w_sync(k0, tg0, gcount);
+        __syncthreads();
+        compute(tg0, gcount);
+      }
+    }
+  } else {
+    // perf mode: stage s = (slice, tap group).  While the MFMAs of stage s run, the global loads of stage
+    // s+1 (weights, and the next slice's halo when the slice changes) are in flight into registers; they
+    // are written to LDS after the barrier that ends stage s.
+    load_halo_regs(0);
+    load_w_regs(0, 0, p.ntaps < TG ? p.ntaps : TG);
+    store_halo_regs();
+    store_w_regs(p.ntaps < TG ? p.ntaps : TG);
+    __syncthreads();
+    int sl = 0, tg0 = 0;
+    for (int st = 0; st < nstages; ++st) {
+      const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
+      int nsl = sl, ntg0 = tg0 + TG;
+      if (ntg0 >= p.ntaps) { ntg0 = 0; nsl = sl + 1; }
+      const bool has_next = st + 1 < nstages;
+      const int ngcount = (p.ntaps - ntg0) < TG ? (p.ntaps - ntg0) : TG;
+      if (has_next) {
+        load_w_regs(nsl << 6, ntg0, ngcount);
+        if (nsl != sl) load_halo_regs(nsl << 6);
+      }
+      compute(tg0, gcount);
+      __syncthreads();
+      if (has_next) {
+        store_w_regs(ngcount);
+        if (nsl != sl) store_halo_regs();
+      }
+      __syncthreads();
+      sl = nsl; tg0 = ntg0;
     }
   }
 
   // ---------------- epilogue: mask, BN partial statistics, (residual), store
-  // accumulator register q of fragment (i,j): pixel m = (wm*FM+i)*32 + (q&3) + 8*(q>>2) + 4*khalf,
-  // channel n0 + nrow[j].
+  // accumulator register q of fragment (i,j) holds MFMA row (q&3) + 8*(q>>2) + 4*khalf, i.e. (see
+  // frag_row_to_pixel) tile row 2*(wm*FM+i) + ((popc(q>>2) + khalf) & 1), column q; channel n0 + nrow[j].
   const bool full = (r0 + TH <= p.OHt) && (c0 + TW <= p.OWt);
   T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * p.Cout;
   const T* resg = p.res_g ? reinterpret_cast<const T*>(p.res_g) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
@@ -169,8 +275,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int m = (wm * FM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
-      const int r = r0 + (m >> 4), c = c0 + (m & 15);
+      const int r = r0 + (wm * FM + i) * 2 + ((__popc(q >> 2) + khalf) & 1), c = c0 + q;
       const bool valid = full || (r < p.OHt && c < p.OWt);
       const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0;
 #pragma unroll

@@ -226,7 +226,37 @@ __global__ void pack_w_stem_kernel(const float* __restrict__ w, bf16* __restrict
   planes[i] = a; planes[7 * 64 * 32 + i] = b; planes[2 * 7 * 64 * 32 + i] = c;
 }
 
+// all conv weights of one network in ONE launch: thread i walks the concatenated fwd-layout index space
+__global__ void pack_all_kernel(PhPackAll t, bf16* __restrict__ packed, int nplanes) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.total) return;
+  int u = 0;
+#pragma unroll 1
+  while (u + 1 < t.n && i >= t.start[u + 1]) ++u;
+  const size_t e = i - t.start[u];
+  const int O = t.O[u], I = t.I[u], NT = t.NT[u];
+  const size_t n = (size_t)NT * O * I;
+  const int ii = e % I, o = (e / I) % O, tp = e / ((size_t)I * O);
+  const float v = t.w[u][((size_t)o * I + ii) * NT + tp];
+  bf16 a, b, c;
+  split3_bf16(v, a, b, c);
+  const size_t fdst = t.dst_fwd[u] + e;                                     // [tap][O][I]
+  const size_t ddst = t.dst_dg[u] + ((size_t)tp * I + ii) * O + o;          // [tap][I][O]
+  packed[fdst] = a; packed[ddst] = a;
+  if (nplanes == 3) {
+    packed[fdst + n] = b; packed[fdst + 2 * n] = c;
+    packed[ddst + n] = b; packed[ddst + 2 * n] = c;
+  }
+}
+
 }  // namespace
+
+int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_t st) {
+  hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, st, *t, (bf16*)packed,
+                     nplanes);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
 
 int ph_wgrad_tile_h(int S) { return S == 1 ? 8 : 4; }
 

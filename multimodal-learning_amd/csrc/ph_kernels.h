@@ -73,6 +73,16 @@ int ph_pack_w_fwd_launch(const float* w, void* planes, int O, int I, int KS, hip
 int ph_pack_w_dgrad_launch(const float* w, void* planes, int O, int I, int KS, hipStream_t st); // [tap][I][O]
 int ph_pack_w_stem_launch(const float* w, void* planes, hipStream_t st);                        // [7][64][32]
 
+// all 3x3 / 1x1 conv weights of one network in one launch (stem handled by ph_pack_w_stem_launch)
+struct PhPackAll {
+  const float* w[20];
+  size_t dst_fwd[20], dst_dg[20], start[21];
+  int O[20], I[20], NT[20];
+  int n;
+  size_t total;
+};
+int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_t st);
+
 // ---- BatchNorm / elementwise (bn_act.hip).  `prec` selects the activation type (bf16 | float).
 int ph_pack_input_launch(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st);
 // partial slab [nparts][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale

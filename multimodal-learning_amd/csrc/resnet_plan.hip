@@ -50,7 +50,7 @@ int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
   const int th = ph_wgrad_tile_h(u.S);
   const int ntiles = B * cdiv(u.OH, th) * cdiv(u.OW, 16);
   const int blocks = (u.Cout / 64) * (u.Cin / 64);
-  int want = cdiv(1024, blocks);           // aim for ~1024 workgroups
+  int want = cdiv(256, blocks);            // ~1 workgroup per CU: fewer partial slabs to reduce (HBM-bound)
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   int tpc = cdiv(ntiles, want);
@@ -160,20 +160,22 @@ int ph_resnet_unit_shape(const PhResnetPlan* P, int u, int* out4) {
 int ph_resnet_pack_weights(const PhResnetPlan* P, const void* const* params, void* packed, hipStream_t st) {
   if (!P || !params || !packed) return PH_EINVAL;
   bf16* pk = reinterpret_cast<bf16*>(packed);
-  for (size_t i = 0; i < P->units.size(); ++i) {
+  int rc = ph_pack_w_stem_launch(reinterpret_cast<const float*>(params[0]), pk + P->units[0].wf_off, st);
+  if (rc) return rc;
+  PhPackAll t{};
+  size_t acc = 0;
+  for (size_t i = 1; i < P->units.size(); ++i) {
     const Unit& u = P->units[i];
-    const float* w = reinterpret_cast<const float*>(params[i * 6 + 0]);
-    int rc;
-    if (i == 0) {
-      rc = ph_pack_w_stem_launch(w, pk + u.wf_off, st);
-    } else {
-      rc = ph_pack_w_fwd_launch(w, pk + u.wf_off, u.Cout, u.Cin, u.KS, st);
-      if (rc) return rc;
-      rc = ph_pack_w_dgrad_launch(w, pk + u.wd_off, u.Cout, u.Cin, u.KS, st);
-    }
-    if (rc) return rc;
+    const int k = t.n++;
+    t.w[k] = reinterpret_cast<const float*>(params[i * 6 + 0]);
+    t.dst_fwd[k] = u.wf_off; t.dst_dg[k] = u.wd_off;
+    t.O[k] = u.Cout; t.I[k] = u.Cin; t.NT[k] = u.KS * u.KS;
+    t.start[k] = acc;
+    acc += u.wplane;
   }
-  return PH_OK;
+  t.start[t.n] = acc;
+  t.total = acc;
+  return ph_pack_all_launch(&t, pk, P->prec == PH_PREC_BF16 ? 1 : 3, st);
 }
 
 }  // extern "C"

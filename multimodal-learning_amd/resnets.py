@@ -195,7 +195,13 @@ class ResNet(nn.Module):
         return self._plans[key]
 
     def _get_packed(self, plan):
-        vers = (ops.weight_epoch(),) + tuple((c.weight._version, c.weight.data_ptr()) for c, _ in self._units())
+        # raw-pointer updates (fused Adam / EMA kernels) are invisible to torch's version counters: networks
+        # that receive them follow the global weight epoch; frozen networks (the teacher) are packed once
+        follow = getattr(self, "_follow_epoch", None)
+        if follow is None:
+            follow = any(c.weight.requires_grad for c, _ in self._units())
+        vers = (ops.weight_epoch() if follow else -1,) + tuple((c.weight._version, c.weight.data_ptr())
+                                                                for c, _ in self._units())
         if self._packed is None or self._packed_versions != vers or self._packed.numel() != plan.packed_bytes:
             dev = self.conv1.weight.device
             if self._packed is None or self._packed.numel() != plan.packed_bytes:

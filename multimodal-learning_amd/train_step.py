@@ -136,6 +136,9 @@ class FusedAdam(torch.optim.Optimizer):
 def update_ema_variables(model, ema_model, alpha, global_step):
     """train_test_path_multi_distill.py:34-38 - parameters only, BN buffers untouched."""
     alpha = min(1 - 1 / (global_step + 1), alpha)
+    for mod in ema_model.modules():
+        if hasattr(mod, "_get_packed"):
+            mod._follow_epoch = True       # its weights change through raw pointers
     with torch.no_grad():
         for ema_param, param in zip(ema_model.parameters(), model.parameters()):
             check(lib().ph_ema_update(ptr(ema_param.data), ptr(param.data), param.numel(), alpha, stream()),
@@ -201,6 +204,9 @@ class DistillStep:
         flat = self.optimizer.flat
         n_student = len(list(self.model.parameters()))
         self.ema_flat = FlatParams(list(self.ema_model.parameters()))
+        for mod in self.ema_model.modules():
+            if hasattr(mod, "_get_packed"):
+                mod._follow_epoch = True   # updated by the fused Adam+EMA kernel through raw pointers
         end = flat.offsets[n_student] if n_student < len(flat.offsets) else flat.numel
         self.optimizer.ema_flat = self.ema_flat
         self.optimizer.ema_range = (0, end)
