@@ -101,6 +101,10 @@ int ph_outer(const float* o1, const float* o2, float* o12, int B, int D1, int D2
              ph_stream_t stream);
 /* nn.Dropout / nn.AlphaDropout, training mode, counter-based RNG (fusion.py:22-32; networks_new.py:193) */
 int ph_dropout(float* x, size_t n, float p, uint64_t seed, uint64_t offset, int alpha, ph_stream_t stream);
+/* HIP-graph-replayable form: the per-step part of the counter is read from device memory */
+int ph_dropout_dev(float* x, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_counter,
+                   int alpha, ph_stream_t stream);
+int ph_counter_inc(uint64_t* counter, ph_stream_t stream);
 int ph_sum(const float* x, float* out, int n, float scale, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -135,6 +139,9 @@ int ph_gk_scale(const float* gram, const float* const* losses /* device array of
 int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, size_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int step, double ema_alpha,
                      ph_stream_t stream);
+/* HIP-graph-replayable form: hyper = device float[4] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha} */
+int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1,
+                         double beta2, double eps, double weight_decay, const float* hyper, ph_stream_t stream);
 int ph_ema_update(float* ema, const float* p, size_t n, float alpha, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

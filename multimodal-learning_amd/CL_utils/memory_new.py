@@ -128,6 +128,6 @@ class ContrastMemory_v3(nn.Module):
     def loss(self, epoch, v1, v2, y, idx, select_pos_mode="mid", ranks=None):
         if ranks is None:
             ranks = self.draw_ranks(epoch, select_pos_mode)
-        if ranks is not None:
-            ranks = torch.as_tensor(ranks, dtype=torch.int32).to(v1.device, non_blocking=True)
+        if ranks is not None and not (torch.is_tensor(ranks) and ranks.is_cuda and ranks.dtype == torch.int32):
+            ranks = torch.as_tensor(np.asarray(ranks), dtype=torch.int32).to(v1.device, non_blocking=True)
         return _CRDCoreFn.apply(v1, v2, self, y, idx, ranks)

@@ -41,6 +41,8 @@ SIGNATURES = {
     "ph_eltwise": (i32, [vp, vp, vp, sz, i32, vp]),
     "ph_outer": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_dropout": (i32, [vp, sz, f32, u64, u64, i32, vp]),
+    "ph_dropout_dev": (i32, [vp, sz, f32, u64, u64, vp, i32, vp]),
+    "ph_counter_inc": (i32, [vp, vp]),
     "ph_sum": (i32, [vp, vp, i32, f32, vp]),
     "ph_crd_score": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "ph_crd_select": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
@@ -51,6 +53,7 @@ SIGNATURES = {
     "ph_gram": (i32, [vp, vp, i32, i32, vp]),
     "ph_gk_scale": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),
     "ph_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, f64, vp]),
+    "ph_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, vp, vp]),
     "ph_ema_update": (i32, [vp, vp, sz, f32, vp]),
     "ph_prof_enable": (i32, [i32]),
     "ph_prof_reset": (i32, []),

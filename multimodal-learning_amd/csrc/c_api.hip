@@ -20,7 +20,7 @@ __global__ void parts_sum_kernel(const float* __restrict__ parts, int nparts, in
 int chunks_for(int B, int OH, int OW, int S, int Cout, int Cin, int* tpc) {
   const int th = ph_wgrad_tile_h(S);
   const int ntiles = B * cdiv(OH, th) * cdiv(OW, 16);
-  int want = cdiv(1024, (Cout / 64) * (Cin / 64));
+  int want = cdiv(512, (Cout / 64) * (Cin / 64));
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   *tpc = cdiv(ntiles, want);

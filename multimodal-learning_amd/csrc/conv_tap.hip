@@ -29,7 +29,8 @@ struct TapCfg {
   static constexpr int B_BYTES = TG * BNT * 128;
   static constexpr int NP = SPLIT ? PH_NPLANES : 1;
   static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) * NP;
-  static_assert(WM * WN == 4, "4 waves");
+  static constexpr int NTH = WM * WN * 64;
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert(WM * FM * 32 == TH * TW, "M tiling");
   static_assert(WN * FN * 32 == BNT, "N tiling");
 };
@@ -50,12 +51,12 @@ __device__ __forceinline__ void frag_row_to_pixel(int i, int& fr, int& c) {
 }
 
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
-__global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
+__global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   using C = TapCfg<T, S, TH, BNT, WM, WN, FM, FN, TG>;
   constexpr bool SPLIT = C::SPLIT;
-  constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP, NP = C::NP;
-  constexpr int HCH = (HP * 8 + 255) / 256;          // halo 16-B chunks per thread
-  constexpr int WCH = (TG * BNT * 8 + 255) / 256;    // weight 16-B chunks per thread (full tap group)
+  constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP, NP = C::NP, NTH = C::NTH;
+  constexpr int HCH = (HP * 8 + NTH - 1) / NTH;          // halo 16-B chunks per thread
+  constexpr int WCH = (TG * BNT * 8 + NTH - 1) / NTH;    // weight 16-B chunks per thread (full tap group)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;                      // NP planes of A_BYTES
   unsigned char* ldsB = smem + C::A_BYTES * NP;    // NP planes of B_BYTES
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
     return in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8;
   };
   auto stage_halo_sync = [&](int k0) {   // parity mode: load, split into 3 planes, store
-    for (int i = tid; i < HP * 8; i += 256) {
+    for (int i = tid; i < HP * 8; i += NTH) {
       bool ok;
       const T* src = halo_src(i, k0, ok);
       const int off = lds_off(i >> 3, i & 7);
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
     }
   };
   auto stage_w_sync = [&](int k0, int tg0, int gcount) {
-    for (int i = tid; i < gcount * BNT * 8; i += 256) {
+    for (int i = tid; i < gcount * BNT * 8; i += NTH) {
       const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
       const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
       const int off = t * BNT * 128 + lds_off(row, ch);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   auto load_halo_regs = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < HCH; ++e) {
-      const int i = tid + e * 256;
+      const int i = tid + e * NTH;
       bool ok;
       const T* src = halo_src(i, k0, ok);
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -154,14 +155,14 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   auto store_halo_regs = [&]() {
 #pragma unroll
     for (int e = 0; e < HCH; ++e) {
-      const int i = tid + e * 256;
+      const int i = tid + e * NTH;
       if (i < HP * 8) *reinterpret_cast<u32x4*>(ldsA + lds_off(i >> 3, i & 7)) = hreg[e];
     }
   };
   auto load_w_regs = [&](int k0, int tg0, int gcount) {
 #pragma unroll
     for (int e = 0; e < WCH; ++e) {
-      const int i = tid + e * 256;
+      const int i = tid + e * NTH;
       if (i < gcount * BNT * 8) {
         const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
         const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   auto store_w_regs = [&](int gcount) {
 #pragma unroll
     for (int e = 0; e < WCH; ++e) {
-      const int i = tid + e * 256;
+      const int i = tid + e * NTH;
       if (i < gcount * BNT * 8) {
         const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
         *reinterpret_cast<u32x4*>(ldsB + t * BNT * 128 + lds_off(row, ch)) = wreg[e];
@@ -271,11 +272,16 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
   float s1[FN], s2[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  constexpr int BM = TH * TW;
+  constexpr int CROW = BNT * 2;                       // bytes of one pixel row of the bf16 C image in LDS
+  unsigned char* ldsC = smem;                          // perf mode: [BM][BNT] bf16 (the main loop's LDS is free)
+  float* red = reinterpret_cast<float*>(smem + (SPLIT ? 0 : BM * CROW));   // [WM][2][BNT]
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int r = r0 + (wm * FM + i) * 2 + ((__popc(q >> 2) + khalf) & 1), c = c0 + q;
+      const int rl = (wm * FM + i) * 2 + ((__popc(q >> 2) + khalf) & 1);
+      const int r = r0 + rl, c = c0 + q;
       const bool valid = full || (r < p.OHt && c < p.OWt);
       const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0;
 #pragma unroll
@@ -283,25 +289,53 @@ __global__ __launch_bounds__(256) void tapconv_kernel(PhTapConv p) {
         float v = valid ? acc[i][j][q] : 0.f;
         s1[j] += v;
         s2[j] += v * v;
-        if (valid) {
-          if (resg) {
-            float g = ldf(resg + o + nrow[j]);
-            if (resa) g = (ldf(resa + o + nrow[j]) > 0.f) ? g : 0.f;
-            v += g;
+        if constexpr (SPLIT) {
+          if (valid) {
+            if (resg) {
+              float g = ldf(resg + o + nrow[j]);
+              if (resa) g = (ldf(resa + o + nrow[j]) > 0.f) ? g : 0.f;
+              v += g;
+            }
+            stf(out + o + nrow[j], v);
           }
-          stf(out + o + nrow[j], v);
+        } else {
+          *reinterpret_cast<bf16*>(ldsC + (rl * TW + q) * CROW + nrow[j] * 2) = (bf16)v;
         }
       }
     }
   }
+  if constexpr (!SPLIT) {
+    // coalesced store: the C tile is re-read from LDS as 16-B chunks, BNT/8 consecutive lanes per pixel
+    __syncthreads();
+    constexpr int CPR = BNT / 8;                       // chunks per pixel row
+    for (int id = tid; id < BM * CPR; id += NTH) {
+      const int m = id / CPR, ch = id - m * CPR;
+      const int r = r0 + (m >> 4), c = c0 + (m & 15);
+      if (!(full || (r < p.OHt && c < p.OWt))) continue;
+      const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + ch * 8;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(ldsC + m * CROW + ch * 16);
+      if (resg) {
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(resg + o);
+        if (resa) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(resa + o);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + ((float)a[k] > 0.f ? (float)g[k] : 0.f));
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (bf16)((float)v[k] + (float)g[k]);
+        }
+      }
+      *reinterpret_cast<bf16x8*>(out + o) = v;
+    }
+  }
   if (p.stats) {
-    __syncthreads();   // all MFMA reads of LDS done; reuse smem as float[WM][2][BNT]
-    float* red = reinterpret_cast<float*>(smem);
+    if constexpr (SPLIT) __syncthreads();   // all MFMA reads of LDS done; smem is reused as float[WM][2][BNT]
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
       float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
-      if (khalf == 0) {
+      if (khalf == 0 && wn * FN * 32 + j * 32 + (lane & 31) == nrow[j]) {
+        // WN > 1: waves with the same wm cover disjoint channel ranges, so each (wm, channel) has one writer
         red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
         red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
       }
@@ -334,7 +368,7 @@ int launch_cfg(const PhTapConv& p, hipStream_t st) {
   if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
     ph_prof_begin(S == 2 ? PH_CLS_TAPCONV_S2 : (BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128),
                   2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
@@ -345,7 +379,12 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
   constexpr bool SPLIT = is_f32<T>::value;
   constexpr int TG = SPLIT ? 1 : 3;   // parity mode stages one tap at a time (3 planes must fit 160 KB LDS)
   if (S == 1) {
-    if (p.Cout % 128 == 0) return launch_cfg<T, 1, 8, 128, 2, 2, 2, 2, TG>(p, st);
+    if (p.Cout % 128 == 0) {
+      // perf mode: 256 x 128 tile, 8 waves (weights staged once per 256 pixels: LDS traffic per FLOP halves);
+      // parity mode keeps the 128 x 128 tile (3 planes must fit the 160 KB LDS)
+      if constexpr (SPLIT) return launch_cfg<T, 1, 8, 128, 2, 2, 2, 2, TG>(p, st);
+      else return launch_cfg<T, 1, 16, 128, 4, 2, 2, 2, TG>(p, st);
+    }
     return launch_cfg<T, 1, 16, 64, 4, 1, 2, 2, TG>(p, st);
   } else {
     if (p.Cout % 128) return PH_EINVAL;   // stride-2 forward convs of ResNet-18 all have Cout >= 128
@@ -358,7 +397,7 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
-  const int TH = (S == 1) ? ((p->Cout % 128 == 0) ? 8 : 16) : (prec == PH_PREC_BF16 ? 4 : 2);
+  const int TH = (S == 1) ? ((p->Cout % 128 == 0 && prec != PH_PREC_BF16) ? 8 : 16) : (prec == PH_PREC_BF16 ? 4 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
 }
 

@@ -354,6 +354,26 @@ __global__ void dropout_kernel(float* __restrict__ x, size_t n, float p, uint64_
   }
 }
 
+// graph-replayable variant: the per-step part of the RNG counter lives in device memory
+__global__ void dropout_dev_kernel(float* __restrict__ x, size_t n, float p, uint64_t seed, uint64_t site_offset,
+                                   const uint64_t* __restrict__ step_ctr, int alpha) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t ctr = (*step_ctr << 34) ^ (site_offset + i);
+  const bool keep = u01(seed, ctr) >= p;
+  if (!alpha) {
+    x[i] = keep ? x[i] / (1.f - p) : 0.f;
+  } else {
+    const float ap = -1.7580993408473766f;
+    const float a = rsqrtf((1.f - p) * (1.f + p * ap * ap));
+    const float b = -a * ap * p;
+    x[i] = a * (keep ? x[i] : ap) + b;
+  }
+}
+__global__ void counter_inc_kernel(uint64_t* c) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += 1;
+}
+
 __global__ void sum_kernel(const float* __restrict__ x, float* out, int n, float scale) {
   __shared__ float sh[16];
   float s = 0.f;
@@ -457,6 +477,18 @@ int ph_outer(const float* o1, const float* o2, float* o12, int B, int D1, int D2
 int ph_dropout(float* x, size_t n, float p, uint64_t seed, uint64_t offset, int alpha, hipStream_t st) {
   if (p <= 0.f) return PH_OK;
   hipLaunchKernelGGL(dropout_kernel, dim3(nblk(n)), dim3(256), 0, st, x, n, p, seed, offset, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_dropout_dev(float* x, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_ctr, int alpha,
+                   hipStream_t st) {
+  if (p <= 0.f) return PH_OK;
+  hipLaunchKernelGGL(dropout_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, x, n, p, seed, site_offset, step_ctr, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_counter_inc(uint64_t* ctr, hipStream_t st) {
+  hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(64), 0, st, ctr);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -96,6 +96,44 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
   }
 }
 
+// same update, per-step scalars read from device memory (hyper = [lr, bc1, sqrt(bc2), ema_alpha]) so that the
+// launch can live inside a captured HIP graph and be replayed with new values
+__global__ void adam_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                    float* __restrict__ v, float* __restrict__ ema, size_t n, float b1, float b2,
+                                    float eps, float wd, const float* __restrict__ hyper) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float step = hyper[0] / hyper[1], bc2_sqrt = hyper[2], ema_alpha = hyper[3];
+  if (i + 4 <= n) {
+    f32x4 P = *reinterpret_cast<f32x4*>(p + i), Gr = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 M = *reinterpret_cast<f32x4*>(m + i), V = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = Gr[k] + wd * P[k];
+      M[k] = b1 * M[k] + (1.f - b1) * gg;
+      V[k] = b2 * V[k] + (1.f - b2) * gg * gg;
+      P[k] -= step * M[k] / (sqrtf(V[k]) / bc2_sqrt + eps);
+    }
+    *reinterpret_cast<f32x4*>(p + i) = P;
+    *reinterpret_cast<f32x4*>(m + i) = M;
+    *reinterpret_cast<f32x4*>(v + i) = V;
+    if (ema) {
+      f32x4 E = *reinterpret_cast<f32x4*>(ema + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) E[k] = ema_alpha * E[k] + (1.f - ema_alpha) * P[k];
+      *reinterpret_cast<f32x4*>(ema + i) = E;
+    }
+  } else {
+    for (size_t e = i; e < n; ++e) {
+      const float gg = g[e] + wd * p[e];
+      m[e] = b1 * m[e] + (1.f - b1) * gg;
+      v[e] = b2 * v[e] + (1.f - b2) * gg * gg;
+      p[e] -= step * m[e] / (sqrtf(v[e]) / bc2_sqrt + eps);
+      if (ema) ema[e] = ema_alpha * ema[e] + (1.f - ema_alpha) * p[e];
+    }
+  }
+}
+
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n, float alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ema[i] = alpha * ema[i] + (1.f - alpha) * p[i];
@@ -130,6 +168,15 @@ int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, s
   const size_t nt = (n + 3) / 4;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, m, v, ema, n, (float)lr,
                      (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1, bc2s, (float)ema_alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1, double beta2,
+                         double eps, double weight_decay, const float* hyper, hipStream_t st) {
+  const size_t nt = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_ema_dev_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, m, v, ema, n,
+                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, hyper);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -50,7 +50,7 @@ int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
   const int th = ph_wgrad_tile_h(u.S);
   const int ntiles = B * cdiv(u.OH, th) * cdiv(u.OW, 16);
   const int blocks = (u.Cout / 64) * (u.Cin / 64);
-  int want = cdiv(256, blocks);            // ~1 workgroup per CU: fewer partial slabs to reduce (HBM-bound)
+  int want = cdiv(512, blocks);            // ~2 workgroups per CU; few partial slabs to reduce (HBM-bound)
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   int tpc = cdiv(ntiles, want);

@@ -34,13 +34,14 @@ class BilinearFusion(nn.Module):
         self.dropout_rate = dropout_rate
         self._rng_offset = 0
         self.rng_seed = 0x5EED
+        self.register_buffer("rng_step", torch.zeros(1, dtype=torch.int64), persistent=False)
         init_max_weights(self)
         if not (use_bilinear and gate1 and gate2) or skip:
             raise NotImplementedError("hot path uses use_bilinear=1, gates on, skip=0 (options.py:143-146)")
 
     def _drop(self, x):
         if self.training and self.dropout_rate > 0:
-            ops.dropout_(x, self.dropout_rate, self.rng_seed, self._rng_offset, alpha=False)
+            ops.dropout_(x, self.dropout_rate, self.rng_seed, self._rng_offset, self.rng_step, alpha=False)
             self._rng_offset += x.numel()
         return x
 
@@ -55,6 +56,7 @@ class BilinearFusion(nn.Module):
                                         any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("BilinearFusion backward (stage-1 teacher training) is the 'next' row f-1; "
                                       "run the frozen teacher under torch.no_grad() as the reference hot loop does")
+        self._rng_offset = 0     # per-call-site offsets are static; the device step counter makes steps differ
         v1 = ops.eltwise(vec1, None, ops.EW_RELU)                                   # fusion.py:38-39
         v2 = ops.eltwise(vec2, None, ops.EW_RELU)
         Bn, D1 = v1.shape
@@ -73,4 +75,6 @@ class BilinearFusion(nn.Module):
         out = self._drop(self._bn_relu(out, self.encoder1[1]))
         out = ops.linear_fwd(out, self.encoder2[0].weight, self.encoder2[0].bias)
         out = self._drop(self._bn_relu(out, self.encoder2[1]))
+        if self.training and self.dropout_rate > 0:
+            ops.counter_inc(self.rng_step)
         return out

@@ -116,6 +116,7 @@ class MaxNet(nn.Module):
         self.dropout_rate = dropout_rate
         self.rng_seed = 0xA11CE
         self._rng_offset = 0
+        self.register_buffer("rng_step", torch.zeros(1, dtype=torch.int64), persistent=False)
 
     def forward(self, **kwargs):
         x = kwargs["x_omic"]
@@ -124,12 +125,15 @@ class MaxNet(nn.Module):
         if self.return_grad == "True":
             raise NotImplementedError("return_grad needs the reference's absent my_utils.compute_gradients")
         h = x
+        self._rng_offset = 0
         for i in range(4):
             lin = self.encoder[i][0]
             h = ops.linear_fwd(h, lin.weight, lin.bias, ops.ACT_ELU)
             if self.training and self.dropout_rate > 0:
-                ops.dropout_(h, self.dropout_rate, self.rng_seed, self._rng_offset, alpha=True)
+                ops.dropout_(h, self.dropout_rate, self.rng_seed, self._rng_offset, self.rng_step, alpha=True)
                 self._rng_offset += h.numel()
+        if self.training and self.dropout_rate > 0:
+            ops.counter_inc(self.rng_step)
         features = ops.eltwise(h, None, ops.EW_RELU)
         out = ops.linear_fwd(features, self.classifier[0].weight, self.classifier[0].bias)
         pred = None

@@ -223,10 +223,17 @@ def eltwise(a, b, op):
     return out
 
 
-def dropout_(x, p, seed, offset, alpha=False):
+def dropout_(x, p, seed, site_offset, step_counter, alpha=False):
+    """In-place (alpha-)dropout; `step_counter` is a device uint64 advanced once per forward so that the launch
+    is replayable inside a captured HIP graph."""
     if p > 0:
-        check(lib().ph_dropout(ptr(x), x.numel(), p, seed, offset, int(alpha), stream()), "ph_dropout")
+        check(lib().ph_dropout_dev(ptr(x), x.numel(), p, seed, site_offset, ptr(step_counter), int(alpha), stream()),
+              "ph_dropout_dev")
     return x
+
+
+def counter_inc(counter):
+    check(lib().ph_counter_inc(ptr(counter), stream()), "ph_counter_inc")
 
 
 def outer(o1, o2, append_one):

@@ -65,6 +65,9 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_flat = None      # optional FlatParams of the EMA model to update in the same kernel
         self.ema_alpha = None
         self.ema_range = None
+        self._hyper = None        # device float[4] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha}: graph-replayable
+        self._hyper_host = None
+        self._prepared = False
 
     def _ensure_flat(self):
         if self._flat is None:
@@ -75,8 +78,25 @@ class FusedAdam(torch.optim.Optimizer):
             self._m = torch.zeros_like(self._flat.flat)
             self._v = torch.zeros_like(self._flat.flat)
             self._segs = self._flat.segments(lambda t: t.requires_grad)
+            self._hyper = torch.zeros(4, device=ps[0].device, dtype=torch.float32)
+            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
             ops.bump_weight_epoch()
         return self._flat
+
+    def prepare_step(self):
+        """Host side of a step: advance t, compute the bias corrections in double (as torch.optim.Adam's Python
+        scalars) and enqueue their copy to device memory.  Split from step() so that the kernel launches can be
+        captured in a HIP graph while these per-step scalars keep changing."""
+        self._ensure_flat()
+        g = self.param_groups[0]
+        self._step += 1
+        b1, b2 = g["betas"]
+        self._hyper_host[0] = g["lr"]
+        self._hyper_host[1] = 1.0 - b1 ** self._step
+        self._hyper_host[2] = math.sqrt(1.0 - b2 ** self._step)
+        self._hyper_host[3] = self.ema_alpha if self.ema_alpha is not None else 0.0
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._prepared = True
 
     @property
     def flat(self):
@@ -99,7 +119,9 @@ class FusedAdam(torch.optim.Optimizer):
                 f.grad[o:o + t.numel()].copy_(t.grad.reshape(-1))
                 t.grad = f.grad[o:o + t.numel()].view(t.shape)
         g = self.param_groups[0]
-        self._step += 1
+        if not self._prepared:
+            self.prepare_step()
+        self._prepared = False
         segs = []
         for (s, e) in self._segs:      # split at the EMA boundary (student params | embed params)
             if self.ema_flat is not None and self.ema_range is not None and s < self.ema_range[1] < e:
@@ -108,13 +130,11 @@ class FusedAdam(torch.optim.Optimizer):
                 segs.append((s, e))
         for (s, e) in segs:
             ema = None
-            alpha = 0.0
             if self.ema_flat is not None and self.ema_range is not None and s >= self.ema_range[0] and e <= self.ema_range[1]:
                 ema = self.ema_flat.flat[s:e]
-                alpha = self.ema_alpha
-            check(lib().ph_adam_ema_step(ptr(f.flat[s:e]), ptr(f.grad[s:e]), ptr(self._m[s:e]), ptr(self._v[s:e]),
-                                         ptr(ema), e - s, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                                         g["weight_decay"], self._step, alpha, stream()), "ph_adam_ema_step")
+            check(lib().ph_adam_ema_step_dev(ptr(f.flat[s:e]), ptr(f.grad[s:e]), ptr(self._m[s:e]), ptr(self._v[s:e]),
+                                             ptr(ema), e - s, g["betas"][0], g["betas"][1], g["eps"],
+                                             g["weight_decay"], ptr(self._hyper), stream()), "ph_adam_ema_step_dev")
         ops.bump_weight_epoch()
 
     def state_dict(self):
@@ -199,6 +219,8 @@ class DistillStep:
         self.optimizer = define_optimizer(opt, self.module_list)                   # :211
         self.scheduler = define_scheduler(opt, self.optimizer)                     # :212
         self.iter_num = opt.global_step
+        self._want_graph = False
+        self._static = None
         self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
         # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
         flat = self.optimizer.flat
@@ -213,34 +235,17 @@ class DistillStep:
         if sync is not None:
             sync.attach(self)
 
-    def step(self, batch, epoch=0, ranks=None):
+    # ------------------------------------------------------------------ one step
+    def _device_body(self, x_path, ema_x_path, x_omic, grade, index, sample_idx, bnorm, e, r1, r2):
+        """Everything of the step that runs on the device (capturable in one HIP graph)."""
         opt = self.opt
-        (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
-        dev = self.device
-        x_path = x_path.to(dev, non_blocking=True)                                 # ONE H2D copy (reference: three)
-        ema_x_path = ema_x_path.to(dev, non_blocking=True)
-        x_omic = x_omic.to(dev, non_blocking=True)
-        grade = grade.to(dev, non_blocking=True)
-        index = index.to(dev, non_blocking=True)
-        sample_idx = sample_idx.to(dev, non_blocking=True)
-        bnorm = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))
-        self.criterion_div.batch_norm_size = bnorm
-        self.criterion_kd.contrast.batch_norm_size = bnorm
-        self.criterion_kd_path.contrast.batch_norm_size = bnorm
-
-        _, path_feat, logit_path, pred_path, _ = self.model(x_path=x_path, x_grph=x_grph, x_omic=x_omic)   # :249
+        _, path_feat, logit_path, pred_path, _ = self.model(x_path=x_path)                                   # :249
         with torch.no_grad():
             _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                      # :254
             fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
-        if opt.num_teachers != 2 or opt.distill != "crd":
-            raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd)")
         loss_div1 = self.criterion_div(logit_path, logits[-1].detach())                                     # :264
         loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
-        r1 = r2 = None
-        if ranks is not None:
-            r1, r2 = ranks
-        e = epoch / opt.niter_decay
         loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx, ranks=r1)         # :278
         loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx, ranks=r2)  # :279
         loss_div1 = opt.alpha * loss_div1; loss_div2 = opt.alpha * loss_div2                                # :293-294
@@ -256,11 +261,87 @@ class DistillStep:
         loss.backward()                                                                                     # :327
         if self.sync is not None:
             self.sync.all_reduce_grads(self.optimizer.flat)
-        self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)                          # :36
         self.optimizer.step()                                                                               # :328 (+ :329 fused)
-        self.iter_num += 1
         return dict(loss=loss.detach(), loss_cls=loss_cls.detach(), loss_div1=loss_div1.detach(),
                     loss_div2=loss_div2.detach(), loss_kd1=loss_kd1.detach(), loss_kd2=loss_kd2.detach(),
                     scale=scale, logit_path=logit_path.detach(), pred_path=pred_path.detach(),
                     path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
                     fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+
+    def _draw_ranks(self, epoch, ranks):
+        """Host-RNG rank draws of memory_new.py:311 for the two CRD calls (kd1 then kd2), as device int32."""
+        e = epoch / self.opt.niter_decay
+        out = []
+        for i, crd in enumerate((self.criterion_kd, self.criterion_kd_path)):
+            r = ranks[i] if ranks is not None else crd.contrast.draw_ranks(e, crd.select_pos_mode)
+            out.append(None if r is None else torch.as_tensor(np.asarray(r), dtype=torch.int32))
+        return e, out
+
+    def enable_graph(self):
+        """Replay the device part of the step from ONE captured HIP graph (the step is ~700 kernel launches;
+        eager dispatch makes it host-bound).  Call after at least two eager steps (first-call CRD Z, lazy plans);
+        shapes must stay fixed afterwards."""
+        self._want_graph = True
+
+    def step(self, batch, epoch=0, ranks=None):
+        opt = self.opt
+        if opt.num_teachers != 2 or opt.distill != "crd":
+            raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd)")
+        (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
+        dev = self.device
+        bnorm = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))
+        self.criterion_div.batch_norm_size = bnorm
+        self.criterion_kd.contrast.batch_norm_size = bnorm
+        self.criterion_kd_path.contrast.batch_norm_size = bnorm
+        e, rk = self._draw_ranks(epoch, ranks)
+        self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)                          # :36
+        use_graph = getattr(self, "_want_graph", False) and self.iter_num - opt.global_step >= 2
+        if not use_graph:
+            x_path = x_path.to(dev, non_blocking=True)                             # ONE H2D copy (reference: three)
+            ema_x_path = ema_x_path.to(dev, non_blocking=True)
+            x_omic = x_omic.to(dev, non_blocking=True)
+            grade = grade.to(dev, non_blocking=True)
+            index = index.to(dev, non_blocking=True)
+            sample_idx = sample_idx.to(dev, non_blocking=True)
+            r1, r2 = [None if r is None else r.to(dev, non_blocking=True) for r in rk]
+            self.optimizer.prepare_step()
+            out = self._device_body(x_path, ema_x_path, x_omic, grade, index, sample_idx, bnorm, e, r1, r2)
+            self.iter_num += 1
+            return out
+        # ---- graph path: static input buffers, per-step scalars in device memory
+        st = getattr(self, "_static", None)
+        key = (tuple(x_path.shape), tuple(x_omic.shape), tuple(sample_idx.shape))
+        if st is None or st["key"] != key:
+            mk = lambda t, dt=None: torch.empty(t.shape, device=dev, dtype=dt or t.dtype)
+            st = dict(key=key, x_path=mk(x_path), ema_x_path=mk(ema_x_path), x_omic=mk(x_omic), grade=mk(grade),
+                      index=mk(index), sample_idx=mk(sample_idx),
+                      r=[None if r is None else torch.empty(r.shape, device=dev, dtype=torch.int32) for r in rk],
+                      graph=None, out=None)
+            self._static = st
+        for name, src in (("x_path", x_path), ("ema_x_path", ema_x_path), ("x_omic", x_omic), ("grade", grade),
+                          ("index", index), ("sample_idx", sample_idx)):
+            if src.data_ptr() != st[name].data_ptr():
+                st[name].copy_(src, non_blocking=True)
+        for dst, src in zip(st["r"], rk):
+            if dst is not None:
+                dst.copy_(src, non_blocking=True)
+        self.optimizer.prepare_step()
+        if st["graph"] is None:
+            lib().ph_prof_enable(0)          # event timing is an eager-mode facility
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                self.optimizer._prepared = True
+                st["out"] = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"], st["index"],
+                                              st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
+            st["graph"] = g
+            # capture does not execute: the prepared scalars are still pending for the first replay
+        self.optimizer._prepared = False
+        st["graph"].replay()
+        self.iter_num += 1
+        return st["out"]
+
+    def static_inputs(self):
+        """The graph path's resident input buffers (fill them in place to skip the device-to-device copy)."""
+        st = getattr(self, "_static", None)
+        return None if st is None else {k: st[k] for k in ("x_path", "ema_x_path", "x_omic", "grade", "index", "sample_idx")}
