@@ -37,7 +37,7 @@ size_t ph_conv2d_workspace_bytes(int B, int Cin, int IH, int IW, int Cout, int K
   const size_t parts = up((size_t)ph_tapconv_stat_parts(&t, stride, PH_PREC_BF16X6) * 2 * Cout * sizeof(float));
   int tpc; const int nc = chunks_for(B, OH, OW, stride, Cout, Cin, &tpc);
   const size_t slab = up((size_t)nc * KS * KS * Cin * Cout * sizeof(float));
-  return wbytes + (parts > slab ? parts : slab);
+  return wbytes + (parts > slab ? parts : slab) + 256;
 }
 
 int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* ch_sumsq, int B, int Cin, int IH,
@@ -109,7 +109,10 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, in
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhWgrad g{};
-  g.x = x; g.dy = dy; g.slab = reinterpret_cast<float*>(ws + up(PH_NPLANES * plane * sizeof(bf16)));
+  // layout: [256 B zero page][slab]
+  if (hipMemsetAsync(ws, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
+  g.zeros = ws;
+  g.x = x; g.dy = dy; g.slab = reinterpret_cast<float*>(ws + 256);
   g.B = B; g.IH = IH; g.IW = IW; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.S = stride; g.pad = pad; g.KS = KS;
   g.nchunks = chunks_for(B, OH, OW, stride, Cout, Cin, &g.tiles_per_chunk);
   int rc = ph_wgrad_launch(&g, prec, st);

@@ -25,7 +25,7 @@ struct TapCfg {
   static constexpr int HPH = (TH - 1) * S + 3;
   static constexpr int HPW = (TW - 1) * S + 3;
   static constexpr int HP = HPH * HPW;
-  static constexpr int A_BYTES = HP * 128;
+  static constexpr int A_BYTES = (HP + 1) / 2 * 256;   // lds_off() addresses rows in 256-B pairs
   static constexpr int B_BYTES = TG * BNT * 128;
   static constexpr int NP = SPLIT ? PH_NPLANES : 1;
   static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) * NP;
@@ -389,7 +389,7 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
   } else {
     if (p.Cout % 128) return PH_EINVAL;   // stride-2 forward convs of ResNet-18 all have Cout >= 128
     if constexpr (SPLIT) return launch_cfg<T, 2, 2, 128, 1, 4, 1, 1, 1>(p, st);
-    else return launch_cfg<T, 2, 4, 128, 1, 4, 2, 1, 3>(p, st);
+    else return launch_cfg<T, 2, 8, 128, 2, 4, 2, 1, 3>(p, st);   // 128 x 128 tile, 8 waves, 121 KB LDS
   }
 }
 
@@ -397,7 +397,7 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
-  const int TH = (S == 1) ? ((p->Cout % 128 == 0 && prec != PH_PREC_BF16) ? 8 : 16) : (prec == PH_PREC_BF16 ? 4 : 2);
+  const int TH = (S == 1) ? ((p->Cout % 128 == 0 && prec != PH_PREC_BF16) ? 8 : 16) : (prec == PH_PREC_BF16 ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
 }
 

@@ -22,9 +22,11 @@ struct WgCfg {
   static constexpr bool SPLIT = is_f32<T>::value;
   static constexpr int TW = 16, BM = TH * TW;
   static constexpr int HPH = (TH - 1) * S + KS, HPW = (TW - 1) * S + KS, HP = HPH * HPW;
-  static constexpr int D_BYTES = BM * 128, X_BYTES = HP * 128;
+  static constexpr int HPP = (HP + 7) / 8 * 8;            // halo pixels padded to whole 1-KiB LDS-DMA pieces
+  static constexpr int D_BYTES = BM * 128, X_BYTES = HPP * 128;
   static constexpr int NP = SPLIT ? PH_NPLANES : 1;
-  static constexpr int LDS_BYTES = (D_BYTES + X_BYTES) * NP;
+  // perf mode: two LDS buffers (tile t+1 lands by LDS-DMA while tile t feeds the MFMAs)
+  static constexpr int LDS_BYTES = SPLIT ? (D_BYTES + X_BYTES) * NP : 2 * (D_BYTES + X_BYTES);
   static constexpr int NT = KS * KS;
 };
 
@@ -89,29 +91,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   const int q4 = (lane & 15) >> 2, p4 = lane & 3, colhalf = (lane >> 4) & 1, khalf = lane >> 5;
   const int pieceA = cf * 2 + colhalf, pieceB = kf * 2 + colhalf;
 
-  for (int tt = t_begin; tt < t_end; ++tt) {
-    const int b = tt / tiles_img, ti = tt - b * tiles_img;
-    const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
-    __syncthreads();
-    // ---- stage dY tile [BM pix][64 cout] and X halo [HP pix][64 cin]
-    for (int i = tid; i < BM * 8; i += 256) {
-      const int pix = i >> 3, ch = i & 7;
-      const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
-      const bool ok = r < p.OH && c < p.OW;
-      const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
-      stage_row<T>(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8, ok, ldsD, C::D_BYTES, off);
-    }
-    const int iy_base = r0 * S - p.pad, ix_base = c0 * S - p.pad;
-    for (int i = tid; i < HP * 8; i += 256) {
-      const int pix = i >> 3, ch = i & 7;
-      const int hr = pix / HPW, hc = pix - hr * HPW;
-      const int iy = iy_base + hr, ix = ix_base + hc;
-      const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
-      stage_row<T>(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8, ok, ldsX, C::X_BYTES, off);
-    }
-    __syncthreads();
-    // ---- K loop over the tile's pixels, 16 per MFMA
+  // ---- MFMA over one staged tile (K = the tile's pixels, 16 per MFMA)
+  auto compute = [&](const unsigned char* dD, const unsigned char* dX) {
 #pragma unroll 2
     for (int kk = 0; kk < BM / 16; ++kk) {
       // the two 4-pixel row groups this lane's tr-reads address
@@ -120,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       const int offA1 = t1 * 128 + sw_piece(t1, pieceA) * 32 + p4 * 8;
       bf16x8 a[NP];
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) a[pl] = tr_pair(ldsD + pl * C::D_BYTES, offA0, offA1);
+      for (int pl = 0; pl < NP; ++pl) a[pl] = tr_pair(dD + pl * C::D_BYTES, offA0, offA1);
       const int hb0 = ((t0 >> 4) * S) * HPW + (t0 & 15) * S;
       const int hb1 = ((t1 >> 4) * S) * HPW + (t1 & 15) * S;
 #pragma unroll
@@ -131,7 +112,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int offB1 = h1 * 128 + sw_piece(h1, pieceB) * 32 + p4 * 8;
         bf16x8 bq[NP];
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) bq[pl] = tr_pair(ldsX + pl * C::X_BYTES, offB0, offB1);
+        for (int pl = 0; pl < NP; ++pl) bq[pl] = tr_pair(dX + pl * C::X_BYTES, offB0, offB1);
         if constexpr (SPLIT) {
 #define PH_MM(PI, PJ) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ], acc[t], 0, 0, 0);
           PH_SPLIT_PAIRS(PH_MM)
@@ -140,6 +121,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[t], 0, 0, 0);
         }
       }
+    }
+  };
+
+  if constexpr (SPLIT) {
+    for (int tt = t_begin; tt < t_end; ++tt) {
+      const int b = tt / tiles_img, ti = tt - b * tiles_img;
+      const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
+      __syncthreads();
+      // ---- stage dY tile [BM pix][64 cout] and X halo [HP pix][64 cin]
+      for (int i = tid; i < BM * 8; i += 256) {
+        const int pix = i >> 3, ch = i & 7;
+        const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
+        const bool ok = r < p.OH && c < p.OW;
+        const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
+        stage_row<T>(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8, ok, ldsD, C::D_BYTES, off);
+      }
+      const int iy_base = r0 * S - p.pad, ix_base = c0 * S - p.pad;
+      for (int i = tid; i < HP * 8; i += 256) {
+        const int pix = i >> 3, ch = i & 7;
+        const int hr = pix / HPW, hc = pix - hr * HPW;
+        const int iy = iy_base + hr, ix = ix_base + hc;
+        const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
+        stage_row<T>(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8, ok, ldsX, C::X_BYTES, off);
+      }
+      __syncthreads();
+      compute(ldsD, ldsX);
+    }
+  } else {
+    // perf mode: LDS-DMA (global_load_lds_dwordx4) straight from HBM/L2 into the swizzled LDS image.  The LDS
+    // destination of one wave-instruction is linear (base + lane*16 = 8 pixel rows), so the XOR swizzle is
+    // applied to the per-lane SOURCE chunk instead; out-of-image pixels read a zero page.  Tile t+1 is issued
+    // into the other buffer before the MFMAs of tile t; the single barrier per tile (which drains vmcnt) comes
+    // after them, so the loads have the whole MFMA block to land.
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int BUF = C::D_BYTES + C::X_BYTES;
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zeros);
+    auto issue = [&](int tt, int buf) {
+      const int b = tt / tiles_img, ti = tt - b * tiles_img;
+      const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
+      unsigned char* dD = smem + buf * BUF;
+      unsigned char* dX = dD + C::D_BYTES;
+      for (int i0 = wave * 64; i0 < BM * 8; i0 += 256) {
+        const int i = i0 + lane, pix = i >> 3, pos = i & 7;
+        const int ch = sw_piece(pix, pos >> 1) * 2 + (pos & 1);          // source chunk of this LDS slot
+        const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
+        const bool ok = r < p.OH && c < p.OW;
+        const void* src = ok ? (const void*)(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8)
+                             : (const void*)zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (lds_void*)(dD + i0 * 16), 16, 0, 0);
+      }
+      const int iy_base = r0 * S - p.pad, ix_base = c0 * S - p.pad;
+      for (int i0 = wave * 64; i0 < C::HPP * 8; i0 += 256) {
+        const int i = i0 + lane, pix = i >> 3, pos = i & 7;
+        const int ch = sw_piece(pix, pos >> 1) * 2 + (pos & 1);
+        const int hr = pix / HPW, hc = pix - hr * HPW;
+        const int iy = iy_base + hr, ix = ix_base + hc;
+        const bool ok = pix < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const void* src = ok ? (const void*)(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8)
+                             : (const void*)zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (lds_void*)(dX + i0 * 16), 16, 0, 0);
+      }
+    };
+    if (t_begin < t_end) issue(t_begin, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int tt = t_begin; tt < t_end; ++tt) {
+      if (tt + 1 < t_end) issue(tt + 1, buf ^ 1);
+      compute(smem + buf * BUF, smem + buf * BUF + C::D_BYTES);
+      __syncthreads();
+      buf ^= 1;
     }
   }
   // ---- partial slab: acc[t][q] -> row (cout) = (q&3)+8*(q>>2)+4*khalf, col (cin) = lane&31

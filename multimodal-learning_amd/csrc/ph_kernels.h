@@ -40,6 +40,7 @@ struct PhWgrad {
   const void* x;         // [B][IH][IW][Cin]
   const void* dy;        // [B][OH][OW][Cout]
   float* slab;           // [nchunks][KS*KS][Cout][Cin] fp32 partial sums
+  const void* zeros;     // >= 16 B of device zeros (source of out-of-image pixels for the LDS-DMA path)
   int B, IH, IW, Cin, OH, OW, Cout;
   int S, pad, KS;
   int nchunks, tiles_per_chunk;

@@ -38,7 +38,7 @@ struct PhResnetPlan {
   std::vector<Unit> units;
   std::vector<Block> blocks;
   size_t x4_off, p0_off, idx_off, parts_off, parts_bytes;
-  size_t g0_off, g1_off, dy_off, da_off, slab_off, slab_bytes, bparts_off, cc_off;
+  size_t g0_off, g1_off, dy_off, da_off, slab_off, slab_bytes, bparts_off, cc_off, zero_off;
   size_t ws_bytes, packed_bytes;
   int PH0, PW0;   // pooled dims
   size_t act_max;   // max block-level activation bytes
@@ -140,6 +140,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   P->slab_off = take(slab_max);
   P->bparts_off = take((size_t)ph_bn_bwd_parts((size_t)B * s.OH * s.OW) * 2 * 512 * sizeof(float));
   P->cc_off = take(2 * 512 * sizeof(float));
+  P->zero_off = take(256);
   P->ws_bytes = off;
   P->packed_bytes = woff * sizeof(bf16);
   return P;
@@ -266,6 +267,7 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
   const Unit& u = P->units[ui];
   PhWgrad w{};
   w.x = x; w.dy = dy; w.slab = reinterpret_cast<float*>(c.ws + P->slab_off);
+  w.zeros = c.ws + P->zero_off;
   w.B = P->B; w.IH = u.IH; w.IW = u.IW; w.Cin = u.Cin; w.OH = u.OH; w.OW = u.OW; w.Cout = u.Cout;
   w.S = u.S; w.pad = u.pad; w.KS = u.KS;
   w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk);
@@ -358,6 +360,7 @@ int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const v
   unsigned char* dyb = ws + P->dy_off;
   unsigned char* dab = ws + P->da_off;
   int rc;
+  if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
   {
     const Block& b = P->blocks[7];
     if ((rc = ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st))) return rc;
