@@ -170,11 +170,13 @@ def main():
             tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(str(dom))
+                    traffic = json.load(open(tf)).get(str(dom), {}).get("bytes_per_launch")
                 except Exception:
                     traffic = None
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                               "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction)",
                                "kernel": CLS_NAMES[dom], "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                                "all_kernels": [{"kernel": k, "launches": int(a), "total_ms": round(b, 3),

@@ -23,7 +23,7 @@ class ReplicaSync:
 
     # 1 -------------------------------------------------------------------------------------------------
     def all_reduce_grads(self, flat):
-        g = flat.grad if hasattr(flat, "grad") else flat
+        g = flat if torch.is_tensor(flat) else flat.grad     # a FlatParams or a plain flat tensor
         n = g.numel()
         works = []
         for s in range(0, n, self.bucket_elems):

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs that `gpurun` merged into gpurun_out/<run>/ into the compact summaries committed
+under profiles/ (kernel stats table, PMC table, per-launch HBM traffic of the MFMA kernels).
+
+    python profiles/summarize.py gpurun_out/r01 r01
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE come from separate
+--pmc passes; both are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of wide coalesced streaming
+reads, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(k):
+    for a, b in (("(anonymous namespace)::", ""), ("void ", ""), ("_ZN12_GLOBAL__N_1", "")):
+        k = k.replace(a, b)
+    return k
+
+
+def cls_of(name):
+    """kernel name -> class index of ph_prof_summary / bench.py CLS_NAMES"""
+    n = name
+    if "tapconv_kernel" in n:
+        if "Li2ELi8ELi128" in n or ", 2, 8, 128" in n:
+            return 2
+        if "16, 64, 4, 1" in n or "Li16ELi64ELi4ELi1" in n:
+            return 0
+        if "16, 128, 4, 2" in n or "Li16ELi128ELi4ELi2" in n:
+            return 1
+        return None
+    if "stem_wgrad_kernel" in n:
+        return 5
+    if "stem_fwd_kernel" in n:
+        return 4
+    if "wgrad_kernel" in n and "reduce" not in n:
+        return 3
+    return None
+
+
+def load_pmc(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k].add(r["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in cnt.items()}
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    out = os.path.dirname(os.path.abspath(__file__))
+    # ---- kernel stats
+    f = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+    if f:
+        rows = list(csv.DictReader(open(f[0])))
+        tot = sum(int(r["TotalDurationNs"]) for r in rows)
+        with open(os.path.join(out, f"{tag}_kernel_stats.txt"), "w") as o:
+            o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3   (total kernel time {tot/1e6:.1f} ms)\n")
+            o.write(f"{'kernel':<100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}\n")
+            for r in rows[:45]:
+                o.write(f"{short(r['Name'])[:100]:<100s} {r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} "
+                        f"{float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}\n")
+    # ---- SQ counters
+    f = glob.glob(os.path.join(src, "sq", "*", "*counter_collection.csv"))
+    if f:
+        agg, cnt = load_pmc(f[0])
+        with open(os.path.join(out, f"{tag}_pmc_sq.txt"), "w") as o:
+            o.write("# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
+                    "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 (eager bench, 6 steps)\n")
+            o.write(f"{'kernel':<80s} {'n':>5s} {'lds_conflict/lds_active':>24s} {'wait_any/wave_cycles':>22s} {'mfma_busy/busy/4':>18s}\n")
+            for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0))[:14]:
+                d = agg[k]
+                o.write(f"{short(k)[:80]:<80s} {cnt[k]:5d} "
+                        f"{d.get('SQ_LDS_BANK_CONFLICT',0)/max(d.get('SQ_LDS_IDX_ACTIVE',0),1):24.3f} "
+                        f"{d.get('SQ_WAIT_ANY',0)/max(d.get('SQ_WAVE_CYCLES',0),1):22.3f} "
+                        f"{d.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/max(d.get('SQ_BUSY_CYCLES',0),1)/4:18.3f}\n")
+    # ---- HBM traffic per launch of the MFMA kernel classes
+    ff = glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))
+    fw = glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))
+    if ff and fw:
+        fa, fc = load_pmc(ff[0])
+        wa, wc = load_pmc(fw[0])
+        traffic = {}
+        lines = []
+        per = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
+        for k in fa:
+            c = cls_of(k)
+            if c is not None:
+                per[c][0] += fa[k].get("FETCH_SIZE", 0.0); per[c][2] += fc[k]
+        for k in wa:
+            c = cls_of(k)
+            if c is not None:
+                per[c][1] += wa[k].get("WRITE_SIZE", 0.0); per[c][3] += wc[k]
+        for c, (fe, wr, nf, nw) in sorted(per.items()):
+            rd = 2.0 * fe * 1024 / max(nf, 1)        # gfx950: FETCH_SIZE counts 64 B per 128-B request
+            ww = wr * 1024 / max(nw, 1)
+            traffic[str(c)] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(ww),
+                               "bytes_per_launch": round(rd + ww), "launches_sampled": nf}
+            lines.append(f"class {c}: read {rd/1e6:9.2f} MB  write {ww/1e6:9.2f} MB  per launch ({nf} launches)")
+        json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
+        open(os.path.join(out, f"{tag}_traffic.txt"), "w").write(
+            "# HBM traffic per launch (FETCH_SIZE x2 correction, WRITE_SIZE exact; separate --pmc passes)\n" + "\n".join(lines) + "\n")
+    print("wrote", sorted(os.listdir(out)))
+
+
+if __name__ == "__main__":
+    main()
