@@ -55,6 +55,10 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
   t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cin; t.Cout = Cout; t.OHt = OH; t.OWt = OW; t.OH = OH; t.OW = OW;
   t.os = 1; t.iy0 = -pad; t.ix0 = -pad; t.ntaps = KS * KS;
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = k; }
+  if (KS == 1 && stride == 2) {   // strided view (see resnet_plan.hip conv_fwd)
+    t.in_pix_stride = 2L * Cin; t.in_row_stride = 2L * IW * Cin; t.in_img_stride = (long)IH * IW * Cin;
+    t.IH = OH; t.IW = OW; stride = 1;
+  }
   if ((rc = ph_tapconv_launch(&t, stride, prec, st))) return rc;
   if (ch_sum || ch_sumsq) {
     hipLaunchKernelGGL(parts_sum_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, st, t.stats,
@@ -114,7 +118,11 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, in
   g.zeros = ws;
   g.x = x; g.dy = dy; g.slab = reinterpret_cast<float*>(ws + 256);
   g.B = B; g.IH = IH; g.IW = IW; g.Cin = Cin; g.OH = OH; g.OW = OW; g.Cout = Cout; g.S = stride; g.pad = pad; g.KS = KS;
-  g.nchunks = chunks_for(B, OH, OW, stride, Cout, Cin, &g.tiles_per_chunk);
+  if (KS == 1 && stride == 2) {
+    g.x_pix_stride = 2L * Cin; g.x_row_stride = 2L * IW * Cin; g.x_img_stride = (long)IH * IW * Cin;
+    g.IH = OH; g.IW = OW; g.S = 1;
+  }
+  g.nchunks = chunks_for(B, OH, OW, g.S, Cout, Cin, &g.tiles_per_chunk);
   int rc = ph_wgrad_launch(&g, prec, st);
   if (rc) return rc;
   return ph_wgrad_reduce_launch(g.slab, dw, g.nchunks, KS, Cout, Cin, st);

@@ -28,7 +28,12 @@ struct TapCfg {
   static constexpr int A_BYTES = (HP + 1) / 2 * 256;   // lds_off() addresses rows in 256-B pairs
   static constexpr int B_BYTES = TG * BNT * 128;
   static constexpr int NP = SPLIT ? PH_NPLANES : 1;
-  static constexpr int LDS_BYTES = (A_BYTES + B_BYTES) * NP;
+  // perf-mode 8-wave tiles stream the weight stages by LDS-DMA into a 2-deep ring when it fits the 160 KB LDS
+  // (measured r01: 597 vs 672 TFLOP/s for the register-prefetch path - 6 x 1-KiB DMA pieces per wave and
+  // stage cost more issue time than they save - so the ring is compiled out until the stage is restructured)
+  static constexpr bool DMA_ENABLED = false;
+  static constexpr bool DMA = DMA_ENABLED && !SPLIT && (WM * WN == 8) && (A_BYTES + 2 * B_BYTES <= 160 * 1024);
+  static constexpr int LDS_BYTES = DMA ? (A_BYTES + 2 * B_BYTES) : (A_BYTES + B_BYTES) * NP;
   static constexpr int NTH = WM * WN * 64;
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert(WM * FM * 32 == TH * TW, "M tiling");
@@ -68,7 +73,10 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
   const int n0 = blockIdx.y * BNT;
   const int b = blockIdx.z;
-  const T* in = reinterpret_cast<const T*>(p.in) + (size_t)b * p.IH * p.IW * p.Cin;
+  const long pix_st = p.in_pix_stride ? p.in_pix_stride : p.Cin;
+  const long row_st = p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin;
+  const long img_st = p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin;
+  const T* in = reinterpret_cast<const T*>(p.in) + (size_t)b * img_st;
   const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
   const int iy_base = r0 * S + p.iy0, ix_base = c0 * S + p.ix0;
 
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     const int hr = pix / HPW, hc = pix - hr * HPW;
     const int iy = iy_base + hr, ix = ix_base + hc;
     ok = (i < HP * 8) && (iy >= 0) && (iy < p.IH) && (ix >= 0) && (ix < p.IW);
-    return in + ((size_t)iy * p.IW + ix) * p.Cin + k0 + ch * 8;
+    return in + (size_t)iy * row_st + (size_t)ix * pix_st + k0 + ch * 8;
   };
   auto stage_halo_sync = [&](int k0) {   // parity mode: load, split into 3 planes, store
     for (int i = tid; i < HP * 8; i += NTH) {
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     }
   };
   // perf mode: register prefetch (issue the global loads before the MFMA block, write LDS after it)
-  u32x4 hreg[SPLIT ? 1 : HCH], wreg[SPLIT ? 1 : WCH];
+  u32x4 hreg[SPLIT ? 1 : HCH], wreg[(SPLIT || C::DMA) ? 1 : WCH];
   auto load_halo_regs = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < HCH; ++e) {
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     }
   };
   // ---- MFMA over one staged tap group -----------------------------------------------------------------
-  auto compute = [&](int tg0, int gcount) {
+  auto compute = [&](int tg0, int gcount, const unsigned char* ldsBcur) {
     for (int t = 0; t < gcount; ++t) {
       const int toff = p.dy[tg0 + t] * HPW + p.dx[tg0 + t];
       int hp[FM];
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
             a[pl][i] = *reinterpret_cast<const bf16x8*>(ldsA + pl * C::A_BYTES + lds_off(hp[i], chunk));
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsB + pl * C::B_BYTES + t * BNT * 128 + lds_off(nrow[j], chunk));
+            bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsBcur + pl * C::B_BYTES + t * BNT * 128 + lds_off(nrow[j], chunk));
         }
         if constexpr (SPLIT) {
 #define PH_MM(PI, PJ)                                                                                   \
@@ -228,8 +236,50 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         if (tg0 > 0) __syncthreads();
         stage_w_sync(k0, tg0, gcount);
         __syncthreads();
-        compute(tg0, gcount);
+        compute(tg0, gcount, ldsB);
       }
+    }
+  } else if constexpr (C::DMA) {
+    // perf mode, LDS-DMA weight stream: global_load_lds_dwordx4 writes 1 KiB (8 weight rows) per wave-instruction
+    // straight into the swizzled image of the NEXT stage's ring slot - the LDS side is linear, so the XOR swizzle
+    // is applied to each lane's SOURCE (row, chunk).  No VGPR staging and no ds_write for the weights; the one
+    // barrier per stage sits after the MFMA block, so the DMA has that whole block to land.  The halo of the next
+    // 64-channel slice still goes through registers (it needs the zero fill of out-of-image pixels).
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto issue_w = [&](int k0, int tg0, int gcount, unsigned char* dst) {
+      for (int i0 = wave * 64; i0 < gcount * BNT * 8; i0 += NTH) {
+        const int i = i0 + lane;
+        const int t = i / (BNT * 8), rem = i - t * BNT * 8;
+        const int rp = rem >> 4, sl = (rem & 15) ^ (rp & 15);       // row pair, un-swizzled slot
+        const int row = 2 * rp + (sl >> 3), ch = sl & 7;
+        const bf16* src = wbase + ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (lds_void*)(dst + i0 * 16), 16, 0, 0);
+      }
+    };
+    const int g0 = p.ntaps < TG ? p.ntaps : TG;
+    load_halo_regs(0);
+    issue_w(0, 0, g0, ldsB);
+    store_halo_regs();
+    __syncthreads();
+    int sl = 0, tg0 = 0, cur = 0;
+    for (int st = 0; st < nstages; ++st) {
+      const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
+      int nsl = sl, ntg0 = tg0 + TG;
+      if (ntg0 >= p.ntaps) { ntg0 = 0; nsl = sl + 1; }
+      const bool has_next = st + 1 < nstages;
+      const int ngcount = (p.ntaps - ntg0) < TG ? (p.ntaps - ntg0) : TG;
+      if (has_next) {
+        issue_w(nsl << 6, ntg0, ngcount, ldsB + (cur ^ 1) * C::B_BYTES);
+        if (nsl != sl) load_halo_regs(nsl << 6);
+      }
+      compute(tg0, gcount, ldsB + cur * C::B_BYTES);
+      __syncthreads();                       // MFMA reads of A/B[cur] done; DMA into B[cur^1] landed (vmcnt drained)
+      if (has_next && nsl != sl) {
+        store_halo_regs();
+        __syncthreads();
+      }
+      sl = nsl; tg0 = ntg0; cur ^= 1;
     }
   } else {
     // perf mode: stage s = (slice, tap group).  While the MFMAs of stage s run, the global loads of stage
@@ -251,7 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         load_w_regs(nsl << 6, ntg0, ngcount);
         if (nsl != sl) load_halo_regs(nsl << 6);
       }
-      compute(tg0, gcount);
+      compute(tg0, gcount, ldsB);
       __syncthreads();
       if (has_next) {
         store_w_regs(ngcount);

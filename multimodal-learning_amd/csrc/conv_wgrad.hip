@@ -80,6 +80,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   const int t_end = min(ntiles, t_begin + p.tiles_per_chunk);
   const T* X = reinterpret_cast<const T*>(p.x);
   const T* DY = reinterpret_cast<const T*>(p.dy);
+  const long xpix = p.x_pix_stride ? p.x_pix_stride : p.Cin;
+  const long xrow = p.x_row_stride ? p.x_row_stride : (long)p.IW * p.Cin;
+  const long ximg = p.x_img_stride ? p.x_img_stride : (long)p.IH * p.IW * p.Cin;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int iy = iy_base + hr, ix = ix_base + hc;
         const bool ok = iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
-        stage_row<T>(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8, ok, ldsX, C::X_BYTES, off);
+        stage_row<T>(X + (size_t)b * ximg + (size_t)iy * xrow + (size_t)ix * xpix + ci0 + ch * 8, ok, ldsX, C::X_BYTES, off);
       }
       __syncthreads();
       compute(ldsD, ldsX);
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int hr = pix / HPW, hc = pix - hr * HPW;
         const int iy = iy_base + hr, ix = ix_base + hc;
         const bool ok = pix < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const void* src = ok ? (const void*)(X + (((size_t)b * p.IH + iy) * p.IW + ix) * p.Cin + ci0 + ch * 8)
+        const void* src = ok ? (const void*)(X + (size_t)b * ximg + (size_t)iy * xrow + (size_t)ix * xpix + ci0 + ch * 8)
                              : (const void*)zero;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (lds_void*)(dX + i0 * 16), 16, 0, 0);

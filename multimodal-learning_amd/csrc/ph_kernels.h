@@ -32,6 +32,9 @@ struct PhTapConv {
   int ntaps;
   int dy[9], dx[9];      // 0..2
   int wtap[9];           // weight slab index of each tap
+  // element strides of the input view (0 = dense NHWC: Cin, IW*Cin, IH*IW*Cin).  A 1x1 stride-2 convolution is run
+  // as a 1x1 stride-1 tap-conv over the view {pixel stride 2*Cin, row stride 2*IW*Cin} (no wasted halo pixels).
+  long in_pix_stride, in_row_stride, in_img_stride;
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec);
@@ -44,6 +47,7 @@ struct PhWgrad {
   int B, IH, IW, Cin, OH, OW, Cout;
   int S, pad, KS;
   int nchunks, tiles_per_chunk;
+  long x_pix_stride, x_row_stride, x_img_stride;   // element strides of the x view (0 = dense NHWC)
 };
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st);
 int ph_wgrad_tile_h(int S);

@@ -47,7 +47,7 @@ struct PhResnetPlan {
 namespace {
 
 int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
-  const int th = ph_wgrad_tile_h(u.S);
+  const int th = ph_wgrad_tile_h((u.KS == 1) ? 1 : u.S);
   const int ntiles = B * cdiv(u.OH, th) * cdiv(u.OW, 16);
   const int blocks = (u.Cout / 64) * (u.Cin / 64);
   int want = cdiv(512, blocks);            // ~2 workgroups per CU; few partial slabs to reduce (HBM-bound)
@@ -112,7 +112,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
         u.y_off = take((size_t)B * u.OH * u.OW * cout * es);
         u.st_off = take(4 * (size_t)cout * sizeof(float));
         PhTapConv tc{}; tc.B = B; tc.Cout = cout; tc.OHt = u.OH; tc.OWt = u.OW;
-        parts_max = std::max(parts_max, (size_t)ph_tapconv_stat_parts(&tc, st, prec) * 2 * cout * sizeof(float));
+        parts_max = std::max(parts_max, (size_t)ph_tapconv_stat_parts(&tc, (ks == 1 ? 1 : st), prec) * 2 * cout * sizeof(float));
         int tpc; int nc = wgrad_chunks(u, B, &tpc);
         slab_max = std::max(slab_max, (size_t)nc * ks * ks * cin * cout * sizeof(float));
         P->units.push_back(u);
@@ -205,9 +205,14 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
   t.OHt = u.OH; t.OWt = u.OW; t.OH = u.OH; t.OW = u.OW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
   t.iy0 = -u.pad; t.ix0 = -u.pad; t.ntaps = u.KS * u.KS;
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / u.KS; t.dx[k] = k % u.KS; t.wtap[k] = k; }
-  int rc = ph_tapconv_launch(&t, u.S, P->prec, c.st);
+  int S = u.S;
+  if (u.KS == 1 && u.S == 2) {   // 1x1 / stride 2 == 1x1 / stride 1 over the even-pixel view of the input
+    t.in_pix_stride = 2L * u.Cin; t.in_row_stride = 2L * u.IW * u.Cin; t.in_img_stride = (long)u.IH * u.IW * u.Cin;
+    t.IH = u.OH; t.IW = u.OW; S = 1;
+  }
+  int rc = ph_tapconv_launch(&t, S, P->prec, c.st);
   if (rc) return rc;
-  const int nparts = ph_tapconv_stat_parts(&t, u.S, P->prec);
+  const int nparts = ph_tapconv_stat_parts(&t, S, P->prec);
   float* rm = c.update_running ? (float*)c.params[ui * 6 + 3] : nullptr;
   return ph_bn_finalize_launch(t.stats, nparts, u.Cout, (double)P->B * u.OH * u.OW, 1e-5f, 0.1f,
                                (const float*)c.params[ui * 6 + 1], (const float*)c.params[ui * 6 + 2], c.stat(u, 0),
@@ -270,6 +275,10 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
   w.zeros = c.ws + P->zero_off;
   w.B = P->B; w.IH = u.IH; w.IW = u.IW; w.Cin = u.Cin; w.OH = u.OH; w.OW = u.OW; w.Cout = u.Cout;
   w.S = u.S; w.pad = u.pad; w.KS = u.KS;
+  if (u.KS == 1 && u.S == 2) {   // strided view, as in conv_fwd
+    w.x_pix_stride = 2L * u.Cin; w.x_row_stride = 2L * u.IW * u.Cin; w.x_img_stride = (long)u.IH * u.IW * u.Cin;
+    w.IH = u.OH; w.IW = u.OW; w.S = 1;
+  }
   w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk);
   int rc = ph_wgrad_launch(&w, P->prec, c.st);
   if (rc) return rc;
