@@ -128,6 +128,7 @@ def main():
         # the in-library HIP-event timer brackets individual launches, which a graph replay does not expose:
         # time the same kernels in 3 eager steps right after the timed region (same data, same shapes)
         step._want_graph = False
+        step._side_stream = None         # one stream: un-overlapped per-kernel durations
         step.step(batches[0], epoch=1)
         L.ph_prof_reset(); L.ph_prof_enable(1)
         for i in range(3):

@@ -16,6 +16,7 @@ constexpr int TH = 8, TW = 16, HPH = (TH - 1) * 2 + 7, HPW = (TW - 1) * 2 + 8;  
 constexpr int HP = HPH * HPW;
 constexpr int XB = HP * 8;            // bytes of one bf16 halo plane
 constexpr int WB = 7 * 64 * 64;       // bytes of one weight plane [7][64][32] bf16
+constexpr int STEM_TPW = 8;           // output tiles per forward workgroup (weights staged once per workgroup)
 
 __device__ __forceinline__ int wsw(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
@@ -52,12 +53,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   unsigned char* ldsX = smem;               // NP planes of XB
   unsigned char* ldsW = smem + XB * NP;     // NP planes of WB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_w = (p.OW + TW - 1) / TW;
-  const int tile = blockIdx.x, b = blockIdx.z;
-  const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
+  const int tiles_w = (p.OW + TW - 1) / TW, tiles_h = (p.OH + TH - 1) / TH;
+  const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * p.B;
   const T* x4 = reinterpret_cast<const T*>(p.x4);
 
-  stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
+  // the 28 KB (x planes) weight image is staged ONCE per workgroup and reused for STEM_TPW consecutive tiles
   for (int i = tid; i < 7 * 64 * 4; i += 256) {   // 16-B chunks of the weight plane(s)
     const int ch = i & 3, row = i >> 2;           // row = kh*64 + cout
     const int off = row * 64 + (wsw(row, ch) << 4);
@@ -66,59 +66,66 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       *reinterpret_cast<u32x4*>(ldsW + pl * WB + off) =
           reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(p.w) + (size_t)pl * p.wplane)[i];
   }
-  __syncthreads();
-
-  f32x16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
   const int m = wave * 32 + (lane & 31), khalf = lane >> 5;
   const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  const int t_begin = blockIdx.x * STEM_TPW, t_end = min(ntiles, t_begin + STEM_TPW);
+  for (int tt = t_begin; tt < t_end; ++tt) {
+    const int b = tt / tiles_img, tile = tt - b * tiles_img;
+    const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
+    __syncthreads();   // previous tile's fragment reads of ldsX are done (and, first time, nothing)
+    stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
+    __syncthreads();
+
+    f32x16 acc[2];
 #pragma unroll
-  for (int kh = 0; kh < 7; ++kh) {
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int chunk = s * 2 + khalf;
-      const int aoff = (pbase + kh * HPW + 4 * s + 2 * khalf) * 8;
-      bf16x8 a[NP], bq[NP][2];
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) {
-        a[pl] = *reinterpret_cast<const bf16x8*>(ldsX + pl * XB + aoff);
+    for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int row = kh * 64 + j * 32 + (lane & 31);
-          bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsW + pl * WB + row * 64 + (wsw(row, chunk) << 4));
+      for (int s = 0; s < 2; ++s) {
+        const int chunk = s * 2 + khalf;
+        const int aoff = (pbase + kh * HPW + 4 * s + 2 * khalf) * 8;
+        bf16x8 a[NP], bq[NP][2];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          a[pl] = *reinterpret_cast<const bf16x8*>(ldsX + pl * XB + aoff);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = kh * 64 + j * 32 + (lane & 31);
+            bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsW + pl * WB + row * 64 + (wsw(row, chunk) << 4));
+          }
         }
-      }
-      if constexpr (SPLIT) {
+        if constexpr (SPLIT) {
 #define PH_MM(PI, PJ)                                                                               \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ][j], acc[j], 0, 0, 0);
-        PH_SPLIT_PAIRS(PH_MM)
+          PH_SPLIT_PAIRS(PH_MM)
 #undef PH_MM
-      } else {
+        } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0][j], acc[j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0][j], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- per-tile epilogue: mask, accumulate statistics in registers, store
+    T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+      const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+      const bool valid = r < p.OH && c < p.OW;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v = valid ? acc[j][q] : 0.f;
+        s1[j] += v; s2[j] += v * v;
+        if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
       }
     }
   }
-  // ---- epilogue (as conv_tap.hip): mask, statistics, store
-  T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * 64;
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
-    const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
-    const bool valid = r < p.OH && c < p.OW;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float v = valid ? acc[j][q] : 0.f;
-      s1[j] += v; s2[j] += v * v;
-      if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
-    }
-  }
-  if (p.stats) {
+  if (p.stats) {   // one partial row per workgroup
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][64]
 #pragma unroll
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * 64 + n];
-      p.stats[(((size_t)b * gridDim.x + tile) * 2 + which) * 64 + n] = v;
+      p.stats[((size_t)blockIdx.x * 2 + which) * 64 + n] = v;
     }
   }
 }
@@ -285,10 +292,10 @@ int set_lds(K kern, int bytes, bool& done) {
 
 }  // namespace
 
-int ph_stem_stat_parts(int B, int OH, int OW) { return B * cdiv(OH, TH) * cdiv(OW, TW); }
+int ph_stem_stat_parts(int B, int OH, int OW) { return cdiv(B * cdiv(OH, TH) * cdiv(OW, TW), STEM_TPW); }
 
 int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
-  dim3 grid(cdiv(p->OH, TH) * cdiv(p->OW, TW), 1, p->B);
+  dim3 grid(ph_stem_stat_parts(p->B, p->OH, p->OW));
   void* tok = nullptr;
   if (ph_prof_on()) ph_prof_begin(PH_CLS_STEM_FWD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0, st, &tok);
   struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};

@@ -20,7 +20,8 @@ def stage2_opt(**overrides):
         # optimiser / schedule (options.py:125-137,155-158)
         optimizer_type="adam", lr=5e-4, beta1=0.9, beta2=0.999, weight_decay=4e-4, lr_policy="linear", niter=0,
         niter_decay=30, epoch_count=1, lambda_cox=1.0, lambda_nll=1.0, lambda_reg=3e-4, ema_decay=0.99,
-        global_step=0, batch_size=16)
+        global_step=0, batch_size=16,
+        overlap_teachers=True)     # ours: run the EMA / teacher forwards on a second HIP stream
     for k, v in overrides.items():
         if not hasattr(o, k):
             raise AttributeError("unknown option %r" % k)

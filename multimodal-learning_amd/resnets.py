@@ -222,11 +222,20 @@ class ResNet(nn.Module):
         return self._ws_cache[key]
 
     def _alloc_trunk_grads(self):
+        """Gradient destinations of ph_resnet_backward.  With `_direct_grad` (set by DistillStep, whose optimiser
+        keeps zeroed flat `.grad` views) the kernels write straight into `p.grad` - every trunk parameter receives
+        exactly one contribution per backward, so overwrite == accumulate-into-zero - and autograd gets None for
+        it (saves ~60 tiny AccumulateGrad launches per step).  Otherwise fresh tensors are returned to autograd."""
         grads, gptrs = [], []
+        direct = getattr(self, "_direct_grad", False)
         for p in self._trunk_params():
-            g = torch.empty_like(p)
-            grads.append(g)
-            gptrs.append(g.data_ptr())
+            if direct and p.grad is not None and p.grad.is_contiguous() and p.grad.dtype == torch.float32:
+                grads.append(None)
+                gptrs.append(p.grad.data_ptr())
+            else:
+                g = torch.empty_like(p)
+                grads.append(g)
+                gptrs.append(g.data_ptr())
         return grads, gptrs
 
     # ------------------------------------------------------------------ reference API

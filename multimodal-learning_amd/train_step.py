@@ -221,11 +221,13 @@ class DistillStep:
         self.iter_num = opt.global_step
         self._want_graph = False
         self._static = None
+        self._side_stream = torch.cuda.Stream(device=self.device) if getattr(opt, "overlap_teachers", True) else None
         self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
         # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
         flat = self.optimizer.flat
         n_student = len(list(self.model.parameters()))
         self.ema_flat = FlatParams(list(self.ema_model.parameters()))
+        self.model._direct_grad = True     # trunk gradients are written straight into the flat .grad views
         for mod in self.ema_model.modules():
             if hasattr(mod, "_get_packed"):
                 mod._follow_epoch = True   # updated by the fused Adam+EMA kernel through raw pointers
@@ -239,10 +241,24 @@ class DistillStep:
     def _device_body(self, x_path, ema_x_path, x_omic, grade, index, sample_idx, bnorm, e, r1, r2):
         """Everything of the step that runs on the device (capturable in one HIP graph)."""
         opt = self.opt
+        # The two teachers' forwards do not depend on the student's: they run on a second stream (a parallel branch
+        # of the captured graph) so their small-kernel tails overlap the student's convolutions.
+        main = torch.cuda.current_stream()
+        side = self._side_stream
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
+                fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
+                for t in (ema_path_feat, ema_logit_path, fuse_feat, logits[-1]):
+                    t.record_stream(main)
         _, path_feat, logit_path, pred_path, _ = self.model(x_path=x_path)                                   # :249
-        with torch.no_grad():
-            _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                      # :254
-            fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            with torch.no_grad():
+                _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
+                fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
         loss_div1 = self.criterion_div(logit_path, logits[-1].detach())                                     # :264
         loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
