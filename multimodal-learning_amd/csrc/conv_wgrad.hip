@@ -241,18 +241,34 @@ int launch_wg_T(const PhWgrad& p, hipStream_t st) {
   return PH_EINVAL;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nchunks, int NT,
-                                    int Cout, int Cin) {
-  // one thread per (tap, cout, cin); writes OIHW: dw[((co*Cin + ci)*NT) + tap]
+// slab[nchunks][NT][Cout][Cin] -> OIHW.  64 outputs x 4 chunk-lanes per block, 4 independent partial sums per
+// thread (loads in flight), fixed summation order (bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                           int nchunks, int NT, int Cout, int Cin) {
   const size_t n = (size_t)NT * Cout * Cin;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int ci = i % Cin;
-  const int co = (i / Cin) % Cout;
-  const int t = i / ((size_t)Cin * Cout);
-  float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += slab[(size_t)c * n + i];
-  dw[((size_t)co * Cin + ci) * NT + t] = s;
+  const int e = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int c = cl;
+    for (; c + 12 < nchunks; c += 16) {
+      s0 += slab[(size_t)c * n + i];
+      s1 += slab[(size_t)(c + 4) * n + i];
+      s2 += slab[(size_t)(c + 8) * n + i];
+      s3 += slab[(size_t)(c + 12) * n + i];
+    }
+    for (; c < nchunks; c += 4) s0 += slab[(size_t)c * n + i];
+  }
+  __shared__ float sh[4][64];
+  sh[cl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (cl == 0 && i < n) {
+    const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+    const int ci = i % Cin;
+    const int co = (i / Cin) % Cout;
+    const int t = i / ((size_t)Cin * Cout);
+    dw[((size_t)co * Cin + ci) * NT + t] = s;
+  }
 }
 
 __global__ void pack_w_kernel(const float* __restrict__ w, bf16* __restrict__ planes, int O, int I, int NT,
@@ -326,7 +342,7 @@ int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
 
 int ph_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, int KS, int Cout, int Cin, hipStream_t st) {
   const size_t n = (size_t)KS * KS * Cout * Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dw, nchunks,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, dw, nchunks,
                      KS * KS, Cout, Cin);
   PH_LAUNCH_CHECK();
   return PH_OK;

@@ -9,7 +9,7 @@ namespace {
 // ------------------------------------------------------------------ generic strided SGEMM
 // C[m][n] (ldc) = act( sum_k A(m,k) * B(k,n) + bias[n] ) (+ C if accumulate)
 //   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
-constexpr int GT = 64, GK = 16;
+constexpr int GT = 64, GK = 32;   // all global loads of a K step are issued before any is consumed
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                     const float* __restrict__ bias, float* __restrict__ Cm, int M,
                                                     int N, int K, long sam, long sak, long sbk, long sbn, long ldc,
@@ -26,16 +26,29 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
   // loader mapping: pick the unit-stride direction of each operand as the fast thread index
   const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
   for (int k0 = 0; k0 < K; k0 += GK) {
+    constexpr int PER = GT * GK / 256;
+    float ra[PER], rb[PER];
 #pragma unroll
-    for (int e = tid; e < GT * GK; e += 256) {
+    for (int q = 0; q < PER; ++q) {          // phase 1: every load in flight together
+      const int e = tid + q * 256;
       int m, k;
       if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
       const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
+      ra[q] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
       int n, kk;
       if (b_nfast) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
       const int gn = n0 + n, gk2 = k0 + kk;
-      Bs[kk][n] = (gn < N && gk2 < K) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+      rb[q] = (gn < N && gk2 < K) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {          // phase 2: LDS
+      const int e = tid + q * 256;
+      int m, k;
+      if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
+      As[k][m] = ra[q];
+      int n, kk;
+      if (b_nfast) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
+      Bs[kk][n] = rb[q];
     }
     __syncthreads();
 #pragma unroll
@@ -86,16 +99,29 @@ __global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restri
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
   for (int k0 = kb; k0 < ke; k0 += GK) {
+    constexpr int PER = GT * GK / 256;
+    float ra[PER], rb[PER];
 #pragma unroll
-    for (int e = tid; e < GT * GK; e += 256) {
+    for (int q = 0; q < PER; ++q) {          // phase 1: every load in flight together
+      const int e = tid + q * 256;
       int m, k;
       if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
       const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < M && gk < ke) ? A[gm * sam + gk * sak] : 0.f;
+      ra[q] = (gm < M && gk < ke) ? A[gm * sam + gk * sak] : 0.f;
       int n, kk;
       if (b_nfast) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
       const int gn = n0 + n, gk2 = k0 + kk;
-      Bs[kk][n] = (gn < N && gk2 < ke) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+      rb[q] = (gn < N && gk2 < ke) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {          // phase 2: LDS
+      const int e = tid + q * 256;
+      int m, k;
+      if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
+      As[k][m] = ra[q];
+      int n, kk;
+      if (b_nfast) { n = e % GT; kk = e / GT; } else { kk = e % GK; n = e / GK; }
+      Bs[kk][n] = rb[q];
     }
     __syncthreads();
 #pragma unroll
