@@ -136,6 +136,11 @@ int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, co
 int ph_gram(const float* G /* [ng][n] */, float* gram /* [ng*ng] */, int ng, int n, ph_stream_t stream);
 int ph_gk_scale(const float* gram, const float* const* losses /* device array of nl device scalars */, int ng, int nl,
                 float mult, float* scale, float* total, ph_stream_t stream);
+/* momentum_AEKD_loss ("MIA 2022/train_test_path_multi_distill_v2.py":89-132): cosine Gram row sums without the
+ * x len(list) factor, optional > thresh binarisation (:114-115), EMA of the weights (:121-124; *mo_init == 0 on the
+ * first call, set to 1 by the kernel) */
+int ph_gk_scale_momentum(const float* gram, int ng, int use_thresh, float thresh, float momentum, float* mo_scale,
+                         int* mo_init, ph_stream_t stream);
 int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, size_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int step, double ema_alpha,
                      ph_stream_t stream);

@@ -17,7 +17,7 @@ class _CRDCoreFn(torch.autograd.Function):
     """(v1, v2) -> NCE loss (s_loss + t_loss of CRD_loss.py:172-174) with analytic gradients."""
 
     @staticmethod
-    def forward(ctx, v1, v2, mem, y, idx, ranks):
+    def forward(ctx, v1, v2, mem, y, idx, ranks, per_sample=False):
         v1, v2 = ops._f32(v1), ops._f32(v2)
         B, D = v1.shape
         P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
@@ -59,8 +59,11 @@ class _CRDCoreFn(torch.autograd.Function):
         check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(mem.memory_v1), ptr(mem.memory_v2),
                                  ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, PK, P2, K2, D, float(mem.nLem),
                                  1.0 / bnorm, st), "ph_crd_loss_grad")
-        loss = torch.empty((), device=dev, dtype=torch.float32)
-        check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
+        if per_sample:
+            loss = lossp       # [B] per-sample losses (each already divided by the batch normaliser)
+        else:
+            loss = torch.empty((), device=dev, dtype=torch.float32)
+            check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
         # momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica
         # applies the update of the whole global batch
         if mem.sync is not None:
@@ -70,13 +73,16 @@ class _CRDCoreFn(torch.autograd.Function):
         check(L.ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
                               yy.shape[0], D, st), "ph_crd_update")
         ctx.save_for_backward(dv1, dv2)
+        ctx.per_sample = per_sample
         mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dv1, dv2 = ctx.saved_tensors
-        return dv1 * g, dv2 * g, None, None, None, None
+        if ctx.per_sample:
+            g = g.reshape(-1, 1)      # d loss_b / d v_b is row b of dv
+        return dv1 * g, dv2 * g, None, None, None, None, None
 
 
 class ContrastMemory_v3(nn.Module):

@@ -139,7 +139,33 @@ __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p,
   if (i < n) ema[i] = alpha * ema[i] + (1.f - alpha) * p[i];
 }
 
+// MIA-2022 / MIA-2023 form: cosine Gram without multiplier, optional binarisation (> thresh -> 1 else 0), optional
+// EMA of the weights across iterations (mo = m*mo + (1-m)*scale; first call: mo = scale when *mo_init == 0)
+__global__ void gk_scale2_kernel(const float* __restrict__ gram, int ng, int use_thresh, float thresh, float momentum,
+                                 float* __restrict__ mo_scale, int* __restrict__ mo_init) {
+  if (threadIdx.x != 0) return;
+  const int first = mo_init ? (*mo_init == 0) : 1;
+  for (int i = 0; i < ng; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < ng; ++j) {
+      float r = gram[i * ng + j] / (sqrtf(gram[i * ng + i]) * sqrtf(gram[j * ng + j]));
+      if (use_thresh) r = r > thresh ? 1.f : 0.f;
+      s += r;
+    }
+    mo_scale[i] = first ? s : momentum * mo_scale[i] + (1.f - momentum) * s;
+  }
+  if (mo_init) *mo_init = 1;
+}
+
 }  // namespace
+
+int ph_gk_scale_momentum(const float* gram, int ng, int use_thresh, float thresh, float momentum, float* mo_scale,
+                         int* mo_init, hipStream_t st) {
+  hipLaunchKernelGGL(gk_scale2_kernel, dim3(1), dim3(64), 0, st, gram, ng, use_thresh, thresh, momentum, mo_scale,
+                     mo_init);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
 
 int ph_gram(const float* G, float* gram, int ng, int n, hipStream_t st) {
   switch (ng) {

@@ -186,6 +186,31 @@ def AEKD_loss(opt, optimizer, main_loss, feat_s, loss_t_list, sync=None):
     return scale, total_KD_loss
 
 
+def momentum_AEKD_loss(opt, optimizer, main_loss, feat_s, loss_t_list, mo_scale, sync=None):
+    """GK-Refine of the MIA-2022 trainer ("MIA 2022/train_test_path_multi_distill_v2.py":89-132): like AEKD_loss but
+    the cosine Gram is NOT multiplied by len(loss_t_list) (:113), may be binarised with `opt.thresh` when
+    opt.grads_thresh == "True" (:114-115) and the weights are an EMA over iterations with opt.grads_m (:121-124).
+    `mo_scale` is None on the first call; returns (mo_scale, total_KD_loss)."""
+    losses = list(loss_t_list) + ([main_loss] if opt.CE_grads else [])
+    grads = [torch.autograd.grad(l, feat_s, retain_graph=True)[0] for l in losses]
+    ng = len(grads)
+    G = torch.stack([g.reshape(-1) for g in grads]).contiguous()
+    gram = torch.empty(ng * ng, device=G.device, dtype=torch.float32)
+    check(lib().ph_gram(ptr(G), ptr(gram), ng, G.shape[1], stream()), "ph_gram")
+    if sync is not None:
+        sync.all_reduce_sum(gram)
+    if mo_scale is None:
+        state = torch.zeros(ng, device=G.device, dtype=torch.float32)
+        init = torch.zeros(1, device=G.device, dtype=torch.int32)
+    else:
+        state = mo_scale.detach().clone()
+        init = torch.ones(1, device=G.device, dtype=torch.int32)
+    check(lib().ph_gk_scale_momentum(ptr(gram), ng, 1 if opt.grads_thresh == "True" else 0, float(opt.thresh),
+                                     float(opt.grads_m), ptr(state), ptr(init), stream()), "ph_gk_scale_momentum")
+    total_KD_loss = torch.dot(state[:-1], torch.stack(list(loss_t_list)))
+    return state, total_KD_loss
+
+
 # ----------------------------------------------------------------------------------------- the hot loop
 class DistillStep:
     """The batch body of train() (train_test_path_multi_distill.py:242-330) over the drop-in modules:

@@ -1,0 +1,102 @@
+"""CPU restatement of the MIA-2022 / MIA-2023 stage-2 variants of the hot path (TEST INFRASTRUCTURE).
+
+MIA-2022:
+  * momentum_aekd_loss  <- "MIA 2022/train_test_path_multi_distill_v2.py":89-132
+  * crd_v3_loss         <- "MIA 2022/CL_utils/CRD_criterion_v3.py":25-81 (ContrastMemory), :168-189 (CRDLoss),
+                           :192-224 (ContrastLoss with per-sample weights)
+MIA-2023:
+  * distill_kl_per_sample  <- "MIA 2023/stage2_unimodal_student/KD_loss.py":14-20
+  * assign_sample_weights  <- ".../train_test_path_multi_distill.py":131-158
+  * gk_refine_thresh       <- ".../train_test_path_multi_distill.py":81-128
+  * crd_v10_loss           <- ".../CL_utils/CRD_criterion_v10.py":45-176 (pos_extra="neighbors"), :241-314
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .losses import embed_forward, EPS
+
+
+class CRDv3State:
+    """ContrastMemory of CRD_criterion_v3.py:8-23: params = [K, T, Z_v1, Z_v2, momentum] (no P)."""
+
+    def __init__(self, n_data, feat_dim=128, K=1024, T=0.07, momentum=0.5, seed=0, embed_s=None, embed_t=None):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        stdv = 1.0 / math.sqrt(feat_dim / 3)
+        self.params = torch.tensor([K, T, -1, -1, momentum], dtype=torch.float32)
+        self.memory_v1 = torch.rand(n_data, feat_dim, generator=g).mul_(2 * stdv).add_(-stdv)
+        self.memory_v2 = torch.rand(n_data, feat_dim, generator=g).mul_(2 * stdv).add_(-stdv)
+        self.embed_s, self.embed_t, self.n_data = embed_s, embed_t, n_data
+
+
+def _bank_update(st, v1, v2, y):
+    momentum = st.params[4].item()
+    with torch.no_grad():
+        l_pos = torch.index_select(st.memory_v1, 0, y.view(-1)) * momentum + v1 * (1 - momentum)
+        st.memory_v1.index_copy_(0, y, l_pos / l_pos.pow(2).sum(1, keepdim=True).pow(0.5))
+        ab_pos = torch.index_select(st.memory_v2, 0, y.view(-1)) * momentum + v2 * (1 - momentum)
+        st.memory_v2.index_copy_(0, y, ab_pos / ab_pos.pow(2).sum(1, keepdim=True).pow(0.5))
+
+
+def _contrast_loss_weighted(w, x, n_data):
+    """ContrastLoss.forward(sample_weights, x) of CRD_criterion_v3.py:200-224 (slot 0 = the positive)."""
+    bsz = x.shape[0]
+    m = x.size(1) - 1
+    Pn = 1 / float(n_data)
+    P_pos = x.select(1, 0)
+    log_D1 = torch.div(P_pos, P_pos.add(m * Pn + EPS)).log()
+    P_neg = x.narrow(1, 1, m)
+    log_D0 = torch.div(torch.full_like(P_neg, m * Pn), P_neg.add(m * Pn + EPS)).log()
+    sample_loss = -(log_D1 + log_D0.sum(1))
+    return (w * sample_loss).sum(0) / bsz
+
+
+def crd_v3_loss(st, sample_weights, f_s, f_t, y, idx):
+    """CRDLoss.forward of CRD_criterion_v3.py:168-189 -> tensor of shape [1] (as the reference returns)."""
+    v1 = embed_forward(f_s, st.embed_s["linear.weight"], st.embed_s["linear.bias"])
+    v2 = embed_forward(f_t, st.embed_t["linear.weight"], st.embed_t["linear.bias"])
+    K = int(st.params[0].item()); T = st.params[1].item()
+    B, D = v1.shape
+    n_out = st.memory_v1.size(0)
+    w1 = torch.index_select(st.memory_v1, 0, idx.view(-1)).detach().view(B, K + 1, D)
+    out_v2 = torch.exp(torch.bmm(w1, v2.view(B, D, 1)) / T)
+    w2 = torch.index_select(st.memory_v2, 0, idx.view(-1)).detach().view(B, K + 1, D)
+    out_v1 = torch.exp(torch.bmm(w2, v1.view(B, D, 1)) / T)
+    if st.params[2].item() < 0:
+        st.params[2] = out_v1.mean().detach() * n_out
+    if st.params[3].item() < 0:
+        st.params[3] = out_v2.mean().detach() * n_out
+    out_v1 = out_v1 / st.params[2].item()
+    out_v2 = out_v2 / st.params[3].item()
+    _bank_update(st, v1, v2, y)
+    return _contrast_loss_weighted(sample_weights, out_v1, st.n_data) + \
+        _contrast_loss_weighted(sample_weights, out_v2, st.n_data)
+
+
+def momentum_aekd_loss(main_loss, feat_s, loss_t_list, mo_scale, grads_m=0.9, grads_thresh="False", thresh=0.0,
+                       ce_grads=True):
+    """momentum_AEKD_loss (train_test_path_multi_distill_v2.py:89-132): cosine Gram WITHOUT the x len(list)
+    factor of the MICCAI version, optional binarisation, EMA of the weights across iterations."""
+    losses = list(loss_t_list) + ([main_loss] if ce_grads else [])
+    grads = [torch.autograd.grad(l, feat_s, retain_graph=True)[0].detach().clone() for l in losses]
+    all_grads = torch.stack(grads).view(len(grads), -1)
+    norm = torch.norm(all_grads, p=2, dim=1, keepdim=True)
+    rel = torch.matmul(all_grads, all_grads.T) / torch.matmul(norm, norm.T)
+    if grads_thresh == "True":
+        rel = torch.where(rel > thresh, 1.0, 0.0)
+    scale = rel.sum(dim=1)
+    mo_scale = scale if mo_scale is None else grads_m * mo_scale + (1 - grads_m) * scale
+    total = torch.dot(mo_scale[:-1], torch.stack(list(loss_t_list)))
+    return mo_scale, total
+
+
+# ------------------------------------------------------------------------------------------------ MIA-2023
+def distill_kl_per_sample(y_s, y_t, T=1.0):
+    """DistillKL.forward of MIA-2023 KD_loss.py:14-20 -> (loss, sample_loss[B])."""
+    p_s = F.log_softmax(y_s / T, dim=1)
+    p_t = F.softmax(y_t / T, dim=1)
+    sample_loss = torch.sum(F.kl_div(p_s, p_t, reduction="none"), dim=-1) * (T ** 2)
+    return sample_loss.sum() / y_s.shape[0], sample_loss

@@ -141,3 +141,55 @@ def test_aekd_loss_vs_oracle():
     gt, = torch.autograd.grad(tot, f2)
     gr, = torch.autograd.grad(tot_ref, f1)
     assert torch.allclose(gt.cpu(), gr, rtol=1e-3, atol=1e-6)
+
+
+def test_mia2022_crd_v3_golden(golden_dir):
+    """vanilla K+1 CRD bank with a per-sample-weighted loss vs the MIA-2022 reference."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.CL_utils import CRD_criterion_v3 as V3
+    from oracle import weights as W
+    from oracle.variants import CRDv3State
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "mia2022_crd_v3.npz"))
+    opt = m.stage2_opt(nce_k=int(g["K"]))
+    crd = V3.CRDLoss(opt, int(g["n_data"]))
+    assert set(crd.state_dict()) == {"embed_s.linear.weight", "embed_s.linear.bias", "embed_t.linear.weight",
+                                     "embed_t.linear.bias", "contrast.params", "contrast.memory_v1", "contrast.memory_v2"}
+    assert crd.contrast.params.numel() == 5
+    crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 30))
+    crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 31))
+    st = CRDv3State(int(g["n_data"]), K=int(g["K"]), seed=int(g["bank_seed"]))
+    crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+    crd = crd.cuda(); crd.contrast.verbose = False
+    R = Report("MIA-2022 CRD_criterion_v3 vs reference golden")
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).cuda().requires_grad_(True)
+        loss = crd(float(g[f"w{it}"]), f_s, torch.as_tensor(g[f"f_t{it}"]).cuda(), torch.as_tensor(g[f"index{it}"]).cuda(),
+                   torch.as_tensor(g[f"sidx{it}"]).cuda())
+        assert tuple(loss.shape) == (1,)
+        gs = torch.autograd.grad(loss.sum(), [f_s, crd.embed_s.linear.weight, crd.embed_t.linear.weight])
+        R.close(g[f"loss{it}"], loss, 1e-4, 1e-5, f"loss call {it}")
+        R.close(g[f"g_fs{it}"], gs[0], 1e-6, 1e-3, f"d f_s call {it}"); R.close(g[f"g_ws{it}"], gs[1], 1e-6, 1e-3, f"d W_s call {it}")
+        R.close(g[f"g_wt{it}"], gs[2], 1e-6, 1e-3, f"d W_t call {it}")
+        R.close(g[f"params{it}"], crd.contrast.params, 1e-2, 1e-4, f"params/Z call {it}")
+        R.close(g[f"bank_v1_rows{it}"], crd.contrast.memory_v1[torch.as_tensor(g[f"index{it}"]).cuda()], 1e-6, 0, f"bank rows call {it}")
+    R.finish()
+
+
+def test_mia2022_momentum_gk_golden(golden_dir):
+    import multimodal_learning_amd as m
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "mia2022_momentum_gk.npz"))
+    ws = torch.as_tensor(g["ws"]).cuda()
+    R = Report("MIA-2022 momentum_AEKD_loss vs reference golden")
+    for name, gth, th in (("plain", "False", 0.0), ("thresh", "True", 0.25)):
+        opt = m.stage2_opt()
+        opt.grads_thresh, opt.thresh, opt.grads_m = gth, th, 0.9
+        mo = None
+        for it in range(3):
+            feat = (torch.as_tensor(g["feat"]).cuda() * (1 + 0.1 * it)).clone().requires_grad_(True)
+            losses = [((feat * w).sum(1) ** 2).mean() * (0.1 + i) + (feat ** 2).mean() * (i % 2) for i, w in enumerate(ws)]
+            mo, total = m.momentum_AEKD_loss(opt, None, losses[4], feat, losses[:4], mo)
+            R.close(g[f"{name}_scale{it}"], mo, 1e-4, 1e-4, f"{name} mo_scale it {it}")
+            R.close(g[f"{name}_total{it}"], total, 1e-4, 1e-4, f"{name} total it {it}")
+    R.finish()
