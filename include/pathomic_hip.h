@@ -92,6 +92,13 @@ int ph_kl_fwd(const float* y_s, const float* y_t, float* loss, int B, int C, flo
               ph_stream_t stream);
 int ph_kl_bwd(const float* gscalar, const float* y_s, const float* y_t, float* dy_s, int B, int C, float T,
               float inv_bnorm, ph_stream_t stream);
+/* MIA-2023 per-sample DistillKL ("MIA 2023/stage2_unimodal_student/KD_loss.py":14-20) and its backward */
+int ph_kl_rows_fwd(const float* y_s, const float* y_t, float* sample_loss, int B, int C, float T, ph_stream_t stream);
+int ph_kl_rows_bwd(const float* g_rows, const float* y_s, const float* y_t, float* dy_s, int B, int C, float T,
+                   ph_stream_t stream);
+/* assign_sample_weights ("MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":131-158), from logits */
+int ph_conf_discrepancy(const float* logit_s, const float* logit_t, const int64_t* gt, float* out, int B, int C,
+                        float max_discrep, ph_stream_t stream);
 /* Normalize(2) of Embed (CL_utils/CRD_loss.py:263-267,276-279) */
 int ph_l2norm_fwd(const float* x, float* y, float* norm, int B, int D, ph_stream_t stream);
 int ph_l2norm_bwd(const float* g, const float* y, const float* norm, float* dx, int B, int D, ph_stream_t stream);
@@ -113,19 +120,29 @@ int ph_sum(const float* x, float* out, int n, float scale, ph_stream_t stream);
  * mem1/mem2 = memory_v1/memory_v2 [n_data][128] f32, params = the module's `params` buffer
  * [K, T, Z_v1, Z_v2, momentum, P].
  * ---------------------------------------------------------------------------------------------- */
-int ph_crd_score(const float* v1, const float* v2, const int64_t* idx /* [B][P+K] */, const float* mem1,
-                 const float* mem2, float* out1, float* out2, float* diff /* each [B][P+K] */, int B, int PK,
-                 int feat_dim, float T, ph_stream_t stream);
+/* idx_bank2: optional second index array for memory_v2 (MIA-2023 v10: each bank has its own KNN positives); NULL = idx */
+int ph_crd_score(const float* v1, const float* v2, const int64_t* idx /* [B][P+K] */, const int64_t* idx_bank2,
+                 const float* mem1, const float* mem2, float* out1, float* out2, float* diff /* each [B][P+K] */,
+                 int B, int PK, int feat_dim, float T, ph_stream_t stream);
 /* ranks: the P2 host-RNG ranks of memory_new.py:311 (int32, device) or NULL for "hard" (:308) */
 int ph_crd_select(const float* diff, const float* out1, const float* out2, const int* ranks, int* sel /* [B][P2+K2] */,
                   float* xs, float* xt /* gathered raw scores [B][P2+K2] */, int B, int P, int K, int P2, int K2,
-                  int select_neg, ph_stream_t stream);
+                  int select_neg, int select_pos /* 0: keep every positive column in order (v3 / v10 banks) */,
+                  ph_stream_t stream);
 int ph_crd_zsum(const float* xs, const float* xt, float* sums2, int n, ph_stream_t stream);
 int ph_crd_setz(float* params, const float* sums2, float count, float n_data, ph_stream_t stream);
 /* loss partials lossp[B] (sum = s_loss + t_loss) and d loss/d v1, d loss/d v2 [B][128] */
-int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const float* mem1,
-                     const float* mem2, const float* params, float* lossp, float* dv1, float* dv2, int B, int PK,
-                     int P2, int K2, int feat_dim, float n_data, float inv_bnorm, ph_stream_t stream);
+/* posw_s / posw_t: optional per-positive weights [B][P2] (MIA-2023 ContrastLoss_v2: similarity / sum similarity,
+ * "MIA 2023/stage2_unimodal_student/CL_utils/CRD_criterion_v10.py":281-314); NULL = 1/P2 */
+int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                     const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
+                     const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
+                     int feat_dim, float n_data, float inv_bnorm, ph_stream_t stream);
+/* MIA-2023 v10 KNN positives (CRD_criterion_v10.py:72-79,110-116): class-masked full-bank cosine top-num_pos of each
+ * query's own bank row, for both banks; labels = class of every bank row (int32 [n_data]) */
+int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, const int64_t* idx, int PK,
+                     const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
+                     int64_t* nb2, float* sim1, float* sim2, ph_stream_t stream);
 int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
                   int B, int feat_dim, ph_stream_t stream);
 
@@ -141,6 +158,10 @@ int ph_gk_scale(const float* gram, const float* const* losses /* device array of
  * first call, set to 1 by the kernel) */
 int ph_gk_scale_momentum(const float* gram, int ng, int use_thresh, float thresh, float momentum, float* mo_scale,
                          int* mo_init, ph_stream_t stream);
+/* GK_refine_thresh ("MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":81-128): per-sample cosine
+ * matrix of the ng gradients G[ng][B][128] -> all_scale[B][ng] */
+int ph_gk_rows(const float* G, int ng, int B, int D, int use_thresh, float thresh, float* all_scale,
+               ph_stream_t stream);
 int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, size_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int step, double ema_alpha,
                      ph_stream_t stream);

@@ -1,0 +1,106 @@
+"""Drop-in for the reference's "MIA 2023/stage2_unimodal_student/CL_utils/CRD_criterion_v10.py" (SURVEY row a18),
+`pos_extra == "neighbors"` (the shipped train_20230805.sh): CRD bank whose positives are the num_pos same-class
+nearest neighbours (cosine) of the query's own bank row, weighted by their similarity, with per-sample loss weights.
+
+The reference copies both banks to the host and calls sklearn's cosine_similarity + two torch.sort over n_data per
+query every step (:72-79,110-116); here `ph_crd_bank_topk` scans the bank on the GPU.
+`pos_extra == "centers"` (k-means class centres, sklearn KMeans) is parity-unpinned in SURVEY section 8-c and not built."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .CRD_loss import Embed, Normalize   # noqa: F401
+from .memory_new import _CRDCoreFn
+from .._lib import lib, check, ptr, stream
+
+eps = 1e-7
+
+
+class ContrastMemory(nn.Module):
+    """CRD_criterion_v10.py:20-43: params = [K, T, Z_v1, Z_v2, momentum] + the class of every bank row."""
+
+    def __init__(self, inputSize, outputSize, train_class_idx, K, T=0.07, momentum=0.5):
+        super().__init__()
+        self.nLem = outputSize
+        self.K = K
+        self.class_idx = train_class_idx
+        labels = torch.zeros(outputSize, dtype=torch.int32)
+        for c, members in enumerate(train_class_idx):
+            labels[torch.as_tensor(np.asarray(members)).long()] = c
+        self.register_buffer("all_sample_labels", labels, persistent=False)
+        self.T = T
+        self.select_neg_pairs = "False"
+        self.register_buffer("params", torch.tensor([K, T, -1, -1, momentum], dtype=torch.float32))
+        stdv = 1.0 / math.sqrt(inputSize / 3)
+        self.register_buffer("memory_v1", torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
+        self.register_buffer("memory_v2", torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
+        self._z_set = False
+        self.sync = None
+        self.batch_norm_size = None
+        self.verbose = True
+        self.last = None
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._z_set = bool((self.params[2:4] > 0).all().item())
+
+
+class CRDLoss(nn.Module):
+    """CRD_criterion_v10.py:180-239: forward(sample_weights, f_s, f_t, batch_label, idx, contrast_idx)
+    -> (loss, sample_loss[B])."""
+
+    def __init__(self, opt, n_data, train_class_idx):
+        super().__init__()
+        self.embed_s = Embed(opt.s_dim, opt.feat_dim)
+        self.embed_t = Embed(opt.t_dim, opt.feat_dim)
+        self.contrast = ContrastMemory(opt.feat_dim, n_data, train_class_idx, opt.nce_k, opt.nce_t, opt.nce_m)
+        self.num_pos = opt.nce_p
+        self.pos_extra = opt.pos_extra
+        if self.pos_extra != "neighbors":
+            raise NotImplementedError("pos_extra '%s': only 'neighbors' (train_20230805.sh) is built; 'centers' needs "
+                                      "sklearn KMeans and is parity-unpinned (SURVEY section 8-c)" % self.pos_extra)
+        self.criterion_t = ContrastLoss_v2(n_data)
+        self.criterion_s = ContrastLoss_v2(n_data)
+
+    def forward(self, sample_weights, f_s, f_t, batch_label, idx, contrast_idx=None):
+        mem = self.contrast
+        NP, K = self.num_pos, mem.K
+        if contrast_idx is None or contrast_idx.shape[1] != K + 1:
+            raise RuntimeError("contrast_idx must be [B, nce_k + 1]")
+        v1 = self.embed_s(f_s)
+        v2 = self.embed_t(f_t)
+        B = v1.shape[0]
+        dev = v1.device
+        contrast_idx = contrast_idx.contiguous()
+        batch_label = batch_label.to(dev).long().contiguous()
+        nb1 = torch.empty(B, NP, device=dev, dtype=torch.int64); nb2 = torch.empty_like(nb1)
+        sim1 = torch.empty(B, NP, device=dev, dtype=torch.float32); sim2 = torch.empty_like(sim1)
+        check(lib().ph_crd_bank_topk(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(mem.all_sample_labels),
+                                     ptr(contrast_idx), K + 1, ptr(batch_label), B, mem.nLem, NP, v1.shape[1], ptr(nb1),
+                                     ptr(nb2), ptr(sim1), ptr(sim2), stream()), "ph_crd_bank_topk")
+        # column lists: [num_pos KNN rows of that bank] + [the K sampled negatives]  (:80, :117)
+        idx1 = torch.cat((nb1, contrast_idx[:, 1:]), 1).contiguous()
+        idx2 = torch.cat((nb2, contrast_idx[:, 1:]), 1).contiguous()
+        # out_s = out_v1 comes from bank 2 and is weighted by the bank-2 similarities (:226), and vice versa (:227)
+        mem.P, mem.P2, mem.K2 = NP, NP, K
+        mem._idx_bank2 = idx2
+        mem._posw_s = (sim2 / sim2.sum(1, keepdim=True)).contiguous()
+        mem._posw_t = (sim1 / sim1.sum(1, keepdim=True)).contiguous()
+        rows = _CRDCoreFn.apply(v1, v2, mem, idx, idx1, None, True)          # [B]: (s + t) sample losses / bsz
+        mem.last.update(nb1=nb1, nb2=nb2, sim1=sim1, sim2=sim2)
+        w = sample_weights.to(dev).reshape(-1) if torch.is_tensor(sample_weights) else float(sample_weights)
+        sample_loss = w * rows * B                                           # the reference's per-sample values
+        return sample_loss.sum(0) / B, sample_loss
+
+
+class ContrastLoss_v2(nn.Module):
+    """API placeholder: CRD_criterion_v10.py:281-314 is fused into ph_crd_loss_grad (similarity-weighted positives)."""
+
+    def __init__(self, n_data):
+        super().__init__()
+        self.n_data = n_data
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("fused into the CRD loss kernel; call CRDLoss.forward")

@@ -33,13 +33,17 @@ class _CRDCoreFn(torch.autograd.Function):
         L = lib()
         st = stream()
         T = mem.T
-        check(L.ph_crd_score(ptr(v1), ptr(v2), ptr(idx), ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(out1), ptr(out2),
-                             ptr(diff), B, PK, D, T, st), "ph_crd_score")
+        idx2 = getattr(mem, "_idx_bank2", None)          # MIA-2023 v10: bank-specific positive rows
+        posw_s = getattr(mem, "_posw_s", None)
+        posw_t = getattr(mem, "_posw_t", None)
+        check(L.ph_crd_score(ptr(v1), ptr(v2), ptr(idx), ptr(idx2), ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(out1),
+                             ptr(out2), ptr(diff), B, PK, D, T, st), "ph_crd_score")
         sel = torch.empty(B, S2, device=dev, dtype=torch.int32)
         xs = torch.empty(B, S2, device=dev, dtype=torch.float32)
         xt = torch.empty_like(xs)
         check(L.ph_crd_select(ptr(diff), ptr(out1), ptr(out2), ptr(ranks), ptr(sel), ptr(xs), ptr(xt), B, P, K, P2, K2,
-                              1 if mem.select_neg_pairs == "True" else 0, st), "ph_crd_select")
+                              1 if mem.select_neg_pairs == "True" else 0,
+                              1 if getattr(mem, "select_pos_pairs", False) is True else 0, st), "ph_crd_select")
         if not mem._z_set:
             sums = torch.empty(2, device=dev, dtype=torch.float32)
             check(L.ph_crd_zsum(ptr(xs), ptr(xt), ptr(sums), B * S2, st), "ph_crd_zsum")
@@ -56,7 +60,8 @@ class _CRDCoreFn(torch.autograd.Function):
         dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
         dv2 = torch.empty_like(dv1)
         bnorm = float(mem.batch_norm_size or B)
-        check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(mem.memory_v1), ptr(mem.memory_v2),
+        check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(posw_s), ptr(posw_t),
+                                 ptr(mem.memory_v1), ptr(mem.memory_v2),
                                  ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, PK, P2, K2, D, float(mem.nLem),
                                  1.0 / bnorm, st), "ph_crd_loss_grad")
         if per_sample:

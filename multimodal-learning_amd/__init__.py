@@ -18,6 +18,7 @@ from .kd_loss import DistillKL
 from .CL_utils import CRDLoss, ContrastLoss_v2, Embed, Normalize, ContrastMemory_v3
 from .train_step import AEKD_loss, momentum_AEKD_loss, update_ema_variables, DistillStep, FusedAdam, FlatParams
 from . import dist
+from . import mia2023
 from .options import stage2_opt
 
 __all__ = ["build", "lib", "set_precision", "get_precision", "init_net", "init_max_weights", "count_parameters",

@@ -44,11 +44,16 @@ SIGNATURES = {
     "ph_dropout_dev": (i32, [vp, sz, f32, u64, u64, vp, i32, vp]),
     "ph_counter_inc": (i32, [vp, vp]),
     "ph_sum": (i32, [vp, vp, i32, f32, vp]),
-    "ph_crd_score": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
-    "ph_crd_select": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ph_crd_score": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    "ph_crd_select": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "ph_crd_bank_topk": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "ph_kl_rows_fwd": (i32, [vp, vp, vp, i32, i32, f32, vp]),
+    "ph_kl_rows_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "ph_conf_discrepancy": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    "ph_gk_rows": (i32, [vp, i32, i32, i32, i32, f32, vp, vp]),
     "ph_crd_zsum": (i32, [vp, vp, vp, i32, vp]),
     "ph_crd_setz": (i32, [vp, vp, f32, f32, vp]),
-    "ph_crd_loss_grad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
+    "ph_crd_loss_grad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp]),
     "ph_crd_update": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ph_gram": (i32, [vp, vp, i32, i32, vp]),
     "ph_gk_scale": (i32, [vp, vp, i32, i32, f32, vp, vp, vp]),

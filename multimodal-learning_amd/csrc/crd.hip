@@ -28,6 +28,7 @@ __device__ __forceinline__ float half_sum(float v) {   // reduce within each 32-
 // grid (ceil(PK/64), B), block 256 = 8 half-waves, each half-wave walks 8 of the block's 64 columns
 __global__ __launch_bounds__(256) void crd_score_kernel(const float* __restrict__ v1, const float* __restrict__ v2,
                                                         const int64_t* __restrict__ idx,
+                                                        const int64_t* __restrict__ idx_b2,
                                                         const float* __restrict__ mem1,
                                                         const float* __restrict__ mem2, float* __restrict__ out1,
                                                         float* __restrict__ out2, float* __restrict__ diff, int PK,
@@ -44,8 +45,9 @@ __global__ __launch_bounds__(256) void crd_score_kernel(const float* __restrict_
     const int j = j0 + jj;
     if (j >= PK) break;
     const int64_t row = idx[(size_t)b * PK + j];
+    const int64_t row2 = idx_b2[(size_t)b * PK + j];   // MIA-2023 v10: the two banks have their own KNN positives
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(mem1 + row * D + l * 4);
-    const f32x4 m2 = *reinterpret_cast<const f32x4*>(mem2 + row * D + l * 4);
+    const f32x4 m2 = *reinterpret_cast<const f32x4*>(mem2 + row2 * D + l * 4);
     float d12 = 0.f, d21 = 0.f, d11 = 0.f, d22 = 0.f, q1 = 0.f, q2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void crd_select_kernel(const float* __restrict
                                                          const float* __restrict__ out2,
                                                          const int* __restrict__ ranks, int* __restrict__ sel,
                                                          float* __restrict__ xs, float* __restrict__ xt, int P, int K,
-                                                         int P2, int K2, int select_neg) {
+                                                         int P2, int K2, int select_neg, int select_pos) {
   extern __shared__ float sd[];   // [P+K] discrepancies, then int rank_to_col[P]
   const int b = blockIdx.x, PK = P + K, S2 = P2 + K2;
   int* r2c = reinterpret_cast<int*>(sd + PK);
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void crd_select_kernel(const float* __restrict
   for (int t = threadIdx.x; t < P2; t += blockDim.x) {
     int col = r2c[ranks ? ranks[t] : t];   // "hard": ranks 0..P2-1 (:308); "mid"/"random": host-drawn ranks (:311-318)
     if (t == 0) col = 0;                    // slot 0 := exact positive (:325)
+    if (!select_pos) col = t;               // vanilla / v10 banks: every positive column, in order
     sel[(size_t)b * S2 + t] = col;
     xs[(size_t)b * S2 + t] = out1[(size_t)b * PK + col];
     xt[(size_t)b * S2 + t] = out2[(size_t)b * PK + col];
@@ -143,6 +146,9 @@ __global__ __launch_bounds__(256) void crd_loss_grad_kernel(const float* __restr
                                                             const float* __restrict__ xt,
                                                             const int* __restrict__ sel,
                                                             const int64_t* __restrict__ idx,
+                                                            const int64_t* __restrict__ idx_b2,
+                                                            const float* __restrict__ posw_s,
+                                                            const float* __restrict__ posw_t,
                                                             const float* __restrict__ mem1,
                                                             const float* __restrict__ mem2,
                                                             const float* __restrict__ params,
@@ -159,16 +165,20 @@ __global__ __launch_bounds__(256) void crd_loss_grad_kernel(const float* __restr
     const float x1 = xs[(size_t)b * S2 + j] / Z1, x2 = xt[(size_t)b * S2 + j] / Z2;
     float c1, c2;
     if (j < P2) {
-      ls += (logf(x1 / (x1 + c)) + logf(x2 / (x2 + c))) / (float)P2;
-      c1 = -(c / (x1 + c)) * invT * inv_bnorm / (float)P2;
-      c2 = -(c / (x2 + c)) * invT * inv_bnorm / (float)P2;
+      // weight of positive j: 1/P2 (MICCAI / v3) or similarity_j / sum_p similarity_p (MIA-2023 ContrastLoss_v2)
+      const float w1 = posw_s ? posw_s[(size_t)b * P2 + j] : 1.f / (float)P2;
+      const float w2 = posw_t ? posw_t[(size_t)b * P2 + j] : 1.f / (float)P2;
+      ls += logf(x1 / (x1 + c)) * w1 + logf(x2 / (x2 + c)) * w2;
+      c1 = -(c / (x1 + c)) * invT * inv_bnorm * w1;
+      c2 = -(c / (x2 + c)) * invT * inv_bnorm * w2;
     } else {
       ls += logf(mPn / (x1 + c)) + logf(mPn / (x2 + c));
       c1 = (x1 / (x1 + c)) * invT * inv_bnorm;
       c2 = (x2 / (x2 + c)) * invT * inv_bnorm;
     }
-    const int64_t row = idx[(size_t)b * PK + sel[(size_t)b * S2 + j]];
-    const f32x4 m2 = *reinterpret_cast<const f32x4*>(mem2 + row * D + l * 4);
+    const int col = sel[(size_t)b * S2 + j];
+    const int64_t row = idx[(size_t)b * PK + col], row2 = idx_b2[(size_t)b * PK + col];
+    const f32x4 m2 = *reinterpret_cast<const f32x4*>(mem2 + row2 * D + l * 4);
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(mem1 + row * D + l * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) { g1[k] += c1 * m2[k]; g2[k] += c2 * m1[k]; }
@@ -211,23 +221,109 @@ __global__ __launch_bounds__(256) void crd_update_kernel(float* __restrict__ mem
   mem[row * D + 64 + lane] = a1 / n;
 }
 
+// MIA-2023 v10 positives (CL_utils/CRD_criterion_v10.py:72-79,110-116): for each query the num_pos bank rows of
+// the query's class with the largest cosine similarity to the query's OWN bank row.  One block per (query, bank);
+// every thread scans a strided slice keeping a private top-NP list, the lists are merged through LDS.  The
+// reference copies the whole bank to the host and calls sklearn per step; here the bank is read once from L2/HBM.
+constexpr int TOPK_MAX = 8;
+__global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restrict__ mem1,
+                                                            const float* __restrict__ mem2,
+                                                            const int* __restrict__ labels,
+                                                            const int64_t* __restrict__ idx, int PK,
+                                                            const int64_t* __restrict__ batch_label, int n_data, int NP,
+                                                            int64_t* __restrict__ nb1, int64_t* __restrict__ nb2,
+                                                            float* __restrict__ sim1, float* __restrict__ sim2) {
+  const int b = blockIdx.x, bank = blockIdx.y;
+  const float* mem = bank ? mem2 : mem1;
+  const int64_t qrow = idx[(size_t)b * PK];
+  const int lab = (int)batch_label[b];
+  __shared__ float q[D];
+  __shared__ float qn;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) q[d] = mem[qrow * D + d];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = q[threadIdx.x] * q[threadIdx.x] + q[threadIdx.x + 64] * q[threadIdx.x + 64];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) qn = sqrtf(s);
+  }
+  __syncthreads();
+  float bv[TOPK_MAX]; int bi[TOPK_MAX];
+#pragma unroll
+  for (int k = 0; k < TOPK_MAX; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
+  for (int j = threadIdx.x; j < n_data; j += blockDim.x) {
+    float v = 0.f;                                   // other classes are masked to similarity 0 (class_mask *)
+    if (labels[j] == lab) {
+      float dot = 0.f, nn = 0.f;
+      const f32x4* r = reinterpret_cast<const f32x4*>(mem + (size_t)j * D);
+#pragma unroll 8
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const f32x4 m = r[d4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dot += m[k] * q[d4 * 4 + k]; nn += m[k] * m[k]; }
+      }
+      const float den = sqrtf(nn) * qn;
+      v = den > 0.f ? dot / den : 0.f;
+    }
+    // insert (v, j) into the descending private list (ties: lower index first)
+    if (v > bv[TOPK_MAX - 1] || (v == bv[TOPK_MAX - 1] && j < bi[TOPK_MAX - 1])) {
+      int pos = TOPK_MAX - 1;
+#pragma unroll
+      for (int k = TOPK_MAX - 1; k > 0; --k) {
+        const bool up = (v > bv[k - 1]) || (v == bv[k - 1] && j < bi[k - 1]);
+        if (up) { bv[k] = bv[k - 1]; bi[k] = bi[k - 1]; pos = k - 1; }
+      }
+      bv[pos] = v; bi[pos] = j;
+    }
+  }
+  __shared__ float sv[256 * TOPK_MAX];
+  __shared__ int si[256 * TOPK_MAX];
+#pragma unroll
+  for (int k = 0; k < TOPK_MAX; ++k) { sv[threadIdx.x * TOPK_MAX + k] = bv[k]; si[threadIdx.x * TOPK_MAX + k] = bi[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // serial merge of 256 sorted lists (NP <= 8 picks of 2048 candidates)
+    int head[1];
+    for (int pick = 0; pick < NP; ++pick) {
+      float best = -INFINITY; int besti = 0x7fffffff, bestslot = -1;
+      for (int e = 0; e < 256 * TOPK_MAX; ++e) {
+        const float v = sv[e]; const int i = si[e];
+        if (i != 0x7fffffff && (v > best || (v == best && i < besti))) { best = v; besti = i; bestslot = e; }
+      }
+      (void)head;
+      if (bestslot >= 0) si[bestslot] = 0x7fffffff;
+      (bank ? nb2 : nb1)[(size_t)b * NP + pick] = besti;
+      (bank ? sim2 : sim1)[(size_t)b * NP + pick] = best;
+    }
+  }
+}
+
 }  // namespace
 
-int ph_crd_score(const float* v1, const float* v2, const int64_t* idx, const float* mem1, const float* mem2,
-                 float* out1, float* out2, float* diff, int B, int PK, int feat_dim, float T, hipStream_t st) {
+int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, const int64_t* idx, int PK,
+                     const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
+                     int64_t* nb2, float* sim1, float* sim2, hipStream_t st) {
+  if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX) return PH_EINVAL;
+  hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2), dim3(256), 0, st, mem1, mem2, labels, idx, PK, batch_label,
+                     n_data, num_pos, nb1, nb2, sim1, sim2);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_crd_score(const float* v1, const float* v2, const int64_t* idx, const int64_t* idx_bank2, const float* mem1,
+                 const float* mem2, float* out1, float* out2, float* diff, int B, int PK, int feat_dim, float T,
+                 hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
-  hipLaunchKernelGGL(crd_score_kernel, dim3(cdiv(PK, 64), B), dim3(256), 0, st, v1, v2, idx, mem1, mem2, out1, out2,
-                     diff, PK, 1.f / T);
+  hipLaunchKernelGGL(crd_score_kernel, dim3(cdiv(PK, 64), B), dim3(256), 0, st, v1, v2, idx,
+                     idx_bank2 ? idx_bank2 : idx, mem1, mem2, out1, out2, diff, PK, 1.f / T);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 
 int ph_crd_select(const float* diff, const float* out1, const float* out2, const int* ranks, int* sel, float* xs,
-                  float* xt, int B, int P, int K, int P2, int K2, int select_neg, hipStream_t st) {
-  if (P2 > P || K2 > K) return PH_EINVAL;
+                  float* xt, int B, int P, int K, int P2, int K2, int select_neg, int select_pos, hipStream_t st) {
+  if (P2 > P || K2 > K || (!select_pos && P2 != P)) return PH_EINVAL;
   const size_t lds = (size_t)(P + K) * 4 + (size_t)P * 4;
   hipLaunchKernelGGL(crd_select_kernel, dim3(B), dim3(256), lds, st, diff, out1, out2, ranks, sel, xs, xt, P, K, P2,
-                     K2, select_neg);
+                     K2, select_neg, select_pos);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -242,12 +338,13 @@ int ph_crd_setz(float* params, const float* sums, float count, float n_data, hip
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
-int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const float* mem1,
-                     const float* mem2, const float* params, float* lossp, float* dv1, float* dv2, int B, int PK,
-                     int P2, int K2, int feat_dim, float n_data, float inv_bnorm, hipStream_t st) {
+int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                     const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
+                     const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
+                     int feat_dim, float n_data, float inv_bnorm, hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
-  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B), dim3(256), 0, st, xs, xt, sel, idx, mem1, mem2, params, lossp, dv1,
-                     dv2, PK, P2, K2, n_data, inv_bnorm);
+  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B), dim3(256), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
+                     posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, n_data, inv_bnorm);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

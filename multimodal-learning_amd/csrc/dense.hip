@@ -301,6 +301,59 @@ __global__ void kl_bwd_kernel(const float* __restrict__ gs, const float* __restr
     dys[b * C + c] = k * (expf(ys[b * C + c] / T - ms) / ss - expf(yt[b * C + c] / T - mt) / st);
 }
 
+// MIA-2023 DistillKL ("MIA 2023/stage2_unimodal_student/KD_loss.py":14-20): per-sample KL rows
+__global__ void kl_rows_fwd_kernel(const float* __restrict__ ys, const float* __restrict__ yt,
+                                   float* __restrict__ sample_loss, int B, int C, float T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int c = 0; c < C; ++c) { ms = fmaxf(ms, ys[b * C + c] / T); mt = fmaxf(mt, yt[b * C + c] / T); }
+  float ss = 0.f, st = 0.f;
+  for (int c = 0; c < C; ++c) { ss += expf(ys[b * C + c] / T - ms); st += expf(yt[b * C + c] / T - mt); }
+  const float ls = ms + logf(ss), lt = mt + logf(st);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float lpt = yt[b * C + c] / T - lt, lps = ys[b * C + c] / T - ls;
+    const float pt = expf(lpt);
+    if (pt > 0.f) s += pt * (lpt - lps);
+  }
+  sample_loss[b] = s * T * T;
+}
+// d sample_loss_b / d ys[b] = T (softmax(ys/T) - softmax(yt/T)); g = upstream gradient per sample
+__global__ void kl_rows_bwd_kernel(const float* __restrict__ g, const float* __restrict__ ys,
+                                   const float* __restrict__ yt, float* __restrict__ dys, int B, int C, float T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int c = 0; c < C; ++c) { ms = fmaxf(ms, ys[b * C + c] / T); mt = fmaxf(mt, yt[b * C + c] / T); }
+  float ss = 0.f, st = 0.f;
+  for (int c = 0; c < C; ++c) { ss += expf(ys[b * C + c] / T - ms); st += expf(yt[b * C + c] / T - mt); }
+  const float k = g[b] * T;
+  for (int c = 0; c < C; ++c)
+    dys[b * C + c] = k * (expf(ys[b * C + c] / T - ms) / ss - expf(yt[b * C + c] / T - mt) / st);
+}
+// assign_sample_weights (".../train_test_path_multi_distill.py":131-158) on logits: conf = log p_gt - log max_{c != gt} p_c,
+// discrepancy = min(max(conf_t - conf_s, 0), max_discrep)
+__global__ void conf_discrepancy_kernel(const float* __restrict__ logit_s, const float* __restrict__ logit_t,
+                                        const int64_t* __restrict__ gt, float* __restrict__ out, int B, int C,
+                                        float max_discrep) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int g = (int)gt[b];
+  float conf[2];
+  for (int w = 0; w < 2; ++w) {
+    const float* y = (w ? logit_t : logit_s) + b * C;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, y[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(y[c] - mx);
+    float top2 = 0.f;                                  // max over c != gt of p_c   (p * (1 - onehot) has 0 at gt)
+    for (int c = 0; c < C; ++c) if (c != g) top2 = fmaxf(top2, expf(y[c] - mx) / s);
+    conf[w] = logf(expf(y[g] - mx) / s) - logf(top2);
+  }
+  out[b] = fminf(fmaxf(conf[1] - conf[0], 0.f), max_discrep);
+}
+
 // ------------------------------------------------------------------ L2 normalise rows (Normalize, CRD_loss.py:276-279)
 __global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm, int B,
                                   int D) {
@@ -476,6 +529,23 @@ int ph_kl_fwd(const float* ys, const float* yt, float* loss, int B, int C, float
 int ph_kl_bwd(const float* gs, const float* ys, const float* yt, float* dys, int B, int C, float T, float inv_bnorm,
               hipStream_t st) {
   hipLaunchKernelGGL(kl_bwd_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, gs, ys, yt, dys, B, C, T, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_kl_rows_fwd(const float* ys, const float* yt, float* sample_loss, int B, int C, float T, hipStream_t st) {
+  hipLaunchKernelGGL(kl_rows_fwd_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, ys, yt, sample_loss, B, C, T);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_kl_rows_bwd(const float* g, const float* ys, const float* yt, float* dys, int B, int C, float T, hipStream_t st) {
+  hipLaunchKernelGGL(kl_rows_bwd_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, g, ys, yt, dys, B, C, T);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_conf_discrepancy(const float* logit_s, const float* logit_t, const int64_t* gt, float* out, int B, int C,
+                        float max_discrep, hipStream_t st) {
+  hipLaunchKernelGGL(conf_discrepancy_kernel, dim3(nblk(B, 64)), dim3(64), 0, st, logit_s, logit_t, gt, out, B, C,
+                     max_discrep);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

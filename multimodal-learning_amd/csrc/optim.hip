@@ -157,7 +157,56 @@ __global__ void gk_scale2_kernel(const float* __restrict__ gram, int ng, int use
   if (mo_init) *mo_init = 1;
 }
 
+// MIA-2023 GK_refine_thresh (".../train_test_path_multi_distill.py":81-128): PER-SAMPLE cosine matrix of the ng
+// gradients (sklearn cosine_similarity: zero-norm rows give 0), column sums of max(cos, 0) or of (cos > thresh).
+// One wave per sample; G is [ng][B][D] with D = 128.
+template <int NG>
+__global__ __launch_bounds__(256) void gk_rows_kernel(const float* __restrict__ G, int B, int use_thresh, float thresh,
+                                                      float* __restrict__ all_scale) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float v[NG][2];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    v[i][0] = G[((size_t)i * B + b) * 128 + lane];
+    v[i][1] = G[((size_t)i * B + b) * 128 + 64 + lane];
+  }
+  float gram[NG][NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i)
+#pragma unroll
+    for (int j = i; j < NG; ++j) {
+      const float s = wave_sum(v[i][0] * v[j][0] + v[i][1] * v[j][1]);
+      gram[i][j] = s; gram[j][i] = s;
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const float den = sqrtf(gram[i][i]) * sqrtf(gram[j][j]);
+        const float c = den > 0.f ? gram[i][j] / den : 0.f;
+        s += use_thresh ? (c > thresh ? 1.f : 0.f) : (c > 0.f ? c : 0.f);
+      }
+      all_scale[(size_t)b * NG + j] = s;
+    }
+  }
+}
+
 }  // namespace
+
+int ph_gk_rows(const float* G, int ng, int B, int D, int use_thresh, float thresh, float* all_scale, hipStream_t st) {
+  if (D != 128) return PH_EINVAL;
+  dim3 grid(cdiv(B, 4));
+  switch (ng) {
+    case 3: hipLaunchKernelGGL(gk_rows_kernel<3>, grid, dim3(256), 0, st, G, B, use_thresh, thresh, all_scale); break;
+    case 5: hipLaunchKernelGGL(gk_rows_kernel<5>, grid, dim3(256), 0, st, G, B, use_thresh, thresh, all_scale); break;
+    default: return PH_EINVAL;
+  }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
 
 int ph_gk_scale_momentum(const float* gram, int ng, int use_thresh, float thresh, float momentum, float* mo_scale,
                          int* mo_init, hipStream_t st) {

@@ -22,6 +22,7 @@ def stage2_opt(**overrides):
         niter_decay=30, epoch_count=1, lambda_cox=1.0, lambda_nll=1.0, lambda_reg=3e-4, ema_decay=0.99,
         global_step=0, batch_size=16,
         grads_m=0.9, grads_thresh="False", thresh=0.0,   # MIA-2022 momentum GK-Refine ("MIA 2022/options.py":80-82)
+        pos_extra="neighbors", use_grads_thresh="True", max_discrep=1, discrep_scale=1, start_reweight=0,   # MIA-2023
         overlap_teachers=True)     # ours: run the EMA / teacher forwards on a second HIP stream
     for k, v in overrides.items():
         if not hasattr(o, k):

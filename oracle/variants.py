@@ -100,3 +100,87 @@ def distill_kl_per_sample(y_s, y_t, T=1.0):
     p_t = F.softmax(y_t / T, dim=1)
     sample_loss = torch.sum(F.kl_div(p_s, p_t, reduction="none"), dim=-1) * (T ** 2)
     return sample_loss.sum() / y_s.shape[0], sample_loss
+
+
+def assign_sample_weights(pred_s, pred_t, gt, max_discrep):
+    """assign_sample_weights of MIA-2023 train_test_path_multi_distill.py:131-158 (pred_* are probabilities)."""
+    gt = F.one_hot(gt, 3).float()
+    conf_t = torch.log(torch.sum(pred_t * gt, 1)) - torch.log(torch.max(pred_t * (1 - gt), 1)[0])
+    conf_s = torch.log(torch.sum(pred_s * gt, 1)) - torch.log(torch.max(pred_s * (1 - gt), 1)[0])
+    d = torch.maximum(conf_t - conf_s, torch.zeros_like(conf_t)).detach()
+    return torch.minimum(d, max_discrep * torch.ones_like(conf_t))
+
+
+def gk_refine_thresh(main_loss, feat_s, loss_t_list, use_grads_thresh="True", grads_thresh=0.25, ce_grads=True):
+    """GK_refine_thresh (MIA-2023 train_test_path_multi_distill.py:81-128): per-sample cosine of the gradients
+    (sklearn cosine_similarity semantics: zero rows -> 0), per-sample loss weights [B, n], batch-mean scale."""
+    losses = [l.sum() for l in loss_t_list] + ([main_loss] if ce_grads else [])
+    grads = torch.stack([torch.autograd.grad(l, feat_s, retain_graph=True)[0].detach() for l in losses])   # [n,B,D]
+    B = grads.shape[1]
+    g = grads.permute(1, 0, 2)                                    # [B, n, D]
+    nrm = g.norm(dim=2, keepdim=True)
+    gn = torch.where(nrm > 0, g / nrm.clamp_min(1e-30), torch.zeros_like(g))
+    cos = torch.bmm(gn, gn.transpose(1, 2))                       # [B, n, n]
+    if use_grads_thresh == "True":
+        all_scale = torch.where(cos > grads_thresh, 1.0, 0.0).sum(1)
+    else:
+        all_scale = torch.where(cos > 0, cos, torch.zeros_like(cos)).sum(1)
+    total = torch.sum(all_scale[:, :-1].transpose(0, 1) * torch.stack(list(loss_t_list))) / B
+    return all_scale.mean(0), total, all_scale
+
+
+class CRDv10State(CRDv3State):
+    """ContrastMemory of CRD_criterion_v10.py:20-43: v3 buffers + the class label of every bank row."""
+
+    def __init__(self, n_data, labels, **kw):
+        super().__init__(n_data, **kw)
+        self.labels = torch.as_tensor(labels).long()
+
+
+def crd_v10_loss(st, sample_weights, f_s, f_t, batch_label, y, idx, num_pos):
+    """CRDLoss.forward with pos_extra == "neighbors" (CRD_criterion_v10.py:45-176, :210-239, :281-314).
+    Returns (loss, sample_loss[B])."""
+    v1 = embed_forward(f_s, st.embed_s["linear.weight"], st.embed_s["linear.bias"])
+    v2 = embed_forward(f_t, st.embed_t["linear.weight"], st.embed_t["linear.bias"])
+    K = int(st.params[0].item()); T = st.params[1].item()
+    B, D = v1.shape
+    n_out = st.memory_v1.size(0)
+    mask = (st.labels.view(1, -1) == batch_label.view(-1, 1)).float()            # batch_class_mask :57-60
+
+    def side(mem):
+        w = torch.index_select(mem, 0, idx.view(-1)).detach().view(B, K + 1, D)
+        q = w[:, 0, :]
+        cos = F.normalize(q, dim=1) @ F.normalize(mem, dim=1).T                  # sklearn cosine_similarity :72-73
+        sim = mask * cos
+        srt = torch.sort(sim, descending=True, dim=-1)
+        nb, nbs = srt[1][:, :num_pos], srt[0][:, :num_pos]
+        knn = torch.index_select(mem, 0, nb.reshape(-1)).detach().view(B, num_pos, D)
+        return torch.cat((knn, w[:, 1:, :]), 1), nbs, nb
+
+    w1, s1, nb1 = side(st.memory_v1)
+    out_v2 = torch.exp(torch.bmm(w1, v2.view(B, D, 1)) / T)
+    w2, s2, nb2 = side(st.memory_v2)
+    out_v1 = torch.exp(torch.bmm(w2, v1.view(B, D, 1)) / T)
+    if st.params[2].item() < 0:
+        st.params[2] = out_v1.mean().detach() * n_out
+    if st.params[3].item() < 0:
+        st.params[3] = out_v2.mean().detach() * n_out
+    out_v1 = out_v1 / st.params[2].item()
+    out_v2 = out_v2 / st.params[3].item()
+    _bank_update(st, v1, v2, y)
+
+    def closs(x, knn_sim):                                                       # ContrastLoss_v2 :286-314
+        P = num_pos
+        m = x.size(1) - P
+        Pn = 1 / float(st.n_data)
+        P_pos = x.narrow(1, 0, P)
+        log_D1 = torch.div(P_pos, P_pos.add(m * Pn + EPS)).log()
+        P_neg = x.narrow(1, P, m)
+        log_D0 = torch.div(torch.full_like(P_neg, m * Pn), P_neg.add(m * Pn + EPS)).log()
+        sl = -((log_D1.squeeze(-1) + log_D0.sum(1).view(B, 1).repeat(1, P)) * knn_sim).sum(1) / knn_sim.sum(1)
+        sl = sample_weights.view(-1) * sl
+        return sl.sum(0) / B, sl
+
+    ls, sls = closs(out_v1, s2)      # criterion_s(out_s, t_similarity)  :226-227
+    lt, slt = closs(out_v2, s1)
+    return ls + lt, sls + slt, dict(nb1=nb1, nb2=nb2, sim1=s1, sim2=s2)

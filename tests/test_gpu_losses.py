@@ -81,7 +81,7 @@ def test_crd_select_kernel_bit_exact():
                 r = None if ranks is None else torch.as_tensor(ranks, dtype=torch.int32).cuda()
                 d, o1, o2 = diff.cuda(), out1.cuda(), out2.cuda()
                 check(L.ph_crd_select(ptr(d), ptr(o1), ptr(o2), ptr(r), ptr(sel), ptr(xs), ptr(xt), B, P, K, P2, k2,
-                                      select_neg, stream()), "select")
+                                      select_neg, 1, stream()), "select")
                 assert torch.equal(sel.cpu().long(), ref)
                 assert torch.equal(xs.cpu(), torch.gather(out1, 1, ref)) and torch.equal(xt.cpu(), torch.gather(out2, 1, ref))
 
@@ -192,4 +192,89 @@ def test_mia2022_momentum_gk_golden(golden_dir):
             mo, total = m.momentum_AEKD_loss(opt, None, losses[4], feat, losses[:4], mo)
             R.close(g[f"{name}_scale{it}"], mo, 1e-4, 1e-4, f"{name} mo_scale it {it}")
             R.close(g[f"{name}_total{it}"], total, 1e-4, 1e-4, f"{name} total it {it}")
+    R.finish()
+
+
+def test_mia2023_crd_v10_golden(golden_dir):
+    """class-masked full-bank KNN positives on the GPU + similarity-weighted, per-sample-weighted NCE
+    vs the MIA-2023 reference (which does the bank scan with sklearn on the host)."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.CL_utils import CRD_criterion_v10 as V10
+    from oracle import weights as W
+    from oracle.variants import CRDv10State
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "mia2023_crd_v10.npz"))
+    labels = torch.as_tensor(g["labels"])
+    class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+    opt = m.stage2_opt(nce_k=int(g["K"]), nce_p=int(g["num_pos"]))
+    crd = V10.CRDLoss(opt, int(g["n_data"]), class_idx)
+    crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 50))
+    crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 51))
+    st = CRDv10State(int(g["n_data"]), labels, K=int(g["K"]), seed=int(g["bank_seed"]))
+    crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+    crd = crd.cuda(); crd.contrast.verbose = False
+    R = Report("MIA-2023 CRD_criterion_v10 (neighbors) vs reference golden")
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).cuda().requires_grad_(True)
+        loss, sl = crd(torch.as_tensor(g[f"w{it}"]).cuda(), f_s, torch.as_tensor(g[f"f_t{it}"]).cuda(),
+                       torch.as_tensor(g[f"grade{it}"]).cuda(), torch.as_tensor(g[f"index{it}"]).cuda(),
+                       torch.as_tensor(g[f"sidx{it}"]).cuda())
+        gs = torch.autograd.grad(loss, [f_s, crd.embed_s.linear.weight, crd.embed_t.linear.weight])
+        R.close(g[f"loss{it}"], loss, 1e-4, 1e-5, f"loss call {it}")
+        R.close(g[f"sample_loss{it}"], sl, 1e-3, 1e-5, f"sample_loss call {it}")
+        R.close(g[f"g_fs{it}"], gs[0], 1e-6, 1e-3, f"d f_s call {it}"); R.close(g[f"g_ws{it}"], gs[1], 1e-6, 1e-3, f"d W_s call {it}")
+        R.close(g[f"g_wt{it}"], gs[2], 1e-6, 1e-3, f"d W_t call {it}")
+        R.close(g[f"params{it}"], crd.contrast.params, 1e-2, 1e-4, f"params/Z call {it}")
+        R.close(g[f"bank_v1_rows{it}"], crd.contrast.memory_v1[torch.as_tensor(g[f"index{it}"]).cuda()], 1e-6, 0, f"bank rows call {it}")
+    R.finish()
+
+
+def test_mia2023_bank_topk_bit_exact():
+    """The KNN indices are integer work: identical to torch.sort of the class-masked cosine on the same bank."""
+    from multimodal_learning_amd._lib import lib, ptr, stream, check
+    import torch.nn.functional as F
+    L = lib()
+    g = torch.Generator().manual_seed(2)
+    n, B, NP = 65536, 8, 6          # BASELINE config 5 bank size
+    mem1 = torch.rand(n, 128, generator=g) - 0.5; mem2 = torch.rand(n, 128, generator=g) - 0.5
+    labels = torch.randint(0, 3, (n,), generator=g).int()
+    idx = torch.randint(0, n, (B, 5), generator=g)
+    bl = labels[idx[:, 0]].long()
+    d = lambda t: t.cuda()
+    nb1 = torch.empty(B, NP, dtype=torch.int64, device="cuda"); nb2 = torch.empty_like(nb1)
+    s1 = torch.empty(B, NP, device="cuda"); s2 = torch.empty_like(s1)
+    m1, m2, lb, ix, blc = d(mem1), d(mem2), d(labels), d(idx), d(bl)     # keep the device tensors alive across the launch
+    check(L.ph_crd_bank_topk(ptr(m1), ptr(m2), ptr(lb), ptr(ix), 5, ptr(blc), B, n, NP, 128,
+                             ptr(nb1), ptr(nb2), ptr(s1), ptr(s2), stream()), "topk")
+    for mem, nb, s in ((mem1, nb1, s1), (mem2, nb2, s2)):
+        sim = (labels.view(1, -1) == bl.view(-1, 1)).float() * (F.normalize(mem[idx[:, 0]], dim=1) @ F.normalize(mem, dim=1).T)
+        srt = torch.sort(sim, descending=True, dim=-1)
+        assert torch.equal(nb.cpu(), srt[1][:, :NP])
+        assert torch.allclose(s.cpu(), srt[0][:, :NP], atol=1e-6)
+
+
+def test_mia2023_rows_golden(golden_dir):
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd import mia2023
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "mia2023_rows.npz"))
+    R = Report("MIA-2023 per-sample KL / sample weights / GK_refine_thresh vs reference golden")
+    B = g["ys"].shape[0]
+    for T in (1, 2):
+        ys = torch.as_tensor(g["ys"]).cuda().requires_grad_(True)
+        loss, sl = mia2023.DistillKL(float(T))(ys, torch.as_tensor(g["yt"]).cuda())
+        gg, = torch.autograd.grad((sl * torch.arange(1, B + 1).float().cuda()).sum(), ys)
+        R.close(g[f"kl_loss_T{T}"], loss, 1e-6, 1e-5, f"kl loss T={T}"); R.close(g[f"kl_rows_T{T}"], sl, 1e-6, 1e-5, f"kl rows T={T}")
+        R.close(g[f"kl_g_T{T}"], gg, 1e-5, 1e-5, f"kl grad T={T}")
+    ys, yt = torch.as_tensor(g["ys"]).cuda(), torch.as_tensor(g["yt"]).cuda()
+    d = mia2023.assign_sample_weights(torch.softmax(ys, 1), torch.softmax(yt, 1), torch.as_tensor(g["grade"]).cuda(), 1, 1)
+    R.close(g["discrep"], d, 1e-5, 0, "assign_sample_weights")
+    ws = torch.as_tensor(g["ws"]).cuda()
+    for name, use, th in (("thr", "True", 0.25), ("relu", "False", 0.2)):
+        opt = m.stage2_opt(batch_size=B)
+        opt.use_grads_thresh, opt.grads_thresh = use, th
+        feat = torch.as_tensor(g["feat"]).cuda().clone().requires_grad_(True)
+        rows = [((feat * w).sum(1) ** 2) * (0.1 + i) + (feat ** 2).mean(1) * (i % 2) for i, w in enumerate(ws)]
+        scale, total = mia2023.GK_refine_thresh(opt, None, rows[4].mean(), feat, rows[:4])
+        R.close(g[f"gk_{name}_scale"], scale, 1e-4, 1e-4, f"GK {name} scale"); R.close(g[f"gk_{name}_total"], total, 1e-4, 1e-4, f"GK {name} total")
     R.finish()
