@@ -56,7 +56,8 @@ int ph_resnet_unit_shape(const PhResnetPlan* plan, int unit, int* out4 /* Cout, 
 /* OIHW fp32 -> MFMA operand layouts (bf16 hi/lo planes, fwd [tap][O][I] and dgrad [tap][I][O]); call after
  * every optimiser step */
 int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, void* packed, ph_stream_t stream);
-/* x_nchw [B,3,H,W] f32 -> f3 [B,256], f4 [B,512] f32 (either may be NULL).  flags bit0: update running stats */
+/* x_nchw [B,3,H,W] f32 -> f3 [B,256], f4 [B,512] f32 (either may be NULL).  flags bit0: train mode, update the running
+ * statistics; bit1: eval mode (normalise with the running statistics; no backward) */
 int ph_resnet_forward(const PhResnetPlan* plan, const void* const* params, const void* packed, const float* x_nchw,
                       void* workspace, float* f3, float* f4, int flags, ph_stream_t stream);
 int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
@@ -77,6 +78,9 @@ int ph_sgemm_splitk(const float* A, const float* B, const float* bias, float* C,
 int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
                 float* running_mean, float* running_var, int64_t* num_batches_tracked, int B, int C, float eps,
                 float momentum, int relu, ph_stream_t stream);
+/* eval mode (module.eval(): running statistics), used by the reference's test() (train_test_path_multi_distill.py:409-411) */
+int ph_bn1d_eval(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float* y, int B, int C, float eps, int relu, ph_stream_t stream);
 int ph_bn1d_bwd(const float* g, const float* y, const float* x, const float* mean, const float* invstd,
                 const float* gamma, float* dx, float* dgamma, float* dbeta, int B, int C, int relu,
                 ph_stream_t stream);

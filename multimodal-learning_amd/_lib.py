@@ -29,6 +29,7 @@ SIGNATURES = {
     "ph_sgemm": (i32, [vp, vp, vp, vp, i32, i32, i32, lng, lng, lng, lng, lng, i32, i32, vp]),
     "ph_sgemm_splitk": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, lng, lng, lng, lng, lng, i32, vp]),
     "ph_bn1d_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp]),
+    "ph_bn1d_eval": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
     "ph_bn1d_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "ph_log_softmax": (i32, [vp, vp, i32, i32, vp]),
     "ph_log_softmax_bwd": (i32, [vp, vp, vp, i32, i32, vp]),

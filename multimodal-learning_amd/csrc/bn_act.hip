@@ -62,6 +62,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
+// eval mode (model.eval(), reference test() train_test_path_multi_distill.py:409-411): scale/shift of every BN unit
+// of a network from its RUNNING statistics, one launch for all units
+__global__ void bn_eval_params_kernel(PhBnEvalTable t, float eps) {
+  const int u = blockIdx.x;
+  for (int c = threadIdx.x; c < t.C[u]; c += blockDim.x) {
+    const float is = rsqrtf(t.running_var[u][c] + eps);
+    const float sc = t.gamma[u][c] * is;
+    t.mean[u][c] = t.running_mean[u][c];
+    t.invstd[u][c] = is;
+    t.scale[u][c] = sc;
+    t.shift[u][c] = t.beta[u][c] - t.running_mean[u][c] * sc;
+  }
+}
+
 // out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] ), 8 channels per thread
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
@@ -331,6 +345,12 @@ int ph_bn_finalize_launch(const float* parts, int nparts, int C, double count, f
                            float* shift, float* running_mean, float* running_var, int64_t* nbt, hipStream_t st) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, eps, momentum, gamma, beta,
                      mean, invstd, scale, shift, running_mean, running_var, nbt);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(t->n), dim3(256), 0, st, *t, eps);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

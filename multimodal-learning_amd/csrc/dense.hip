@@ -192,6 +192,18 @@ __global__ void bn1d_fwd_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
+// eval mode: normalise with the running statistics
+__global__ void bn1d_eval_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ rm,
+                                 const float* __restrict__ rv, float* __restrict__ y, int B, int C, float eps, int relu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int c = i % C;
+  float v = (x[i] - rm[c]) * rsqrtf(rv[c] + eps) * gamma[c] + beta[c];
+  if (relu) v = v > 0.f ? v : 0.f;
+  y[i] = v;
+}
+
 // g: grad wrt the (relu'd) output y; dz = g * (y > 0) when relu
 __global__ void bn1d_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ x,
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -491,6 +503,13 @@ int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y,
                 int relu, hipStream_t st) {
   hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, x, gamma, beta, y, mean, invstd,
                      running_mean, running_var, nbt, B, C, eps, momentum, relu);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_bn1d_eval(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float* y, int B, int C, float eps, int relu, hipStream_t st) {
+  hipLaunchKernelGGL(bn1d_eval_kernel, dim3(nblk((size_t)B * C)), dim3(256), 0, st, x, gamma, beta, running_mean,
+                     running_var, y, B, C, eps, relu);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -96,6 +96,13 @@ int ph_bn_finalize_launch(const float* parts, int nparts, int C, double count, f
                           const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
                           float* shift, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                           hipStream_t st);
+struct PhBnEvalTable {
+  const float* gamma[20]; const float* beta[20]; const float* running_mean[20]; const float* running_var[20];
+  float* mean[20]; float* invstd[20]; float* scale[20]; float* shift[20];
+  int C[20];
+  int n;
+};
+int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st);
 // out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] )
 int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
                        const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,

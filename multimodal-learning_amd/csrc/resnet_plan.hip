@@ -190,6 +190,7 @@ struct Ctx {
   unsigned char* ws;
   hipStream_t st;
   int update_running;
+  int eval;
   float* stat(const Unit& u, int which) const {
     return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
   }
@@ -200,7 +201,7 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
   const Unit& u = P->units[ui];
   PhTapConv t{};
   t.in = in; t.w = c.pk + u.wf_off; t.wplane = u.wplane;
-  t.out = c.ws + u.y_off; t.stats = reinterpret_cast<float*>(c.ws + P->parts_off);
+  t.out = c.ws + u.y_off; t.stats = c.eval ? nullptr : reinterpret_cast<float*>(c.ws + P->parts_off);
   t.B = P->B; t.IH = u.IH; t.IW = u.IW; t.Cin = u.Cin; t.Cout = u.Cout;
   t.OHt = u.OH; t.OWt = u.OW; t.OH = u.OH; t.OW = u.OW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
   t.iy0 = -u.pad; t.ix0 = -u.pad; t.ntaps = u.KS * u.KS;
@@ -212,6 +213,7 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
   }
   int rc = ph_tapconv_launch(&t, S, P->prec, c.st);
   if (rc) return rc;
+  if (c.eval) return PH_OK;    // scale/shift were preset from the running statistics
   const int nparts = ph_tapconv_stat_parts(&t, S, P->prec);
   float* rm = c.update_running ? (float*)c.params[ui * 6 + 3] : nullptr;
   return ph_bn_finalize_launch(t.stats, nparts, u.Cout, (double)P->B * u.OH * u.OW, 1e-5f, 0.1f,
@@ -306,23 +308,36 @@ int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* 
 
 extern "C" {
 
-// flags: bit0 = update BN running statistics
+// flags: bit0 = update BN running statistics (train mode); bit1 = eval mode (normalise with the running statistics)
 int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const void* packed, const float* x_nchw,
                       void* ws_, float* f3, float* f4, int flags, hipStream_t st) {
   if (!P || !params || !packed || !x_nchw || !ws_) return PH_EINVAL;
-  Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, flags & 1};
+  Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st,
+        (flags & 2) ? 0 : (flags & 1), (flags & 2) ? 1 : 0};
   unsigned char* ws = c.ws;
   int rc = ph_pack_input_launch(x_nchw, ws + P->x4_off, P->B, P->H, P->W, P->prec, st);
   if (rc) return rc;
+  if (c.eval) {
+    PhBnEvalTable t{};
+    t.n = (int)P->units.size();
+    for (int i = 0; i < t.n; ++i) {
+      const Unit& u = P->units[i];
+      t.gamma[i] = (const float*)params[i * 6 + 1]; t.beta[i] = (const float*)params[i * 6 + 2];
+      t.running_mean[i] = (const float*)params[i * 6 + 3]; t.running_var[i] = (const float*)params[i * 6 + 4];
+      t.mean[i] = c.stat(u, 0); t.invstd[i] = c.stat(u, 1); t.scale[i] = c.stat(u, 2); t.shift[i] = c.stat(u, 3);
+      t.C[i] = u.Cout;
+    }
+    if ((rc = ph_bn_eval_params_launch(&t, 1e-5f, st))) return rc;
+  }
   {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
     const Unit& u = P->units[0];
     PhStem s{};
     s.x4 = ws + P->x4_off; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
-    s.out = ws + u.y_off; s.stats = reinterpret_cast<float*>(ws + P->parts_off);
+    s.out = ws + u.y_off; s.stats = c.eval ? nullptr : reinterpret_cast<float*>(ws + P->parts_off);
     s.B = P->B; s.IH = P->H; s.IW = P->W; s.OH = u.OH; s.OW = u.OW;
     if ((rc = ph_stem_fwd_launch(&s, P->prec, st))) return rc;
     float* rm = c.update_running ? (float*)params[3] : nullptr;
-    if ((rc = ph_bn_finalize_launch(s.stats, ph_stem_stat_parts(P->B, u.OH, u.OW), 64, (double)P->B * u.OH * u.OW,
+    if (!c.eval && (rc = ph_bn_finalize_launch(s.stats, ph_stem_stat_parts(P->B, u.OH, u.OW), 64, (double)P->B * u.OH * u.OW,
                                     1e-5f, 0.1f, (const float*)params[1], (const float*)params[2], c.stat(u, 0),
                                     c.stat(u, 1), c.stat(u, 2), c.stat(u, 3), rm, (float*)params[4],
                                     (int64_t*)params[5], st)))

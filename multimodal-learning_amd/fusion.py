@@ -47,7 +47,7 @@ class BilinearFusion(nn.Module):
 
     def _bn_relu(self, x, bn):
         if not self.training:
-            raise NotImplementedError("eval-mode BatchNorm1d: SURVEY.md section 8 'next' row f-3")
+            return ops.bn1d_eval(x, bn, relu=True)
         return ops.BN1dFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 True, True)
 

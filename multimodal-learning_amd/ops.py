@@ -131,6 +131,15 @@ class BN1dFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+def bn1d_eval(x, bn, relu):
+    """nn.BatchNorm1d in eval mode (running statistics), optionally + ReLU; forward only."""
+    x = _f32(x)
+    y = torch.empty_like(x)
+    check(lib().ph_bn1d_eval(ptr(x), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), ptr(y),
+                             x.shape[0], x.shape[1], bn.eps, int(relu), stream()), "ph_bn1d_eval")
+    return y
+
+
 class LogSoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

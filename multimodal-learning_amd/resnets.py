@@ -83,7 +83,7 @@ class _TrunkFn(torch.autograd.Function):
         f3 = torch.empty(B, 256, device=x.device, dtype=torch.float32)
         f4 = torch.empty(B, 512, device=x.device, dtype=torch.float32)
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4),
-                                      1 if net.training else 0, stream()), "ph_resnet_forward")
+                                      1 if net.training else 2, stream()), "ph_resnet_forward")
         ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table
         ctx.set_materialize_grads(False)
         ctx.nparams = len(params)
@@ -240,12 +240,22 @@ class ResNet(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def _forward_impl(self, x):
-        if not self.training:
-            raise NotImplementedError("eval-mode (running-statistics) forward is the 'next' row f-3 of SURVEY.md "
-                                      "section 8; the hot loop runs all three networks in train mode "
-                                      "(train_test_path_multi_distill.py:231-232)")
-        f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())
         lin, bn = self.fc_new1[0], self.fc_new1[1]
+        if not self.training:
+            # eval mode (the reference's test(), train_test_path_multi_distill.py:409-431): BatchNorm uses the running
+            # statistics.  Forward only - the reference never back-propagates through an eval-mode net.
+            with torch.no_grad():
+                f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())
+                h = ops.linear_fwd(f4, lin.weight, lin.bias)
+                features = ops.bn1d_eval(h, bn, relu=True)
+                hazard = ops.linear_fwd(features, self.fc_new2.weight, self.fc_new2.bias)
+                pred = None
+                if self.act is not None:
+                    if not isinstance(self.act, nn.LogSoftmax):
+                        raise NotImplementedError("only act_type 'LSM' (grading task) is on the hot path")
+                    pred = ops.LogSoftmaxFn.apply(hazard)
+            return f3, features, hazard, pred, None
+        f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())
         h = ops.LinearFn.apply(f4, lin.weight, lin.bias)
         features = ops.BN1dFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                     True, True)

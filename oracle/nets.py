@@ -15,8 +15,10 @@ import torch.nn.functional as F
 
 
 class Rounding:
-    """mode 'fp32' = the reference's arithmetic; 'bf16' = perf-mode emulation."""
+    """mode 'fp32' = the reference's arithmetic; 'bf16' = perf-mode emulation.
+    `training` False = module.eval(): BatchNorm normalises with the running statistics (reference test())."""
     mode = "fp32"
+    training = True
 
     @classmethod
     def q(cls, x):
@@ -60,6 +62,9 @@ def _bn_train(x, sd, name, update_running=True, eps=1e-5, momentum=0.1):
     of ~1e4+ rounding errors and is far below the comparison tolerance).
     """
     xs = _store(x)
+    if not Rounding.training:
+        return F.batch_norm(xs, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
+                            sd[name + ".bias"], False, momentum, eps)
     if update_running:
         rm, rv = sd[name + ".running_mean"], sd[name + ".running_var"]
         with torch.no_grad():

@@ -115,3 +115,34 @@ def test_teacher_forward_parity_mode(golden_dir):
         R.finish()
     finally:
         m.set_precision("bf16")
+
+
+def test_eval_mode_forward_vs_reference(golden_dir):
+    """model.eval() / fix_model.eval() (reference test()): running-statistics BN, dropout off, no autograd graph."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import synthetic_batch, default_opt
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "modules_eval_b4_h96.npz"))
+    m.set_precision("bf16x6")
+    try:
+        R = Report("eval-mode student + teacher forward vs reference golden (B=4, 96x96)")
+        bt = synthetic_batch(int(g["B"]), int(g["H"]), seed=int(g["batch_seed"]))
+        net = _student().eval()
+        rm_before = net.bn1.running_mean.clone()
+        out = net(x_path=bt["x_path"].cuda())
+        assert len(out) == 5 and out[4] is None and not out[2].requires_grad
+        assert torch.equal(rm_before, net.bn1.running_mean), "eval mode must not touch the running statistics"
+        R.close(g["f3"], out[0], 1e-3, 0, "f3"); R.close(g["feat"], out[1], 1e-3, 0, "features")
+        R.close(g["hazard"], out[2], 1e-3, 0, "hazard"); R.close(g["pred"], out[3], 1e-3, 0, "pred")
+        t = m.define_net(default_opt(dropout_rate=0.25), 1)      # dropout must be inactive in eval mode
+        t.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+        t = t.cuda().eval()
+        with torch.no_grad():
+            o = t(x_path=bt["x_path"].cuda(), x_omic=bt["x_omic"].cuda())
+        R.close(g["t_fuse"], o[0], 1e-3, 0, "teacher fuse feat"); R.close(g["t_path_vec"], o[1], 1e-3, 0, "teacher path vec")
+        R.close(g["t_omic_vec"], o[2], 1e-4, 0, "teacher omic vec"); R.close(g["t_h_fuse"], o[4][2], 1e-3, 0, "teacher fuse logits")
+        R.close(g["t_pred"], o[5], 1e-3, 0, "teacher pred"); R.close(g["t_pred_omic"], o[7], 1e-4, 0, "teacher pred omic")
+        R.finish()
+    finally:
+        m.set_precision("bf16")

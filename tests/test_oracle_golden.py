@@ -133,3 +133,19 @@ def test_full_step_b16_h224(golden_dir, faithful):
         _close(g[f"params0_{it}"], orc.crd[0].params, 1.0, 1e-4)
         _close(g[f"bank0_v1_rows{it}"], orc.crd[0].memory_v1[bt["index"]], 1e-4)
         _close(g[f"bank1_v2_rows{it}"], orc.crd[1].memory_v2[bt["index"]], 1e-4)
+
+
+def test_eval_mode_forward(golden_dir):
+    """module.eval(): running-statistics BatchNorm (the reference's test())."""
+    g = _ld(golden_dir, "modules_eval_b4_h96.npz")
+    bt = synthetic_batch(int(g["B"]), int(g["H"]), seed=int(g["batch_seed"]))
+    from oracle.nets import Rounding
+    Rounding.training = False
+    try:
+        with torch.no_grad():
+            f3, feat, hazard, pred, _ = oracle.resnet_forward(bt["x_path"], W.make_state_dict(W.student_shapes(), 1))
+            t = oracle.pathomic_forward(bt["x_path"], bt["x_omic"], W.make_state_dict(W.teacher_shapes(320), 3))
+    finally:
+        Rounding.training = True
+    _close(g["f3"], f3); _close(g["feat"], feat); _close(g["hazard"], hazard); _close(g["pred"], pred)
+    _close(g["t_fuse"], t[0]); _close(g["t_h_fuse"], t[4][2]); _close(g["t_pred"], t[5]); _close(g["t_pred_omic"], t[7])
