@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the step from a captured HIP graph")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
+                    "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,7 +91,7 @@ def main():
     device = torch.device("cuda", local_rank)
     import multimodal_learning_amd as m
     sync = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=device)
         sync = m.dist.ReplicaSync()
@@ -188,7 +190,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if sync is not None:
         torch.distributed.destroy_process_group()
 
 

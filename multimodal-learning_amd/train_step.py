@@ -371,12 +371,23 @@ class DistillStep:
             lib().ph_prof_enable(0)          # event timing is an eager-mode facility
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
-                self.optimizer._prepared = True
-                st["out"] = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"], st["index"],
-                                              st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
-            st["graph"] = g
-            # capture does not execute: the prepared scalars are still pending for the first replay
+            try:
+                with torch.cuda.graph(g):
+                    self.optimizer._prepared = True
+                    st["out"] = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"],
+                                                  st["index"], st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
+                st["graph"] = g
+                # capture does not execute: the prepared scalars are still pending for the first replay
+            except Exception as exc:     # e.g. a collective that cannot be captured on this stack: stay eager
+                import warnings
+                warnings.warn("HIP graph capture of the distill step failed (%r); continuing with eager launches" % (exc,))
+                torch.cuda.synchronize()
+                self._want_graph = False
+                self._static = None
+                out = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"], st["index"],
+                                        st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
+                self.iter_num += 1
+                return out
         self.optimizer._prepared = False
         st["graph"].replay()
         self.iter_num += 1
