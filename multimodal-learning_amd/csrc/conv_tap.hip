@@ -15,8 +15,12 @@
 //   products to ~2^-24 (fp32 accumulate as in the reference).
 #include "ph_common.h"
 #include "ph_kernels.h"
+#include "tap_common.h"
 
 namespace {
+#ifdef PH_TAP_TRACE
+__device__ unsigned long long ph_tap_trace[PH_TRACE_WGS * 12];
+#endif
 
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
 struct TapCfg {
@@ -28,32 +32,17 @@ struct TapCfg {
   static constexpr int A_BYTES = (HP + 1) / 2 * 256;   // lds_off() addresses rows in 256-B pairs
   static constexpr int B_BYTES = TG * BNT * 128;
   static constexpr int NP = SPLIT ? PH_NPLANES : 1;
-  // perf-mode 8-wave tiles stream the weight stages by LDS-DMA into a 2-deep ring when it fits the 160 KB LDS
-  // (measured r01: 597 vs 672 TFLOP/s for the register-prefetch path - 6 x 1-KiB DMA pieces per wave and
-  // stage cost more issue time than they save - so the ring is compiled out until the stage is restructured)
-  static constexpr bool DMA_ENABLED = false;
-  static constexpr bool DMA = DMA_ENABLED && !SPLIT && (WM * WN == 8) && (A_BYTES + 2 * B_BYTES <= 160 * 1024);
-  static constexpr int LDS_BYTES = DMA ? (A_BYTES + 2 * B_BYTES) : (A_BYTES + B_BYTES) * NP;
+  // perf-mode 8-wave tiles double-buffer the weight stages in LDS when A + 2 B fits the 160 KB: the refill of
+  // stage s+1 is written while stage s computes and one barrier per stage remains.  (An LDS-DMA ring for the same
+  // purpose measured slower, r01: 597 vs 672 TFLOP/s - 6 x 1-KiB DMA pieces per wave and stage cost more issue time
+  // than the VGPR round trip.)
+  static constexpr bool DB = !SPLIT && (WM * WN == 8) && (A_BYTES + 2 * B_BYTES <= 160 * 1024);
+  static constexpr int LDS_BYTES = DB ? (A_BYTES + 2 * B_BYTES) : (A_BYTES + B_BYTES) * NP;
   static constexpr int NTH = WM * WN * 64;
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
   static_assert(WM * FM * 32 == TH * TW, "M tiling");
   static_assert(WN * FN * 32 == BNT, "N tiling");
 };
-
-// LDS image addressing shared by the A (halo pixels) and B (weight rows) tiles: 128-B rows (64 bf16), two rows
-// per 256-B bank row, 16-B chunk slot XOR-swizzled with 4 bits of the row-pair index.  With the lane->pixel
-// permutation below every 16-lane ds_read_b128 group touches 16 distinct slots (no bank conflicts); the
-// previous 3-bit swizzle measured 38-54 % conflict cycles (profiles/r01_pmc_before.txt).
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return (row >> 1) * 256 + (((((row & 1) << 3) | chunk) ^ ((row >> 1) & 15)) << 4);
-}
-// MFMA A-fragment row i (0..31) -> pixel (fr, c) inside a 2 x 16 patch such that the hardware's
-// ds_read_b128 lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} each read 16 CONSECUTIVE pixels of one row
-__device__ __forceinline__ void frag_row_to_pixel(int i, int& fr, int& c) {
-  const int k = i >> 2;
-  fr = __popc(k) & 1;
-  c = ((k >> 1) << 2) | (i & 3);
-}
 
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
 __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
@@ -61,7 +50,9 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   constexpr bool SPLIT = C::SPLIT;
   constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP, NP = C::NP, NTH = C::NTH;
   constexpr int HCH = (HP * 8 + NTH - 1) / NTH;          // halo 16-B chunks per thread
-  constexpr int WCH = (TG * BNT * 8 + NTH - 1) / NTH;    // weight 16-B chunks per thread (full tap group)
+  constexpr int WPT = BNT * 8 / NTH;                     // weight 16-B chunks per thread and tap
+  constexpr int WCH = TG * WPT;                          // ... per stage (full tap group)
+  static_assert((BNT * 8) % NTH == 0, "a tap's weight block must split evenly over the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsA = smem;                      // NP planes of A_BYTES
   unsigned char* ldsB = smem + C::A_BYTES * NP;    // NP planes of B_BYTES
@@ -78,6 +69,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const long img_st = p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin;
   const T* in = reinterpret_cast<const T*>(p.in) + (size_t)b * img_st;
   const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
+  PH_TRACE(0);
+  PH_TRACE_HWID();
   const int iy_base = r0 * S + p.iy0, ix_base = c0 * S + p.ix0;
 
   f32x16 acc[FM][FN];
@@ -104,6 +97,20 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const int nslices = p.Cin >> 6;
   const int ngroups = (p.ntaps + TG - 1) / TG;
   const int nstages = nslices * ngroups;
+  // tap table in a VGPR (lane t holds tap t): the per-tap weight slab and halo offset are fetched with
+  // v_readlane instead of kernarg loads, so no memory round trip (and no s_waitcnt) sits on the stage path
+  int tap_tab = 0;
+  if (lane < p.ntaps) tap_tab = (p.wtap[lane] << 16) | (p.dy[lane] * HPW + p.dx[lane]);
+  auto tap_slab = [&](int t) { return __builtin_amdgcn_readlane(tap_tab, t) >> 16; };
+  auto tap_off = [&](int t) { return __builtin_amdgcn_readlane(tap_tab, t) & 0xffff; };
+  // per-lane constant parts of the weight staging addresses: chunk e of a tap is row (tid + e*NTH) >> 3, 16-B piece & 7
+  int w_goff[WPT], w_loff[WPT];
+#pragma unroll
+  for (int e = 0; e < WPT; ++e) {
+    const int i = tid + e * NTH;
+    w_goff[e] = (i >> 3) * p.Cin + (i & 7) * 8;
+    w_loff[e] = lds_off(i >> 3, i & 7);
+  }
 
   // ---- staging helpers ------------------------------------------------------------------------------
   auto halo_src = [&](int i, int k0, bool& ok) -> const T* {
@@ -137,18 +144,18 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     }
   };
   auto stage_w_sync = [&](int k0, int tg0, int gcount) {
-    for (int i = tid; i < gcount * BNT * 8; i += NTH) {
-      const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
-      const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
-      const int off = t * BNT * 128 + lds_off(row, ch);
+    for (int t = 0; t < gcount; ++t) {
+      const bf16* base = wbase + ((size_t)tap_slab(tg0 + t) * p.Cout + n0) * p.Cin + k0;
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl)
-        *reinterpret_cast<u32x4*>(ldsB + pl * C::B_BYTES + off) =
-            *reinterpret_cast<const u32x4*>(wbase + (size_t)pl * p.wplane + g);
+      for (int e = 0; e < WPT; ++e)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          *reinterpret_cast<u32x4*>(ldsB + pl * C::B_BYTES + t * BNT * 128 + w_loff[e]) =
+              *reinterpret_cast<const u32x4*>(base + (size_t)pl * p.wplane + w_goff[e]);
     }
   };
   // perf mode: register prefetch (issue the global loads before the MFMA block, write LDS after it)
-  u32x4 hreg[SPLIT ? 1 : HCH], wreg[(SPLIT || C::DMA) ? 1 : WCH];
+  u32x4 hreg[SPLIT ? 1 : HCH], wreg[SPLIT ? 1 : WCH];
   auto load_halo_regs = [&](int k0) {
 #pragma unroll
     for (int e = 0; e < HCH; ++e) {
@@ -169,29 +176,27 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   };
   auto load_w_regs = [&](int k0, int tg0, int gcount) {
 #pragma unroll
-    for (int e = 0; e < WCH; ++e) {
-      const int i = tid + e * NTH;
-      if (i < gcount * BNT * 8) {
-        const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
-        const size_t g = ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
-        wreg[e] = *reinterpret_cast<const u32x4*>(wbase + g);
+    for (int t = 0; t < TG; ++t) {
+      if (t < gcount) {   // uniform
+        const bf16* base = wbase + ((size_t)tap_slab(tg0 + t) * p.Cout + n0) * p.Cin + k0;
+#pragma unroll
+        for (int e = 0; e < WPT; ++e) wreg[t * WPT + e] = *reinterpret_cast<const u32x4*>(base + w_goff[e]);
       }
     }
   };
-  auto store_w_regs = [&](int gcount) {
+  auto store_w_regs = [&](int gcount, unsigned char* dstB) {
 #pragma unroll
-    for (int e = 0; e < WCH; ++e) {
-      const int i = tid + e * NTH;
-      if (i < gcount * BNT * 8) {
-        const int ch = i & 7, row = (i >> 3) % BNT, t = (i >> 3) / BNT;
-        *reinterpret_cast<u32x4*>(ldsB + t * BNT * 128 + lds_off(row, ch)) = wreg[e];
+    for (int t = 0; t < TG; ++t) {
+      if (t < gcount) {
+#pragma unroll
+        for (int e = 0; e < WPT; ++e) *reinterpret_cast<u32x4*>(dstB + t * BNT * 128 + w_loff[e]) = wreg[t * WPT + e];
       }
     }
   };
   // ---- MFMA over one staged tap group -----------------------------------------------------------------
   auto compute = [&](int tg0, int gcount, const unsigned char* ldsBcur) {
     for (int t = 0; t < gcount; ++t) {
-      const int toff = p.dy[tg0 + t] * HPW + p.dx[tg0 + t];
+      const int toff = tap_off(tg0 + t);
       int hp[FM];
 #pragma unroll
       for (int i = 0; i < FM; ++i) hp[i] = prow[i] + toff;
@@ -239,48 +244,55 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         compute(tg0, gcount, ldsB);
       }
     }
-  } else if constexpr (C::DMA) {
-    // perf mode, LDS-DMA weight stream: global_load_lds_dwordx4 writes 1 KiB (8 weight rows) per wave-instruction
-    // straight into the swizzled image of the NEXT stage's ring slot - the LDS side is linear, so the XOR swizzle
-    // is applied to each lane's SOURCE (row, chunk).  No VGPR staging and no ds_write for the weights; the one
-    // barrier per stage sits after the MFMA block, so the DMA has that whole block to land.  The halo of the next
-    // 64-channel slice still goes through registers (it needs the zero fill of out-of-image pixels).
-    typedef __attribute__((address_space(3))) void lds_void;
-    auto issue_w = [&](int k0, int tg0, int gcount, unsigned char* dst) {
-      for (int i0 = wave * 64; i0 < gcount * BNT * 8; i0 += NTH) {
-        const int i = i0 + lane;
-        const int t = i / (BNT * 8), rem = i - t * BNT * 8;
-        const int rp = rem >> 4, sl = (rem & 15) ^ (rp & 15);       // row pair, un-swizzled slot
-        const int row = 2 * rp + (sl >> 3), ch = sl & 7;
-        const bf16* src = wbase + ((size_t)p.wtap[tg0 + t] * p.Cout + n0 + row) * p.Cin + k0 + ch * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (lds_void*)(dst + i0 * 16), 16, 0, 0);
-      }
+  } else if constexpr (C::DB) {
+    // perf mode, weights double-buffered in LDS.  Register prefetch runs two stages ahead: at the top of stage s
+    // the weights of stage s+1 (loaded during stage s-1) are written to the other B buffer and the loads of stage
+    // s+2 are issued; the MFMAs of stage s follow; ONE barrier ends the stage.  Only a slice change (new halo into
+    // the single A buffer) still needs the write phase between two barriers.
+    auto advance = [&](int& sl_, int& tg_) {
+      tg_ += TG;
+      if (tg_ >= p.ntaps) { tg_ = 0; ++sl_; }
     };
-    const int g0 = p.ntaps < TG ? p.ntaps : TG;
+    auto gc = [&](int tg_) { return (p.ntaps - tg_) < TG ? (p.ntaps - tg_) : TG; };
+    int sl = 0, tg0 = 0, sl1 = 0, tg1 = 0;
+    advance(sl1, tg1);
     load_halo_regs(0);
-    issue_w(0, 0, g0, ldsB);
+    load_w_regs(0, 0, gc(0));
     store_halo_regs();
+    store_w_regs(gc(0), ldsB);
+    if (nstages > 1) load_w_regs(sl1 << 6, tg1, gc(tg1));
     __syncthreads();
-    int sl = 0, tg0 = 0, cur = 0;
+    PH_TRACE(1);
+    unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0, cyc_d = 0, cyc_e = 0;
+    const unsigned long long ql0_ = PH_CLK();
+    (void)ql0_;
     for (int st = 0; st < nstages; ++st) {
-      const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
-      int nsl = sl, ntg0 = tg0 + TG;
-      if (ntg0 >= p.ntaps) { ntg0 = 0; nsl = sl + 1; }
-      const bool has_next = st + 1 < nstages;
-      const int ngcount = (p.ntaps - ntg0) < TG ? (p.ntaps - ntg0) : TG;
-      if (has_next) {
-        issue_w(nsl << 6, ntg0, ngcount, ldsB + (cur ^ 1) * C::B_BYTES);
-        if (nsl != sl) load_halo_regs(nsl << 6);
-      }
-      compute(tg0, gcount, ldsB + cur * C::B_BYTES);
-      __syncthreads();                       // MFMA reads of A/B[cur] done; DMA into B[cur^1] landed (vmcnt drained)
-      if (has_next && nsl != sl) {
+      int sl2 = sl1, tg2 = tg1;
+      advance(sl2, tg2);
+      const bool has1 = st + 1 < nstages, has2 = st + 2 < nstages;
+      const bool new_slice = has1 && sl1 != sl;
+      unsigned char* Bcur = ldsB + (st & 1) * C::B_BYTES;
+      unsigned char* Bnext = ldsB + ((st + 1) & 1) * C::B_BYTES;
+      const unsigned long long q0_ = PH_CLK();
+      if (has1) store_w_regs(gc(tg1), Bnext);
+      const unsigned long long q1_ = PH_CLK();
+      if (has2) load_w_regs(sl2 << 6, tg2, gc(tg2));
+      if (new_slice) load_halo_regs(sl1 << 6);
+      const unsigned long long q2_ = PH_CLK();
+      compute(tg0, gc(tg0), Bcur);
+      const unsigned long long q3_ = PH_CLK();
+      __syncthreads();
+      const unsigned long long q4_ = PH_CLK();
+      if (new_slice) {
         store_halo_regs();
         __syncthreads();
       }
-      sl = nsl; tg0 = ntg0; cur ^= 1;
+      const unsigned long long q5_ = PH_CLK();
+      cyc_a += q1_ - q0_; cyc_b += q2_ - q1_; cyc_c += q3_ - q2_; cyc_d += q4_ - q3_; cyc_e += q5_ - q4_;
+      sl = sl1; tg0 = tg1; sl1 = sl2; tg1 = tg2;
     }
+    PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_d); PH_TRACE_ACC(9, cyc_e);
+    PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)nstages | (cyc_a << 8) | (cyc_b << 36));
   } else {
     // perf mode: stage s = (slice, tap group).  While the MFMAs of stage s run, the global loads of stage
     // s+1 (weights, and the next slice's halo when the slice changes) are in flight into registers; they
@@ -288,8 +300,12 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     load_halo_regs(0);
     load_w_regs(0, 0, p.ntaps < TG ? p.ntaps : TG);
     store_halo_regs();
-    store_w_regs(p.ntaps < TG ? p.ntaps : TG);
+    store_w_regs(p.ntaps < TG ? p.ntaps : TG, ldsB);
     __syncthreads();
+    PH_TRACE(1);
+    unsigned long long cyc_compute = 0, cyc_bar1 = 0, cyc_write = 0;
+    const unsigned long long kl0_ = PH_CLK();
+    (void)kl0_;
     int sl = 0, tg0 = 0;
     for (int st = 0; st < nstages; ++st) {
       const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
@@ -301,17 +317,25 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         load_w_regs(nsl << 6, ntg0, ngcount);
         if (nsl != sl) load_halo_regs(nsl << 6);
       }
+      const unsigned long long k0_ = PH_CLK();
       compute(tg0, gcount, ldsB);
+      const unsigned long long k1_ = PH_CLK();
       __syncthreads();
+      const unsigned long long k2_ = PH_CLK();
       if (has_next) {
-        store_w_regs(ngcount);
+        store_w_regs(ngcount, ldsB);
         if (nsl != sl) store_halo_regs();
       }
       __syncthreads();
+      const unsigned long long k3_ = PH_CLK();
+      cyc_compute += k1_ - k0_; cyc_bar1 += k2_ - k1_; cyc_write += k3_ - k2_;
       sl = nsl; tg0 = ntg0;
     }
+    PH_TRACE_ACC(6, cyc_compute); PH_TRACE_ACC(8, cyc_bar1); PH_TRACE_ACC(9, cyc_write);
+    PH_TRACE_ACC(10, PH_CLK() - kl0_); PH_TRACE_ACC(11, (unsigned long long)nstages);
   }
 
+  PH_TRACE(2);
   // ---------------- epilogue: mask, BN partial statistics, (residual), store
   // accumulator register q of fragment (i,j) holds MFMA row (q&3) + 8*(q>>2) + 4*khalf, i.e. (see
   // frag_row_to_pixel) tile row 2*(wm*FM+i) + ((popc(q>>2) + khalf) & 1), column q; channel n0 + nrow[j].
@@ -357,6 +381,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   if constexpr (!SPLIT) {
     // coalesced store: the C tile is re-read from LDS as 16-B chunks, BNT/8 consecutive lanes per pixel
     __syncthreads();
+    PH_TRACE(3);
     constexpr int CPR = BNT / 8;                       // chunks per pixel row
     for (int id = tid; id < BM * CPR; id += NTH) {
       const int m = id / CPR, ch = id - m * CPR;
@@ -378,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       *reinterpret_cast<bf16x8*>(out + o) = v;
     }
   }
+  PH_TRACE(4);
   if (p.stats) {
     if constexpr (SPLIT) __syncthreads();   // all MFMA reads of LDS done; smem is reused as float[WM][2][BNT]
 #pragma unroll
@@ -400,6 +426,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       p.stats[(part * 2 + which) * p.Cout + n0 + n] = v;
     }
   }
+  PH_TRACE(5);
 }
 
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
@@ -457,3 +484,12 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (prec == PH_PREC_BF16X6) return launch_T<float>(*p, S, st);
   return PH_EINVAL;
 }
+
+#ifdef PH_TAP_TRACE
+extern "C" int ph_debug_tap_trace(unsigned long long* host_out, int nwg) {
+  if (nwg > PH_TRACE_WGS) nwg = PH_TRACE_WGS;
+  if (hipDeviceSynchronize() != hipSuccess) return PH_ELAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ph_tap_trace), (size_t)nwg * 12 * sizeof(unsigned long long)) == hipSuccess
+             ? PH_OK : PH_ELAUNCH;
+}
+#endif

@@ -36,14 +36,14 @@ void ph_prof_begin(int cls, double work, hipStream_t st, void** token) {
   hipEvent_t a = take_event(), b = take_event();
   if (!a || !b) return;
   g_recs.push_back(Rec{a, b, cls, work});
-  hipEventRecord(a, st);
+  (void)hipEventRecord(a, st);
   *token = reinterpret_cast<void*>(g_recs.size());   // index + 1
 }
 
 void ph_prof_end(void* token, hipStream_t st) {
   if (!token) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  hipEventRecord(g_recs[reinterpret_cast<size_t>(token) - 1].b, st);
+  (void)hipEventRecord(g_recs[reinterpret_cast<size_t>(token) - 1].b, st);
 }
 
 extern "C" {
