@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 CLS_NAMES = ["tapconv_kernel<bf16,S=1,TH=16,BNT=64> (Cout=64 fwd+dgrad)",
-             "tapconv_kernel<bf16,S=1,TH=16,BNT=128,8 waves> (Cout>=128 fwd+dgrad)",
+             "tapconv2_kernel<2,2> 3x3 stride-1 + tapconv_kernel<bf16,S=1,BNT=128> 1x1/parity classes (Cout>=128 fwd+dgrad)",
              "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
              "stem_wgrad_kernel<bf16>"]
 

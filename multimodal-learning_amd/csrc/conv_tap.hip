@@ -474,12 +474,14 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
+  if (const int th2 = ph_tapconv2_tile_h(p, S, prec)) return p->B * cdiv(p->OHt, th2) * cdiv(p->OWt, 16);
   const int TH = (S == 1) ? ((p->Cout % 128 == 0 && prec != PH_PREC_BF16) ? 8 : 16) : (prec == PH_PREC_BF16 ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
 }
 
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->ntaps < 1 || p->ntaps > 9 || (S != 1 && S != 2)) return PH_EINVAL;
+  if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
   if (prec == PH_PREC_BF16X6) return launch_T<float>(*p, S, st);
   return PH_EINVAL;

@@ -1,0 +1,506 @@
+// Tap-convolution implicit GEMM, second generation (perf mode bf16, stride-1 3x3): ONE wave per SIMD, 128 x 64 wave
+// tiles, LDS-DMA operand streams, persistent workgroups.
+//
+// Why (measured with the phase tracer and its ablation builds, layer-4 3x3 conv, cycles per 3-tap stage and CU):
+// the first-generation kernel (conv_tap.hip: 8 waves, 64 x 64 wave tiles) needs 3072 MFMA cycles per SIMD but also
+// 2640 cycles of ds_read_b128 for the fragments (one fragment read per MFMA) plus the ds_write_b128 of the weight
+// refill - the LDS, not the matrix pipe, paces it (6240 cycles per stage).  A 128 x 64 wave tile re-uses every B
+// fragment for 4 and every A fragment for 2 MFMAs: 0.75 fragment reads per MFMA instead of 1.  Its 128 accumulator
+// registers only fit with the whole 512-entry register file, so the workgroup is 4 waves (one per SIMD) and all
+// latency hiding happens inside the wave:
+//   * fragment reads run one k-step ahead in a second register set (also across the tap barrier);
+//   * weights (one tap = 16 KiB per step, ring of 4) and the next slice's halo (second A buffer) arrive by LDS-DMA
+//     (global_load_lds_dwordx4), issued three taps / up to eight taps ahead - no VGPR staging, no ds_write.  The DMA
+//     is emitted as inline asm on purpose: the compiler serialises every ds_read behind an outstanding LDS-DMA it
+//     knows of (s_waitcnt vmcnt(0), "may alias"), and register-staged prefetch across a loop back-edge gets the
+//     same conservative vmcnt(0).  Completion is tracked by hand: vmcnt retires in order, so "all but the youngest
+//     4 (+2 halo) DMAs" at the end of a tap means the tap after next is complete; the s_barrier publishes it;
+//   * the workgroup is persistent: the operand streams never drain at a tile edge, the epilogue of tile k runs
+//     while tile k+1's first operands are already in LDS.
+// The LDS side of a DMA is linear (M0 + lane*16), so the XOR swizzle of the LDS image is applied to each lane's
+// SOURCE (row, chunk); out-of-image halo pixels read a zero page.
+//
+// Same GEMM view, LDS image and epilogue semantics as conv_tap.hip (PhTapConv; forward and stride-1 dgrad with the
+// fused residual mask; per-tile BatchNorm partial sums).  Workgroup tile: (8*WM) x 16 pixels x (64*WN) channels.
+#include "ph_common.h"
+#include <type_traits>
+#include "ph_kernels.h"
+#include "tap_common.h"
+
+namespace {
+#ifdef PH_TAP_TRACE
+__device__ unsigned long long ph_tap_trace[PH_TRACE_WGS * 12];
+#endif
+
+__device__ const u32x4 ph_zero16[4] = {};   // source of out-of-image halo pixels
+
+typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+
+// one LDS-DMA wave-instruction: lane l copies 16 B from its global address g to LDS byte lds_addr + 16*l
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
+#ifdef PH_ABL_NODMA   // timing ablation only (results are garbage)
+  asm volatile("" : : "s"(lds_addr), "v"(g) : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+#endif
+}
+#define PH_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define PH_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int WM, int WN>
+struct Tap2Cfg {
+  static constexpr int FM = 4, FN = 2, NTAPS = 9, RING = 4;
+  static constexpr int TH = WM * 8, TW = 16;
+  static constexpr int BNT = WN * 64;
+  static constexpr int HPH = TH + 2, HPW = TW + 2, HP = HPH * HPW;
+  static constexpr int A_BYTES = (((HP + 1) / 2 * 256) + 1023) / 1024 * 1024;   // whole 1-KiB DMA pieces
+  static constexpr int NHD = A_BYTES / 1024;       // halo DMA wave-instructions per slice
+  static constexpr int NHE = (NHD + 3) / 4;        // ... per wave
+  static constexpr int TAPB = BNT * 128;           // bytes of one tap's weight block
+  static constexpr int NBE = TAPB / 1024 / 4;      // weight DMA wave-instructions per wave and tap
+  static constexpr int HALO_TAPS = 6;              // taps 0..5 of a slice issue the next slice's halo ...
+  static constexpr int HPT = (NHE + HALO_TAPS - 1) / HALO_TAPS;   // ... HPT pieces per wave each
+  static constexpr int LDS_BYTES = 2 * A_BYTES + RING * TAPB;
+  static constexpr int NTH = WM * WN * 64;
+  static constexpr int C_BYTES = WM * 4 * TW * BNT * 2;      // half of the C tile (bf16) staged for the coalesced store
+  static constexpr int RED_BYTES = WM * 2 * BNT * 4;
+  static_assert(NTH == 256, "4 waves: one per SIMD");
+  static_assert(TAPB % 4096 == 0, "weight tap block splits into 1-KiB pieces over 4 waves");
+  static_assert(HPT == 2, "the vmcnt bookkeeping below assumes 2 halo pieces per wave and tap");
+  static_assert(C_BYTES + RED_BYTES <= A_BYTES, "the epilogue stages through one A buffer");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
+  using C = Tap2Cfg<WM, WN>;
+  constexpr int FM = C::FM, FN = C::FN, TH = C::TH, TW = C::TW, BNT = C::BNT;
+  constexpr int HPW = C::HPW, HP = C::HP, NTH = C::NTH, NTAPS = C::NTAPS;
+  typedef __bf16 T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(lds_uchar*)smem;   // LDS byte address of the allocation
+  // LDS: A[0] | A[1] | B ring (RING taps)
+  constexpr int B_BASE = 2 * C::A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int khalf = lane >> 5;
+  const int tiles_w = (p.OWt + TW - 1) / TW;
+  const int tiles_sp = tiles_w * ((p.OHt + TH - 1) / TH);
+  const int nblk = p.Cout / BNT;
+  const int total = tiles_sp * nblk * p.B;
+  const long pix_st = p.in_pix_stride ? p.in_pix_stride : p.Cin;
+  const long row_st = p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin;
+  const long img_st = p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin;
+  const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
+  PH_TRACE(0);
+
+  // ---- tile list of this (persistent) workgroup.  Linear tile id -> (spatial tile fastest, Cout block, image).
+  // The workgroups of one XCD (blockIdx.x % 8: hardware round-robin) walk one contiguous eighth of the list, so
+  // neighbouring halos and the weight block of a Cout block are shared inside one L2.
+  struct TileCtx { int tile, r0, c0, n0, b, iy_base, ix_base; const T* in; };
+  auto decode = [&](int t) -> TileCtx {
+    TileCtx c;
+    c.tile = t % tiles_sp;
+    const int rest = t / tiles_sp;
+    c.n0 = (rest % nblk) * BNT;
+    c.b = rest / nblk;
+    c.r0 = (c.tile / tiles_w) * TH;
+    c.c0 = (c.tile % tiles_w) * TW;
+    c.iy_base = c.r0 + p.iy0;
+    c.ix_base = c.c0 + p.ix0;
+    c.in = reinterpret_cast<const T*>(p.in) + (size_t)c.b * img_st;
+    return c;
+  };
+  const int G = gridDim.x;
+  const bool xcd_map = (G & 7) == 0 && G < total;
+  const int per_xcd = (total + 7) >> 3;
+  auto tile_id = [&](int k) -> int {   // k-th tile of this workgroup, -1 when the list is exhausted
+    if (!xcd_map) {
+      const int t = (int)blockIdx.x + k * G;
+      return t < total ? t : -1;
+    }
+    const int local = ((int)blockIdx.x >> 3) + k * (G >> 3);
+    const int t = ((int)blockIdx.x & 7) * per_xcd + local;
+    return (local < per_xcd && t < total) ? t : -1;
+  };
+
+  const int nslices = p.Cin >> 6;
+  // tap table in a VGPR (lane t holds tap t), read with v_readlane: no memory access on the tap path
+  int tap_tab = 0;
+  if (lane < NTAPS) tap_tab = p.wtap[lane] << 16;
+  auto tap_slab = [&](int t) { return __builtin_amdgcn_readlane(tap_tab, t) >> 16; };
+
+  // ---- per-lane DMA sources.  Piece d of an LDS image covers row pairs 4d..4d+3; lane l writes slot l & 15 of row
+  // pair rp = 4d + (l >> 4), which the swizzle assigns to (row 2*rp + (u >> 3), chunk u & 7), u = (l & 15) ^ (rp & 15)
+  int wb_off[C::NBE];   // weights: byte offset of this lane's chunk inside a [BNT][Cin] tap block
+#pragma unroll
+  for (int e = 0; e < C::NBE; ++e) {
+    const int rp = (wave * C::NBE + e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & 15);
+    wb_off[e] = ((2 * rp + (u >> 3)) * p.Cin + (u & 7) * 8) * 2;
+  }
+  // halo piece h = wave + 4e: byte offset of this lane's chunk relative to the tile's halo origin pixel, and the halo
+  // (row, column) packed for the per-tile in-image test (-1: padding of the last piece)
+  int h_off[C::NHE], h_rc[C::NHE];
+#pragma unroll
+  for (int e = 0; e < C::NHE; ++e) {
+    const int rp = (wave + 4 * e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & 15);
+    const int pix = 2 * rp + (u >> 3), hr = pix / HPW, hc = pix - hr * HPW;
+    h_rc[e] = pix < HP ? ((hr << 8) | hc) : -1;
+    h_off[e] = (int)(((long)hr * row_st + (long)hc * pix_st + (u & 7) * 8) * 2);
+  }
+  // bit e of the result: piece e of this lane lies inside the image for a tile whose halo origin is (iy_base, ix_base)
+  auto halo_mask = [&](int iy_base, int ix_base) {
+    int m = 0;
+#pragma unroll
+    for (int e = 0; e < C::NHE; ++e) {
+      const int iy = iy_base + (h_rc[e] >> 8), ix = ix_base + (h_rc[e] & 255);
+      const bool ok = h_rc[e] >= 0 && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      m |= ok ? (1 << e) : 0;
+    }
+    return m;
+  };
+  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(ph_zero16);
+
+  // ---- per-lane fragment addressing
+  int prow[FM];   // halo pixel index of this lane's row in M fragment i (fragment f covers tile rows 2f, 2f+1)
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int fr, c;
+    frag_row_to_pixel(lane & 31, fr, c);
+    prow[i] = ((wm * FM + i) * 2 + fr) * HPW + c;
+  }
+  int nrow[FN], bx[FN];   // channel row of this lane in N fragment j and its offset in a tap block at k-step 0
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    nrow[j] = (wn * FN + j) * 32 + (lane & 31);
+    bx[j] = lds_off(nrow[j], khalf);
+  }
+
+  f32x16 acc[FM][FN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[i][j][k] = 0.f;
+  };
+
+  // ---- epilogue of one tile: mask, BN partial statistics, (residual), store.  Accumulator register q of fragment
+  // (i,j) holds MFMA row (q&3) + 8*(q>>2) + 4*khalf, i.e. (frag_row_to_pixel) tile row 2*(wm*FM+i) + ((popc(q>>2) +
+  // khalf) & 1), column q; channel n0 + nrow[j].  The C tile goes through LDS (the A buffer the tile just finished
+  // with, two halves of FM/2 fragments) so that the global stores are 16-B chunks, BNT/8 consecutive lanes per pixel.
+  // Staging writes are 4-byte: lanes l, l^1 hold neighbouring channels of the same pixels, so they swap one value of
+  // each column pair (2m, 2m+1) by DPP and each writes one [even channel, odd channel] word - half the LDS
+  // instructions of 2-byte writes and no two lanes in one dword (measured: 50 cycles per value with ds_write_b16).
+  unsigned long long ep_w = 0, ep_b = 0, ep_s = 0;   // trace build: epilogue phase cycles
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  auto epilogue = [&](const TileCtx& tc, unsigned char* stage, auto fullc) {
+    constexpr bool FULL = decltype(fullc)::value;   // the tile lies completely inside the output: no masking
+    const int r0 = tc.r0, c0 = tc.c0, n0 = tc.n0;
+    T* out = reinterpret_cast<T*>(p.out) + (size_t)tc.b * p.OH * p.OW * p.Cout;
+    const T* resg = p.res_g ? reinterpret_cast<const T*>(p.res_g) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
+    const T* resa = p.res_a ? reinterpret_cast<const T*>(p.res_a) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
+    constexpr int CROW = BNT * 2;      // bytes of one pixel row of the staged C image
+    constexpr int CPR = BNT / 8;       // 16-B chunks per pixel
+    constexpr int NIT = WM * 4 * TW * CPR / NTH;   // store-loop trips per thread and half
+    unsigned char* ldsC = stage;
+    float* red = reinterpret_cast<float*>(stage + C::C_BYTES);   // [WM][2][BNT]
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    // byte selector of v_perm_b32 {neighbour's packed pair, own packed pair}: even lanes build [own lo | neighbour lo],
+    // odd lanes [neighbour hi | own hi]
+    const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+    f32x2 s1[FN], s2[FN];   // per column parity; added at the end
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned long long e0_ = PH_CLK();
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * h + ii;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
+          const int r = r0 + (wm * FM + i) * 2 + fr;
+          const int lr = wm * 4 + ii * 2 + fr;            // row of the staged half image
+          unsigned char* dst = ldsC + (lr * TW + 2 * m + (lane & 1)) * CROW;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            f32x2 v = {acc[i][j][2 * m], acc[i][j][2 * m + 1]};
+            if constexpr (!FULL) {
+              v[0] = (r < p.OHt && c0 + 2 * m < p.OWt) ? v[0] : 0.f;
+              v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
+            }
+            s1[j] += v;
+            s2[j] += v * v;
+            bf16x2 own;
+            own[0] = (bf16)v[0];
+            own[1] = (bf16)v[1];
+            const unsigned x = __builtin_bit_cast(unsigned, own);
+            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            *reinterpret_cast<unsigned*>(dst + (nrow[j] & ~1) * 2) = __builtin_amdgcn_perm(y, x, psel);
+          }
+        }
+      }
+      const unsigned long long e1_ = PH_CLK();
+      __syncthreads();
+      const unsigned long long e2_ = PH_CLK();
+      bf16x8 cv[NIT];
+      size_t co[NIT];
+      bool cok[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int id = tid + it * NTH;
+        const int m = id / CPR, ch = id - m * CPR;
+        const int lr = m >> 4, col = m & 15;
+        const int r = r0 + ((lr >> 2) * FM + 2 * h + ((lr >> 1) & 1)) * 2 + (lr & 1), c = c0 + col;
+        cok[it] = FULL || (r < p.OHt && c < p.OWt);
+        co[it] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + ch * 8;
+        cv[it] = *reinterpret_cast<const bf16x8*>(ldsC + m * CROW + ch * 16);
+      }
+      if (resg) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          if (!cok[it]) continue;
+          const bf16x8 g = *reinterpret_cast<const bf16x8*>(resg + co[it]);
+          if (resa) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(resa + co[it]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cv[it][k] = (bf16)((float)cv[it][k] + ((float)a[k] > 0.f ? (float)g[k] : 0.f));
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cv[it][k] = (bf16)((float)cv[it][k] + (float)g[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (cok[it]) *reinterpret_cast<bf16x8*>(out + co[it]) = cv[it];
+      const unsigned long long e3_ = PH_CLK();
+      __syncthreads();
+      const unsigned long long e4_ = PH_CLK();
+      ep_w += e1_ - e0_; ep_b += (e2_ - e1_) + (e4_ - e3_); ep_s += e3_ - e2_;
+    }
+    if (p.stats) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const float t1 = s1[j][0] + s1[j][1], t2 = s2[j][0] + s2[j][1];
+        const float a1 = t1 + __shfl_xor(t1, 32, 64);
+        const float a2 = t2 + __shfl_xor(t2, 32, 64);
+        if (khalf == 0) {   // waves with the same wm cover disjoint channel ranges: one writer per (wm, channel)
+          red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
+          red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * BNT) {
+        const int which = tid / BNT, n = tid % BNT;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BNT + n];
+        const size_t part = (size_t)tc.b * tiles_sp + tc.tile;
+        p.stats[(part * 2 + which) * p.Cout + n0 + n] = v;
+      }
+      __syncthreads();
+    }
+  };
+
+  // ---- the tap stream.  Tile (outer loop) -> 64-channel slice -> 9 taps (fully unrolled: tap offsets, the piece of
+  // the next halo a tap issues and the ring arithmetic are then compile-time).  Every tap issues exactly NBE weight
+  // pieces (tap +3 of the stream) and, in taps 0..5, HPT pieces of the next slice's halo into the other A buffer; past
+  // the end of the stream the same pieces are issued from the current tile again (harmless refills of buffers nobody
+  // reads) so that the vmcnt bookkeeping has no special cases.
+  TileCtx tcur = decode(tile_id(0));
+  int tn = tile_id(1);
+  bool nvalid = tn >= 0;
+  TileCtx tnext = tcur;
+  if (nvalid) tnext = decode(tn);
+  int hm_cur = halo_mask(tcur.iy_base, tcur.ix_base);
+  int hm_next = nvalid ? halo_mask(tnext.iy_base, tnext.ix_base) : hm_cur;
+  auto halo_base = [&](const TileCtx& tc, int k0) {   // address of channel k0 of the halo origin pixel (may lie outside)
+    return reinterpret_cast<const unsigned char*>(tc.in) + ((long)tc.iy_base * row_st + (long)tc.ix_base * pix_st + k0) * 2;
+  };
+  auto w_base = [&](int n0, int k0, int tap) {
+    return reinterpret_cast<const unsigned char*>(wbase + ((size_t)tap_slab(tap) * p.Cout + n0) * p.Cin + k0);
+  };
+
+  // prologue: first halo and the first RING-1 taps of weights
+  {
+    const unsigned char* hb = halo_base(tcur, 0);
+#pragma unroll
+    for (int e = 0; e < C::NHE; ++e)
+      if (wave + 4 * e < C::NHD)
+        lds_dma16(((hm_cur >> e) & 1) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
+#pragma unroll
+    for (int j = 0; j < C::RING - 1; ++j) {
+      const unsigned char* wb = w_base(tcur.n0, 0, j);
+#pragma unroll
+      for (int e = 0; e < C::NBE; ++e)
+        lds_dma16(wb + wb_off[e], lds0 + B_BASE + j * C::TAPB + (wave * C::NBE + e) * 1024);
+    }
+  }
+  zero_acc();
+  PH_WAIT_VMCNT(0);
+  PH_BARRIER();
+  PH_TRACE(1);
+
+  // fragment registers: two sets (k-steps alternate), and the LDS addresses of the tap in flight.  k-step ks of a
+  // fragment row sits at (its address at ks = 0) ^ (ks << 5): one v_xor per read.
+  bf16x8 fa[2][FM], fb[2][FN];
+  int aaddr[FM], bxs[FN];
+  auto tap_addr = [&](int toff, int abuf, int slot) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) aaddr[i] = abuf * C::A_BYTES + lds_off(prow[i] + toff, khalf);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bxs[j] = B_BASE + slot * C::TAPB + bx[j];
+  };
+  // ---- one k-step = 8 MFMAs (4 x 2 fragments), each of the first six followed by one fragment read of the NEXT
+  // k-step into the other register set, in the order the next k-step consumes them; F0..F7 are filler statements (one
+  // DMA piece, or a few VALU of address arithmetic) that ride in the shadow of the MFMA issued just before them.  The
+  // MFMAs are inline asm with the accumulators pinned to AGPRs ("+a"): left to itself the register allocator keeps
+  // the loop-carried accumulators in VGPRs and copies all 128 into and out of AGPRs around every tap.
+  // sched_barrier(0) after every slot keeps the compiler from regrouping (it cannot classify the asm as an MFMA);
+  // the s_waitcnt lgkmcnt(N) in front of each MFMA is still inserted by the compiler, which sees the ds_reads.
+  // (Macros, not lambdas: clang rejects asm operands that name captured variables inside a generic lambda.)
+#ifdef PH_ABL_NOMFMA   // timing ablation only
+#define PH_MM(CB, I, J) asm volatile("" : "+a"(acc[I][J]) : "v"(fa[CB][I]), "v"(fb[CB][J]))
+#else
+#define PH_MM(CB, I, J)                                                                                  \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fa[CB][I]), "v"(fb[CB][J]))
+#endif
+#ifdef PH_ABL_NOLDS   // timing ablation only
+#define PH_LDA(AA, I, KS) (fa[0][0])
+#else
+#define PH_LDA(AA, I, KS) (*reinterpret_cast<const bf16x8*>(smem + ((AA)[I] ^ ((KS) << 5))))
+#endif
+#define PH_SB() __builtin_amdgcn_sched_barrier(0)
+#define PH_KSTEP(CB, NB, KS, F0, F1, F2, F3, F4, F5, F6, F7)             \
+  PH_MM(CB, 0, 0); fa[NB][0] = PH_LDA(aaddr, 0, KS); F0; PH_SB();         \
+  PH_MM(CB, 0, 1); fb[NB][0] = PH_LDA(bxs, 0, KS); F1; PH_SB();           \
+  PH_MM(CB, 1, 0); fb[NB][1] = PH_LDA(bxs, 1, KS); F2; PH_SB();           \
+  PH_MM(CB, 1, 1); fa[NB][1] = PH_LDA(aaddr, 1, KS); F3; PH_SB();         \
+  PH_MM(CB, 2, 0); fa[NB][2] = PH_LDA(aaddr, 2, KS); F4; PH_SB();         \
+  PH_MM(CB, 2, 1); fa[NB][3] = PH_LDA(aaddr, 3, KS); F5; PH_SB();         \
+  PH_MM(CB, 3, 0); F6; PH_SB();                                           \
+  PH_MM(CB, 3, 1); F7; PH_SB()
+#define PH_NOP_ ((void)0)
+  tap_addr(0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < FM; ++i) fa[0][i] = PH_LDA(aaddr, i, 0);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) fb[0][j] = PH_LDA(bxs, j, 0);
+
+  unsigned long long cyc_c = 0, cyc_b = 0, cyc_e = 0;
+  const unsigned long long ql0_ = PH_CLK();
+  (void)ql0_;
+  int acur = 0, gt = 0;
+  for (int k = 0;; ++k) {   // tiles of this workgroup
+    for (int sl = 0; sl < nslices; ++sl) {
+      const bool last_sl = sl + 1 == nslices;
+      // source of the next slice's halo (next slice of this tile / slice 0 of the next tile / past the end: this tile)
+      const bool h_next_tile = last_sl && nvalid;
+      const unsigned char* hb = h_next_tile ? halo_base(tnext, 0) : halo_base(tcur, last_sl ? 0 : (sl + 1) << 6);
+      const int hm = h_next_tile ? hm_next : hm_cur;
+      // weights of the taps that wrap into the next slice / tile
+      const int wn0 = (last_sl && nvalid) ? tnext.n0 : tcur.n0;
+      const int wk0 = last_sl ? 0 : (sl + 1) << 6;
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        const unsigned long long q0_ = PH_CLK();
+        // weight pieces of stream tap gt+3 -> ring slot (gt+3) & 3 (released by the barrier that ended tap gt-1)
+        const unsigned char* wb = (t + 3 < NTAPS) ? w_base(tcur.n0, sl << 6, t + 3) : w_base(wn0, wk0, t + 3 - NTAPS);
+        const unsigned wdst = lds0 + B_BASE + ((gt + 3) & 3) * C::TAPB + wave * C::NBE * 1024;
+        const unsigned hdst = lds0 + (acur ^ 1) * C::A_BYTES + wave * 1024;
+#define PH_DMA_B(E) lds_dma16(wb + wb_off[E], wdst + (E) * 1024)
+#define PH_DMA_H(E)                                                                                         \
+  do {                                                                                                      \
+    if ((E) < C::NHE && wave + 4 * (E) < C::NHD)                                                            \
+      lds_dma16(((hm >> (E)) & 1) ? hb + h_off[(E) < C::NHE ? (E) : 0] : zero_src, hdst + (E) * 4096);      \
+  } while (0)
+        // ---- 32 MFMAs; the tap's DMA pieces and the next tap's addresses ride between them
+        PH_KSTEP(0, 1, 1, PH_NOP_, PH_DMA_B(0), PH_NOP_, PH_NOP_, PH_DMA_B(1), PH_NOP_, PH_NOP_, PH_DMA_B(2));
+        PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, PH_DMA_B(3), PH_NOP_, PH_NOP_,
+                 if (t < C::HALO_TAPS) PH_DMA_H(2 * t), PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t + 1));
+        PH_KSTEP(0, 1, 3, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+        tap_addr(((t + 1) % NTAPS) / 3 * HPW + ((t + 1) % NTAPS) % 3, t + 1 == NTAPS ? (acur ^ 1) : acur, (gt + 1) & 3);
+        PH_KSTEP(1, 0, 0, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+        const unsigned long long q1_ = PH_CLK();
+        // ---- tap end: the weight pieces of stream tap gt+2 (and a halo that is due) have landed once at most the
+        // pieces issued during this tap are still in flight; the barrier publishes them and releases ring slot gt & 3
+        if (t < C::HALO_TAPS) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(4);
+        PH_BARRIER();
+        const unsigned long long q2_ = PH_CLK();
+        cyc_c += q1_ - q0_; cyc_b += q2_ - q1_;
+        ++gt;
+      }
+      acur ^= 1;
+    }
+    const unsigned long long q3_ = PH_CLK();
+    // (stages through the A buffer the tile finished with; ends on a barrier)
+    if ((tcur.r0 + TH <= p.OHt) && (tcur.c0 + TW <= p.OWt)) epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::true_type{});
+    else epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::false_type{});
+    zero_acc();
+    cyc_e += PH_CLK() - q3_;
+    if (!nvalid) break;
+    tcur = tnext;
+    hm_cur = hm_next;
+    tn = tile_id(k + 2);
+    nvalid = tn >= 0;
+    if (nvalid) {
+      tnext = decode(tn);
+      hm_next = halo_mask(tnext.iy_base, tnext.ix_base);
+    }
+  }
+  PH_WAIT_VMCNT(0);   // the refills issued past the end of the stream must not outlive the workgroup's LDS
+  PH_TRACE(5);
+  PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_b); PH_TRACE_ACC(3, cyc_e); PH_TRACE_ACC(9, ep_w); PH_TRACE_ACC(4, ep_b); PH_TRACE_ACC(7, ep_s); (void)ep_w; (void)ep_b; (void)ep_s;
+  PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)gt);
+}
+
+template <int WM, int WN>
+int launch2(const PhTapConv& p, hipStream_t st) {
+  using C = Tap2Cfg<WM, WN>;
+  auto kern = tapconv2_kernel<WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess)
+      return PH_ELAUNCH;
+    attr_done = true;
+  }
+  const int total = cdiv(p.OHt, C::TH) * cdiv(p.OWt, C::TW) * (p.Cout / C::BNT) * p.B;
+  const int resident = ph_num_cus();   // one workgroup per CU (LDS)
+  dim3 grid(total < resident ? total : resident);
+  void* tok = nullptr;
+  if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
+    ph_prof_begin(C::BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128,
+                  2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
+  ph_prof_end(tok, st);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+}  // namespace
+
+// 0: not eligible (the first-generation kernel runs); otherwise the tile height of the configuration chosen
+int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec) {
+  if (S != 1 || prec != PH_PREC_BF16 || p->ntaps != 9 || p->Cout % 128) return 0;
+  for (int k = 0; k < 9; ++k)   // the kernel hard-codes the 3x3 tap geometry (only the weight slab order is a table)
+    if (p->dy[k] != k / 3 || p->dx[k] != k % 3) return 0;
+  return 16;
+}
+
+int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) { return launch2<2, 2>(*p, st); }
+
+#ifdef PH_TAP_TRACE
+extern "C" int ph_debug_tap2_trace(unsigned long long* host_out, int nwg) {
+  if (nwg > PH_TRACE_WGS) nwg = PH_TRACE_WGS;
+  if (hipDeviceSynchronize() != hipSuccess) return PH_ELAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ph_tap_trace), (size_t)nwg * 12 * sizeof(unsigned long long)) == hipSuccess
+             ? PH_OK : PH_ELAUNCH;
+}
+#endif

@@ -13,6 +13,7 @@
 #define PH_CLS_STEM_WGRAD 5
 #define PH_NUM_CLS 6
 bool ph_prof_on();
+int ph_num_cus();   // compute units of the current device (cached)
 void ph_prof_begin(int cls, double work, hipStream_t st, void** token);
 void ph_prof_end(void* token, hipStream_t st);
 
@@ -38,6 +39,9 @@ struct PhTapConv {
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec);
+// second-generation stride-1 perf-mode kernel (conv_tap2.hip): tile height of the configuration it would run, 0 = not eligible
+int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec);
+int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st);
 
 struct PhWgrad {
   const void* x;         // [B][IH][IW][Cin]
