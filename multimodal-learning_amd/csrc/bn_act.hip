@@ -197,7 +197,8 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ g, T* __restrict__ 
 }
 
 // ---------------------------------------------------------------- BN backward
-// dz sources: (a) plain block BN: dz = g * (a > 0) ; (b) stem: g scattered through the max-pool argmax.
+// dz source of a plain block BN: dz = g * (a > 0).  (The stem - g scattered through the max-pool argmax - has its own
+// geometry-aware kernel below.)
 template <typename T>
 struct DzPlain {
   const T* g; const T* a; const T* y;
@@ -209,45 +210,6 @@ struct DzPlain {
       load8(a + i8 * 8, m);
 #pragma unroll
       for (int k = 0; k < 8; ++k) dz[k] = m[k] > 0.f ? dz[k] : 0.f;
-    }
-  }
-};
-
-template <typename T>
-struct DzStem {
-  const T* dpool; const uint8_t* idx; const T* y; const float* scale; const float* shift;
-  int H, W, C8;
-  __device__ __forceinline__ void get(size_t i8, float (&dz)[8], float (&yy)[8]) const {
-    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-    const int cg = (int)(i8 % C8);
-    size_t pix = i8 / C8;
-    const int w = (int)(pix % W); pix /= W;
-    const int h = (int)(pix % H);
-    const size_t b = pix / H;
-    load8(y + i8 * 8, yy);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dz[k] = 0.f;
-    const int ph0 = h >> 1, ph1 = (h + 1) >> 1, pw0 = w >> 1, pw1 = (w + 1) >> 1;
-    for (int ph = ph0; ph <= ph1; ++ph) {
-      if (ph >= OH) continue;
-      const int kh = h - (2 * ph - 1);
-      for (int pw = pw0; pw <= pw1; ++pw) {
-        if (pw >= OW) continue;
-        const int code = kh * 3 + (w - (2 * pw - 1));
-        const size_t o8 = ((b * OH + ph) * OW + pw) * C8 + cg;
-        const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o8 * 8);
-        float g8[8];
-        load8(dpool + o8 * 8, g8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          if ((int)((packed >> (8 * k)) & 0xff) == code) dz[k] += g8[k];
-      }
-    }
-    const int c = cg * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float a = yy[k] * scale[c + k] + shift[c + k];
-      dz[k] = a > 0.f ? dz[k] : 0.f;
     }
   }
 };
@@ -328,6 +290,87 @@ __global__ void bn_bwd_apply_kernel(Src src, const float* __restrict__ mean, con
   store8(dy + i * 8, dz);
 }
 
+// ---- stem (C = 64): max-pool backward + ReLU mask + BN backward with the image geometry on the grid - a block walks
+// STEM_ROWS image rows, thread = (8-channel group, pixel lane), so no per-element 64-bit div/mod and the per-channel
+// constants live in registers (the generic kernels above spent most of their time there: 23-32 % of the HBM roofline)
+constexpr int STEM_ROWS = 16;
+
+template <typename T>
+__device__ __forceinline__ void stem_dz(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, int OH, int OW,
+                                        size_t b, int h, int w, int cg, float (&dz)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dz[k] = 0.f;
+  const int ph0 = h >> 1, ph1 = (h + 1) >> 1, pw0 = w >> 1, pw1 = (w + 1) >> 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ph = a ? ph1 : ph0;
+    if ((a && ph1 == ph0) || ph >= OH) continue;
+    const int kh = h - (2 * ph - 1);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int pw = c ? pw1 : pw0;
+      if ((c && pw1 == pw0) || pw >= OW) continue;
+      const unsigned code = (unsigned)(kh * 3 + (w - (2 * pw - 1)));
+      const size_t o8 = ((b * OH + ph) * OW + pw) * 8 + cg;
+      const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o8 * 8);
+      float g8[8];
+      load8(dpool + o8 * 8, g8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (((unsigned)(packed >> (8 * k)) & 0xffu) == code) dz[k] += g8[k];
+    }
+  }
+}
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                       const T* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ c1, const float* __restrict__ c2,
+                                                       float* __restrict__ parts, T* __restrict__ dy, int B, int H, int W) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const int cg = threadIdx.x & 7, wl = threadIdx.x >> 3, c = cg * 8;
+  float sc[8], sf[8], mu[8], is[8], ga[8], k1[8], k2[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean[c + k]; is[k] = invstd[c + k];
+    s1[k] = 0.f; s2[k] = 0.f;
+    if (APPLY) { ga[k] = gamma[c + k] * is[k]; k1[k] = c1[c + k]; k2[k] = c2[c + k]; }
+  }
+  const int row0 = blockIdx.x * STEM_ROWS, row1 = min(B * H, row0 + STEM_ROWS);
+  for (int row = row0; row < row1; ++row) {
+    const size_t b = row / H;
+    const int h = row - (int)b * H;
+    for (int w = wl; w < W; w += 32) {
+      const size_t i8 = ((size_t)row * W + w) * 8 + cg;
+      float dz[8], yy[8];
+      load8(y + i8 * 8, yy);
+      stem_dz(dpool, idx, OH, OW, b, h, w, cg, dz);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        dz[k] = (yy[k] * sc[k] + sf[k]) > 0.f ? dz[k] : 0.f;
+        const float xh = (yy[k] - mu[k]) * is[k];
+        if (APPLY) dz[k] = ga[k] * (dz[k] - k1[k] - xh * k2[k]);
+        else { s1[k] += dz[k]; s2[k] += dz[k] * xh; }
+      }
+      if (APPLY) store8(dy + i8 * 8, dz);
+    }
+  }
+  if (!APPLY) {
+    __shared__ float sh[2][256][9];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+      float t = 0.f;
+      for (int q = 0; q < 32; ++q) t += sh[which][q * 8 + (ch >> 3)][ch & 7];
+      parts[((size_t)blockIdx.x * 2 + which) * 64 + ch] = t;
+    }
+  }
+}
+
 inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -401,14 +444,16 @@ int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int ac
   return PH_OK;
 }
 
-int ph_bn_bwd_parts(size_t npix) {
-  size_t b = (npix + 255) / 256;
+// number of partial rows (= reduce blocks): about 8 eight-channel vectors per thread, so that the small late layers
+// (16 k pixels x 512 channels) still fill the chip - with one block per 256 pixels layer 4 ran on 64 workgroups
+int ph_bn_bwd_parts(size_t npix, int C) {
+  const size_t b = (npix * (size_t)(C / 8) + 2047) / 2048;
   return (int)(b < (size_t)BWD_BLOCKS_MAX ? (b ? b : 1) : BWD_BLOCKS_MAX);
 }
 
 int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                             float* parts, size_t npix, int C, int prec, hipStream_t st) {
-  const int nb = ph_bn_bwd_parts(npix);
+  const int nb = ph_bn_bwd_parts(npix, C);
   if (prec == PH_PREC_BF16) {
     DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y};
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, DzPlain<bf16>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
@@ -442,18 +487,19 @@ int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const fl
   return PH_OK;
 }
 
+int ph_stem_bwd_parts(int B, int H) { return (B * H + STEM_ROWS - 1) / STEM_ROWS; }
+
 int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
                               int W, int C, int prec, hipStream_t st) {
-  const size_t npix = (size_t)B * H * W;
-  const int nb = ph_bn_bwd_parts(npix);
-  if (prec == PH_PREC_BF16) {
-    DzStem<bf16> s{(const bf16*)dpool, idx, (const bf16*)y0, scale, shift, H, W, C / 8};
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, DzStem<bf16>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
-  } else {
-    DzStem<float> s{(const float*)dpool, idx, (const float*)y0, scale, shift, H, W, C / 8};
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, DzStem<float>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
-  }
+  if (C != 64) return PH_EINVAL;
+  const int nb = ph_stem_bwd_parts(B, H);
+  if (prec == PH_PREC_BF16)
+    hipLaunchKernelGGL((stem_bwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx, (const bf16*)y0,
+                       scale, shift, mean, invstd, nullptr, nullptr, nullptr, parts, (bf16*)nullptr, B, H, W);
+  else
+    hipLaunchKernelGGL((stem_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, (const float*)dpool, idx, (const float*)y0,
+                       scale, shift, mean, invstd, nullptr, nullptr, nullptr, parts, (float*)nullptr, B, H, W);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -462,14 +508,14 @@ int ph_stem_bwd_apply_launch(const void* dpool, const uint8_t* idx, const void* 
                              const float* invstd, const float* scale, const float* shift, const float* gamma,
                              const float* c1, const float* c2, void* dy0, int B, int H, int W, int C, int prec,
                              hipStream_t st) {
-  const size_t n8 = (size_t)B * H * W * (C / 8);
-  if (prec == PH_PREC_BF16) {
-    DzStem<bf16> s{(const bf16*)dpool, idx, (const bf16*)y0, scale, shift, H, W, C / 8};
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, DzStem<bf16>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (bf16*)dy0, n8, C / 8);
-  } else {
-    DzStem<float> s{(const float*)dpool, idx, (const float*)y0, scale, shift, H, W, C / 8};
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, DzStem<float>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (float*)dy0, n8, C / 8);
-  }
+  if (C != 64) return PH_EINVAL;
+  const int nb = ph_stem_bwd_parts(B, H);
+  if (prec == PH_PREC_BF16)
+    hipLaunchKernelGGL((stem_bwd_kernel<bf16, true>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx, (const bf16*)y0,
+                       scale, shift, mean, invstd, gamma, c1, c2, nullptr, (bf16*)dy0, B, H, W);
+  else
+    hipLaunchKernelGGL((stem_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, st, (const float*)dpool, idx, (const float*)y0,
+                       scale, shift, mean, invstd, gamma, c1, c2, nullptr, (float*)dy0, B, H, W);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

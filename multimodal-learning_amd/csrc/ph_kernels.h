@@ -117,7 +117,8 @@ int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec,
 // d_x (+)= g / HW  broadcast
 int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int accumulate, int prec, hipStream_t st);
 // BN backward: dz = g * (a > 0 ? 1 : 0) (a may be null).  reduce -> parts [nparts][2][C] (sum dz, sum dz*xhat)
-int ph_bn_bwd_parts(size_t npix);
+int ph_bn_bwd_parts(size_t npix, int C);   // <= 1024
+int ph_stem_bwd_parts(int B, int H);         // partial rows written by ph_stem_bwd_reduce_launch
 int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                             float* parts, size_t npix, int C, int prec, hipStream_t st);
 // parts -> dgamma, dbeta, c1 = mean(dz), c2 = mean(dz*xhat)

@@ -138,7 +138,11 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   P->dy_off = take((size_t)B * s.OH * s.OW * 64 * es);
   P->slab_bytes = slab_max;
   P->slab_off = take(slab_max);
-  P->bparts_off = take((size_t)ph_bn_bwd_parts((size_t)B * s.OH * s.OW) * 2 * 512 * sizeof(float));
+  {  // BN-backward partial rows: ph_bn_bwd_parts() <= 1024 rows of [2][C <= 512]; the stem writes its own count of [2][64]
+    const size_t stem_rows = (size_t)ph_stem_bwd_parts(B, s.OH);
+    const size_t a = (size_t)1024 * 2 * 512, b = stem_rows * 2 * 64;
+    P->bparts_off = take((a > b ? a : b) * sizeof(float));
+  }
   P->cc_off = take(2 * 512 * sizeof(float));
   P->zero_off = take(256);
   P->ws_bytes = off;
@@ -298,7 +302,7 @@ int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* 
   const void* y = c.ws + u.y_off;
   int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, c.st);
   if (rc) return rc;
-  rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix), u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
+  rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix, u.Cout), u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
   if (rc) return rc;
   return ph_bn_bwd_apply_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), (const float*)c.params[ui * 6 + 1], c1, c2, dy, npix,
                                 u.Cout, P->prec, c.st);
@@ -423,7 +427,7 @@ int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const v
     if ((rc = ph_stem_bwd_reduce_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
                                         c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
-    if ((rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix), 64, (double)npix, (float*)grads[1],
+    if ((rc = ph_bn_bwd_finalize_launch(parts, ph_stem_bwd_parts(P->B, u.OH), 64, (double)npix, (float*)grads[1],
                                         (float*)grads[2], c1, c2, st)))
       return rc;
     if ((rc = ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
