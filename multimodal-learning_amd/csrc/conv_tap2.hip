@@ -44,13 +44,22 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
 #endif
 }
+// 1: the epilogue stores straight from registers; 0: stages the C tile through LDS for 16-B stores (kept for A/B runs)
+#ifndef PH_EPI_DIRECT
+#define PH_EPI_DIRECT 1
+#endif
 #define PH_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PH_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int WM, int WN>
+// Configurations: <WM, WN, FM, RES>.  Wave tile (32*FM) pixels x 64 channels, workgroup tile 16 x 16 pixels x (64*WN)
+// channels.  RES = false: weights stream through a ring of 4 taps (any Cin).  RES = true (Cin = Cout = 64, ResNet
+// layer 1): all 9 taps stay resident in LDS for the lifetime of the workgroup - no weight traffic and no barrier
+// inside a tile.
+template <int WM, int WN, int FM_, bool RES_>
 struct Tap2Cfg {
-  static constexpr int FM = 4, FN = 2, NTAPS = 9, RING = 4;
-  static constexpr int TH = WM * 8, TW = 16;
+  static constexpr int FM = FM_, FN = 2, NTAPS = 9, RING = 4;
+  static constexpr bool RES = RES_;
+  static constexpr int TH = WM * FM * 2, TW = 16;
   static constexpr int BNT = WN * 64;
   static constexpr int HPH = TH + 2, HPW = TW + 2, HP = HPH * HPW;
   static constexpr int A_BYTES = (((HP + 1) / 2 * 256) + 1023) / 1024 * 1024;   // whole 1-KiB DMA pieces
@@ -60,10 +69,12 @@ struct Tap2Cfg {
   static constexpr int NBE = TAPB / 1024 / 4;      // weight DMA wave-instructions per wave and tap
   static constexpr int HALO_TAPS = 6;              // taps 0..5 of a slice issue the next slice's halo ...
   static constexpr int HPT = (NHE + HALO_TAPS - 1) / HALO_TAPS;   // ... HPT pieces per wave each
-  static constexpr int LDS_BYTES = 2 * A_BYTES + RING * TAPB;
+  static constexpr int LDS_BYTES = 2 * A_BYTES + (RES ? NTAPS : RING) * TAPB;
   static constexpr int NTH = WM * WN * 64;
-  static constexpr int C_BYTES = WM * 4 * TW * BNT * 2;      // half of the C tile (bf16) staged for the coalesced store
+  static constexpr int NHALF = FM / 2;                       // the C tile is staged in NHALF passes of 2 fragments
+  static constexpr int C_BYTES = WM * 4 * TW * BNT * 2;      // one pass of the C tile (bf16)
   static constexpr int RED_BYTES = WM * 2 * BNT * 4;
+  static_assert(TH == 16, "16 x 16 pixel tiles");
   static_assert(NTH == 256, "4 waves: one per SIMD");
   static_assert(TAPB % 4096 == 0, "weight tap block splits into 1-KiB pieces over 4 waves");
   static_assert(HPT == 2, "the vmcnt bookkeeping below assumes 2 halo pieces per wave and tap");
@@ -71,9 +82,9 @@ struct Tap2Cfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int WM, int WN>
+template <int WM, int WN, int FM_, bool RES>
 __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
-  using C = Tap2Cfg<WM, WN>;
+  using C = Tap2Cfg<WM, WN, FM_, RES>;
   constexpr int FM = C::FM, FN = C::FN, TH = C::TH, TW = C::TW, BNT = C::BNT;
   constexpr int HPW = C::HPW, HP = C::HP, NTH = C::NTH, NTAPS = C::NTAPS;
   typedef __bf16 T;
@@ -100,14 +111,25 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   // The workgroups of one XCD (blockIdx.x % 8: hardware round-robin) walk one contiguous eighth of the list, so
   // neighbouring halos and the weight block of a Cout block are shared inside one L2.
   struct TileCtx { int tile, r0, c0, n0, b, iy_base, ix_base; const T* in; };
+  // q = a / d for 0 <= a < 2^22 with a precomputed float reciprocal and one correction step (the decode below runs
+  // once per tile on the critical path; hardware integer division costs ~40 instructions per quotient)
+  const float rcp_sp = 1.0f / (float)tiles_sp, rcp_nb = 1.0f / (float)nblk, rcp_tw = 1.0f / (float)tiles_w;
+  auto fdiv = [](int a, int d, float rcp) {
+    int q = (int)((float)a * rcp);
+    int r = a - q * d;
+    if (r >= d) ++q;
+    if (r < 0) --q;
+    return q;
+  };
   auto decode = [&](int t) -> TileCtx {
     TileCtx c;
-    c.tile = t % tiles_sp;
-    const int rest = t / tiles_sp;
-    c.n0 = (rest % nblk) * BNT;
-    c.b = rest / nblk;
-    c.r0 = (c.tile / tiles_w) * TH;
-    c.c0 = (c.tile % tiles_w) * TW;
+    const int rest = fdiv(t, tiles_sp, rcp_sp);
+    c.tile = t - rest * tiles_sp;
+    c.b = fdiv(rest, nblk, rcp_nb);
+    c.n0 = (rest - c.b * nblk) * BNT;
+    const int trow = fdiv(c.tile, tiles_w, rcp_tw);
+    c.r0 = trow * TH;
+    c.c0 = (c.tile - trow * tiles_w) * TW;
     c.iy_base = c.r0 + p.iy0;
     c.ix_base = c.c0 + p.ix0;
     c.in = reinterpret_cast<const T*>(p.in) + (size_t)c.b * img_st;
@@ -150,14 +172,20 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     h_rc[e] = pix < HP ? ((hr << 8) | hc) : -1;
     h_off[e] = (int)(((long)hr * row_st + (long)hc * pix_st + (u & 7) * 8) * 2);
   }
-  // bit e of the result: piece e of this lane lies inside the image for a tile whose halo origin is (iy_base, ix_base)
+  // bit e of the result: piece e of this lane lies inside the image for a tile whose halo origin is (iy_base, ix_base).
+  // The valid halo rows / columns of a tile are two scalar bit masks; a piece costs two shifts and two ands.
   auto halo_mask = [&](int iy_base, int ix_base) {
+    auto range_bits = [](int lo, int hi) -> unsigned {   // bits lo..hi-1 set (0 <= lo, hi <= 31)
+      return hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+    };
+    const int r_lo = iy_base < 0 ? -iy_base : 0, r_hi = (p.IH - iy_base) < C::HPH ? (p.IH - iy_base) : C::HPH;
+    const int c_lo = ix_base < 0 ? -ix_base : 0, c_hi = (p.IW - ix_base) < HPW ? (p.IW - ix_base) : HPW;
+    const unsigned rowok = range_bits(r_lo, r_hi < 0 ? 0 : r_hi), colok = range_bits(c_lo, c_hi < 0 ? 0 : c_hi);
     int m = 0;
 #pragma unroll
     for (int e = 0; e < C::NHE; ++e) {
-      const int iy = iy_base + (h_rc[e] >> 8), ix = ix_base + (h_rc[e] & 255);
-      const bool ok = h_rc[e] >= 0 && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      m |= ok ? (1 << e) : 0;
+      const unsigned ok = (rowok >> ((h_rc[e] >> 8) & 31)) & (colok >> (h_rc[e] & 31)) & (h_rc[e] >= 0 ? 1u : 0u);
+      m |= (int)(ok & 1u) << e;
     }
     return m;
   };
@@ -206,7 +234,10 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     constexpr int CROW = BNT * 2;      // bytes of one pixel row of the staged C image
     constexpr int CPR = BNT / 8;       // 16-B chunks per pixel
     constexpr int NIT = WM * 4 * TW * CPR / NTH;   // store-loop trips per thread and half
+    constexpr int NITB = 4;
+    static_assert(NIT % NITB == 0, "store loop batches");
     unsigned char* ldsC = stage;
+    (void)ldsC;
     float* red = reinterpret_cast<float*>(stage + C::C_BYTES);   // [WM][2][BNT]
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     // byte selector of v_perm_b32 {neighbour's packed pair, own packed pair}: even lanes build [own lo | neighbour lo],
@@ -215,8 +246,57 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     f32x2 s1[FN], s2[FN];   // per column parity; added at the end
 #pragma unroll
     for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
+#if PH_EPI_DIRECT
+    // direct form: after the lane-pair exchange every lane owns one [even channel, odd channel] word of one pixel and
+    // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier before the statistics
+    {
+      const unsigned long long e0_ = PH_CLK();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+      for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
+          const int r = r0 + (wm * FM + i) * 2 + fr, c = c0 + 2 * m + (lane & 1);
+          const bool mine = FULL || (r < p.OHt && c < p.OWt);
+          const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            f32x2 v = {acc[i][j][2 * m], acc[i][j][2 * m + 1]};
+            if constexpr (!FULL) {
+              v[0] = (r < p.OHt && c0 + 2 * m < p.OWt) ? v[0] : 0.f;
+              v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
+            }
+            s1[j] += v;
+            s2[j] += v * v;
+            bf16x2 own;
+            own[0] = (bf16)v[0];
+            own[1] = (bf16)v[1];
+            const unsigned x = __builtin_bit_cast(unsigned, own);
+            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            bf16x2 w = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(y, x, psel));
+            const size_t oj = o + (nrow[j] & ~1);
+            if (mine) {
+              if (resg) {
+                const bf16x2 g = *reinterpret_cast<const bf16x2*>(resg + oj);
+                if (resa) {
+                  const bf16x2 a = *reinterpret_cast<const bf16x2*>(resa + oj);
+                  w[0] = (bf16)((float)w[0] + ((float)a[0] > 0.f ? (float)g[0] : 0.f));
+                  w[1] = (bf16)((float)w[1] + ((float)a[1] > 0.f ? (float)g[1] : 0.f));
+                } else {
+                  w[0] = (bf16)((float)w[0] + (float)g[0]);
+                  w[1] = (bf16)((float)w[1] + (float)g[1]);
+                }
+              }
+              *reinterpret_cast<bf16x2*>(out + oj) = w;
+            }
+          }
+        }
+      }
+      ep_w += PH_CLK() - e0_;
+    }
+#else
+#pragma unroll
+    for (int h = 0; h < C::NHALF; ++h) {
       const unsigned long long e0_ = PH_CLK();
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
@@ -248,12 +328,13 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       const unsigned long long e1_ = PH_CLK();
       __syncthreads();
       const unsigned long long e2_ = PH_CLK();
-      bf16x8 cv[NIT];
-      size_t co[NIT];
-      bool cok[NIT];
+      for (int it0 = 0; it0 < NIT; it0 += NITB) {   // NITB chunks in flight per thread (register budget)
+      bf16x8 cv[NITB];
+      size_t co[NITB];
+      bool cok[NITB];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int id = tid + it * NTH;
+      for (int it = 0; it < NITB; ++it) {
+        const int id = tid + (it0 + it) * NTH;
         const int m = id / CPR, ch = id - m * CPR;
         const int lr = m >> 4, col = m & 15;
         const int r = r0 + ((lr >> 2) * FM + 2 * h + ((lr >> 1) & 1)) * 2 + (lr & 1), c = c0 + col;
@@ -263,7 +344,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       }
       if (resg) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; it < NITB; ++it) {
           if (!cok[it]) continue;
           const bf16x8 g = *reinterpret_cast<const bf16x8*>(resg + co[it]);
           if (resa) {
@@ -277,13 +358,15 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
         }
       }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)
+      for (int it = 0; it < NITB; ++it)
         if (cok[it]) *reinterpret_cast<bf16x8*>(out + co[it]) = cv[it];
+      }
       const unsigned long long e3_ = PH_CLK();
       __syncthreads();
       const unsigned long long e4_ = PH_CLK();
       ep_w += e1_ - e0_; ep_b += (e2_ - e1_) + (e4_ - e3_); ep_s += e3_ - e2_;
     }
+#endif
     if (p.stats) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
@@ -335,7 +418,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       if (wave + 4 * e < C::NHD)
         lds_dma16(((hm_cur >> e) & 1) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
 #pragma unroll
-    for (int j = 0; j < C::RING - 1; ++j) {
+    for (int j = 0; j < (RES ? NTAPS : C::RING - 1); ++j) {
       const unsigned char* wb = w_base(tcur.n0, 0, j);
 #pragma unroll
       for (int e = 0; e < C::NBE; ++e)
@@ -386,6 +469,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   PH_MM(CB, 2, 1); fa[NB][3] = PH_LDA(aaddr, 3, KS); F5; PH_SB();         \
   PH_MM(CB, 3, 0); F6; PH_SB();                                           \
   PH_MM(CB, 3, 1); F7; PH_SB()
+#define PH_KSTEP2(CB, NB, KS, F0, F1, F2, F3)                            \
+  PH_MM(CB, 0, 0); fa[NB][0] = PH_LDA(aaddr, 0, KS); F0; PH_SB();         \
+  PH_MM(CB, 0, 1); fb[NB][0] = PH_LDA(bxs, 0, KS); F1; PH_SB();           \
+  PH_MM(CB, 1, 0); fb[NB][1] = PH_LDA(bxs, 1, KS); F2; PH_SB();           \
+  PH_MM(CB, 1, 1); fa[NB][1] = PH_LDA(aaddr, 1, KS); F3; PH_SB()
 #define PH_NOP_ ((void)0)
   tap_addr(0, 0, 0);
 #pragma unroll
@@ -393,12 +481,13 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) fb[0][j] = PH_LDA(bxs, j, 0);
 
-  unsigned long long cyc_c = 0, cyc_b = 0, cyc_e = 0;
+  unsigned long long cyc_c = 0, cyc_b = 0, cyc_e = 0, cyc_s = 0, cyc_x = 0;
   const unsigned long long ql0_ = PH_CLK();
   (void)ql0_;
   int acur = 0, gt = 0;
   for (int k = 0;; ++k) {   // tiles of this workgroup
     for (int sl = 0; sl < nslices; ++sl) {
+      const unsigned long long q0_ = PH_CLK();   // (per-slice stamps only: a stamp costs ~50 cycles with its s_waitcnt)
       const bool last_sl = sl + 1 == nslices;
       // source of the next slice's halo (next slice of this tile / slice 0 of the next tile / past the end: this tile)
       const bool h_next_tile = last_sl && nvalid;
@@ -407,9 +496,10 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       // weights of the taps that wrap into the next slice / tile
       const int wn0 = (last_sl && nvalid) ? tnext.n0 : tcur.n0;
       const int wk0 = last_sl ? 0 : (sl + 1) << 6;
+      const unsigned long long q0b_ = PH_CLK();
+      cyc_s += q0b_ - q0_;
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
-        const unsigned long long q0_ = PH_CLK();
         // weight pieces of stream tap gt+3 -> ring slot (gt+3) & 3 (released by the barrier that ended tap gt-1)
         const unsigned char* wb = (t + 3 < NTAPS) ? w_base(tcur.n0, sl << 6, t + 3) : w_base(wn0, wk0, t + 3 - NTAPS);
         const unsigned wdst = lds0 + B_BASE + ((gt + 3) & 3) * C::TAPB + wave * C::NBE * 1024;
@@ -420,31 +510,50 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     if ((E) < C::NHE && wave + 4 * (E) < C::NHD)                                                            \
       lds_dma16(((hm >> (E)) & 1) ? hb + h_off[(E) < C::NHE ? (E) : 0] : zero_src, hdst + (E) * 4096);      \
   } while (0)
-        // ---- 32 MFMAs; the tap's DMA pieces and the next tap's addresses ride between them
-        PH_KSTEP(0, 1, 1, PH_NOP_, PH_DMA_B(0), PH_NOP_, PH_NOP_, PH_DMA_B(1), PH_NOP_, PH_NOP_, PH_DMA_B(2));
-        PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, PH_DMA_B(3), PH_NOP_, PH_NOP_,
-                 if (t < C::HALO_TAPS) PH_DMA_H(2 * t), PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t + 1));
-        PH_KSTEP(0, 1, 3, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
-        tap_addr(((t + 1) % NTAPS) / 3 * HPW + ((t + 1) % NTAPS) % 3, t + 1 == NTAPS ? (acur ^ 1) : acur, (gt + 1) & 3);
-        PH_KSTEP(1, 0, 0, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
-        const unsigned long long q1_ = PH_CLK();
-        // ---- tap end: the weight pieces of stream tap gt+2 (and a halo that is due) have landed once at most the
-        // pieces issued during this tap are still in flight; the barrier publishes them and releases ring slot gt & 3
-        if (t < C::HALO_TAPS) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(4);
-        PH_BARRIER();
-        const unsigned long long q2_ = PH_CLK();
-        cyc_c += q1_ - q0_; cyc_b += q2_ - q1_;
+        const int toff_n = ((t + 1) % NTAPS) / 3 * HPW + ((t + 1) % NTAPS) % 3;
+        const int abuf_n = t + 1 == NTAPS ? (acur ^ 1) : acur;
+        if constexpr (FM == 4) {
+          // ---- 32 MFMAs; the tap's DMA pieces ride between them
+          PH_KSTEP(0, 1, 1, PH_NOP_, PH_DMA_B(0), PH_NOP_, PH_NOP_, PH_DMA_B(1), PH_NOP_, PH_NOP_, PH_DMA_B(2));
+          PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, PH_DMA_B(3), PH_NOP_, PH_NOP_,
+                   if (t < C::HALO_TAPS) PH_DMA_H(2 * t), PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t + 1));
+          PH_KSTEP(0, 1, 3, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+          tap_addr(toff_n, abuf_n, (gt + 1) & 3);
+          PH_KSTEP(1, 0, 0, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+        } else {
+          // ---- 16 MFMAs (resident weights: ring slot = tap)
+          PH_KSTEP2(0, 1, 1, PH_NOP_, PH_NOP_, PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t));
+          PH_KSTEP2(1, 0, 2, PH_NOP_, PH_NOP_, PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t + 1));
+          PH_KSTEP2(0, 1, 3, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+          if (t == NTAPS - 2) {   // the next tile's halo must be visible before the last tap reads its first fragments
+            PH_WAIT_VMCNT(0);
+            PH_BARRIER();
+          }
+          tap_addr(toff_n, abuf_n, (t + 1) % NTAPS);
+          PH_KSTEP2(1, 0, 0, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+        }
+        if constexpr (!RES) {
+          // ---- tap end: the weight pieces of stream tap gt+2 (and a halo that is due) have landed once at most the
+          // pieces issued during this tap are still in flight; the barrier publishes them and releases ring slot gt & 3
+          if (t < C::HALO_TAPS) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(4);
+          PH_BARRIER();
+        }
         ++gt;
       }
       acur ^= 1;
+      cyc_c += PH_CLK() - q0b_;
     }
+    const unsigned long long q2b_ = PH_CLK();
+    if constexpr (RES) PH_BARRIER();   // no per-tap barrier in this configuration: all waves are done with the A buffer
     const unsigned long long q3_ = PH_CLK();
+    cyc_b += q3_ - q2b_;
     // (stages through the A buffer the tile finished with; ends on a barrier)
     if ((tcur.r0 + TH <= p.OHt) && (tcur.c0 + TW <= p.OWt)) epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::true_type{});
     else epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::false_type{});
     zero_acc();
     cyc_e += PH_CLK() - q3_;
     if (!nvalid) break;
+    const unsigned long long x0_ = PH_CLK();
     tcur = tnext;
     hm_cur = hm_next;
     tn = tile_id(k + 2);
@@ -453,17 +562,18 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       tnext = decode(tn);
       hm_next = halo_mask(tnext.iy_base, tnext.ix_base);
     }
+    cyc_x += PH_CLK() - x0_;
   }
   PH_WAIT_VMCNT(0);   // the refills issued past the end of the stream must not outlive the workgroup's LDS
   PH_TRACE(5);
-  PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_b); PH_TRACE_ACC(3, cyc_e); PH_TRACE_ACC(9, ep_w); PH_TRACE_ACC(4, ep_b); PH_TRACE_ACC(7, ep_s); (void)ep_w; (void)ep_b; (void)ep_s;
+  PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_b); PH_TRACE_ACC(3, cyc_e); PH_TRACE_ACC(9, ep_w); PH_TRACE_ACC(4, cyc_s); PH_TRACE_ACC(7, cyc_x); (void)cyc_s; (void)cyc_x; (void)ep_w; (void)ep_b; (void)ep_s;
   PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)gt);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int FM, bool RES>
 int launch2(const PhTapConv& p, hipStream_t st) {
-  using C = Tap2Cfg<WM, WN>;
-  auto kern = tapconv2_kernel<WM, WN>;
+  using C = Tap2Cfg<WM, WN, FM, RES>;
+  auto kern = tapconv2_kernel<WM, WN, FM, RES>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -488,13 +598,17 @@ int launch2(const PhTapConv& p, hipStream_t st) {
 
 // 0: not eligible (the first-generation kernel runs); otherwise the tile height of the configuration chosen
 int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec) {
-  if (S != 1 || prec != PH_PREC_BF16 || p->ntaps != 9 || p->Cout % 128) return 0;
+  if (S != 1 || prec != PH_PREC_BF16 || p->ntaps != 9) return 0;
+  if (p->Cout % 128 && !(p->Cout == 64 && p->Cin == 64)) return 0;
   for (int k = 0; k < 9; ++k)   // the kernel hard-codes the 3x3 tap geometry (only the weight slab order is a table)
     if (p->dy[k] != k / 3 || p->dx[k] != k % 3) return 0;
   return 16;
 }
 
-int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) { return launch2<2, 2>(*p, st); }
+int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
+  if (p->Cout % 128 == 0) return launch2<2, 2, 4, false>(*p, st);
+  return launch2<4, 1, 2, true>(*p, st);   // Cin = Cout = 64: resident weights
+}
 
 #ifdef PH_TAP_TRACE
 extern "C" int ph_debug_tap2_trace(unsigned long long* host_out, int nwg) {
