@@ -110,18 +110,46 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         }
       }
     }
-    // ---- per-tile epilogue: mask, accumulate statistics in registers, store
+    // ---- per-tile epilogue: mask, accumulate statistics in registers, store.  bf16 outputs leave as 4-byte words:
+    // lanes l, l^1 hold neighbouring channels of the same pixels, so they swap one value of each column pair by DPP and
+    // each stores one [even channel, odd channel] word (half the store instructions of 2-byte stores, which bound the
+    // kernel: 537 MB of output left the CU in 128-B wave-instructions)
     T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * 64;
+    if constexpr (!SPLIT) {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
-      const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
-      const bool valid = r < p.OH && c < p.OW;
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int mm = wave * 32 + ((2 * q2) & 3) + 8 * ((2 * q2) >> 2) + 4 * khalf;   // pixel of column 2*q2 (even)
+        const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+        const bool v0ok = r < p.OH && c < p.OW, v1ok = r < p.OH && c + 1 < p.OW;
+        const bool mine = (lane & 1) ? v1ok : v0ok;
+        bf16* dst = reinterpret_cast<bf16*>(out) + ((size_t)r * p.OW + c + (lane & 1)) * 64 + ((lane & 31) & ~1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float v = valid ? acc[j][q] : 0.f;
-        s1[j] += v; s2[j] += v * v;
-        if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
+        for (int j = 0; j < 2; ++j) {
+          const float v0 = v0ok ? acc[j][2 * q2] : 0.f, v1 = v1ok ? acc[j][2 * q2 + 1] : 0.f;
+          s1[j] += v0 + v1;
+          s2[j] += v0 * v0 + v1 * v1;
+          bf16x2 own;
+          own[0] = (bf16)v0;
+          own[1] = (bf16)v1;
+          const unsigned x = __builtin_bit_cast(unsigned, own);
+          const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+          if (mine) *reinterpret_cast<unsigned*>(dst + j * 32) = __builtin_amdgcn_perm(y, x, psel);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
+        const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+        const bool valid = r < p.OH && c < p.OW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float v = valid ? acc[j][q] : 0.f;
+          s1[j] += v; s2[j] += v * v;
+          if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
+        }
       }
     }
   }

@@ -248,21 +248,43 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
 #if PH_EPI_DIRECT
     // direct form: after the lane-pair exchange every lane owns one [even channel, odd channel] word of one pixel and
-    // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier before the statistics
+    // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier before the statistics.
+    // The residual words of a fragment row (dgrad) are all requested before the first is used.
     {
       const unsigned long long e0_ = PH_CLK();
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
+        size_t o[8];
+        bool mine[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
           const int r = r0 + (wm * FM + i) * 2 + fr, c = c0 + 2 * m + (lane & 1);
-          const bool mine = FULL || (r < p.OHt && c < p.OWt);
-          const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0;
+          mine[m] = FULL || (r < p.OHt && c < p.OWt);
+          o[m] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + (nrow[0] & ~1);
+        }
+        bf16x2 rg[8][FN], ra[8][FN];
+        if (resg) {
+#pragma unroll
+          for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              rg[m][j] = bf16x2{(bf16)0.f, (bf16)0.f};
+              ra[m][j] = bf16x2{(bf16)1.f, (bf16)1.f};
+              if (mine[m]) {
+                rg[m][j] = *reinterpret_cast<const bf16x2*>(resg + o[m] + j * 32);
+                if (resa) ra[m][j] = *reinterpret_cast<const bf16x2*>(resa + o[m] + j * 32);
+              }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
             f32x2 v = {acc[i][j][2 * m], acc[i][j][2 * m + 1]};
             if constexpr (!FULL) {
+              const int fr = (__popc(m >> 1) + khalf) & 1;
+              const int r = r0 + (wm * FM + i) * 2 + fr;
               v[0] = (r < p.OHt && c0 + 2 * m < p.OWt) ? v[0] : 0.f;
               v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
             }
@@ -274,21 +296,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
             const unsigned x = __builtin_bit_cast(unsigned, own);
             const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
             bf16x2 w = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(y, x, psel));
-            const size_t oj = o + (nrow[j] & ~1);
-            if (mine) {
-              if (resg) {
-                const bf16x2 g = *reinterpret_cast<const bf16x2*>(resg + oj);
-                if (resa) {
-                  const bf16x2 a = *reinterpret_cast<const bf16x2*>(resa + oj);
-                  w[0] = (bf16)((float)w[0] + ((float)a[0] > 0.f ? (float)g[0] : 0.f));
-                  w[1] = (bf16)((float)w[1] + ((float)a[1] > 0.f ? (float)g[1] : 0.f));
-                } else {
-                  w[0] = (bf16)((float)w[0] + (float)g[0]);
-                  w[1] = (bf16)((float)w[1] + (float)g[1]);
-                }
-              }
-              *reinterpret_cast<bf16x2*>(out + oj) = w;
+            if (resg) {
+              w[0] = (bf16)((float)w[0] + ((float)ra[m][j][0] > 0.f ? (float)rg[m][j][0] : 0.f));
+              w[1] = (bf16)((float)w[1] + ((float)ra[m][j][1] > 0.f ? (float)rg[m][j][1] : 0.f));
             }
+            if (mine[m]) *reinterpret_cast<bf16x2*>(out + o[m] + j * 32) = w;
           }
         }
       }
