@@ -14,6 +14,11 @@
 
 namespace {
 
+// one LDS-DMA wave-instruction: lane l copies 16 B from its global address g to LDS byte lds_addr + 16*l
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+}
+
 // 32-B piece swizzle of a [pixel][64 ch] bf16 image (128-B rows): makes the 4-row tr-reads conflict-free
 __device__ __forceinline__ int sw_piece(int pix, int piece) { return piece ^ (((pix >> 1) & 1) << 1); }
 
@@ -69,7 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   unsigned char* ldsD = smem;                      // NP planes of D_BYTES
   unsigned char* ldsX = smem + C::D_BYTES * NP;    // NP planes of X_BYTES
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar) by construction
   const int cf = wave >> 1, kf = wave & 1;     // 32-wide cout / cin fragment of this wave
   const int cin_blocks = p.Cin >> 6;
   const int co0 = (blockIdx.x / cin_blocks) << 6, ci0 = (blockIdx.x % cin_blocks) << 6;
@@ -156,9 +162,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
     // perf mode: LDS-DMA (global_load_lds_dwordx4) straight from HBM/L2 into the swizzled LDS image.  The LDS
     // destination of one wave-instruction is linear (base + lane*16 = 8 pixel rows), so the XOR swizzle is
     // applied to the per-lane SOURCE chunk instead; out-of-image pixels read a zero page.  Tile t+1 is issued
-    // into the other buffer before the MFMAs of tile t; the single barrier per tile (which drains vmcnt) comes
-    // after them, so the loads have the whole MFMA block to land.
-    typedef __attribute__((address_space(3))) void lds_void;
+    // into the other buffer before the MFMAs of tile t and waited for (s_waitcnt vmcnt(0)) only after them, in
+    // front of the one barrier per tile.  The DMA is inline asm: with the builtin the compiler orders every
+    // ds_read behind an outstanding LDS-DMA ("may alias") and put that vmcnt(0) in FRONT of the MFMA block, i.e.
+    // the two buffers never overlapped anything.
+    typedef __attribute__((address_space(3))) unsigned char lds_uchar;
+    const unsigned lds0 = (unsigned)(size_t)(lds_uchar*)smem;
     constexpr int BUF = C::D_BYTES + C::X_BYTES;
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zeros);
     auto issue = [&](int tt, int buf) {
@@ -173,8 +182,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const bool ok = r < p.OH && c < p.OW;
         const void* src = ok ? (const void*)(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8)
                              : (const void*)zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (lds_void*)(dD + i0 * 16), 16, 0, 0);
+        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dD - smem) + i0 * 16));
       }
       const int iy_base = r0 * S - p.pad, ix_base = c0 * S - p.pad;
       for (int i0 = wave * 64; i0 < C::HPP * 8; i0 += 256) {
@@ -185,17 +193,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const bool ok = pix < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         const void* src = ok ? (const void*)(X + (size_t)b * ximg + (size_t)iy * xrow + (size_t)ix * xpix + ci0 + ch * 8)
                              : (const void*)zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (lds_void*)(dX + i0 * 16), 16, 0, 0);
+        lds_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dX - smem) + i0 * 16));
       }
     };
     if (t_begin < t_end) issue(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
     for (int tt = t_begin; tt < t_end; ++tt) {
       if (tt + 1 < t_end) issue(tt + 1, buf ^ 1);
       compute(smem + buf * BUF, smem + buf * BUF + C::D_BYTES);
-      __syncthreads();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile tt+1 have landed
+      __syncthreads();                                    // ... and everybody's; buffer buf is free again
       buf ^= 1;
     }
   }
