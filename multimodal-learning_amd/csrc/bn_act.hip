@@ -136,10 +136,10 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __r
       load8(y + ((((size_t)b * H + ih) * W + iw) * C8 + cg) * 8, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        float a = v[k] * sc[k] + sh[k];
-        a = a > 0.f ? a : 0.f;
-        // activation is *stored* as T before pooling in the unfused formulation: round the same way
-        if constexpr (!is_f32<T>::value) a = (float)(bf16)a;
+        // (perf mode pools the unrounded activation and rounds the maximum once on store: rounding is monotone, so
+        // the pooled value equals pooling the stored bf16 activation; only an exact-vs-rounded tie can pick another
+        // - equally large after rounding - tap.  Rounding every tap cost a third of this VALU-bound kernel.)
+        const float a = fmaxf(v[k] * sc[k] + sh[k], 0.f);
         if (a > best[k]) { best[k] = a; bi[k] = kh * 3 + kw; }
       }
     }

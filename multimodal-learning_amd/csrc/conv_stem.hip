@@ -8,9 +8,12 @@
 // There is no dgrad (the image needs no gradient on the hot path; dx is produced only on request by a
 // separate small kernel for the parity tests).
 #include "ph_common.h"
+#include <type_traits>
 #include "ph_kernels.h"
 
 namespace {
+
+__device__ const u32x4 stem_zero8[1] = {};   // source of out-of-image halo pixels (perf-mode register prefetch)
 
 constexpr int TH = 8, TW = 16, HPH = (TH - 1) * 2 + 7, HPW = (TW - 1) * 2 + 8;   // 21 x 38
 constexpr int HP = HPH * HPW;
@@ -50,8 +53,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   constexpr bool SPLIT = is_f32<T>::value;
   constexpr int NP = SPLIT ? PH_NPLANES : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ldsX = smem;               // NP planes of XB
-  unsigned char* ldsW = smem + XB * NP;     // NP planes of WB
+  // perf mode: two halo buffers (tile t+1 is written while nobody reads it: one barrier per tile); parity: NP planes
+  constexpr int XBUFS = SPLIT ? NP : 2;
+  unsigned char* ldsX = smem;               // XBUFS x XB
+  unsigned char* ldsW = smem + XB * XBUFS;  // NP planes of WB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_w = (p.OW + TW - 1) / TW, tiles_h = (p.OH + TH - 1) / TH;
   const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * p.B;
@@ -70,12 +75,54 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   const int t_begin = blockIdx.x * STEM_TPW, t_end = min(ntiles, t_begin + STEM_TPW);
+  // perf mode: the halo of tile t+1 is loaded into registers before the MFMAs of tile t (unconditional loads - an
+  // out-of-image pixel reads a zero page - and, for interior tiles, unconditional stores in the epilogue, so the
+  // compiler can count the s_waitcnt instead of draining the queue) and written to the other LDS buffer after them.
+  constexpr int HCH = (HP + 255) / 256;
+  u32x2 hreg[SPLIT ? 1 : HCH];
+  auto load_halo_regs = [&](int t) {
+    if constexpr (!SPLIT) {
+      const int b = t / tiles_img, tile = t - b * tiles_img;
+      const int iy_base = (tile / tiles_w) * TH * 2 - 3, ix_base = (tile % tiles_w) * TW * 2 - 3;
+#pragma unroll
+      for (int e = 0; e < HCH; ++e) {
+        const int i = tid + e * 256;
+        const int hr = i / HPW, hc = i - hr * HPW;
+        const int iy = iy_base + hr, ix = ix_base + hc;
+        const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const T* src = ok ? x4 + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const T*>(stem_zero8);
+        hreg[e] = *reinterpret_cast<const u32x2*>(src);
+      }
+    }
+  };
+  auto store_halo_regs = [&](unsigned char* dst) {
+    if constexpr (!SPLIT) {
+#pragma unroll
+      for (int e = 0; e < HCH; ++e) {
+        const int i = tid + e * 256;
+        if (i < HP) *reinterpret_cast<u32x2*>(dst + i * 8) = hreg[e];
+      }
+    }
+  };
+  if constexpr (!SPLIT) {
+    if (t_begin < t_end) {
+      load_halo_regs(t_begin);
+      store_halo_regs(ldsX);
+    }
+    __syncthreads();   // (also publishes the weight image)
+  }
   for (int tt = t_begin; tt < t_end; ++tt) {
     const int b = tt / tiles_img, tile = tt - b * tiles_img;
     const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
-    __syncthreads();   // previous tile's fragment reads of ldsX are done (and, first time, nothing)
-    stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
-    __syncthreads();
+    const unsigned char* ldsXc = ldsX;
+    if constexpr (SPLIT) {
+      __syncthreads();   // previous tile's fragment reads of ldsX are done (and, first time, nothing)
+      stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
+      __syncthreads();
+    } else {
+      ldsXc = ldsX + ((tt - t_begin) & 1) * XB;
+      if (tt + 1 < t_end) load_halo_regs(tt + 1);
+    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -91,7 +138,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         bf16x8 a[NP], bq[NP][2];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-          a[pl] = *reinterpret_cast<const bf16x8*>(ldsX + pl * XB + aoff);
+          a[pl] = *reinterpret_cast<const bf16x8*>(ldsXc + pl * XB + aoff);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = kh * 64 + j * 32 + (lane & 31);
@@ -118,26 +165,34 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     if constexpr (!SPLIT) {
       typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
       const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+      auto store_tile = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-      for (int q2 = 0; q2 < 8; ++q2) {
-        const int mm = wave * 32 + ((2 * q2) & 3) + 8 * ((2 * q2) >> 2) + 4 * khalf;   // pixel of column 2*q2 (even)
-        const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
-        const bool v0ok = r < p.OH && c < p.OW, v1ok = r < p.OH && c + 1 < p.OW;
-        const bool mine = (lane & 1) ? v1ok : v0ok;
-        bf16* dst = reinterpret_cast<bf16*>(out) + ((size_t)r * p.OW + c + (lane & 1)) * 64 + ((lane & 31) & ~1);
+        for (int q2 = 0; q2 < 8; ++q2) {
+          const int mm = wave * 32 + ((2 * q2) & 3) + 8 * ((2 * q2) >> 2) + 4 * khalf;   // pixel of column 2*q2 (even)
+          const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+          const bool v0ok = FULL || (r < p.OH && c < p.OW), v1ok = FULL || (r < p.OH && c + 1 < p.OW);
+          const bool mine = (lane & 1) ? v1ok : v0ok;
+          bf16* dst = reinterpret_cast<bf16*>(out) + ((size_t)r * p.OW + c + (lane & 1)) * 64 + ((lane & 31) & ~1);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float v0 = v0ok ? acc[j][2 * q2] : 0.f, v1 = v1ok ? acc[j][2 * q2 + 1] : 0.f;
-          s1[j] += v0 + v1;
-          s2[j] += v0 * v0 + v1 * v1;
-          bf16x2 own;
-          own[0] = (bf16)v0;
-          own[1] = (bf16)v1;
-          const unsigned x = __builtin_bit_cast(unsigned, own);
-          const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-          if (mine) *reinterpret_cast<unsigned*>(dst + j * 32) = __builtin_amdgcn_perm(y, x, psel);
+          for (int j = 0; j < 2; ++j) {
+            const float v0 = v0ok ? acc[j][2 * q2] : 0.f, v1 = v1ok ? acc[j][2 * q2 + 1] : 0.f;
+            s1[j] += v0 + v1;
+            s2[j] += v0 * v0 + v1 * v1;
+            bf16x2 own;
+            own[0] = (bf16)v0;
+            own[1] = (bf16)v1;
+            const unsigned x = __builtin_bit_cast(unsigned, own);
+            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            if (FULL || mine) *reinterpret_cast<unsigned*>(dst + j * 32) = __builtin_amdgcn_perm(y, x, psel);
+          }
         }
-      }
+        // the next tile's halo (requested before the MFMAs) goes to the buffer nobody reads; one barrier per tile
+        if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * XB);
+      };
+      if (r0 + TH <= p.OH && c0 + TW <= p.OW) store_tile(std::true_type{});
+      else store_tile(std::false_type{});
+      __syncthreads();
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -329,7 +384,7 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
   struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
   if (prec == PH_PREC_BF16) {
     static bool done = false;
-    const int lds = XB + WB;
+    const int lds = 2 * XB + WB;
     if (set_lds(stem_fwd_kernel<bf16>, lds, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, *p);
   } else if (prec == PH_PREC_BF16X6) {

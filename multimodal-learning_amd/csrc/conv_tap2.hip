@@ -300,7 +300,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
               w[0] = (bf16)((float)w[0] + ((float)ra[m][j][0] > 0.f ? (float)rg[m][j][0] : 0.f));
               w[1] = (bf16)((float)w[1] + ((float)ra[m][j][1] > 0.f ? (float)rg[m][j][1] : 0.f));
             }
+#ifdef PH_ABL_NOSTORE   // timing ablation only
+            asm volatile("" ::"v"(w));
+#else
             if (mine[m]) *reinterpret_cast<bf16x2*>(out + o[m] + j * 32) = w;
+#endif
           }
         }
       }
