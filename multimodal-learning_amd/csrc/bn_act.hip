@@ -298,28 +298,33 @@ constexpr int STEM_ROWS = 16;
 template <typename T>
 __device__ __forceinline__ void stem_dz(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, int OH, int OW,
                                         size_t b, int h, int w, int cg, float (&dz)[8]) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) dz[k] = 0.f;
+  // the (up to) four pooling windows that contain input pixel (h, w).  All four argmax words and gradient vectors
+  // are requested unconditionally (indices clamped, contribution masked) so that the eight loads are in flight
+  // together: with a branch per window the kernel paid four dependent memory round trips per pixel (535 us).
   const int ph0 = h >> 1, ph1 = (h + 1) >> 1, pw0 = w >> 1, pw1 = (w + 1) >> 1;
+  uint64_t packed[4];
+  float g8[4][8];
+  unsigned code[4];
+  bool ok[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int ph = a ? ph1 : ph0;
-    if ((a && ph1 == ph0) || ph >= OH) continue;
-    const int kh = h - (2 * ph - 1);
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int pw = c ? pw1 : pw0;
-      if ((c && pw1 == pw0) || pw >= OW) continue;
-      const unsigned code = (unsigned)(kh * 3 + (w - (2 * pw - 1)));
-      const size_t o8 = ((b * OH + ph) * OW + pw) * 8 + cg;
-      const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o8 * 8);
-      float g8[8];
-      load8(dpool + o8 * 8, g8);
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (((unsigned)(packed >> (8 * k)) & 0xffu) == code) dz[k] += g8[k];
+      const int ph = a ? ph1 : ph0, pw = c ? pw1 : pw0;
+      ok[a * 2 + c] = !(a && ph1 == ph0) && !(c && pw1 == pw0) && ph < OH && pw < OW;
+      const int phc = ph < OH ? ph : OH - 1, pwc = pw < OW ? pw : OW - 1;
+      code[a * 2 + c] = (unsigned)((h - (2 * ph - 1)) * 3 + (w - (2 * pw - 1)));
+      const size_t o8 = ((b * OH + phc) * OW + pwc) * 8 + cg;
+      packed[a * 2 + c] = *reinterpret_cast<const uint64_t*>(idx + o8 * 8);
+      load8(dpool + o8 * 8, g8[a * 2 + c]);
     }
-  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dz[k] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      dz[k] += (ok[q] && ((unsigned)(packed[q] >> (8 * k)) & 0xffu) == code[q]) ? g8[q][k] : 0.f;
 }
 
 template <typename T, bool APPLY>
