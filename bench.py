@@ -22,10 +22,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-CLS_NAMES = ["tapconv_kernel<bf16,S=1,TH=16,BNT=64> (Cout=64 fwd+dgrad)",
-             "tapconv2_kernel<2,2> 3x3 stride-1 + tapconv_kernel<bf16,S=1,BNT=128> 1x1/parity classes (Cout>=128 fwd+dgrad)",
+CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad parity classes)",
+             "tapconv_kernel<bf16,S=1,BNT=128> (first generation: 1x1 and dgrad parity classes, Cout>=128)",
              "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
-             "stem_wgrad_kernel<bf16>"]
+             "stem_wgrad_kernel<bf16>",
+             "tapconv2_kernel<2,2,4,false> (3x3 stride-1 fwd+dgrad, Cout>=128)",
+             "tapconv2_kernel<4,1,2,true> (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1)"]
+NCLS = len(CLS_NAMES)
 
 
 def make_batch(B, H, n_data, opt, device, seed):
@@ -163,10 +166,10 @@ def main():
                           "launch": "eager" if args.eager else "one captured HIP graph per step"}}
         # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region)
         if not args.no_kernel_timer:
-            buf = (ctypes.c_double * 18)()
-            L.ph_prof_summary(buf, 6)
-            rows = [(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c in range(6)]
-            dom = max(range(6), key=lambda c: buf[3 * c + 1])
+            buf = (ctypes.c_double * (3 * NCLS))()
+            L.ph_prof_summary(buf, NCLS)
+            rows = [(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c in range(NCLS)]
+            dom = max(range(NCLS), key=lambda c: buf[3 * c + 1])
             n, ms, fl = buf[3 * dom], buf[3 * dom + 1], buf[3 * dom + 2]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = None

@@ -189,8 +189,10 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
 
 /* ------------------------------------------------------------------------------------------------
  * In-library kernel timer for bench.py's `roofline` object: HIP events around every MFMA kernel launch on the
- * launch stream.  Classes: 0 tap-conv Cout=64, 1 tap-conv Cout>=128 stride 1, 2 tap-conv stride 2,
- * 3 wgrad, 4 stem forward, 5 stem wgrad.  out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic FLOPs}.
+ * launch stream.  Classes: 0 first-generation tap-conv Cout=64 (dgrad parity classes), 1 first-generation tap-conv
+ * Cout>=128 stride 1 (1x1, dgrad parity classes), 2 tap-conv stride 2, 3 wgrad, 4 stem forward, 5 stem wgrad,
+ * 6 tapconv2 3x3 stride-1 Cout>=128 (fwd + dgrad), 7 tapconv2 3x3 stride-1 Cin=Cout=64 (layer 1).
+ * out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic FLOPs}; 8 classes.
  * ---------------------------------------------------------------------------------------------- */
 int ph_prof_enable(int on);
 int ph_prof_reset(void);

@@ -602,7 +602,7 @@ int launch2(const PhTapConv& p, hipStream_t st) {
   dim3 grid(total < resident ? total : resident);
   void* tok = nullptr;
   if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
-    ph_prof_begin(C::BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128,
+    ph_prof_begin(RES ? PH_CLS_TAPCONV2_RES : PH_CLS_TAPCONV2,
                   2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
   hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);

@@ -5,12 +5,15 @@
 #include <stdint.h>
 
 // in-library kernel timer (prof.hip); classes are indices of ph_prof_summary()
-#define PH_CLS_TAPCONV_N64 0    // tapconv_kernel<.., S=1, TH=16, BNT=64 ..>   (Cout = 64 layers)
-#define PH_CLS_TAPCONV_N128 1   // tapconv_kernel<.., S=1, TH=8, BNT=128 ..>   (Cout >= 128, stride 1)
+#define PH_CLS_TAPCONV_N64 0    // tapconv_kernel<.., S=1, BNT=64 ..>   (first generation: Cout = 64 dgrad parity classes)
+#define PH_CLS_TAPCONV_N128 1   // tapconv_kernel<.., S=1, BNT=128 ..>  (first generation: 1x1 and dgrad parity classes, Cout >= 128)
 #define PH_CLS_TAPCONV_S2 2     // tapconv_kernel<.., S=2 ..>
 #define PH_CLS_WGRAD 3
 #define PH_CLS_STEM_FWD 4
 #define PH_CLS_STEM_WGRAD 5
+#define PH_CLS_TAPCONV2 6       // tapconv2_kernel<2,2,4,false>: 3x3 stride-1 fwd + dgrad, Cout >= 128  (the dominant kernel)
+#define PH_CLS_TAPCONV2_RES 7   // tapconv2_kernel<4,1,2,true>: 3x3 stride-1 fwd + dgrad, Cin = Cout = 64 (layer 1)
+#define PH_NCLS 8
 #define PH_NUM_CLS 6
 bool ph_prof_on();
 int ph_num_cus();   // compute units of the current device (cached)

@@ -18,7 +18,7 @@ shapes = [("layer1 3x3", 64, 64, H0 // 4, 3, 1, 1), ("layer2.0.c1 s2", 64, 128, 
           ("layer2 3x3", 128, 128, H0 // 8, 3, 1, 1), ("layer2 ds 1x1 s2", 64, 128, H0 // 4, 1, 2, 0),
           ("layer3.0.c1 s2", 128, 256, H0 // 8, 3, 2, 1), ("layer3 3x3", 256, 256, H0 // 16, 3, 1, 1),
           ("layer4.0.c1 s2", 256, 512, H0 // 16, 3, 2, 1), ("layer4 3x3", 512, 512, H0 // 32, 3, 1, 1)]
-buf = (ctypes.c_double * 18)()
+buf = (ctypes.c_double * 24)()
 print(f"B={B} input {H0}x{H0}   TFLOP/s (algorithmic)   [us per launch]")
 for name, Cin, Cout, H, KS, S, pad in shapes:
     OH = (H + 2 * pad - KS) // S + 1
@@ -45,7 +45,7 @@ for name, Cin, Cout, H, KS, S, pad in shapes:
         for _ in range(10):
             run()
         L.ph_prof_enable(0)
-        L.ph_prof_summary(buf, 6)
-        n = sum(buf[3 * c] for c in range(6)); ms = sum(buf[3 * c + 1] for c in range(6)); fl = sum(buf[3 * c + 2] for c in range(6))
+        L.ph_prof_summary(buf, 8)
+        n = sum(buf[3 * c] for c in range(8)); ms = sum(buf[3 * c + 1] for c in range(8)); fl = sum(buf[3 * c + 2] for c in range(8))
         res.append(f"{what} {fl / (ms * 1e-3) / 1e12:7.1f} [{1000 * ms / 10:7.1f}]")
     print(f"{name:<18s} Cin {Cin:4d} Cout {Cout:4d} HW {H:4d}  " + "   ".join(res))
