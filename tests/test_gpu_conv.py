@@ -63,3 +63,47 @@ def test_conv_fwd_dgrad_wgrad(case, prec):
     dw = torch.empty_like(wd)
     check(L.ph_conv2d_wgrad(ptr(xd), ptr(dyd), ptr(dw), B, Cin, H, H, Cout, KS, S, pad, prec, ptr(ws), stream()), "wgrad")
     assert_close(wr.grad, dw.cpu(), 1e-6, 2e-5 if prec == 1 else 2e-3, "conv wgrad")
+
+
+# ---- second-generation kernel (conv_tap2.hip): persistent workgroups walking SEVERAL tiles each.  The cases above
+# give every workgroup one tile; these are sized past 256 tiles so that the cross-tile operand streams (next tile's
+# halo in the other A buffer, the weight ring running across the tile edge, the epilogue between two tiles) are
+# checked against F.conv2d, and the launch is repeated to catch a schedule-dependent (racy) result.
+MULTITILE = [  # Cin, Cout, H, B
+    (128, 128, 64, 20),     # <2,2,4,false>: 2 slices/tile, 320 tiles
+    (64, 64, 64, 24),       # <4,1,2,true> (resident weights): 384 tiles
+    (256, 256, 24, 40),     # ragged 24 = 16 + 8: partial tiles in the stream, 4 slices/tile, 320 tiles
+]
+
+
+@pytest.mark.parametrize("case", MULTITILE)
+def test_tapconv2_multitile_stream(case):
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, B = case
+    g = torch.Generator().manual_seed(Cin + Cout + H + B)
+    x = (torch.randn(B, Cin, H, H, generator=g)).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5)
+    w_r = w.bfloat16().float()
+    dy = torch.randn(B, Cout, H, H, generator=g).bfloat16().float()
+    torch.set_num_threads(8)
+    y_ref = F.conv2d(x, w_r, None, 1, 1)
+    dx_ref = F.conv_transpose2d(dy, w_r, None, 1, 1)
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 1, 1), device="cuda", dtype=torch.uint8)
+    xd = nhwc(x, torch.bfloat16); wd = w.cuda(); dyd = nhwc(dy, torch.bfloat16)
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    outs = []
+    for rep in range(4):
+        y = torch.full((B, H, H, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 1, 1, 0, ptr(ws),
+                              stream()), "fwd")
+        outs.append((y.clone(), s1.clone(), s2.clone()))
+    assert_close(y_ref, nchw_cpu(outs[0][0]), 1e-6, 1.0 / 128, "multi-tile conv fwd")
+    assert_close(y_ref.sum(dim=(0, 2, 3)), outs[0][1].cpu(), 1e-2, 1e-3, "channel sum")
+    assert_close((y_ref ** 2).sum(dim=(0, 2, 3)), outs[0][2].cpu(), 1e-2, 1e-3, "channel sumsq")
+    for rep in range(1, 4):   # bitwise repeatable: no schedule-dependent reads of a buffer still being filled
+        assert torch.equal(outs[0][0].view(torch.int16), outs[rep][0].view(torch.int16)), "fwd differs between launches"
+        assert torch.equal(outs[0][1], outs[rep][1]) and torch.equal(outs[0][2], outs[rep][2])
+    dx = torch.full((B, H, H, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
+    check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx), B, Cin, H, H, Cout, 3, 1, 1, 0, ptr(ws), stream()), "dgrad")
+    assert_close(dx_ref, nchw_cpu(dx), 1e-6, 1.0 / 128, "multi-tile conv dgrad")
