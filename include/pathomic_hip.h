@@ -188,6 +188,21 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
                     int stride, int pad, int prec, void* ws, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * t-SVD low-rank constraint of the MIA-2022 stage-1 trainer ("MIA 2022/train_test_tSVD.py").
+ * Adjacency = ph_sgemm (F F^T) + ph_l2norm_* (update_adj_tensor, :57-70).  Penalty mu/2 ||adj - aux||_F^2 (:418-431):
+ *   out[0] = scale * sum (a - b)^2 ;  gradient out = gscalar[0] * alpha * (a - b).
+ * ph_tsvd_update_aux replaces update_aux(adj, Lambda_global / mu) called at :382-391 (its source is absent from the
+ * reference: this is the tensor-nuclear-norm proximal operator, see csrc/tsvd.hip): adj, aux are [V][B][B] (view-major),
+ * V in {2,4,6,8}, B <= 64; tnn[0] = (1/V) sum over frequency slices of the nuclear norm of the thresholded slice.
+ * ---------------------------------------------------------------------------------------------- */
+int ph_sqdiff_sum(const float* a, const float* b, float* out, size_t n, float scale, ph_stream_t stream);
+int ph_scaled_diff(const float* a, const float* b, const float* gscalar, float alpha, float* out, size_t n,
+                   ph_stream_t stream);
+size_t ph_tsvd_workspace_bytes(int V, int B);
+int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn /* may be NULL */, int V, int B, float tau,
+                       void* workspace, ph_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * In-library kernel timer for bench.py's `roofline` object: HIP events around every MFMA kernel launch on the
  * launch stream.  Classes: 0 first-generation tap-conv Cout=64 (dgrad parity classes), 1 first-generation tap-conv
  * Cout>=128 stride 1 (1x1, dgrad parity classes), 2 tap-conv stride 2, 3 wgrad, 4 stem forward, 5 stem wgrad,

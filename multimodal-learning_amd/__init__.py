@@ -19,6 +19,7 @@ from .CL_utils import CRDLoss, ContrastLoss_v2, Embed, Normalize, ContrastMemory
 from .train_step import AEKD_loss, momentum_AEKD_loss, update_ema_variables, DistillStep, FusedAdam, FlatParams
 from . import dist
 from . import mia2023
+from . import tsvd
 from .options import stage2_opt
 
 __all__ = ["build", "lib", "set_precision", "get_precision", "init_net", "init_max_weights", "count_parameters",

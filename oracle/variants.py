@@ -184,3 +184,41 @@ def crd_v10_loss(st, sample_weights, f_s, f_t, batch_label, y, idx, num_pos):
     ls, sls = closs(out_v1, s2)      # criterion_s(out_s, t_similarity)  :226-227
     lt, slt = closs(out_v2, s1)
     return ls + lt, sls + slt, dict(nb1=nb1, nb2=nb2, sim1=s1, sim2=s2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Row a16: t-SVD low-rank constraint of the MIA-2022 stage-1 trainer ("MIA 2022/train_test_tSVD.py").
+# update_adj_tensor (:57-70) and the penalty (:413-431) are pinned by tests/golden/mia2022_tsvd.npz (produced by running
+# the reference functions).  update_aux is NOT in the reference repository (`from my_utils.TSVD_update_aux import
+# update_aux`, :31 - module absent): parity unpinned.  What follows the call contract of :382-391 (input [B,B,n_views]
+# detached adjacency stack, threshold Lambda_global/mu, returns (aux of the same shape, TNN scalar)) is the standard
+# proximal operator of the tensor nuclear norm: FFT along the view axis, singular-value soft-thresholding of every
+# frontal slice, inverse FFT.  TNN is reported as (1/n_views) * sum over the frequency slices of the nuclear norm of the
+# thresholded slice.  This is OUR choice of algorithm and normalisation; the HIP kernel is tested against this function.
+def update_adj_tensor(feats):
+    """feats: list of [B, D] -> list of row-L2-normalised Gram matrices F.normalize(f f^T)  (train_test_tSVD.py:57-70)"""
+    return [torch.nn.functional.normalize(torch.mm(f, f.t())) for f in feats]
+
+
+def tsvd_penalty(adj, aux, mu):
+    """sum_v mu/2 * ||adj_v - aux_v||_F^2  (train_test_tSVD.py:418-431, one modality)"""
+    loss = 0
+    for a, x in zip(adj, aux):
+        loss = loss + mu / 2.0 * (torch.norm(a - x)) ** 2
+    return loss
+
+
+def update_aux(adj_stack, tau):
+    """adj_stack: [B, B, V] (numpy or tensor).  Returns (aux [B, B, V] float64 numpy, TNN float)."""
+    import numpy as np
+    x = np.asarray(adj_stack.detach().cpu().numpy() if torch.is_tensor(adj_stack) else adj_stack, dtype=np.float64)
+    V = x.shape[2]
+    xf = np.fft.fft(x, axis=2)
+    yf = np.zeros_like(xf)
+    tnn = 0.0
+    for k in range(V):
+        u, s, vh = np.linalg.svd(xf[:, :, k], full_matrices=False)
+        s = np.maximum(s - tau, 0.0)
+        tnn += s.sum()
+        yf[:, :, k] = (u * s) @ vh
+    return np.real(np.fft.ifft(yf, axis=2)), tnn / V

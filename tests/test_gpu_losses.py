@@ -278,3 +278,52 @@ def test_mia2023_rows_golden(golden_dir):
         scale, total = mia2023.GK_refine_thresh(opt, None, rows[4].mean(), feat, rows[:4])
         R.close(g[f"gk_{name}_scale"], scale, 1e-4, 1e-4, f"GK {name} scale"); R.close(g[f"gk_{name}_total"], total, 1e-4, 1e-4, f"GK {name} total")
     R.finish()
+
+
+# ---------------------------------------------------------------------------------------------- row a16 (t-SVD)
+def test_tsvd_adjacency_penalty_golden(golden_dir):
+    """update_adj_tensor + Frobenius penalty vs the fixture produced by running "MIA 2022/train_test_tSVD.py"."""
+    import multimodal_learning_amd as m
+    g = np.load(os.path.join(golden_dir, "mia2022_tsvd.npz"))
+    feats = [torch.tensor(g[f"feat{v}"], device="cuda", requires_grad=True) for v in range(4)]
+    aux = [torch.tensor(g[f"aux{v}"], device="cuda") for v in range(4)]
+    adj = m.tsvd.update_adj_tensor([None] * 4, feats)
+    loss = m.tsvd.tsvd_penalty(adj, aux, float(g["mu"]))
+    grads = torch.autograd.grad(loss, feats)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    for v in range(4):
+        assert np.allclose(adj[v].detach().cpu().numpy(), g[f"adj{v}"], atol=2e-6)
+        ref = g[f"g_feat{v}"]
+        assert np.abs(grads[v].cpu().numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
+
+
+@pytest.mark.parametrize("B,V,tau", [(16, 4, 0.05), (64, 4, 0.3), (24, 2, 0.1), (32, 8, 0.02), (8, 6, 0.5)])
+def test_tsvd_update_aux_vs_oracle(B, V, tau):
+    """ph_tsvd_update_aux (Jacobi eigen-solver in LDS) vs the float64 numpy proximal operator of the oracle.  The
+    algorithm itself is OUR reading of the absent `update_aux` (parity unpinned vs the reference)."""
+    import multimodal_learning_amd as m
+    from oracle import variants as OV
+    rng = np.random.default_rng(B * 10 + V)
+    feats = [torch.tensor(rng.standard_normal((B, 32)).clip(0), dtype=torch.float32) for _ in range(V)]
+    adj = torch.stack(OV.update_adj_tensor(feats), dim=2)          # realistic input: row-normalised Gram matrices
+    ref, tnn_ref = OV.update_aux(adj, tau)
+    aux, tnn = m.tsvd.update_aux(adj.cuda(), tau)
+    err = np.abs(aux.cpu().numpy().astype(np.float64) - ref).max()
+    assert err <= 2e-5 * max(np.abs(ref).max(), 1.0), err
+    assert abs(tnn.item() - tnn_ref) <= 1e-4 * max(abs(tnn_ref), 1.0)
+    # idempotence-like property of a prox: tau = 0 reproduces the input
+    aux0, _ = m.tsvd.update_aux(adj.cuda(), 0.0)
+    assert np.abs(aux0.cpu().numpy() - adj.numpy()).max() <= 2e-5
+
+
+def test_tsvd_state_step_runs_and_schedules_mu():
+    import types
+    import multimodal_learning_amd as m
+    opt = types.SimpleNamespace(n_views=4, Lambda_global=0.05, mu=1e-5, pho=1.1, max_mu=1.0)
+    st = m.tsvd.TSVDState(opt, 16, "cuda")
+    g = torch.Generator().manual_seed(0)
+    feats = [torch.randn(16, 32, generator=g).relu_().cuda().requires_grad_(True) for _ in range(4)]
+    loss = st.step(feats)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(f.grad).all() for f in feats)
+    assert abs(st.mu - 1.1e-5) < 1e-12 and st.tnn is not None
