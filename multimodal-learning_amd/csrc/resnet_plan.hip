@@ -59,7 +59,7 @@ int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
 }
 int stem_chunks(int B, int OH, int OW, int* tpc) {
   const int ntiles = B * cdiv(OH, 8) * cdiv(OW, 16);
-  int want = ntiles < 512 ? ntiles : 512;
+  int want = ntiles < 1024 ? ntiles : 1024;   // 4 workgroups per CU: the per-tile staging latency is hidden by occupancy
   *tpc = cdiv(ntiles, want);
   return cdiv(ntiles, *tpc);
 }
