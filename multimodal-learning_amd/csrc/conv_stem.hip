@@ -187,9 +187,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
             if (FULL || mine) *reinterpret_cast<unsigned*>(dst + j * 32) = __builtin_amdgcn_perm(y, x, psel);
           }
         }
-        // the next tile's halo (requested before the MFMAs) goes to the buffer nobody reads; one barrier per tile
-        if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * XB);
       };
+      // the next tile's halo (requested before the MFMAs) goes to the buffer nobody reads BEFORE this tile's output
+      // stores are issued: the wait in front of the LDS write then covers the loads only, not 16 stores in flight
+      if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * XB);
       if (r0 + TH <= p.OH && c0 + TW <= p.OW) store_tile(std::true_type{});
       else store_tile(std::false_type{});
       __syncthreads();

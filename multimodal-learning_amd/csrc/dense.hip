@@ -83,6 +83,69 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
   }
 }
 
+// Small problems (the heads, the SNN, the embeds: at most 128 x 128 outputs, 32 + 12 launches per step on one or two
+// 64 x 64 tiles): 16 x 16 output tiles so that 16x more workgroups share the K loop, K staged 128 deep with the next
+// step's global loads issued before the current step's FMAs, K-contiguous LDS rows read as float4.
+constexpr int ST = 16, SK = 128, SLD = SK + 4;
+__global__ __launch_bounds__(256) void sgemm_small_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                          const float* __restrict__ bias, float* __restrict__ Cm, int M,
+                                                          int N, int K, long sam, long sak, long sbk, long sbn, long ldc,
+                                                          int act, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float As[ST][SLD];
+  __shared__ __attribute__((aligned(16))) float Bs[ST][SLD];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
+  constexpr int PER = ST * SK / 256;
+  const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
+  float ra[PER], rb[PER];
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid + q * 256;
+      int m, k;
+      if (a_kfast) { k = e % SK; m = e / SK; } else { m = e % ST; k = e / ST; }
+      const int gm = m0 + m, gk = k0 + k;
+      ra[q] = (gm < M && gk < K) ? A[gm * sam + gk * sak] : 0.f;
+      int n, kk;
+      if (b_nfast) { n = e % ST; kk = e / ST; } else { kk = e % SK; n = e / SK; }
+      const int gn = n0 + n, gk2 = k0 + kk;
+      rb[q] = (gn < N && gk2 < K) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
+    }
+  };
+  float acc = 0.f;
+  load_regs(0);
+  for (int k0 = 0; k0 < K; k0 += SK) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = tid + q * 256;
+      int m, k;
+      if (a_kfast) { k = e % SK; m = e / SK; } else { m = e % ST; k = e / ST; }
+      As[m][k] = ra[q];
+      int n, kk;
+      if (b_nfast) { n = e % ST; kk = e / ST; } else { kk = e % SK; n = e / SK; }
+      Bs[n][kk] = rb[q];
+    }
+    __syncthreads();
+    if (k0 + SK < K) load_regs(k0 + SK);   // in flight during the FMAs below
+#pragma unroll 8
+    for (int k = 0; k < SK; k += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[ty][k]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[tx][k]);
+      acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); acc = fmaf(a[3], b[3], acc);
+    }
+    __syncthreads();
+  }
+  const int gm = m0 + ty, gn = n0 + tx;
+  if (gm < M && gn < N) {
+    float v = acc + (bias ? bias[gn] : 0.f);
+    if (act == PH_ACT_RELU) v = v > 0.f ? v : 0.f;
+    else if (act == PH_ACT_ELU) v = v > 0.f ? v : expm1f(v);
+    else if (act == PH_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    if (accumulate) v += Cm[gm * ldc + gn];
+    Cm[gm * ldc + gn] = v;
+  }
+}
+
 // split-K variant for skinny problems (M,N small, K huge: the 16641-wide fusion encoder, bilinear gates)
 __global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                            float* __restrict__ part, int M, int N, int K, long sam,
@@ -479,6 +542,12 @@ inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t)
 
 int ph_sgemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, long sam, long sak,
              long sbk, long sbn, long ldc, int act, int accumulate, hipStream_t st) {
+  if ((long)M * N <= 128L * 128L) {
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3(cdiv(N, ST), cdiv(M, ST)), dim3(256), 0, st, A, B, bias, C, M, N, K, sam,
+                       sak, sbk, sbn, ldc, act, accumulate);
+    PH_LAUNCH_CHECK();
+    return PH_OK;
+  }
   dim3 grid(cdiv(N, GT), cdiv(M, GT));
   hipLaunchKernelGGL(sgemm_kernel, grid, dim3(256), 0, st, A, B, bias, C, M, N, K, sam, sak, sbk, sbn, ldc, act,
                      accumulate);
