@@ -474,7 +474,7 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
-  if (const int th2 = ph_tapconv2_tile_h(p, S, prec)) return p->B * cdiv(p->OHt, th2) * cdiv(p->OWt, 16);
+  if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_stat_parts(p);
   const int TH = (S == 1) ? ((p->Cout % 128 == 0 && prec != PH_PREC_BF16) ? 8 : 16) : (prec == PH_PREC_BF16 ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
 }

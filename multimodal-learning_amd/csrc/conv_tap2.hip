@@ -69,7 +69,8 @@ struct Tap2Cfg {
   static constexpr int NBE = TAPB / 1024 / 4;      // weight DMA wave-instructions per wave and tap
   static constexpr int HALO_TAPS = 6;              // taps 0..5 of a slice issue the next slice's halo ...
   static constexpr int HPT = (NHE + HALO_TAPS - 1) / HALO_TAPS;   // ... HPT pieces per wave each
-  static constexpr int LDS_BYTES = 2 * A_BYTES + (RES ? NTAPS : RING) * TAPB;
+  static constexpr int LDS_MAIN = 2 * A_BYTES + (RES ? NTAPS : RING) * TAPB;
+  static constexpr int LDS_BYTES = LDS_MAIN + 4096;   // + the workgroup's BatchNorm partial row (Cout <= 512)
   static constexpr int NTH = WM * WN * 64;
   static constexpr int NHALF = FM / 2;                       // the C tile is staged in NHALF passes of 2 fragments
   static constexpr int C_BYTES = WM * 4 * TW * BNT * 2;      // one pass of the C tile (bf16)
@@ -225,6 +226,40 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   // instructions of 2-byte writes and no two lanes in one dword (measured: 50 cycles per value with ds_write_b16).
   unsigned long long ep_w = 0, ep_b = 0, ep_s = 0;   // trace build: epilogue phase cycles
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  // BatchNorm partial sums: kept in registers ACROSS the tiles of this workgroup (per column parity; combined at the
+  // flush) and folded into a per-workgroup LDS row [Cout/BNT][2][BNT] only when the Cout block changes or the tile
+  // list ends - ONE partial row per workgroup instead of one per tile (bn_finalize combined 4096 rows for layer 1),
+  // and no per-tile reduction / barriers in the epilogue.  Fixed order of additions: bitwise reproducible.
+  float* stat_acc = reinterpret_cast<float*>(smem + C::LDS_MAIN);
+  for (int i = tid; i < 2 * p.Cout; i += NTH) stat_acc[i] = 0.f;   // (published by the prologue barrier)
+  f32x2 s1[FN], s2[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
+  auto flush_stats = [&](int n0, unsigned char* scratch) {   // all threads; `scratch`: an A buffer nobody reads
+    float* red = reinterpret_cast<float*>(scratch);          // [WM][2][BNT]
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const float t1 = s1[j][0] + s1[j][1], t2 = s2[j][0] + s2[j][1];
+      const float a1 = t1 + __shfl_xor(t1, 32, 64);
+      const float a2 = t2 + __shfl_xor(t2, 32, 64);
+      if (khalf == 0) {   // waves with the same wm cover disjoint channel ranges: one writer per (wm, channel)
+        red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
+        red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
+      }
+      s1[j] = f32x2{0.f, 0.f};
+      s2[j] = f32x2{0.f, 0.f};
+    }
+    __syncthreads();
+    if (tid < 2 * BNT) {
+      const int which = tid / BNT, n = tid % BNT;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BNT + n];
+      stat_acc[((n0 / BNT) * 2 + which) * BNT + n] += v;
+    }
+    __syncthreads();
+  };
   auto epilogue = [&](const TileCtx& tc, unsigned char* stage, auto fullc) {
     constexpr bool FULL = decltype(fullc)::value;   // the tile lies completely inside the output: no masking
     const int r0 = tc.r0, c0 = tc.c0, n0 = tc.n0;
@@ -238,14 +273,9 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     static_assert(NIT % NITB == 0, "store loop batches");
     unsigned char* ldsC = stage;
     (void)ldsC;
-    float* red = reinterpret_cast<float*>(stage + C::C_BYTES);   // [WM][2][BNT]
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
     // byte selector of v_perm_b32 {neighbour's packed pair, own packed pair}: even lanes build [own lo | neighbour lo],
     // odd lanes [neighbour hi | own hi]
     const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
-    f32x2 s1[FN], s2[FN];   // per column parity; added at the end
-#pragma unroll
-    for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
 #if PH_EPI_DIRECT
     // direct form: after the lane-pair exchange every lane owns one [even channel, odd channel] word of one pixel and
     // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier before the statistics.
@@ -383,28 +413,6 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       ep_w += e1_ - e0_; ep_b += (e2_ - e1_) + (e4_ - e3_); ep_s += e3_ - e2_;
     }
 #endif
-    if (p.stats) {
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const float t1 = s1[j][0] + s1[j][1], t2 = s2[j][0] + s2[j][1];
-        const float a1 = t1 + __shfl_xor(t1, 32, 64);
-        const float a2 = t2 + __shfl_xor(t2, 32, 64);
-        if (khalf == 0) {   // waves with the same wm cover disjoint channel ranges: one writer per (wm, channel)
-          red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
-          red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
-        }
-      }
-      __syncthreads();
-      if (tid < 2 * BNT) {
-        const int which = tid / BNT, n = tid % BNT;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BNT + n];
-        const size_t part = (size_t)tc.b * tiles_sp + tc.tile;
-        p.stats[(part * 2 + which) * p.Cout + n0 + n] = v;
-      }
-      __syncthreads();
-    }
   };
 
   // ---- the tap stream.  Tile (outer loop) -> 64-channel slice -> 9 taps (fully unrolled: tap offsets, the piece of
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     // (stages through the A buffer the tile finished with; ends on a barrier)
     if ((tcur.r0 + TH <= p.OHt) && (tcur.c0 + TW <= p.OWt)) epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::true_type{});
     else epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::false_type{});
+    if (p.stats && (!nvalid || tnext.n0 != tcur.n0)) flush_stats(tcur.n0, smem + (acur ^ 1) * C::A_BYTES);
     zero_acc();
     cyc_e += PH_CLK() - q3_;
     if (!nvalid) break;
@@ -581,6 +590,12 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     cyc_x += PH_CLK() - x0_;
   }
   PH_WAIT_VMCNT(0);   // the refills issued past the end of the stream must not outlive the workgroup's LDS
+  if (p.stats) {      // this workgroup's partial row [2][Cout] (zeros for Cout blocks it never visited)
+    for (int i = tid; i < 2 * p.Cout; i += NTH) {
+      const int which = i / p.Cout, ch = i - which * p.Cout;
+      p.stats[((size_t)blockIdx.x * 2 + which) * p.Cout + ch] = stat_acc[((ch / BNT) * 2 + which) * BNT + ch % BNT];
+    }
+  }
   PH_TRACE(5);
   PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_b); PH_TRACE_ACC(3, cyc_e); PH_TRACE_ACC(9, ep_w); PH_TRACE_ACC(4, cyc_s); PH_TRACE_ACC(7, cyc_x); (void)cyc_s; (void)cyc_x; (void)ep_w; (void)ep_b; (void)ep_s;
   PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)gt);
@@ -614,11 +629,19 @@ int launch2(const PhTapConv& p, hipStream_t st) {
 
 // 0: not eligible (the first-generation kernel runs); otherwise the tile height of the configuration chosen
 int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec) {
-  if (S != 1 || prec != PH_PREC_BF16 || p->ntaps != 9) return 0;
+  if (S != 1 || prec != PH_PREC_BF16 || p->ntaps != 9 || p->Cout > 512) return 0;
   if (p->Cout % 128 && !(p->Cout == 64 && p->Cin == 64)) return 0;
   for (int k = 0; k < 9; ++k)   // the kernel hard-codes the 3x3 tap geometry (only the weight slab order is a table)
     if (p->dy[k] != k / 3 || p->dx[k] != k % 3) return 0;
   return 16;
+}
+
+// number of BatchNorm partial rows a launch writes = its (persistent) workgroups
+int ph_tapconv2_stat_parts(const PhTapConv* p) {
+  const int bnt = (p->Cout % 128 == 0) ? 128 : 64;
+  const int total = cdiv(p->OHt, 16) * cdiv(p->OWt, 16) * (p->Cout / bnt) * p->B;
+  const int resident = ph_num_cus();
+  return total < resident ? total : resident;
 }
 
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {

@@ -45,6 +45,7 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec);
 // second-generation stride-1 perf-mode kernel (conv_tap2.hip): tile height of the configuration it would run, 0 = not eligible
 int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec);
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st);
+int ph_tapconv2_stat_parts(const PhTapConv* p);   // one BatchNorm partial row per persistent workgroup
 
 struct PhWgrad {
   const void* x;         // [B][IH][IW][Cin]
