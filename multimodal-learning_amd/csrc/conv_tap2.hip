@@ -44,10 +44,6 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
 #endif
 }
-// 1: the epilogue stores straight from registers; 0: stages the C tile through LDS for 16-B stores (kept for A/B runs)
-#ifndef PH_EPI_DIRECT
-#define PH_EPI_DIRECT 1
-#endif
 #define PH_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PH_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -219,12 +215,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
 
   // ---- epilogue of one tile: mask, BN partial statistics, (residual), store.  Accumulator register q of fragment
   // (i,j) holds MFMA row (q&3) + 8*(q>>2) + 4*khalf, i.e. (frag_row_to_pixel) tile row 2*(wm*FM+i) + ((popc(q>>2) +
-  // khalf) & 1), column q; channel n0 + nrow[j].  The C tile goes through LDS (the A buffer the tile just finished
-  // with, two halves of FM/2 fragments) so that the global stores are 16-B chunks, BNT/8 consecutive lanes per pixel.
-  // Staging writes are 4-byte: lanes l, l^1 hold neighbouring channels of the same pixels, so they swap one value of
-  // each column pair (2m, 2m+1) by DPP and each writes one [even channel, odd channel] word - half the LDS
-  // instructions of 2-byte writes and no two lanes in one dword (measured: 50 cycles per value with ds_write_b16).
-  unsigned long long ep_w = 0, ep_b = 0, ep_s = 0;   // trace build: epilogue phase cycles
+  // khalf) & 1), column q; channel n0 + nrow[j].  Lanes l, l^1 hold neighbouring channels of the same pixels, so they
+  // swap one value of each column pair (2m, 2m+1) by DPP and each lane stores one [even channel, odd channel] 4-byte
+  // word itself.  (Staging the tile through LDS for 16-byte stores measured the same time per tile on layers 2-4 and
+  // 5 % slower on layer 1, at 50 more registers and four more barriers; 2-byte LDS staging writes were 50 cycles/value.)
+  unsigned long long ep_w = 0;   // trace build: cycles in the store part of the epilogues
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   typedef __attribute__((ext_vector_type(2))) float f32x2;
   // BatchNorm partial sums: kept in registers ACROSS the tiles of this workgroup (per column parity; combined at the
@@ -260,23 +255,15 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     }
     __syncthreads();
   };
-  auto epilogue = [&](const TileCtx& tc, unsigned char* stage, auto fullc) {
+  auto epilogue = [&](const TileCtx& tc, auto fullc) {
     constexpr bool FULL = decltype(fullc)::value;   // the tile lies completely inside the output: no masking
     const int r0 = tc.r0, c0 = tc.c0, n0 = tc.n0;
     T* out = reinterpret_cast<T*>(p.out) + (size_t)tc.b * p.OH * p.OW * p.Cout;
     const T* resg = p.res_g ? reinterpret_cast<const T*>(p.res_g) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
     const T* resa = p.res_a ? reinterpret_cast<const T*>(p.res_a) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
-    constexpr int CROW = BNT * 2;      // bytes of one pixel row of the staged C image
-    constexpr int CPR = BNT / 8;       // 16-B chunks per pixel
-    constexpr int NIT = WM * 4 * TW * CPR / NTH;   // store-loop trips per thread and half
-    constexpr int NITB = 4;
-    static_assert(NIT % NITB == 0, "store loop batches");
-    unsigned char* ldsC = stage;
-    (void)ldsC;
     // byte selector of v_perm_b32 {neighbour's packed pair, own packed pair}: even lanes build [own lo | neighbour lo],
     // odd lanes [neighbour hi | own hi]
     const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
-#if PH_EPI_DIRECT
     // direct form: after the lane-pair exchange every lane owns one [even channel, odd channel] word of one pixel and
     // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier before the statistics.
     // The residual words of a fragment row (dgrad) are all requested before the first is used.
@@ -340,79 +327,6 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       }
       ep_w += PH_CLK() - e0_;
     }
-#else
-#pragma unroll
-    for (int h = 0; h < C::NHALF; ++h) {
-      const unsigned long long e0_ = PH_CLK();
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const int i = 2 * h + ii;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
-          const int r = r0 + (wm * FM + i) * 2 + fr;
-          const int lr = wm * 4 + ii * 2 + fr;            // row of the staged half image
-          unsigned char* dst = ldsC + (lr * TW + 2 * m + (lane & 1)) * CROW;
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            f32x2 v = {acc[i][j][2 * m], acc[i][j][2 * m + 1]};
-            if constexpr (!FULL) {
-              v[0] = (r < p.OHt && c0 + 2 * m < p.OWt) ? v[0] : 0.f;
-              v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
-            }
-            s1[j] += v;
-            s2[j] += v * v;
-            bf16x2 own;
-            own[0] = (bf16)v[0];
-            own[1] = (bf16)v[1];
-            const unsigned x = __builtin_bit_cast(unsigned, own);
-            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-            *reinterpret_cast<unsigned*>(dst + (nrow[j] & ~1) * 2) = __builtin_amdgcn_perm(y, x, psel);
-          }
-        }
-      }
-      const unsigned long long e1_ = PH_CLK();
-      __syncthreads();
-      const unsigned long long e2_ = PH_CLK();
-      for (int it0 = 0; it0 < NIT; it0 += NITB) {   // NITB chunks in flight per thread (register budget)
-      bf16x8 cv[NITB];
-      size_t co[NITB];
-      bool cok[NITB];
-#pragma unroll
-      for (int it = 0; it < NITB; ++it) {
-        const int id = tid + (it0 + it) * NTH;
-        const int m = id / CPR, ch = id - m * CPR;
-        const int lr = m >> 4, col = m & 15;
-        const int r = r0 + ((lr >> 2) * FM + 2 * h + ((lr >> 1) & 1)) * 2 + (lr & 1), c = c0 + col;
-        cok[it] = FULL || (r < p.OHt && c < p.OWt);
-        co[it] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + ch * 8;
-        cv[it] = *reinterpret_cast<const bf16x8*>(ldsC + m * CROW + ch * 16);
-      }
-      if (resg) {
-#pragma unroll
-        for (int it = 0; it < NITB; ++it) {
-          if (!cok[it]) continue;
-          const bf16x8 g = *reinterpret_cast<const bf16x8*>(resg + co[it]);
-          if (resa) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(resa + co[it]);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cv[it][k] = (bf16)((float)cv[it][k] + ((float)a[k] > 0.f ? (float)g[k] : 0.f));
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cv[it][k] = (bf16)((float)cv[it][k] + (float)g[k]);
-          }
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < NITB; ++it)
-        if (cok[it]) *reinterpret_cast<bf16x8*>(out + co[it]) = cv[it];
-      }
-      const unsigned long long e3_ = PH_CLK();
-      __syncthreads();
-      const unsigned long long e4_ = PH_CLK();
-      ep_w += e1_ - e0_; ep_b += (e2_ - e1_) + (e4_ - e3_); ep_s += e3_ - e2_;
-    }
-#endif
   };
 
   // ---- the tap stream.  Tile (outer loop) -> 64-channel slice -> 9 taps (fully unrolled: tap offsets, the piece of
@@ -571,9 +485,8 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     if constexpr (RES) PH_BARRIER();   // no per-tap barrier in this configuration: all waves are done with the A buffer
     const unsigned long long q3_ = PH_CLK();
     cyc_b += q3_ - q2b_;
-    // (stages through the A buffer the tile finished with; ends on a barrier)
-    if ((tcur.r0 + TH <= p.OHt) && (tcur.c0 + TW <= p.OWt)) epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::true_type{});
-    else epilogue(tcur, smem + (acur ^ 1) * C::A_BYTES, std::false_type{});
+    if ((tcur.r0 + TH <= p.OHt) && (tcur.c0 + TW <= p.OWt)) epilogue(tcur, std::true_type{});
+    else epilogue(tcur, std::false_type{});
     if (p.stats && (!nvalid || tnext.n0 != tcur.n0)) flush_stats(tcur.n0, smem + (acur ^ 1) * C::A_BYTES);
     zero_acc();
     cyc_e += PH_CLK() - q3_;
@@ -597,7 +510,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     }
   }
   PH_TRACE(5);
-  PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_b); PH_TRACE_ACC(3, cyc_e); PH_TRACE_ACC(9, ep_w); PH_TRACE_ACC(4, cyc_s); PH_TRACE_ACC(7, cyc_x); (void)cyc_s; (void)cyc_x; (void)ep_w; (void)ep_b; (void)ep_s;
+  PH_TRACE_ACC(6, cyc_c); PH_TRACE_ACC(8, cyc_b); PH_TRACE_ACC(3, cyc_e); PH_TRACE_ACC(9, ep_w); PH_TRACE_ACC(4, cyc_s); PH_TRACE_ACC(7, cyc_x); (void)cyc_s; (void)cyc_x; (void)ep_w;
   PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)gt);
 }
 

@@ -393,6 +393,39 @@ class DistillStep:
         self.iter_num += 1
         return st["out"]
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything a bit-identical resume needs.  The reference saves `model_state_dict` + `optimizer_state_dict`
+        only (train_test_path_multi_distill.py:387-402) and silently loses the CRD banks, their normalisation
+        constants Z, the embed heads' optimiser state, the EMA model and the step counter; the first two keys are kept
+        reference-compatible, the rest is added."""
+        rng = {}
+        for name, mod in self.fix_model.named_modules():
+            if hasattr(mod, "rng_step"):
+                rng[name] = mod.rng_step.clone()
+        return dict(model_state_dict=self.model.state_dict(), optimizer_state_dict=self.optimizer.state_dict(),
+                    ema_model_state_dict=self.ema_model.state_dict(), teacher_state_dict=self.fix_model.state_dict(),
+                    crd_kd_state_dict=self.criterion_kd.state_dict(),
+                    crd_kd_path_state_dict=self.criterion_kd_path.state_dict(),
+                    scheduler_state_dict=self.scheduler.state_dict(), iter_num=self.iter_num,
+                    teacher_rng_steps=rng)
+
+    def load_state_dict(self, sd):
+        self.model.load_state_dict(sd["model_state_dict"])
+        self.ema_model.load_state_dict(sd["ema_model_state_dict"])
+        self.fix_model.load_state_dict(sd["teacher_state_dict"])
+        for crd, key in ((self.criterion_kd, "crd_kd_state_dict"), (self.criterion_kd_path, "crd_kd_path_state_dict")):
+            crd.load_state_dict(sd[key])
+            crd.contrast._z_set = bool((crd.contrast.params[2:4] > 0).all().item())
+        self.optimizer.load_state_dict(sd["optimizer_state_dict"])
+        self.scheduler.load_state_dict(sd["scheduler_state_dict"])
+        self.iter_num = sd["iter_num"]
+        for name, mod in self.fix_model.named_modules():
+            if hasattr(mod, "rng_step") and name in sd.get("teacher_rng_steps", {}):
+                mod.rng_step.copy_(sd["teacher_rng_steps"][name])
+        ops.bump_weight_epoch()      # packed MFMA weight images are rebuilt from the loaded parameters
+        self._static = None          # a captured graph keeps pointing at valid buffers, but is rebuilt to be safe
+
     def static_inputs(self):
         """The graph path's resident input buffers (fill them in place to skip the device-to-device copy)."""
         st = getattr(self, "_static", None)

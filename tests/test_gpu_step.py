@@ -141,3 +141,39 @@ def test_perf_mode_step_vs_rounded_oracle_and_determinism():
           f"mean {e_emu.mean():.4f} ; |dloss| HIP {dl_gpu:.4f} emu {dl_emu:.4f} (loss {ref32['loss'].item():.4f})")
     assert e_gpu.mean() <= 2.0 * e_emu.mean() + 1e-3
     assert e_gpu.max() <= 3.0 * e_emu.max() + 1e-3
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """Row f-3 (resume): save after two steps, rebuild a fresh DistillStep from the state dict, and the third step must be
+    bitwise the same as the uninterrupted run - including the CRD banks / Z and the teacher's dropout stream, which the
+    reference's own checkpoint (train_test_path_multi_distill.py:387-402) does not carry."""
+    import copy
+    import multimodal_learning_amd as m
+    from bench import make_batch
+    m.set_precision("bf16")
+    opt = m.stage2_opt(dropout_rate=0.1, batch_size=8)
+    n_data = 256
+    torch.manual_seed(0); np.random.seed(7)
+    a = m.DistillStep(opt, n_data, device="cuda")
+    for crd in (a.criterion_kd, a.criterion_kd_path):
+        crd.contrast.verbose = False
+    batches = [make_batch(8, 64, n_data, opt, "cuda", seed=i) for i in range(3)]
+    ranks = [[list(range(30, 50)), list(range(40, 60))] for _ in range(3)]
+    for i in range(2):
+        a.step(batches[i], epoch=1, ranks=ranks[i])
+    sd = copy.deepcopy(a.state_dict())
+    out_a = a.step(batches[2], epoch=1, ranks=ranks[2])
+    torch.manual_seed(123); np.random.seed(99)             # a differently initialised object ...
+    b = m.DistillStep(m.stage2_opt(dropout_rate=0.1, batch_size=8), n_data, device="cuda")
+    for crd in (b.criterion_kd, b.criterion_kd_path):
+        crd.contrast.verbose = False
+    b.step(batches[0], epoch=1, ranks=ranks[0])            # ... that has even taken a step of its own
+    b.load_state_dict(sd)
+    out_b = b.step(batches[2], epoch=1, ranks=ranks[2])
+    for k in ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2"):
+        assert torch.equal(out_a[k], out_b[k]), k
+    assert torch.equal(a.optimizer.flat.flat, b.optimizer.flat.flat)
+    assert torch.equal(a.ema_flat.flat, b.ema_flat.flat)
+    for ca, cb in ((a.criterion_kd, b.criterion_kd), (a.criterion_kd_path, b.criterion_kd_path)):
+        assert torch.equal(ca.contrast.memory_v1, cb.contrast.memory_v1)
+        assert torch.equal(ca.contrast.params, cb.contrast.params)

@@ -50,4 +50,4 @@ for name, Cin, Cout, H in shapes:
     print(f"{name}: Cin {Cin} Cout {Cout} HW {H}: span {span:.1f} us ({fl / span / 1e6:.0f} TFLOP/s), workgroup life {np.median(life):.1f} us, "
           f"prologue {np.median(prol):.2f} us, {ns:.0f} stages/workgroup")
     print(f"    loop {loop:.0f} cyc = {loop / ns:.0f}/stage ({loop / np.median(life - prol) / 1e3:.2f} GHz): taps (MFMA stream + DMA issue + tap barriers) {med(6) / ns:.0f}, "
-          f"pre-epilogue barrier {med(8) / ns:.0f}, epilogues {med(3) / ns:.0f} (= {med(3) / ntile:.0f} per tile), epilogue phases per tile: C -> LDS {med(9) / ntile:.0f}, slice setup {med(4) / ntile:.0f}, tile switch {med(7) / ntile:.0f} per tile  (MFMA floor 1024/tap)")
+          f"pre-epilogue barrier {med(8) / ns:.0f}, epilogues {med(3) / ns:.0f} (= {med(3) / ntile:.0f} per tile), epilogue store part per tile {med(9) / ntile:.0f}, slice setup {med(4) / ntile:.0f}, tile switch {med(7) / ntile:.0f} per tile  (MFMA floor 1024/tap)")
