@@ -231,33 +231,16 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   f32x2 s1[FN], s2[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
-  const bool bnb = p.bnb_y != nullptr;   // statistics of a BatchNorm BACKWARD (dgrad launch) instead of the forward ones
   auto flush_stats = [&](int n0, unsigned char* scratch) {   // all threads; `scratch`: an A buffer nobody reads
     float* red = reinterpret_cast<float*>(scratch);          // [WM][2][BNT]
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      if (!bnb) {
-        // forward: the lane's own channel nrow[j], the two components are the column parities
-        const float t1 = s1[j][0] + s1[j][1], t2 = s2[j][0] + s2[j][1];
-        const float a1 = t1 + __shfl_xor(t1, 32, 64);
-        const float a2 = t2 + __shfl_xor(t2, 32, 64);
-        if (khalf == 0) {   // waves with the same wm cover disjoint channel ranges: one writer per (wm, channel)
-          red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
-          red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
-        }
-      } else {
-        // backward: accumulated after the lane-pair exchange - lanes l, l^1 both hold the channel pair
-        // (nrow[j] & ~1) + {0,1}, for different pixels
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          float a1 = s1[j][cc], a2 = s2[j][cc];
-          a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
-          a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
-          if (khalf == 0 && (lane & 1) == 0) {
-            red[(wm * 2 + 0) * BNT + nrow[j] + cc] = a1;
-            red[(wm * 2 + 1) * BNT + nrow[j] + cc] = a2;
-          }
-        }
+      const float t1 = s1[j][0] + s1[j][1], t2 = s2[j][0] + s2[j][1];
+      const float a1 = t1 + __shfl_xor(t1, 32, 64);
+      const float a2 = t2 + __shfl_xor(t2, 32, 64);
+      if (khalf == 0) {   // waves with the same wm cover disjoint channel ranges: one writer per (wm, channel)
+        red[(wm * 2 + 0) * BNT + nrow[j]] = a1;
+        red[(wm * 2 + 1) * BNT + nrow[j]] = a2;
       }
       s1[j] = f32x2{0.f, 0.f};
       s2[j] = f32x2{0.f, 0.f};
@@ -282,103 +265,63 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     // odd lanes [neighbour hi | own hi]
     const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
     // direct form: after the lane-pair exchange every lane owns one [even channel, odd channel] word of one pixel and
-    // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier.  The residual words
-    // (dgrad) and the BatchNorm-backward operands of half a fragment row are all requested before the first is used.
+    // stores it itself (a wave-instruction writes four 64-B runs); no LDS staging, no barrier before the statistics.
+    // The residual words of a fragment row (dgrad) are all requested before the first is used.
     {
       const unsigned long long e0_ = PH_CLK();
-      const T* bny = bnb ? reinterpret_cast<const T*>(p.bnb_y) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
-      const T* bna = (bnb && p.bnb_a) ? reinterpret_cast<const T*>(p.bnb_a) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
-      float bmu[FN][2], bis[FN][2];
-      if (bnb) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int cc = 0; cc < 2; ++cc) {
-            bmu[j][cc] = p.bnb_mean[n0 + (nrow[j] & ~1) + cc];
-            bis[j][cc] = p.bnb_invstd[n0 + (nrow[j] & ~1) + cc];
-          }
-      }
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
+        size_t o[8];
+        bool mine[8];
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
-          size_t o[4];
-          bool mine[4];
+        for (int m = 0; m < 8; ++m) {
+          const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
+          const int r = r0 + (wm * FM + i) * 2 + fr, c = c0 + 2 * m + (lane & 1);
+          mine[m] = FULL || (r < p.OHt && c < p.OWt);
+          o[m] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + (nrow[0] & ~1);
+        }
+        bf16x2 rg[8][FN], ra[8][FN];
+        if (resg) {
 #pragma unroll
-          for (int mm = 0; mm < 4; ++mm) {
-            const int m = mh * 4 + mm;
-            const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
-            const int r = r0 + (wm * FM + i) * 2 + fr, c = c0 + 2 * m + (lane & 1);
-            mine[mm] = FULL || (r < p.OHt && c < p.OWt);
-            o[mm] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + (nrow[0] & ~1);
-          }
-          bf16x2 rg[4][FN], ra[4][FN], by[4][FN], ba[4][FN];
-          if (resg) {
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-              for (int j = 0; j < FN; ++j) {
-                rg[mm][j] = bf16x2{(bf16)0.f, (bf16)0.f};
-                ra[mm][j] = bf16x2{(bf16)1.f, (bf16)1.f};
-                if (mine[mm]) {
-                  rg[mm][j] = *reinterpret_cast<const bf16x2*>(resg + o[mm] + j * 32);
-                  if (resa) ra[mm][j] = *reinterpret_cast<const bf16x2*>(resa + o[mm] + j * 32);
-                }
-              }
-          }
-          if (bnb) {
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-              for (int j = 0; j < FN; ++j) {
-                by[mm][j] = bf16x2{(bf16)0.f, (bf16)0.f};
-                ba[mm][j] = bf16x2{(bf16)1.f, (bf16)1.f};
-                if (mine[mm]) {
-                  by[mm][j] = *reinterpret_cast<const bf16x2*>(bny + o[mm] + j * 32);
-                  if (bna) ba[mm][j] = *reinterpret_cast<const bf16x2*>(bna + o[mm] + j * 32);
-                }
-              }
-          }
-#pragma unroll
-          for (int mm = 0; mm < 4; ++mm) {
-            const int m = mh * 4 + mm;
+          for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-              f32x2 v = {acc[i][j][2 * m], acc[i][j][2 * m + 1]};
-              if constexpr (!FULL) {
-                const int fr = (__popc(m >> 1) + khalf) & 1;
-                const int r = r0 + (wm * FM + i) * 2 + fr;
-                v[0] = (r < p.OHt && c0 + 2 * m < p.OWt) ? v[0] : 0.f;
-                v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
+              rg[m][j] = bf16x2{(bf16)0.f, (bf16)0.f};
+              ra[m][j] = bf16x2{(bf16)1.f, (bf16)1.f};
+              if (mine[m]) {
+                rg[m][j] = *reinterpret_cast<const bf16x2*>(resg + o[m] + j * 32);
+                if (resa) ra[m][j] = *reinterpret_cast<const bf16x2*>(resa + o[m] + j * 32);
               }
-              if (!bnb) {   // forward BatchNorm statistics of the fp32 accumulators
-                s1[j] += v;
-                s2[j] += v * v;
-              }
-              bf16x2 own;
-              own[0] = (bf16)v[0];
-              own[1] = (bf16)v[1];
-              const unsigned x = __builtin_bit_cast(unsigned, own);
-              const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
-              bf16x2 w = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(y, x, psel));
-              if (resg) {
-                w[0] = (bf16)((float)w[0] + ((float)ra[mm][j][0] > 0.f ? (float)rg[mm][j][0] : 0.f));
-                w[1] = (bf16)((float)w[1] + ((float)ra[mm][j][1] > 0.f ? (float)rg[mm][j][1] : 0.f));
-              }
-              if (bnb && mine[mm]) {   // BatchNorm-backward partial sums of the gradient exactly as it is stored
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                  const float dz = (float)ba[mm][j][cc] > 0.f ? (float)w[cc] : 0.f;
-                  s1[j][cc] += dz;
-                  s2[j][cc] += dz * (((float)by[mm][j][cc] - bmu[j][cc]) * bis[j][cc]);
-                }
-              }
-#ifdef PH_ABL_NOSTORE   // timing ablation only
-              asm volatile("" ::"v"(w));
-#else
-              if (mine[mm]) *reinterpret_cast<bf16x2*>(out + o[mm] + j * 32) = w;
-#endif
             }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            f32x2 v = {acc[i][j][2 * m], acc[i][j][2 * m + 1]};
+            if constexpr (!FULL) {
+              const int fr = (__popc(m >> 1) + khalf) & 1;
+              const int r = r0 + (wm * FM + i) * 2 + fr;
+              v[0] = (r < p.OHt && c0 + 2 * m < p.OWt) ? v[0] : 0.f;
+              v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
+            }
+            s1[j] += v;
+            s2[j] += v * v;
+            bf16x2 own;
+            own[0] = (bf16)v[0];
+            own[1] = (bf16)v[1];
+            const unsigned x = __builtin_bit_cast(unsigned, own);
+            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            bf16x2 w = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(y, x, psel));
+            if (resg) {
+              w[0] = (bf16)((float)w[0] + ((float)ra[m][j][0] > 0.f ? (float)rg[m][j][0] : 0.f));
+              w[1] = (bf16)((float)w[1] + ((float)ra[m][j][1] > 0.f ? (float)rg[m][j][1] : 0.f));
+            }
+#ifdef PH_ABL_NOSTORE   // timing ablation only
+            asm volatile("" ::"v"(w));
+#else
+            if (mine[m]) *reinterpret_cast<bf16x2*>(out + o[m] + j * 32) = w;
+#endif
           }
         }
       }

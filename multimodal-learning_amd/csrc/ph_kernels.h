@@ -28,14 +28,6 @@ struct PhTapConv {
   float* stats;          // [B*tiles][2][Cout] per-workgroup sum / sum-of-squares partials, or null
   const void* res_g;     // optional: out += res_g * (res_a > 0 | 1)   (dgrad residual fusion)
   const void* res_a;
-  // optional (second-generation kernel, dgrad launches): the gradient this launch writes feeds a BatchNorm backward -
-  // dz = out * (bnb_a > 0), x_hat = (bnb_y - bnb_mean) * bnb_invstd, both tensors laid out like `out` - and the launch
-  // also leaves that BN's partial sums (sum dz, sum dz * x_hat per channel) as rows [workgroups][2][Cout] in `stats`,
-  // which replaces the separate bn_bwd_reduce pass over (g, a, y)
-  const void* bnb_y;
-  const void* bnb_a;
-  const float* bnb_mean;
-  const float* bnb_invstd;
   int B, IH, IW, Cin, Cout;
   int OHt, OWt;          // extent of the (r,c) output-position space this launch covers
   int OH, OW;            // full output tensor dims; output pixel = (r*os+oa_h, c*os+oa_w)

@@ -8,7 +8,6 @@
 // Saved for backward per BasicBlock: x_in, y1, a1, y2, (y_ds), out.
 #include <new>
 #include <vector>
-#include <cstdlib>
 #include "ph_common.h"
 #include "ph_kernels.h"
 #include "ph_dense.h"
@@ -39,7 +38,7 @@ struct PhResnetPlan {
   std::vector<Unit> units;
   std::vector<Block> blocks;
   size_t x4_off, p0_off, idx_off, parts_off, parts_bytes;
-  size_t g0_off, g1_off, dy_off, da_off, slab_off, slab_bytes, bparts_off, bparts2_off, cc_off, zero_off;
+  size_t g0_off, g1_off, dy_off, da_off, slab_off, slab_bytes, bparts_off, cc_off, zero_off;
   size_t ws_bytes, packed_bytes;
   int PH0, PW0;   // pooled dims
   size_t act_max;   // max block-level activation bytes
@@ -144,7 +143,6 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
     const size_t a = (size_t)1024 * 2 * 512, b = stem_rows * 2 * 64;
     P->bparts_off = take((a > b ? a : b) * sizeof(float));
   }
-  P->bparts2_off = take((size_t)1024 * 2 * 512 * sizeof(float));   // BN-backward rows a dgrad launch leaves for the NEXT block's bn2
   P->cc_off = take(2 * 512 * sizeof(float));
   P->zero_off = take(256);
   P->ws_bytes = off;
@@ -228,18 +226,13 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
                                (int64_t*)c.params[ui * 6 + 5], c.st);
 }
 
-// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual).
-// If `bn_unit` >= 0 and the launch runs the second-generation kernel, the epilogue also accumulates the BatchNorm-
-// backward partial sums of unit bn_unit (whose dz = dX * (bn_a > 0)) into `bn_parts` and *bn_nparts is set to the
-// number of rows written; otherwise *bn_nparts stays 0 and the caller runs the separate reduce pass.
-int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a, int bn_unit = -1,
-               const void* bn_a = nullptr, float* bn_parts = nullptr, int* bn_nparts = nullptr) {
+// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual)
+int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhTapConv t{};
   t.in = dy; t.w = c.pk + u.wd_off; t.wplane = u.wplane;
   t.out = dx; t.stats = nullptr; t.res_g = res_g; t.res_a = res_a;
-  if (bn_nparts) *bn_nparts = 0;
   t.B = P->B; t.IH = u.OH; t.IW = u.OW; t.Cin = u.Cout; t.Cout = u.Cin;
   t.OH = u.IH; t.OW = u.IW;
   if (u.S == 1) {
@@ -248,13 +241,6 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
     for (int k = 0; k < t.ntaps; ++k) {
       const int dyy = k / u.KS, dxx = k % u.KS;
       t.dy[k] = dyy; t.dx[k] = dxx; t.wtap[k] = (u.KS - 1 - dyy) * u.KS + (u.KS - 1 - dxx);
-    }
-    static const bool no_fuse = getenv("PH_NO_FUSED_BNB") != nullptr;   // A/B and test switch: separate reduce pass
-    if (!no_fuse && bn_unit >= 0 && bn_parts && bn_nparts && ph_tapconv2_tile_h(&t, 1, P->prec)) {
-      const Unit& bu = P->units[bn_unit];
-      t.bnb_y = c.ws + bu.y_off; t.bnb_a = bn_a; t.bnb_mean = c.stat(bu, 0); t.bnb_invstd = c.stat(bu, 1);
-      t.stats = bn_parts;
-      *bn_nparts = ph_tapconv_stat_parts(&t, 1, P->prec);
     }
     return ph_tapconv_launch(&t, 1, P->prec, c.st);
   }
@@ -306,9 +292,7 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
 }
 
 // BN backward of unit ui: dz = g * (a > 0) -> dgamma/dbeta, dy (into ws dy buffer)
-// (fused_parts / fused_nparts: partial rows the producing dgrad launch already accumulated - no reduce pass then)
-int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta,
-           const float* fused_parts = nullptr, int fused_nparts = 0) {
+int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   const size_t npix = (size_t)P->B * u.OH * u.OW;
@@ -316,16 +300,9 @@ int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* 
   float* c1 = reinterpret_cast<float*>(c.ws + P->cc_off);
   float* c2 = c1 + 512;
   const void* y = c.ws + u.y_off;
-  int rc = PH_OK;
-  int nparts = fused_nparts;
-  const float* rows = fused_parts;
-  if (!(fused_parts && fused_nparts > 0)) {
-    rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, c.st);
-    if (rc) return rc;
-    nparts = ph_bn_bwd_parts(npix, u.Cout);
-    rows = parts;
-  }
-  rc = ph_bn_bwd_finalize_launch(rows, nparts, u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
+  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, c.st);
+  if (rc) return rc;
+  rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix, u.Cout), u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
   if (rc) return rc;
   return ph_bn_bwd_apply_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), (const float*)c.params[ui * 6 + 1], c1, c2, dy, npix,
                                 u.Cout, P->prec, c.st);
@@ -416,9 +393,6 @@ int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const v
     const Block& b = P->blocks[7];
     if ((rc = ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st))) return rc;
   }
-  float* parts1 = reinterpret_cast<float*>(ws + P->bparts_off);    // rows for bn1 of the block in progress
-  float* parts2 = reinterpret_cast<float*>(ws + P->bparts2_off);   // rows for bn2 of the NEXT block to be processed
-  int nparts_bn2 = 0;
   for (int bi = 7; bi >= 0; --bi) {
     const Block& b = P->blocks[bi];
     if (bi == 5 && g_f3)
@@ -426,25 +400,16 @@ int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const v
     const void* out = ws + b.out_off;
     const void* a1 = ws + b.a1_off;
     const void* xin = ws + b.in_off;
-    // bn2 <- d_out * (out > 0)   (its partial sums may already have been left by the previous block's conv1 dgrad)
-    if ((rc = bn_bwd(c, b.u2, gcur, out, dyb, (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2], parts2,
-                     nparts_bn2)))
-      return rc;
-    nparts_bn2 = 0;
+    // bn2 <- d_out * (out > 0)
+    if ((rc = bn_bwd(c, b.u2, gcur, out, dyb, (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]))) return rc;
     if ((rc = conv_wgrad(c, b.u2, a1, dyb, (float*)grads[b.u2 * 3 + 0]))) return rc;
-    // d_a1 = dgrad(conv2); the same launch accumulates bn1's backward partial sums (dz = d_a1 * (a1 > 0), y = y1)
-    int nparts_bn1 = 0;
-    if ((rc = conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr, b.u1, a1, parts1, &nparts_bn1))) return rc;
+    if ((rc = conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr))) return rc;
     // bn1 <- d_a1 * (a1 > 0)
-    if ((rc = bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], parts1,
-                     nparts_bn1)))
-      return rc;
+    if ((rc = bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2]))) return rc;
     if ((rc = conv_wgrad(c, b.u1, xin, dyb, (float*)grads[b.u1 * 3 + 0]))) return rc;
     if (b.uds < 0) {
-      // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue; d_xin is the
-      // gradient of the previous block's output, so the launch also accumulates THAT block's bn2 partial sums
-      const int prev_u2 = bi > 0 ? P->blocks[bi - 1].u2 : -1;
-      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, gcur, out, prev_u2, xin, parts2, &nparts_bn2))) return rc;
+      // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
+      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, gcur, out))) return rc;
     } else {
       if ((rc = conv_dgrad(c, b.u1, dyb, gnext, nullptr, nullptr))) return rc;
       if ((rc = bn_bwd(c, b.uds, gcur, out, dyb, (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]))) return rc;

@@ -146,43 +146,3 @@ def test_eval_mode_forward_vs_reference(golden_dir):
         R.finish()
     finally:
         m.set_precision("bf16")
-
-
-def test_fused_bn_backward_statistics_match_separate_reduce():
-    """Perf mode: the BatchNorm-backward partial sums accumulated in the dgrad epilogue (conv_tap2.hip) against the
-    separate bn_bwd_reduce pass (PH_NO_FUSED_BNB=1 in a child process): every gradient of the student must agree to
-    summation-order noise."""
-    import subprocess, sys, os, tempfile, textwrap
-    code = textwrap.dedent("""
-        import sys, torch, numpy as np
-        sys.path.insert(0, %r)
-        import multimodal_learning_amd as m
-        m.set_precision("bf16")
-        torch.manual_seed(0)
-        opt = m.stage2_opt(dropout_rate=0.0, batch_size=8)
-        net = m.define_net(opt, 1, path_only=True).cuda().train()
-        g = torch.Generator().manual_seed(5)
-        x = (torch.rand(8, 3, 128, 128, generator=g) * 2 - 1).cuda()
-        f3, feat, hazard, pred, _ = net(x_path=x)
-        (pred.square().sum() + feat.sum() * 0.01 + f3.sum() * 0.01).backward()
-        out = {n: p.grad.detach().float().cpu().numpy() for n, p in net.named_parameters() if p.grad is not None}
-        np.savez(sys.argv[1], **out)
-    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = []
-    for env_extra in ({}, {"PH_NO_FUSED_BNB": "1"}):
-        with tempfile.NamedTemporaryFile(suffix=".npz", delete=False) as f:
-            path = f.name
-        env = dict(os.environ, **env_extra)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
-        res.append(dict(np.load(path)))
-        os.unlink(path)
-    fused, sep = res
-    assert set(fused) == set(sep) and len(fused) > 60
-    rel = {k: float(np.abs(fused[k] - sep[k]).max() / max(np.abs(sep[k]).max(), 1e-6)) for k in fused}
-    # The first fused BatchNorm of the backward pass (layer4.1.bn1) sees bit-identical inputs in both runs, so its
-    # dgamma / dbeta differ by fp32 summation order only; everything upstream of it (computed later) then differs by the
-    # bf16 re-rounding of dy that a last-bit change of the statistics causes.
-    assert rel["layer4.1.bn2.weight"] == 0.0 and rel["layer4.1.bn2.bias"] == 0.0, rel     # not fused: identical
-    assert rel["layer4.1.bn1.weight"] < 1e-5 and rel["layer4.1.bn1.bias"] < 1e-5, (rel["layer4.1.bn1.weight"], rel["layer4.1.bn1.bias"])
-    worst = max(rel.values())
-    assert worst < 5e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:5]
