@@ -33,6 +33,8 @@ typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
 #define PH_EW_GATE 1
 #define PH_EW_RELU_BWD 2
 #define PH_EW_ADD 3
+#define PH_EW_ELU_BWD 4  /* a * ELU'(x) given b = ELU(x) */
+#define PH_EW_MUL 5
 
 int ph_abi_version(void);
 
@@ -116,6 +118,15 @@ int ph_dropout(float* x, size_t n, float p, uint64_t seed, uint64_t offset, int 
 int ph_dropout_dev(float* x, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_counter,
                    int alpha, ph_stream_t stream);
 int ph_counter_inc(uint64_t* counter, ph_stream_t stream);
+/* Backward of the SNN / fusion operators (stage-1 teacher training, SURVEY row f-1: train_test_MT.py:42-337 needs the
+ * gradients of networks_new.py:223-251 and fusion.py:36-63).  ph_dropout_bwd_dev re-creates the forward mask from the
+ * same (seed, site_offset, step counter value); ph_gate_bwd: y = sigmoid(z) * h; ph_outer_bwd: the two operands of
+ * ph_outer. */
+int ph_dropout_bwd_dev(float* g, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_counter,
+                       int alpha, ph_stream_t stream);
+int ph_gate_bwd(const float* g, const float* z, const float* h, float* dz, float* dh, size_t n, ph_stream_t stream);
+int ph_outer_bwd(const float* g, const float* o1, const float* o2, float* do1, float* do2, int B, int D1, int D2,
+                 int append_one, ph_stream_t stream);
 int ph_sum(const float* x, float* out, int n, float scale, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

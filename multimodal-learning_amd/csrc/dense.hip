@@ -481,6 +481,8 @@ __global__ void eltwise_kernel(const float* __restrict__ a, const float* __restr
     case PH_EW_GATE: v = (1.f / (1.f + expf(-a[i]))) * b[i]; break;   // sigmoid(z) * h
     case PH_EW_RELU_BWD: v = b[i] > 0.f ? a[i] : 0.f; break;          // g * (y > 0)
     case PH_EW_ADD: v = a[i] + b[i]; break;
+    case PH_EW_ELU_BWD: v = b[i] > 0.f ? a[i] : a[i] * (b[i] + 1.f); break;   // g * ELU'(x), from y = ELU(x)
+    case PH_EW_MUL: v = a[i] * b[i]; break;
     default: v = a[i];
   }
   o[i] = v;
@@ -526,6 +528,52 @@ __global__ void dropout_kernel(float* __restrict__ x, size_t n, float p, uint64_
 }
 
 // graph-replayable variant: the per-step part of the RNG counter lives in device memory
+// backward of the (alpha-)dropout applied by dropout_dev_kernel with the same (seed, site_offset, step counter):
+// g <- g * d(out)/d(in)   (plain: keep / (1-p); alpha: a * keep)
+__global__ void dropout_bwd_dev_kernel(float* __restrict__ g, size_t n, float p, uint64_t seed, uint64_t site_offset,
+                                       const uint64_t* __restrict__ step_ctr, int alpha) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t ctr = (*step_ctr << 34) ^ (site_offset + i);
+  const bool keep = u01(seed, ctr) >= p;
+  if (!alpha) {
+    g[i] = keep ? g[i] / (1.f - p) : 0.f;
+  } else {
+    const float ap = -1.7580993408473766f;
+    const float a = rsqrtf((1.f - p) * (1.f + p * ap * ap));
+    g[i] = keep ? a * g[i] : 0.f;
+  }
+}
+
+// backward of y = sigmoid(z) * h  (fusion.py:44-45,51-52)
+__global__ void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ h,
+                                float* __restrict__ dz, float* __restrict__ dh, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = 1.f / (1.f + expf(-z[i]));
+  dz[i] = g[i] * h[i] * s * (1.f - s);
+  dh[i] = g[i] * s;
+}
+
+// backward of outer_kernel: do1[b][i] = sum_j g[b][i*E2+j] * o2e[b][j], do2[b][j] = sum_i g[b][i*E2+j] * o1e[b][i]
+// (o?e = o? with the implicit trailing 1 when append_one).  One block per batch row.
+__global__ __launch_bounds__(256) void outer_bwd_kernel(const float* __restrict__ g, const float* __restrict__ o1,
+                                                        const float* __restrict__ o2, float* __restrict__ do1,
+                                                        float* __restrict__ do2, int D1, int D2, int append_one) {
+  const int b = blockIdx.x, E1 = D1 + append_one, E2 = D2 + append_one;
+  const float* gb = g + (size_t)b * E1 * E2;
+  for (int i = threadIdx.x; i < D1; i += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < E2; ++j) s += gb[(size_t)i * E2 + j] * (j < D2 ? o2[(size_t)b * D2 + j] : 1.f);
+    do1[(size_t)b * D1 + i] = s;
+  }
+  for (int j = threadIdx.x; j < D2; j += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < E1; ++i) s += gb[(size_t)i * E2 + j] * (i < D1 ? o1[(size_t)b * D1 + i] : 1.f);
+    do2[(size_t)b * D2 + j] = s;
+  }
+}
+
 __global__ void dropout_dev_kernel(float* __restrict__ x, size_t n, float p, uint64_t seed, uint64_t site_offset,
                                    const uint64_t* __restrict__ step_ctr, int alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -685,6 +733,24 @@ int ph_dropout_dev(float* x, size_t n, float p, uint64_t seed, uint64_t site_off
                    hipStream_t st) {
   if (p <= 0.f) return PH_OK;
   hipLaunchKernelGGL(dropout_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, x, n, p, seed, site_offset, step_ctr, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_dropout_bwd_dev(float* g, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_ctr,
+                       int alpha, hipStream_t st) {
+  if (p <= 0.f) return PH_OK;
+  hipLaunchKernelGGL(dropout_bwd_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, g, n, p, seed, site_offset, step_ctr, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_gate_bwd(const float* g, const float* z, const float* h, float* dz, float* dh, size_t n, hipStream_t st) {
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(nblk(n)), dim3(256), 0, st, g, z, h, dz, dh, n);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_outer_bwd(const float* g, const float* o1, const float* o2, float* do1, float* do2, int B, int D1, int D2,
+                 int append_one, hipStream_t st) {
+  hipLaunchKernelGGL(outer_bwd_kernel, dim3(B), dim3(256), 0, st, g, o1, o2, do1, do2, D1, D2, append_one);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

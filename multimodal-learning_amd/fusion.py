@@ -2,8 +2,8 @@
 parameter names and forward(vec1, vec2) -> [B, mmhid]; the arithmetic runs through the C-ABI dense
 kernels.  The Kronecker product o1 (x) o2 is formed by ``ph_outer`` and contracted by a split-K SGEMM.
 
-Forward only (the teacher is frozen on the stage-2 hot path, train_test_path_multi_distill.py:170-173);
-training this module is the stage-1 'next' row f-1.
+The frozen stage-2 teacher (train_test_path_multi_distill.py:170-173) runs the fused forward-only calls; when a gradient
+is required (stage-1 teacher training, row f-1) the same arithmetic runs taped through ops.*Fn.
 """
 import torch
 import torch.nn as nn
@@ -54,8 +54,7 @@ class BilinearFusion(nn.Module):
     def forward(self, vec1, vec2):
         if torch.is_grad_enabled() and (vec1.requires_grad or vec2.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("BilinearFusion backward (stage-1 teacher training) is the 'next' row f-1; "
-                                      "run the frozen teacher under torch.no_grad() as the reference hot loop does")
+            return self._forward_autograd(vec1, vec2)     # stage-1 teacher training (row f-1)
         self._rng_offset = 0     # per-call-site offsets are static; the device step counter makes steps differ
         v1 = ops.eltwise(vec1, None, ops.EW_RELU)                                   # fusion.py:38-39
         v2 = ops.eltwise(vec2, None, ops.EW_RELU)
@@ -75,6 +74,36 @@ class BilinearFusion(nn.Module):
         out = self._drop(self._bn_relu(out, self.encoder1[1]))
         out = ops.linear_fwd(out, self.encoder2[0].weight, self.encoder2[0].bias)
         out = self._drop(self._bn_relu(out, self.encoder2[1]))
+        if self.training and self.dropout_rate > 0:
+            ops.counter_inc(self.rng_step)
+        return out
+
+    # ---- taped form of the same arithmetic (same dropout call sites and offsets, so both paths draw the same masks)
+    def _drop_ag(self, x):
+        if self.training and self.dropout_rate > 0:
+            x = ops.DropoutFn.apply(x, self.dropout_rate, self.rng_seed, self._rng_offset, self.rng_step, False)
+            self._rng_offset += x.numel()
+        return x
+
+    def _forward_autograd(self, vec1, vec2):
+        self._rng_offset = 0
+        v1 = ops.ReluFn.apply(ops._f32(vec1))
+        v2 = ops.ReluFn.apply(ops._f32(vec2))
+        D1, D2 = v1.shape[1], v2.shape[1]
+        v12 = ops.OuterFn.apply(v1, v2, 0)
+        h1 = ops.LinearActFn.apply(v1, self.linear_h1[0].weight, self.linear_h1[0].bias, ops.ACT_RELU)
+        z1 = ops.LinearFn.apply(v12, self.linear_z1.weight.view(-1, D1 * D2), self.linear_z1.bias)
+        o1 = self._drop_ag(ops.LinearActFn.apply(ops.GateFn.apply(z1, h1), self.linear_o1[0].weight,
+                                                 self.linear_o1[0].bias, ops.ACT_RELU))
+        h2 = ops.LinearActFn.apply(v2, self.linear_h2[0].weight, self.linear_h2[0].bias, ops.ACT_RELU)
+        z2 = ops.LinearFn.apply(v12, self.linear_z2.weight.view(-1, D1 * D2), self.linear_z2.bias)
+        o2 = self._drop_ag(ops.LinearActFn.apply(ops.GateFn.apply(z2, h2), self.linear_o2[0].weight,
+                                                 self.linear_o2[0].bias, ops.ACT_RELU))
+        o12 = self._drop_ag(ops.OuterFn.apply(o1, o2, 1))
+        out = ops.LinearFn.apply(o12, self.encoder1[0].weight, self.encoder1[0].bias)
+        out = self._drop_ag(self._bn_relu(out, self.encoder1[1]))
+        out = ops.LinearFn.apply(out, self.encoder2[0].weight, self.encoder2[0].bias)
+        out = self._drop_ag(self._bn_relu(out, self.encoder2[1]))
         if self.training and self.dropout_rate > 0:
             ops.counter_inc(self.rng_step)
         return out

@@ -95,7 +95,8 @@ def define_bifusion(fusion_type, skip=1, use_bilinear=1, gate1=1, gate2=1, dim1=
 
 class MaxNet(nn.Module):
     """Genomic SNN (networks_new.py:182-251): 4 x (Linear-ELU-AlphaDropout), ReLU, Linear, act.
-    forward(**kwargs) -> (features, out, pred, None).  Forward only on the stage-2 hot path."""
+    forward(**kwargs) -> (features, out, pred, None).  Fused forward-only calls for the frozen stage-2 teacher; a taped
+    path (ops.LinearActFn / DropoutFn / ReluFn) when a gradient is required (stage-1 training, row f-1)."""
 
     def __init__(self, input_dim=80, omic_dim=32, return_grad="False", dropout_rate=0.25, act=None, label_dim=1,
                  init_max=True):
@@ -120,10 +121,10 @@ class MaxNet(nn.Module):
 
     def forward(self, **kwargs):
         x = kwargs["x_omic"]
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("MaxNet backward (stage-1 teacher training) is the 'next' row f-1")
         if self.return_grad == "True":
             raise NotImplementedError("return_grad needs the reference's absent my_utils.compute_gradients")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_autograd(x)     # stage-1 teacher training (row f-1): same arithmetic, taped
         h = x
         self._rng_offset = 0
         for i in range(4):
@@ -142,6 +143,30 @@ class MaxNet(nn.Module):
                 raise NotImplementedError("only act_type 'LSM' is on the hot path")
             pred = ops.LogSoftmaxFn.apply(out)
         return features, out, pred, None
+
+
+def _maxnet_forward_autograd(self, x):
+    h = x
+    self._rng_offset = 0
+    for i in range(4):
+        lin = self.encoder[i][0]
+        h = ops.LinearActFn.apply(h, lin.weight, lin.bias, ops.ACT_ELU)
+        if self.training and self.dropout_rate > 0:
+            h = ops.DropoutFn.apply(h, self.dropout_rate, self.rng_seed, self._rng_offset, self.rng_step, True)
+            self._rng_offset += h.numel()
+    if self.training and self.dropout_rate > 0:
+        ops.counter_inc(self.rng_step)
+    features = ops.ReluFn.apply(h)
+    out = ops.LinearFn.apply(features, self.classifier[0].weight, self.classifier[0].bias)
+    pred = None
+    if self.act is not None:
+        if not isinstance(self.act, nn.LogSoftmax):
+            raise NotImplementedError("only act_type 'LSM' is on the hot path")
+        pred = ops.LogSoftmaxFn.apply(out)
+    return features, out, pred, None
+
+
+MaxNet._forward_autograd = _maxnet_forward_autograd
 
 
 def get_resnet(path_dim=32, act=None, label_dim=1, **kwargs):

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import lib, check, ptr, stream, require_cuda
 
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
-EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD = 0, 1, 2, 3
+EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD, EW_ELU_BWD, EW_MUL = 0, 1, 2, 3, 4, 5
 PREC_BF16, PREC_BF16X6 = 0, 1
 
 _precision = PREC_BF16
@@ -99,6 +99,117 @@ class LinearFn(torch.autograd.Function):
             db = torch.empty(N, device=g.device, dtype=torch.float32)
             sgemm(_ones(Bn, g.device), g, None, db, 1, N, Bn, 0, 1, N, 1)   # db = 1^T dY
         return dx, dw, db
+
+
+# ---- autograd forms of the SNN / fusion operators (stage-1 teacher training).  The frozen teacher of the
+# stage-2 hot path keeps its fused forward-only calls; these are used when a gradient is required.
+class LinearActFn(torch.autograd.Function):
+    """y = act(x @ w^T + b) with act in {none, relu, elu} fused into the GEMM epilogue; backward from the saved y."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y = linear_fwd(x, w, b, act)
+        ctx.save_for_backward(x, w, y)
+        ctx.act, ctx.has_bias = act, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = _f32(g)
+        if ctx.act == ACT_RELU:
+            g = eltwise(g, y, EW_RELU_BWD)
+        elif ctx.act == ACT_ELU:
+            g = eltwise(g, y, EW_ELU_BWD)
+        elif ctx.act != ACT_NONE:
+            raise NotImplementedError("LinearActFn backward: activation %d" % ctx.act)
+        Bn, K = x.shape
+        N = w.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            sgemm(g, w, None, dx, Bn, K, N, N, 1, K, 1)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            sgemm(g, x, None, dw, N, K, Bn, 1, N, K, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, device=g.device, dtype=torch.float32)
+            sgemm(_ones(Bn, g.device), g, None, db, 1, N, Bn, 0, 1, N, 1)
+        return dx, dw, db, None
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = eltwise(x, None, EW_RELU)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return eltwise(_f32(g), y, EW_RELU_BWD)
+
+
+class DropoutFn(torch.autograd.Function):
+    """(Alpha-)dropout with the counter-based RNG of ph_dropout_dev; the backward re-creates the mask from the step
+    counter value of the forward call (a saved 8-byte device copy), so no mask tensor is stored."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, site_offset, step_counter, alpha):
+        y = _f32(x).clone()
+        check(lib().ph_dropout_dev(ptr(y), y.numel(), p, seed, site_offset, ptr(step_counter), int(alpha), stream()),
+              "ph_dropout_dev")
+        ctx.save_for_backward(step_counter.clone())
+        ctx.args = (p, seed, site_offset, int(alpha))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (ctr,) = ctx.saved_tensors
+        p, seed, site_offset, alpha = ctx.args
+        d = _f32(g).clone()
+        check(lib().ph_dropout_bwd_dev(ptr(d), d.numel(), p, seed, site_offset, ptr(ctr), alpha, stream()),
+              "ph_dropout_bwd_dev")
+        return d, None, None, None, None, None
+
+
+class GateFn(torch.autograd.Function):
+    """y = sigmoid(z) * h  (fusion.py:44-45)"""
+
+    @staticmethod
+    def forward(ctx, z, h):
+        z, h = _f32(z), _f32(h)
+        ctx.save_for_backward(z, h)
+        return eltwise(z, h, EW_GATE)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, h = ctx.saved_tensors
+        g = _f32(g)
+        dz, dh = torch.empty_like(z), torch.empty_like(h)
+        check(lib().ph_gate_bwd(ptr(g), ptr(z), ptr(h), ptr(dz), ptr(dh), z.numel(), stream()), "ph_gate_bwd")
+        return dz, dh
+
+
+class OuterFn(torch.autograd.Function):
+    """o12[b] = vec(o1e[b] (x) o2e[b]) with an optional appended 1 on both operands (fusion.py:43,56-58)"""
+
+    @staticmethod
+    def forward(ctx, o1, o2, append_one):
+        o1, o2 = _f32(o1), _f32(o2)
+        ctx.save_for_backward(o1, o2)
+        ctx.append_one = int(append_one)
+        return outer(o1, o2, ctx.append_one)
+
+    @staticmethod
+    def backward(ctx, g):
+        o1, o2 = ctx.saved_tensors
+        g = _f32(g)
+        d1, d2 = torch.empty_like(o1), torch.empty_like(o2)
+        check(lib().ph_outer_bwd(ptr(g), ptr(o1), ptr(o2), ptr(d1), ptr(d2), o1.shape[0], o1.shape[1], o2.shape[1],
+                                 ctx.append_one, stream()), "ph_outer_bwd")
+        return d1, d2, None
 
 
 class BN1dFn(torch.autograd.Function):

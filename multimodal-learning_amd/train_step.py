@@ -430,3 +430,80 @@ class DistillStep:
         """The graph path's resident input buffers (fill them in place to skip the device-to-device copy)."""
         st = getattr(self, "_static", None)
         return None if st is None else {k: st[k] for k in ("x_path", "ema_x_path", "x_omic", "grade", "index", "sample_idx")}
+
+
+class TeacherStage1Step:
+    """The batch body of the stage-1 mean-teacher trainer (MICCAI-2022/train_test_MT.py:121-230) for the
+    grading task: student PathomicNet forward/backward, EMA PathomicNet forward, three-branch NLL (:208-212),
+    `pred_KD_loss` consistency (CL_utils/KD_losses.py:12-36; --num_teachers 1/2/3, :180-201), Adam, EMA update.
+    CRD / SP / orthogonality terms of that trainer (--CRD_distill, --SP_distill, --orth_loss) are not wired here."""
+
+    def __init__(self, opt, device="cuda", k=1, models=None):
+        from .networks_new import define_net, define_optimizer, define_scheduler
+        self.opt = opt
+        self.device = torch.device(device)
+        if opt.task != "grad":
+            raise NotImplementedError("stage-1 step implements the grading task (survival/Cox is out of scope)")
+        if models is None:
+            self.model = define_net(opt, k).to(self.device)
+            self.ema_model = define_net(opt, k).to(self.device)
+        else:
+            self.model, self.ema_model = models
+        for p in self.ema_model.parameters():
+            p.detach_()                                                             # train_test_MT.py:74-76
+        self.optimizer = define_optimizer(opt, self.model)                          # :86
+        self.scheduler = define_scheduler(opt, self.optimizer)
+        self.iter_num = opt.global_step
+        self.model.train(); self.ema_model.train()
+        self.ema_flat = FlatParams(list(self.ema_model.parameters()))
+        for mod in self.ema_model.modules():
+            if hasattr(mod, "_get_packed"):
+                mod._follow_epoch = True
+        self.optimizer.ema_flat = self.ema_flat
+        self.optimizer.ema_range = (0, self.optimizer.flat.numel)
+
+    @staticmethod
+    def pred_KD_loss(p_s, p_t):
+        """KD_losses.py:27-29 (grading, sample_KD False): sum(kl_div(p_s, exp(p_t))) / B on log-probabilities - the KL
+        kernel at T = 1 (log_softmax of a log-probability vector is the vector itself)."""
+        return ops.KLFn.apply(p_s, p_t.detach(), 1.0, float(p_s.shape[0]))
+
+    def step(self, batch):
+        opt = self.opt
+        (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
+        dev = self.device
+        x_path, ema_x_path = x_path.to(dev, non_blocking=True), ema_x_path.to(dev, non_blocking=True)
+        x_omic, grade = x_omic.to(dev, non_blocking=True), grade.to(dev, non_blocking=True)
+        B = float(x_path.shape[0])
+        self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)
+        fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
+            x_path=x_path, x_omic=x_omic)                                                        # :137
+        with torch.no_grad():
+            _, _, _, _, _, ema_pred, ema_pred_path, ema_pred_omic, _, _, _ = self.ema_model(
+                x_path=ema_x_path, x_omic=x_omic)                                                # :143-145
+        kd = self.pred_KD_loss
+        if getattr(opt, "pred_distill", 1) == 1:
+            nt = opt.num_teachers
+            kd_fuse = kd(pred, ema_pred)
+            if nt == 1:
+                kd_path, kd_omic = kd(pred_path, ema_pred_path), kd(pred_omic, ema_pred_omic)
+            elif nt == 2:
+                kd_path = (kd(pred_path, ema_pred_path) + kd(pred_path, ema_pred)) / 2.0
+                kd_omic = (kd(pred_omic, ema_pred_omic) + kd(pred_omic, ema_pred)) / 2.0
+            elif nt == 3:
+                kd_path = (kd(pred_path, ema_pred_path) + kd(pred_path, ema_pred) + kd(pred_path, ema_pred_omic)) / 3.0
+                kd_omic = (kd(pred_omic, ema_pred_omic) + kd(pred_omic, ema_pred) + kd(pred_omic, ema_pred_path)) / 3.0
+            else:
+                raise NotImplementedError("num_teachers in {1,2,3}")
+            loss_pred_KD = getattr(opt, "KD_weight", 1.0) * (kd_fuse + kd_path + kd_omic)       # :203
+        else:
+            loss_pred_KD = torch.zeros((), device=dev)
+        nll = lambda p: ops.NLLFn.apply(p, grade, B)
+        loss_nll = nll(pred_path) + nll(pred_omic) + nll(pred)                                  # :208-212
+        loss = opt.lambda_nll * loss_nll + loss_pred_KD                                         # :214 (reg_type none)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()                                                                   # + EMA (:229) fused
+        self.iter_num += 1
+        return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),
+                    pred=pred.detach(), pred_path=pred_path.detach(), pred_omic=pred_omic.detach())

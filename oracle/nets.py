@@ -192,11 +192,13 @@ def bilinear_fusion_forward(vec1, vec2, sd, prefix="fusion.", dropout_rate=0.0, 
     return out
 
 
-def pathomic_forward(x_path, x_omic, sd, dropout_rate=0.0, gen=None, update_running=True):
-    """PathomicNet.forward (networks_new.py:294-353) -> the reference's 11-tuple."""
+def pathomic_forward(x_path, x_omic, sd, dropout_rate=0.0, gen=None, update_running=True, cut_fuse_grad=True):
+    """PathomicNet.forward (networks_new.py:294-353) -> the reference's 11-tuple.  cut_fuse_grad (:302-306): the fusion
+    branch sees detached unimodal features (the shipped stage-2 flag); False lets the fused loss train both encoders."""
     f3, path_vec, h_path, pred_path, _ = resnet_forward(x_path, sd, "path_net.", update_running)
     omic_vec, h_omic, pred_omic, _ = maxnet_forward(x_omic, sd, "omic_net.", dropout_rate, gen)
-    feats = bilinear_fusion_forward(path_vec.detach(), omic_vec.detach(), sd, "fusion.",
+    feats = bilinear_fusion_forward(path_vec.detach() if cut_fuse_grad else path_vec,
+                                    omic_vec.detach() if cut_fuse_grad else omic_vec, sd, "fusion.",
                                     dropout_rate, gen, update_running)
     hazard = F.linear(feats, sd["classifier.0.weight"], sd["classifier.0.bias"])
     pred = F.log_softmax(hazard, dim=1)

@@ -177,3 +177,53 @@ def test_checkpoint_resume_is_bit_identical():
     for ca, cb in ((a.criterion_kd, b.criterion_kd), (a.criterion_kd_path, b.criterion_kd_path)):
         assert torch.equal(ca.contrast.memory_v1, cb.contrast.memory_v1)
         assert torch.equal(ca.contrast.params, cb.contrast.params)
+
+
+def test_stage1_teacher_step_vs_reference_golden(golden_dir):
+    """Row f-1: two stage-1 mean-teacher steps (train_test_MT.py:121-230, grading task, num_teachers 2) in parity mode
+    against the fixture produced by the reference's modules.  Step 0 (identical weights on both sides) is asserted
+    tightly; step 1 runs on Adam-updated weights and is asserted at the post-update noise floor."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import synthetic_batch
+    g = np.load(os.path.join(golden_dir, "stage1_b4_h64.npz"))
+    m.set_precision("bf16x6")
+    try:
+        opt = m.stage2_opt(dropout_rate=0.0, batch_size=4, cut_fuse_grad=False, num_teachers=2)
+        opt.pred_distill, opt.KD_weight = 1, float(g["KD_weight"])
+        opt.lr, opt.weight_decay, opt.ema_decay = float(g["lr"]), float(g["weight_decay"]), float(g["ema_decay"])
+        model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+        sd = W.make_state_dict(W.teacher_shapes(320), 3)
+        model.load_state_dict(sd); ema.load_state_dict(sd)
+        st = m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda()))
+        for it in range(2):
+            bt = synthetic_batch(4, 64, seed=20 + it)
+            z = torch.zeros(4)
+            batch = ((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"])
+            out = st.step(batch)
+            tol = 1e-3 if it == 0 else 5e-2
+            for k in ("loss", "loss_nll"):
+                assert abs(out[k].item() - float(g[f"{k}{it}"])) <= tol * abs(float(g[f"{k}{it}"])), (it, k, out[k].item())
+            # (the consistency term is the difference of two nearly equal networks: after the sign-like first Adam step it is
+            # the most update-noise-sensitive quantity of the step)
+            kd_tol = tol if it == 0 else 0.25
+            assert abs(out["loss_pred_KD"].item() - float(g[f"loss_kd{it}"])) <= kd_tol * max(abs(float(g[f"loss_kd{it}"])), 1e-2)
+            for k in ("pred", "pred_path", "pred_omic"):
+                assert np.abs(out[k].cpu().numpy() - g[f"{k}{it}"]).max() <= tol * 10, (it, k)
+            if it == 0:   # weights after the first Adam step and the EMA copies
+                msd, esd = st.model.state_dict(), st.ema_model.state_dict()
+                for key in g.files:
+                    if key.startswith("w0_"):
+                        name = key[3:]
+                        ref = g[key]
+                        # Adam's first step moves every weight by ~lr * sign(g): compare the update, not the weight
+                        upd_ref = ref - sd[name].numpy()
+                        upd = msd[name].cpu().numpy() - sd[name].numpy()
+                        frac_bad = float((np.abs(upd - upd_ref) > 0.2 * float(g["lr"])).mean())
+                        assert frac_bad < 0.02, (name, frac_bad)
+                        # alpha = 0 at the first step: the EMA copy equals the updated student (same rare sign flips)
+                        ebad = float((np.abs(esd[name].cpu().numpy() - g["e0_" + name]) > 0.2 * float(g["lr"])).mean())
+                        assert ebad < 0.02, (name, ebad)
+                        assert np.abs(esd[name].cpu().numpy() - msd[name].cpu().numpy()).max() <= 1e-7, name
+    finally:
+        m.set_precision("bf16")

@@ -149,3 +149,54 @@ def test_eval_mode_forward(golden_dir):
         Rounding.training = True
     _close(g["f3"], f3); _close(g["feat"], feat); _close(g["hazard"], hazard); _close(g["pred"], pred)
     _close(g["t_fuse"], t[0]); _close(g["t_h_fuse"], t[4][2]); _close(g["t_pred"], t[5]); _close(g["t_pred_omic"], t[7])
+
+
+def _teacher_bwd_check(named_grads, dx_omic, loss, g, tag, rtol):
+    """Compare gradients {name: tensor} with the (partly sampled) fixture entries of one tag."""
+    import numpy as np
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) <= 1e-4 * abs(float(g[f"{tag}_loss"]))
+    ref = g[f"{tag}_dx_omic"]
+    assert np.abs(dx_omic - ref).max() <= rtol * max(np.abs(ref).max(), 1e-6)
+    n = 0
+    for key in g.files:
+        if key.startswith(f"{tag}_g_"):
+            name = key[len(tag) + 3:]
+            got, ref = named_grads[name], g[key]
+            # (a Linear bias in front of a BatchNorm has a mathematically zero gradient: 1e-8-level rounding noise)
+            assert np.abs(got - ref).max() <= rtol * np.abs(ref).max() + 2e-6, name
+            n += 1
+        elif key.startswith(f"{tag}_gs_"):
+            name = key[len(tag) + 4:]
+            flat = named_grads[name].reshape(-1)
+            stride = flat.size // 4096
+            ref = g[key]
+            assert np.abs(flat[::stride][:4096] - ref).max() <= rtol * np.abs(ref).max() + 2e-6, name
+            nrm = float(g[f"{tag}_gn_{name}"])
+            assert abs(float(np.linalg.norm(flat.astype(np.float64))) - nrm) <= rtol * nrm, name
+            n += 1
+    assert n >= 30
+
+
+def test_teacher_backward_vs_reference_golden(golden_dir):
+    """Row f-1: gradients of the three-branch NLL through MaxNet / BilinearFusion / PathomicNet, with and without
+    cut_fuse_grad (fixture: the reference's PathomicNet run by tests/golden/make_golden_teacher_bwd.py)."""
+    import os
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import weights as W
+    from oracle.nets import pathomic_forward
+    from oracle.step import synthetic_batch
+    g = np.load(os.path.join(golden_dir, "teacher_bwd_b4_h64.npz"))
+    bt = synthetic_batch(4, 64, seed=7)
+    for tag, cut in (("cut", True), ("nocut", False)):
+        sd = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and "running_" not in k) else v.clone())
+              for k, v in W.make_state_dict(W.teacher_shapes(320), 3).items()}
+        x_omic = bt["x_omic"].clone().requires_grad_(True)
+        out = pathomic_forward(bt["x_path"], x_omic, sd, cut_fuse_grad=cut)
+        pred, pred_path, pred_omic = out[5], out[6], out[7]
+        loss = F.nll_loss(pred_path, bt["grade"]) + F.nll_loss(pred_omic, bt["grade"]) + F.nll_loss(pred, bt["grade"])
+        names = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad]
+        grads = torch.autograd.grad(loss, [sd[k] for k in names] + [x_omic], allow_unused=True)
+        named = {k: (gr.numpy() if gr is not None else np.zeros(tuple(sd[k].shape), np.float32)) for k, gr in zip(names, grads[:-1])}
+        _teacher_bwd_check(named, grads[-1].numpy(), loss.item(), g, tag, 2e-4)
