@@ -158,9 +158,12 @@ def main():
                "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "BASELINE configs[1]: teacher+student distill step, bf16, batch 64 per GPU, "
-                                      "512x512 tiles, 320-d omic, CRD P=300/K=700->P2=20/K2=512, n_data=1024, "
-                                      "GK-Refine on, Adam+EMA, dropout 0.1",
+               "config": {"workload": "%s: teacher+student distill step, bf16, batch %d per GPU, "
+                                      "%dx%d tiles, 320-d omic, CRD P=300/K=700->P2=20/K2=512, n_data=1024, "
+                                      "GK-Refine on, Adam+EMA, dropout 0.1"
+                                      % ("BASELINE configs[1]" if (args.batch, args.size) == (64, 512) else
+                                         "BASELINE configs[0] shape" if (args.batch, args.size) == (16, 224) else "custom",
+                                         args.batch, args.size, args.size),
                           "tiles_per_gpu": args.batch, "tile": args.size, "global_batch": args.batch * world,
                           "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4),
                           "launch": "eager" if args.eager else "one captured HIP graph per step"}}
