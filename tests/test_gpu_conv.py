@@ -73,6 +73,8 @@ MULTITILE = [  # Cin, Cout, H, B
     (128, 128, 64, 20),     # <2,2,4,false>: 2 slices/tile, 320 tiles
     (64, 64, 64, 24),       # <4,1,2,true> (resident weights): 384 tiles
     (256, 256, 24, 40),     # ragged 24 = 16 + 8: partial tiles in the stream, 4 slices/tile, 320 tiles
+    (64, 64, 40, 40),       # resident-weights configuration with partial tiles (40 = 16 + 16 + 8), 360 tiles
+    (512, 512, 16, 80),     # 8 slices/tile, 4 Cout blocks: a workgroup's tile list crosses Cout blocks, 320 tiles
 ]
 
 
