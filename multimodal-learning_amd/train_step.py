@@ -219,10 +219,21 @@ class DistillStep:
     No host synchronisation inside `step` (the reference does >= 7 `.item()` syncs); losses are returned
     as device scalars."""
 
-    def __init__(self, opt, n_data, device="cuda", k=1, sync=None, models=None):
+    def __init__(self, opt, n_data, device="cuda", k=1, sync=None, models=None, variant="miccai2022"):
+        """variant "miccai2022": MICCAI-2022/train_test_path_multi_distill.py:242-330 (DC-Distill CRD + GK-Refine);
+        variant "mia2022": "MIA 2022/train_test_path_multi_distill_v2.py":388-500 (vanilla K+1 CRD bank of
+        CRD_criterion_v3 with the epoch weight, momentum GK-Refine carried over the iterations, row a17)."""
         from .networks_new import define_net, define_optimizer, define_scheduler
         from .kd_loss import DistillKL
-        from .CL_utils import CRDLoss
+        if variant == "mia2022":
+            from .CL_utils.CRD_criterion_v3 import CRDLoss
+        elif variant == "miccai2022":
+            from .CL_utils import CRDLoss
+        else:
+            raise ValueError("variant must be 'miccai2022' or 'mia2022'")
+        self.variant = variant
+        self._mo_state = None     # momentum GK-Refine weights (mia2022), updated in place on the device
+        self._mo_init = None
         self.opt = opt
         self.device = torch.device(device)
         self.sync = sync
@@ -287,12 +298,23 @@ class DistillStep:
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
         loss_div1 = self.criterion_div(logit_path, logits[-1].detach())                                     # :264
         loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
-        loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx, ranks=r1)         # :278
-        loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx, ranks=r2)  # :279
+        if self.variant == "mia2022":
+            # v2 trainer :436-437: the first argument is the epoch weight of the per-sample CRD loss; result shape [1]
+            loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx).reshape(())
+            loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx).reshape(())
+        else:
+            loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx, ranks=r1)         # :278
+            loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx, ranks=r2)  # :279
         loss_div1 = opt.alpha * loss_div1; loss_div2 = opt.alpha * loss_div2                                # :293-294
         loss_kd1 = opt.beta * loss_kd1; loss_kd2 = opt.beta * loss_kd2                                      # :296-297
         KD_loss_list = [loss_div1, loss_div2, loss_kd1, loss_kd2]
-        if opt.assign_weights == "True":
+        if opt.assign_weights == "True" and self.variant == "mia2022":
+            # v2 trainer :474-477: momentum GK-Refine; the weight vector lives in ONE device buffer updated in place
+            # (so that a captured HIP graph keeps reading / writing the same storage), x len(list) unless thresholded
+            scale, loss_KD = self._momentum_gk(loss_cls, path_feat, KD_loss_list)
+            if opt.grads_thresh == "False":
+                loss_KD = loss_KD * len(KD_loss_list)
+        elif opt.assign_weights == "True":
             scale, loss_KD = AEKD_loss(opt, self.optimizer, loss_cls, path_feat, KD_loss_list, self.sync)   # :304
         else:
             scale = None
@@ -309,9 +331,33 @@ class DistillStep:
                     path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
                     fuse_feat=fuse_feat, ema_feat=ema_path_feat)
 
+    def _momentum_gk(self, main_loss, feat_s, loss_t_list):
+        """momentum_AEKD_loss ("MIA 2022/train_test_path_multi_distill_v2.py":89-132) with persistent device state."""
+        opt = self.opt
+        losses = list(loss_t_list) + ([main_loss] if opt.CE_grads else [])
+        grads = [torch.autograd.grad(l, feat_s, retain_graph=True)[0] for l in losses]
+        ng = len(grads)
+        G = torch.stack([g.reshape(-1) for g in grads]).contiguous()
+        gram = torch.empty(ng * ng, device=G.device, dtype=torch.float32)
+        check(lib().ph_gram(ptr(G), ptr(gram), ng, G.shape[1], stream()), "ph_gram")
+        if self.sync is not None:
+            self.sync.all_reduce_sum(gram)
+        if self._mo_state is None:
+            self._mo_state = torch.zeros(ng, device=G.device, dtype=torch.float32)
+            self._mo_init = torch.zeros(1, device=G.device, dtype=torch.int32)
+        check(lib().ph_gk_scale_momentum(ptr(gram), ng, 1 if opt.grads_thresh == "True" else 0, float(opt.thresh),
+                                         float(opt.grads_m), ptr(self._mo_state), ptr(self._mo_init), stream()),
+              "ph_gk_scale_momentum")
+        self._mo_init.fill_(1)
+        scale = self._mo_state.clone()       # a value snapshot for the caller; no graph through the weights
+        total_KD_loss = torch.dot(scale[:-1], torch.stack([l.reshape(()) for l in loss_t_list]))
+        return scale, total_KD_loss
+
     def _draw_ranks(self, epoch, ranks):
         """Host-RNG rank draws of memory_new.py:311 for the two CRD calls (kd1 then kd2), as device int32."""
         e = epoch / self.opt.niter_decay
+        if self.variant == "mia2022":
+            return e, [None, None]         # the vanilla bank has no pair selection
         out = []
         for i, crd in enumerate((self.criterion_kd, self.criterion_kd_path)):
             r = ranks[i] if ranks is not None else crd.contrast.draw_ranks(e, crd.select_pos_mode)
@@ -335,6 +381,13 @@ class DistillStep:
         self.criterion_kd.contrast.batch_norm_size = bnorm
         self.criterion_kd_path.contrast.batch_norm_size = bnorm
         e, rk = self._draw_ranks(epoch, ranks)
+        if self.variant == "mia2022":
+            # the epoch weight multiplies the CRD loss on the device: one persistent scalar so a captured graph
+            # reads the current value instead of baking the capture-time epoch in
+            if getattr(self, "_e_dev", None) is None:
+                self._e_dev = torch.zeros(1, device=dev, dtype=torch.float32)
+            self._e_dev.fill_(float(e))
+            e = self._e_dev
         self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)                          # :36
         use_graph = getattr(self, "_want_graph", False) and self.iter_num - opt.global_step >= 2
         if not use_graph:
@@ -408,7 +461,8 @@ class DistillStep:
                     crd_kd_state_dict=self.criterion_kd.state_dict(),
                     crd_kd_path_state_dict=self.criterion_kd_path.state_dict(),
                     scheduler_state_dict=self.scheduler.state_dict(), iter_num=self.iter_num,
-                    teacher_rng_steps=rng)
+                    teacher_rng_steps=rng,
+                    gk_momentum_scale=None if self._mo_state is None else self._mo_state.clone())
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd["model_state_dict"])
@@ -420,6 +474,12 @@ class DistillStep:
         self.optimizer.load_state_dict(sd["optimizer_state_dict"])
         self.scheduler.load_state_dict(sd["scheduler_state_dict"])
         self.iter_num = sd["iter_num"]
+        mo = sd.get("gk_momentum_scale")
+        if mo is not None:
+            if self._mo_state is None:
+                self._mo_state = torch.zeros_like(mo, device=self.device)
+                self._mo_init = torch.ones(1, device=self.device, dtype=torch.int32)
+            self._mo_state.copy_(mo); self._mo_init.fill_(1)
         for name, mod in self.fix_model.named_modules():
             if hasattr(mod, "rng_step") and name in sd.get("teacher_rng_steps", {}):
                 mod.rng_step.copy_(sd["teacher_rng_steps"][name])
