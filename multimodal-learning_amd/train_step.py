@@ -219,18 +219,31 @@ class DistillStep:
     No host synchronisation inside `step` (the reference does >= 7 `.item()` syncs); losses are returned
     as device scalars."""
 
-    def __init__(self, opt, n_data, device="cuda", k=1, sync=None, models=None, variant="miccai2022"):
+    def __init__(self, opt, n_data, device="cuda", k=1, sync=None, models=None, variant="miccai2022",
+                 train_class_idx=None):
         """variant "miccai2022": MICCAI-2022/train_test_path_multi_distill.py:242-330 (DC-Distill CRD + GK-Refine);
         variant "mia2022": "MIA 2022/train_test_path_multi_distill_v2.py":388-500 (vanilla K+1 CRD bank of
-        CRD_criterion_v3 with the epoch weight, momentum GK-Refine carried over the iterations, row a17)."""
+        CRD_criterion_v3 with the epoch weight, momentum GK-Refine carried over the iterations, row a17);
+        variant "mia2023": "MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":307-448 (per-sample KL
+        rows, confidence-discrepancy query weights, the class-aware KNN bank of CRD_criterion_v10 - needs
+        `train_class_idx`, the per-class lists of bank rows - and the per-sample GK-Refine, row a18)."""
         from .networks_new import define_net, define_optimizer, define_scheduler
         from .kd_loss import DistillKL
         if variant == "mia2022":
             from .CL_utils.CRD_criterion_v3 import CRDLoss
         elif variant == "miccai2022":
             from .CL_utils import CRDLoss
+        elif variant == "mia2023":
+            from .CL_utils.CRD_criterion_v10 import CRDLoss as _CRDv10
+            from .mia2023 import DistillKL
+            if train_class_idx is None:
+                raise ValueError("variant 'mia2023' needs train_class_idx (CRD_criterion_v10.py:25)")
+            if sync is not None:
+                raise NotImplementedError("variant 'mia2023' is single-GPU: its per-sample loss normalisation is not "
+                                          "wired for data parallelism")
+            CRDLoss = lambda o, n: _CRDv10(o, n, train_class_idx)    # noqa: E731
         else:
-            raise ValueError("variant must be 'miccai2022' or 'mia2022'")
+            raise ValueError("variant must be 'miccai2022', 'mia2022' or 'mia2023'")
         self.variant = variant
         self._mo_state = None     # momentum GK-Refine weights (mia2022), updated in place on the device
         self._mo_init = None
@@ -296,6 +309,9 @@ class DistillStep:
                 _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
                 fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
+        if self.variant == "mia2023":
+            return self._mia2023_tail(e, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path,
+                                      ema_path_feat, ema_logit_path, fuse_feat, logits)
         loss_div1 = self.criterion_div(logit_path, logits[-1].detach())                                     # :264
         loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
         if self.variant == "mia2022":
@@ -331,6 +347,40 @@ class DistillStep:
                     path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
                     fuse_feat=fuse_feat, ema_feat=ema_path_feat)
 
+    def _mia2023_tail(self, rw, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path, ema_path_feat,
+                      ema_logit_path, fuse_feat, logits):
+        """Losses, backward and update of the MIA-2023 batch body
+        ("MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":348-448).  `rw` is a device scalar:
+        0 while epoch < opt.start_reweight (query weights are all ones, :373-375), 1 afterwards (1 + discrepancy)."""
+        from .mia2023 import assign_sample_weights, GK_refine_thresh
+        opt = self.opt
+        loss_div1, rows_div1 = self.criterion_div(logit_path, logits[-1].detach())                          # :349
+        loss_div2, rows_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                      # :350
+        # :361-364 - log-probability margins: the softmax normaliser cancels, so the kernel reads the logits
+        w1 = assign_sample_weights(logit_path, logits[-1], grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
+        w2 = assign_sample_weights(logit_path, ema_logit_path, grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
+        w1 = (1.0 + rw * w1).view(-1, 1); w2 = (1.0 + rw * w2).view(-1, 1)                                  # :373-382
+        loss_kd1, rows_kd1 = self.criterion_kd(w1, path_feat, fuse_feat.detach(), grade, index, sample_idx)         # :386
+        loss_kd2, rows_kd2 = self.criterion_kd_path(w2, path_feat, ema_path_feat.detach(), grade, index, sample_idx)  # :388
+        KD_loss_list = [opt.alpha * rows_div1, opt.alpha * rows_div2, opt.beta * rows_kd1, opt.beta * rows_kd2]  # :407-414
+        if opt.assign_weights == "True":
+            if getattr(opt, "loss_weighting", "GK_refine") != "GK_refine":
+                raise NotImplementedError("loss_weighting '%s' (the shipped command uses GK_refine)" % opt.loss_weighting)
+            scale, loss_KD = GK_refine_thresh(opt, self.optimizer, loss_cls, path_feat, KD_loss_list)        # :422
+        else:
+            scale = None
+            loss_KD = opt.alpha * (loss_div1 + loss_div2) + opt.beta * (loss_kd1 + loss_kd2)                # :427
+        loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :431
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()                                                                               # :446-447 fused
+        return dict(loss=loss.detach(), loss_cls=loss_cls.detach(), loss_div1=loss_div1.detach(),
+                    loss_div2=loss_div2.detach(), loss_kd1=loss_kd1.detach(), loss_kd2=loss_kd2.detach(),
+                    rows_div1=rows_div1.detach(), rows_kd1=rows_kd1.detach(), w1=w1.detach(), w2=w2.detach(),
+                    scale=scale, logit_path=logit_path.detach(), pred_path=pred_path.detach(),
+                    path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
+                    fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+
     def _momentum_gk(self, main_loss, feat_s, loss_t_list):
         """momentum_AEKD_loss ("MIA 2022/train_test_path_multi_distill_v2.py":89-132) with persistent device state."""
         opt = self.opt
@@ -356,8 +406,8 @@ class DistillStep:
     def _draw_ranks(self, epoch, ranks):
         """Host-RNG rank draws of memory_new.py:311 for the two CRD calls (kd1 then kd2), as device int32."""
         e = epoch / self.opt.niter_decay
-        if self.variant == "mia2022":
-            return e, [None, None]         # the vanilla bank has no pair selection
+        if self.variant != "miccai2022":
+            return e, [None, None]         # the vanilla / KNN banks have no rank-drawn pair selection
         out = []
         for i, crd in enumerate((self.criterion_kd, self.criterion_kd_path)):
             r = ranks[i] if ranks is not None else crd.contrast.draw_ranks(e, crd.select_pos_mode)
@@ -387,6 +437,11 @@ class DistillStep:
             if getattr(self, "_e_dev", None) is None:
                 self._e_dev = torch.zeros(1, device=dev, dtype=torch.float32)
             self._e_dev.fill_(float(e))
+            e = self._e_dev
+        elif self.variant == "mia2023":
+            if getattr(self, "_e_dev", None) is None:
+                self._e_dev = torch.zeros(1, device=dev, dtype=torch.float32)
+            self._e_dev.fill_(0.0 if epoch < opt.start_reweight else 1.0)         # the re-weighting switch (:373)
             e = self._e_dev
         self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)                          # :36
         use_graph = getattr(self, "_want_graph", False) and self.iter_num - opt.global_step >= 2

@@ -312,3 +312,89 @@ def test_mia2022_variant_steps_vs_reference_golden(golden_dir):
         assert torch.equal(sd1["gk_momentum_scale"], step._mo_state)
     finally:
         m.set_precision("bf16")
+
+
+def test_mia2023_variant_steps_vs_reference_golden(golden_dir):
+    """SURVEY row a18 end to end: DistillStep(variant="mia2023") = the batch body of
+    "MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":318-448 (per-sample KL rows, confidence
+    discrepancy query weights switched on at opt.start_reweight, CRD_criterion_v10 KNN bank, per-sample GK-Refine)
+    against vectors produced by running the reference's own modules (tests/golden/make_golden_mia2023_step.py).
+    Step 0 at 1e-3; steps 1-2 against the fp64 run of the same calls, bounded by 6x the reference's own fp32 distance."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    from oracle.variants import CRDv10State
+    from tests.gpu_util import Report, maxerr
+    g = np.load(os.path.join(golden_dir, "mia2023_step_b8_h64.npz"))
+    t64 = np.load(os.path.join(golden_dir, "mia2023_step_b8_h64_fp64.npz"))
+    B, H, n_data, K = int(g["B"]), int(g["H"]), int(g["n_data"]), int(g["K"])
+    labels = torch.as_tensor(g["labels"])
+    class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+    opt = default_opt(nce_k=K, nce_p=int(g["num_pos"]), pos_extra="neighbors", neg_mode="all_others",
+                      start_reweight=int(g["start_reweight"]), discrep_scale=1, max_discrep=float(g["max_discrep"]),
+                      use_grads_thresh="True", grads_thresh=float(g["grads_thresh"]), loss_weighting="GK_refine",
+                      batch_size=B)
+    m.set_precision("bf16x6")
+    try:
+        step = m.DistillStep(opt, n_data, device="cuda", variant="mia2023", train_class_idx=class_idx)
+        step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+        step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+        step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+        for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+            crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 10 + 2 * i))
+            crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 11 + 2 * i))
+            st = CRDv10State(n_data, labels, K=K, seed=20 + i)
+            crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+            crd.contrast.verbose = False
+        R = Report("3 MIA-2023 distill steps, parity mode vs REFERENCE golden (B=8, 64x64)")
+
+        def ref_d(key):
+            return maxerr(np.asarray(t64[key]), np.asarray(g[key]))[0]
+
+        def floor(key, got, what, extra=0.0):
+            err, mx = maxerr(np.asarray(t64[key]), got)
+            R.rows.append((what + " [vs fp64 truth]", err, mx, 6 * ref_d(key) + extra + 1e-3))
+        names = (("logit_path", "logit_path"), ("path_feat", "path_feat"), ("ema_logit", "ema_logit"),
+                 ("loss_cls", "loss_cls"), ("loss_div1_", "loss_div1"), ("loss_div2_", "loss_div2"),
+                 ("loss_kd1_", "loss_kd1"), ("loss_kd2_", "loss_kd2"), ("scale", "scale"), ("loss", "loss"),
+                 ("w1_", "w1"), ("w2_", "w2"), ("rows_div1_", "rows_div1"), ("rows_kd1_", "rows_kd1"))
+        for it in range(3):
+            bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=400 + it)
+            bt["grade"] = labels[bt["index"]]
+            out = step.step(_tuple(bt), epoch=it)
+            sd = step.model.state_dict(); esd = step.ema_model.state_dict()
+            idx = bt["index"].cuda()
+            R.close(g[f"fuse_logit{it}"], out["fuse_logit"], 1e-3, 0, f"teacher logit step {it}")
+            if it == 0:
+                P = dict(step.model.named_parameters())
+                R.close(g["g0_fc2_w"], P["fc_new2.weight"].grad, 1e-5, 1e-3, "grad fc2")
+                floor("g0_conv1", P["conv1.weight"].grad, "grad conv1")
+                R.close(g["g0_embed_s0"], step.criterion_kd.embed_s.linear.weight.grad, 1e-7, 1e-3, "grad embed_s")
+                R.close(g["g0_embed_t1"], step.criterion_kd_path.embed_t.linear.weight.grad, 1e-7, 1e-3, "grad embed_t")
+                for key, name in names:
+                    R.close(g[f"{key}0"], out[name], 1e-3, 0, f"{name} step 0")
+                R.close(g["p_fc2_0"], sd["fc_new2.weight"], 1e-4, 0, "Adam-updated fc2 step 0")
+                R.close(g["ema_fc2_0"], esd["fc_new2.weight"], 1e-4, 0, "EMA fc2 step 0")
+                R.close(g["bank0_v1_rows0"], step.criterion_kd.contrast.memory_v1[idx], 1e-4, 0, "bank0 rows step 0")
+                R.close(g["bank1_v2_rows0"], step.criterion_kd_path.contrast.memory_v2[idx], 1e-4, 0, "bank1 rows step 0")
+            else:
+                nz = 6 * max(ref_d(f"logit_path{it}"), ref_d(f"ema_logit{it}"), ref_d(f"path_feat{it}"))
+                for key, name in names:
+                    floor(f"{key}{it}", out[name], f"{name} step {it}", extra=nz)
+                floor(f"bank0_v1_rows{it}", step.criterion_kd.contrast.memory_v1[idx], f"bank0 rows step {it}")
+                floor(f"bank1_v2_rows{it}", step.criterion_kd_path.contrast.memory_v2[idx], f"bank1 rows step {it}")
+                R.close(g[f"p_fc2_{it}"], sd["fc_new2.weight"], 1.5e-3, 0, f"Adam-updated fc2 step {it}")
+                R.close(g[f"ema_fc2_{it}"], esd["fc_new2.weight"], 1.5e-3, 0, f"EMA fc2 step {it}")
+        R.finish()
+        assert float(out["w1"].max()) > 1.0, "re-weighting must be on from opt.start_reweight"
+        step.enable_graph()
+        for it in range(3, 6):
+            bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=400 + it)
+            bt["grade"] = labels[bt["index"]]
+            out = step.step(_tuple(bt), epoch=0 if it == 5 else it)
+        torch.cuda.synchronize()
+        assert step._static is not None and step._static["graph"] is not None, "graph path was not taken"
+        assert torch.isfinite(out["loss"]).item()
+        assert float(out["w1"].max()) == 1.0, "the re-weighting switch is a device scalar: replay must follow the epoch"
+    finally:
+        m.set_precision("bf16")
