@@ -44,6 +44,12 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
 #endif
 }
+// 4-byte form: used only to pull cache lines towards the L2 (the LDS side is a scratch row nobody reads)
+__device__ __forceinline__ void lds_dma4(const void* g, unsigned lds_addr) {
+#ifndef PH_ABL_NODMA
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+#endif
+}
 #define PH_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PH_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -514,6 +520,476 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)gt);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layer-1 configuration (Cin = Cout = 64), two wave groups per workgroup.
+//
+// With 64 output channels a wave tile is 64 x 64 (64 accumulator registers), the main loop of a 16 x 16 tile is only
+// 144 MFMAs (4608 cycles) and the epilogue - ~14 VALU per output pair plus the 4-byte stores - is nearly as long: the
+// one-wave-per-SIMD kernel above spent about half of every tile outside the matrix pipe (measured 700 TFLOP/s).
+// Here the workgroup has 8 waves = two groups of four (one wave of each group per SIMD).  Each group owns ONE halo
+// buffer and walks its own tiles; all 9 taps of weights (72 KiB) are resident and shared.  The groups run half a tile
+// out of phase: while group A streams the MFMAs of its tile, group B stores the previous tile, zeroes its
+// accumulators and lets the LDS-DMA of its next halo land - the s_barrier at the end of every half-phase is the only
+// synchronisation (it publishes B's halo to B's waves and releases A's halo buffer for A's next DMA).  VALU / store
+// work of one wave and MFMAs of the other wave on the same SIMD issue concurrently, so the matrix pipe sees a
+// more continuous stream.  Measured (phase tracer, B = 64, 128 x 128 x 64): matrix phase 6000-7000 cycles (floor 4608: the
+// LDS delivers one ds_read_b128 per MFMA and is saturated), store phase 5300-6700; the older group wins the SIMD's
+// issue arbitration and is ~1000 cycles faster in both phases (s_setprio only moves that advantage to the other
+// group, the sum stays).  81-85 us per launch against 102-110 us for the one-wave-per-SIMD configuration on the same
+// box; the kernel moves 304 MB, so ~60 us is its HBM floor.  Registers: 256 VGPRs per wave (two waves per SIMD).
+struct L1Cfg {
+  static constexpr int FM = 2, FN = 2, WM = 4, NTAPS = 9, TH = 16, TW = 16, BNT = 64;
+  static constexpr int HPH = TH + 2, HPW = TW + 2, HP = HPH * HPW;
+  static constexpr int A_BYTES = (((HP + 1) / 2 * 256) + 1023) / 1024 * 1024;
+  static constexpr int NHD = A_BYTES / 1024, NHE = (NHD + 3) / 4;
+  static constexpr int TAPB = BNT * 128;
+  static constexpr int B_BASE = 2 * A_BYTES;
+  static constexpr int LDS_MAIN = B_BASE + NTAPS * TAPB;
+  static constexpr int LDS_BYTES = LDS_MAIN + 8 * 2 * BNT * 4;   // + the final BatchNorm reduce [8 waves][2][64]
+  static constexpr int NTH = 512;
+  static constexpr int NWP = NTAPS * TAPB / 1024 / 8;            // weight DMA pieces per wave in the prologue
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(NTAPS * TAPB % (8 * 1024) == 0, "weights split into 1-KiB pieces over 8 waves");
+};
+
+__global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
+  using C = L1Cfg;
+  constexpr int FM = C::FM, FN = C::FN, TH = C::TH, TW = C::TW, BNT = C::BNT, HPW = C::HPW, HP = C::HP;
+  constexpr int NTAPS = C::NTAPS, B_BASE = C::B_BASE;
+  typedef __bf16 T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(lds_uchar*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wm = wave & 3;   // group, wave inside the group (= its 4-row band of the tile)
+  const int khalf = lane >> 5;
+  const int tiles_w = (p.OWt + TW - 1) / TW;
+  const int tiles_sp = tiles_w * ((p.OHt + TH - 1) / TH);
+  const int total = tiles_sp * p.B;
+  const long pix_st = p.in_pix_stride ? p.in_pix_stride : p.Cin;
+  const long row_st = p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin;
+  const long img_st = p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin;
+  const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
+  PH_TRACE(0);
+
+  struct TileCtx { int r0, c0, b, iy_base, ix_base; const T* in; };
+  const float rcp_sp = 1.0f / (float)tiles_sp, rcp_tw = 1.0f / (float)tiles_w;
+  auto fdiv = [](int a, int d, float rcp) {
+    int q = (int)((float)a * rcp);
+    int r = a - q * d;
+    if (r >= d) ++q;
+    if (r < 0) --q;
+    return q;
+  };
+  auto decode = [&](int t) -> TileCtx {
+    TileCtx c;
+    c.b = fdiv(t, tiles_sp, rcp_sp);
+    const int tile = t - c.b * tiles_sp;
+    const int trow = fdiv(tile, tiles_w, rcp_tw);
+    c.r0 = trow * TH;
+    c.c0 = (tile - trow * tiles_w) * TW;
+    c.iy_base = c.r0 + p.iy0;
+    c.ix_base = c.c0 + p.ix0;
+    c.in = reinterpret_cast<const T*>(p.in) + (size_t)c.b * img_st;
+    return c;
+  };
+  // the workgroup's tile list (same XCD-contiguous order as above); group g takes entries g, g + 2, g + 4, ...
+  const int G = gridDim.x;
+  const bool xcd_map = (G & 7) == 0 && G < total;
+  const int per_xcd = (total + 7) >> 3;
+  auto tile_id = [&](int k) -> int {
+    if (!xcd_map) {
+      const int t = (int)blockIdx.x + k * G;
+      return t < total ? t : -1;
+    }
+    const int local = ((int)blockIdx.x >> 3) + k * (G >> 3);
+    const int t = ((int)blockIdx.x & 7) * per_xcd + local;
+    return (local < per_xcd && t < total) ? t : -1;
+  };
+  int K = 0;
+  while (tile_id(K) >= 0) ++K;
+  const int n_mine = (K - grp + 1) >> 1;       // tiles of this group
+
+  int tap_tab = 0;
+  if (lane < NTAPS) tap_tab = p.wtap[lane] << 16;
+
+  // halo DMA sources of this lane: piece h = wm + 4e of the group's halo image (swizzle applied to the source).  Row
+  // pair rp = 4h + (lane >> 4) advances by 16 per e, so the swizzled slot u is the same for all e and the pixel index
+  // advances by 32 = one halo row + 14 columns: (row, column, byte offset) are carried incrementally instead of kept
+  // in 22 registers per lane (two waves per SIMD: the register file is the scarce resource here).
+  const int rp0 = wm * 4 + (lane >> 4), u0 = (lane & 15) ^ (rp0 & 15);
+  const int pix0 = 2 * rp0 + (u0 >> 3);
+  int hr_base = pix0 / HPW, hc_base = pix0 - hr_base * HPW;
+  int hoff_base = (int)(((long)hr_base * row_st + (long)hc_base * pix_st + (u0 & 7) * 8) * 2);
+  const int hd_row = (int)((row_st + 14 * pix_st) * 2), hd_wrap = (int)((row_st - 18 * pix_st) * 2);
+  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(ph_zero16);
+  const unsigned a_lds = lds0 + grp * C::A_BYTES;
+  // The next halo is issued piece by piece BETWEEN the blocks of the epilogue (halo_piece): issued back to back, the
+  // 11 wave-instructions of 1 KiB each wait ~2400 cycles for the address/data path to accept them.
+  unsigned h_rowok = 0, h_colok = 0;
+  const unsigned char* h_hb = nullptr;
+  int h_hr = 0, h_hc = 0, h_o = 0;
+  auto halo_begin = [&](const TileCtx& tc) {
+    auto range_bits = [](int lo, int hi) -> unsigned {   // bits lo..hi-1 set (0 <= lo, hi <= 31)
+      return hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+    };
+    const int iy = tc.iy_base, ix = tc.ix_base;
+    const int r_lo = iy < 0 ? -iy : 0, r_hi = (p.IH - iy) < C::HPH ? (p.IH - iy) : C::HPH;
+    const int c_lo = ix < 0 ? -ix : 0, c_hi = (p.IW - ix) < HPW ? (p.IW - ix) : HPW;
+    h_rowok = range_bits(r_lo, r_hi < 0 ? 0 : r_hi);
+    h_colok = range_bits(c_lo, c_hi < 0 ? 0 : c_hi);
+    h_hb = reinterpret_cast<const unsigned char*>(tc.in) + ((long)iy * row_st + (long)ix * pix_st) * 2;
+    h_hr = hr_base; h_hc = hc_base; h_o = hoff_base;
+    asm volatile("" : "+v"(h_hr), "+v"(h_hc), "+v"(h_o));   // (opaque: no precomputed per-piece tables)
+  };
+  auto halo_piece = [&](int e) {   // e = 0 .. NHE-1 in order
+    if (wm + 4 * e < C::NHD) {
+      const bool ok = ((h_rowok >> (h_hr & 31)) & (h_colok >> h_hc) & 1u) != 0 && h_hr < C::HPH;
+      lds_dma16(ok ? h_hb + h_o : zero_src, a_lds + (wm + 4 * e) * 1024);
+    }
+    h_hc += 14; h_hr += 1; h_o += hd_row;
+    if (h_hc >= HPW) { h_hc -= HPW; h_hr += 1; h_o += hd_wrap; }
+  };
+  auto issue_halo = [&](const TileCtx& tc) {   // all pieces at once (prologue)
+    halo_begin(tc);
+#pragma unroll
+    for (int e = 0; e < C::NHE; ++e) halo_piece(e);
+  };
+
+  // With ONE halo buffer per group the DMA of the next halo cannot start before the group's matrix phase has ended,
+  // so its memory latency would sit in the store phase (measured: the store phase then waits ~2 us for HBM).  During
+  // the matrix phase every wave therefore touches the next halo's cache lines (one 4-byte LDS-DMA per 128-byte pixel
+  // row into a scratch row): the real DMA one phase later is served by the L2.
+  auto prefetch_halo = [&](const TileCtx& tc) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // (opaque: the per-lane halo coordinates are recomputed, not kept live / spilled -
+                                   // a spill reload here waits, vmcnt(0), for the touch that was just issued)
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+      const int q = wm + 4 * z;             // 6 x 64 lanes cover the 324 halo pixels
+      if (q < (HP + 63) / 64) {
+        const int pidx = q * 64 + ln;
+        int hr = (pidx * 3641) >> 16;       // pidx / 18 for pidx < 384
+        const int hc = pidx - hr * HPW;
+        hr = hr < C::HPH ? hr : C::HPH - 1;
+        int iy = tc.iy_base + hr, ix = tc.ix_base + hc;
+        iy = iy < 0 ? 0 : (iy >= p.IH ? p.IH - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.IW ? p.IW - 1 : ix);
+        lds_dma4(reinterpret_cast<const unsigned char*>(tc.in) + ((long)iy * row_st + (long)ix * pix_st) * 2,
+                 lds0 + C::LDS_MAIN + wave * 256);
+      }
+    }
+  };
+
+  // fragment addressing
+  int prow[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int fr, c;
+    frag_row_to_pixel(lane & 31, fr, c);
+    prow[i] = ((wm * FM + i) * 2 + fr) * HPW + c;
+  }
+  int nrow[FN], bx[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    nrow[j] = j * 32 + (lane & 31);
+    bx[j] = lds_off(nrow[j], khalf);
+  }
+  // Accumulators: D = W_frag x X_frag (the MFMA operands swapped), i.e. TRANSPOSED tiles: lane l holds pixel l % 32 of
+  // the fragment and register q holds channel (q & 3) + 8 * (q >> 2) + 4 * khalf of the 32-channel block.  A lane
+  // then owns whole groups of 4 consecutive channels of ONE pixel: the output is packed with v_cvt_pk_bf16_f32 straight
+  // from neighbouring registers, one v_permlane32_swap per packed pair gives every lane 8 consecutive channels, and the
+  // store is 16 bytes per lane - 4 instructions per 4 outputs where the pixel-major layout needed 9 per 2 (accumulator
+  // reads, DPP exchange, byte permute, 4-byte stores).  The BatchNorm sums become per-lane, per-channel registers
+  // (64 of them), reduced across the 32 pixel lanes once at the end of the kernel.  The accumulators live in VGPRs
+  // (two waves per SIMD: 256 registers per wave, no AGPR round trips in the epilogue) and the first k-step of a
+  // tile multiplies into a zero constant instead of zeroed registers.
+  f32x16 acc[FM][FN];
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 s1[FN][8], s2[FN][8];   // [j][q / 2]: channels j*32 + chan(q), chan(q + 1) - over ALL tiles of this wave
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s1[j][q] = f32x2{0.f, 0.f}; s2[j][q] = f32x2{0.f, 0.f}; }
+  int pfr, pcc;   // this lane's pixel inside a fragment's 2 x 16 patch
+  frag_row_to_pixel(lane & 31, pfr, pcc);
+
+  // FULL (tile inside the output) and RM (0: no residual, 1: + res_g, 2: + res_g masked by res_a > 0) are compile-time:
+  // as run-time tests inside the unrolled loops they cost a branch per stored word.
+  auto epilogue = [&](const TileCtx& tc, auto fullc, auto rmc, const bool halo) {
+    constexpr bool FULL = decltype(fullc)::value;
+    constexpr int RM = decltype(rmc)::value;
+    const size_t img = (size_t)tc.b * p.OH * p.OW * p.Cout;
+    T* out = reinterpret_cast<T*>(p.out) + img;
+    const T* resg = reinterpret_cast<const T*>(p.res_g) + img;
+    const T* resa = reinterpret_cast<const T*>(p.res_a) + img;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int r = tc.r0 + (wm * FM + i) * 2 + pfr, c = tc.c0 + pcc;
+      const bool mine = FULL || (r < p.OHt && c < p.OWt);
+      const unsigned o = (unsigned)(((r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout) + 8 * khalf;
+      u32x4 rg[FN][2], ra[FN][2];
+      if constexpr (RM > 0) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            rg[j][gp] = u32x4{0u, 0u, 0u, 0u};
+            ra[j][gp] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            if (mine) {
+              rg[j][gp] = *reinterpret_cast<const u32x4*>(resg + o + j * 32 + gp * 16);
+              if constexpr (RM > 1) ra[j][gp] = *reinterpret_cast<const u32x4*>(resa + o + j * 32 + gp * 16);
+            }
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        unsigned P[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            f32x2 v = {acc[i][j][4 * g + 2 * h2], acc[i][j][4 * g + 2 * h2 + 1]};
+            if constexpr (!FULL) {
+              v[0] = mine ? v[0] : 0.f;
+              v[1] = mine ? v[1] : 0.f;
+            }
+            s1[j][2 * g + h2] += v;
+            s2[j][2 * g + h2] += v * v;
+            bf16x2 b;
+            b[0] = (bf16)v[0];
+            b[1] = (bf16)v[1];
+            P[g][h2] = __builtin_bit_cast(unsigned, b);
+          }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          {   // 8 blocks per tile carry the 11 pieces of the next halo: 2, 1, 2, 1, 2, 1, 1, 1
+            constexpr int NB_ = FM * FN * 2;
+            const int blk = (i * FN + j) * 2 + gp;
+            const int e0 = blk < 6 ? blk + (blk + 1) / 2 : blk + 3, ne = (blk < 6 && !(blk & 1)) ? 2 : 1;
+            static_assert(NB_ == 8 && C::NHE == 11, "halo piece schedule");
+            if (halo) {
+              halo_piece(e0);
+              if (ne == 2) halo_piece(e0 + 1);
+            }
+          }
+          // lanes < 32 give their upper group to, and take the lower group from, lane + 32 (same pixel, other k-half)
+          const auto a0 = __builtin_amdgcn_permlane32_swap(P[2 * gp][0], P[2 * gp + 1][0], false, false);
+          const auto a1 = __builtin_amdgcn_permlane32_swap(P[2 * gp][1], P[2 * gp + 1][1], false, false);
+          u32x4 w = {a0[0], a1[0], a0[1], a1[1]};   // 8 consecutive channels from j*32 + gp*16 + 8*khalf
+          if constexpr (RM > 0) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              bf16x2 wb = __builtin_bit_cast(bf16x2, w[d]);
+              const bf16x2 gb = __builtin_bit_cast(bf16x2, rg[j][gp][d]), ab = __builtin_bit_cast(bf16x2, ra[j][gp][d]);
+              wb[0] = (bf16)((float)wb[0] + ((RM < 2 || (float)ab[0] > 0.f) ? (float)gb[0] : 0.f));
+              wb[1] = (bf16)((float)wb[1] + ((RM < 2 || (float)ab[1] > 0.f) ? (float)gb[1] : 0.f));
+              w[d] = __builtin_bit_cast(unsigned, wb);
+            }
+          }
+#ifdef PH_ABL_NOSTORE
+          asm volatile("" ::"v"(w));
+#else
+          if (mine) *reinterpret_cast<u32x4*>(out + o + j * 32 + gp * 16) = w;
+#endif
+        }
+      }
+    }
+  };
+  const int rmode = p.res_g ? (p.res_a ? 2 : 1) : 0;
+  auto epilogue_any = [&](const TileCtx& tc, const bool halo) {
+    const bool full = (tc.r0 + TH <= p.OHt) && (tc.c0 + TW <= p.OWt);
+    auto with_full = [&](auto fullc) {
+      if (rmode == 0) epilogue(tc, fullc, std::integral_constant<int, 0>{}, halo);
+      else if (rmode == 1) epilogue(tc, fullc, std::integral_constant<int, 1>{}, halo);
+      else epilogue(tc, fullc, std::integral_constant<int, 2>{}, halo);
+    };
+    if (full) with_full(std::true_type{});
+    else with_full(std::false_type{});
+  };
+
+  // ---- prologue: all 9 taps of weights (8 waves x NWP pieces) and each group's first halo
+  {
+#pragma unroll
+    for (int j = 0; j < C::NWP; ++j) {
+      const int q = wave * C::NWP + j, tap = q >> 3;          // 8 pieces of 1 KiB per tap
+      const int rp = (q & 7) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & 15);
+      const int slab = __builtin_amdgcn_readlane(tap_tab, tap) >> 16;
+      const unsigned char* wb = reinterpret_cast<const unsigned char*>(wbase + (size_t)slab * p.Cout * p.Cin);
+      lds_dma16(wb + ((2 * rp + (u >> 3)) * p.Cin + (u & 7) * 8) * 2, lds0 + B_BASE + q * 1024);
+    }
+  }
+  // tile contexts run one ahead of the store phase: each tile is decoded once
+  TileCtx tc_cur{}, tc_next{};
+  if (n_mine > 0) {
+    tc_cur = decode(tile_id(grp));
+    issue_halo(tc_cur);
+  }
+  if (n_mine > 1) tc_next = decode(tile_id(2 + grp));
+  PH_WAIT_VMCNT(0);
+  PH_BARRIER();
+  PH_TRACE(1);
+
+  bf16x8 fa[2][FM], fb[2][FN];
+  int aaddr[FM], bxs[FN];
+  auto tap_addr = [&](int toff, int slot) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) aaddr[i] = grp * C::A_BYTES + lds_off(prow[i] + toff, khalf);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bxs[j] = B_BASE + slot * C::TAPB + bx[j];
+  };
+#ifdef PH_TRACE_FINE   // stamps inside the store phase (each costs an s_waitcnt lgkmcnt(0), which also waits for LDS-DMA)
+#define PH_CLKF() PH_CLK()
+#else
+#define PH_CLKF() 0ull
+#endif
+  // transposed product, accumulators in VGPRs; PH_MMT0 starts a tile (C = 0)
+#ifdef PH_ABL_NOMFMA
+#define PH_MMT(CB, I, J) asm volatile("" : "+v"(acc[I][J]) : "v"(fb[CB][J]), "v"(fa[CB][I]))
+#define PH_MMT0(CB, I, J) asm volatile("" : "=v"(acc[I][J]) : "v"(fb[CB][J]), "v"(fa[CB][I]))
+#else
+#define PH_MMT(CB, I, J) \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[I][J]) : "v"(fb[CB][J]), "v"(fa[CB][I]))
+#define PH_MMT0(CB, I, J) \
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[I][J]) : "v"(fb[CB][J]), "v"(fa[CB][I]))
+#endif
+#define PH_KSTEP2T(MM, CB, NB, KS)                              \
+  MM(CB, 0, 0); fa[NB][0] = PH_LDA(aaddr, 0, KS); PH_SB();      \
+  MM(CB, 0, 1); fb[NB][0] = PH_LDA(bxs, 0, KS); PH_SB();        \
+  MM(CB, 1, 0); fb[NB][1] = PH_LDA(bxs, 1, KS); PH_SB();        \
+  MM(CB, 1, 1); fa[NB][1] = PH_LDA(aaddr, 1, KS); PH_SB()
+#define PH_KSTEP2T_END(CB) \
+  PH_MMT(CB, 0, 0); PH_MMT(CB, 0, 1); PH_MMT(CB, 1, 0); PH_MMT(CB, 1, 1); PH_SB()
+
+  unsigned long long cyc_m = 0, cyc_e = 0, cyc_b = 0, cyc_e1 = 0, cyc_e2 = 0, cyc_e3 = 0;
+  const unsigned long long ql0_ = PH_CLK();
+  (void)ql0_;
+  // Group 1 enters one barrier late: its matrix phases coincide with group 0's store phases.  Every wave executes
+  // 2 * ceil(K / 2) + 1 barriers in total (the shorter list pads at the end).  The loop body is straight-line on
+  // purpose: with the two phases in the arms of a branch the accumulators were merged in VGPRs at the loop header and
+  // copied to and from the AGPRs (128 moves) in every half-phase.
+  if (grp == 1) PH_BARRIER();
+  for (int i = 0; i < n_mine; ++i) {
+    const unsigned long long q0_ = PH_CLK();
+    {
+      // ---- matrix phase: 9 taps x 4 k-steps x 4 MFMAs from the group's halo buffer and the resident weights.
+      // (The empty asm makes the per-lane bases opaque: otherwise the 9 taps' LDS addresses - loop invariants -
+      // are all hoisted in front of the loop and spilled; they cost a few VALU in MFMA shadows here.)
+#ifndef PH_L1_NOPREFETCH
+      if (i + 1 < n_mine) prefetch_halo(tc_next);
+#endif
+#pragma unroll
+      for (int ii = 0; ii < FM; ++ii) asm volatile("" : "+v"(prow[ii]));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(bx[j]));
+      tap_addr(0, 0);
+#pragma unroll
+      for (int ii = 0; ii < FM; ++ii) fa[0][ii] = PH_LDA(aaddr, ii, 0);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[0][j] = PH_LDA(bxs, j, 0);
+#pragma unroll
+      for (int t = 0; t < NTAPS; ++t) {
+        if (t == 0) { PH_KSTEP2T(PH_MMT0, 0, 1, 1); } else { PH_KSTEP2T(PH_MMT, 0, 1, 1); }
+        PH_KSTEP2T(PH_MMT, 1, 0, 2);
+        PH_KSTEP2T(PH_MMT, 0, 1, 3);
+        if (t + 1 < NTAPS) {
+          tap_addr(((t + 1) / 3) * HPW + (t + 1) % 3, t + 1);
+          PH_KSTEP2T(PH_MMT, 1, 0, 0);
+        } else {
+          PH_KSTEP2T_END(1);
+        }
+      }
+    }
+    const unsigned long long q1_ = PH_CLK();
+    PH_BARRIER();
+    const unsigned long long q2_ = PH_CLK();
+    {
+      // ---- store phase: the halo buffer is free (barrier) -> next halo in flight behind the epilogue
+      const bool halo = i + 1 < n_mine;
+      if (halo) halo_begin(tc_next);
+      const unsigned long long e1_ = PH_CLKF();
+      epilogue_any(tc_cur, halo);
+      tc_cur = tc_next;
+      if (i + 2 < n_mine) tc_next = decode(tile_id(2 * (i + 2) + grp));
+      const unsigned long long e2_ = PH_CLKF();
+      PH_WAIT_VMCNT(0);
+      const unsigned long long e3_ = PH_CLK();
+      cyc_e += e3_ - q2_;
+      cyc_e1 += e1_ - q2_; cyc_e2 += e2_ - e1_; cyc_e3 += e3_ - e2_;
+    }
+    const unsigned long long q3_ = PH_CLK();
+    PH_BARRIER();
+    cyc_m += q1_ - q0_;
+    cyc_b += (q2_ - q1_) + (PH_CLK() - q3_);
+  }
+  for (int r = 2 * (((K + 1) >> 1) - n_mine) + (grp == 0 ? 1 : 0); r > 0; --r) PH_BARRIER();
+
+  if (p.stats) {   // one partial row [2][Cout] per workgroup
+    // per-lane channel sums -> sum over the 32 pixel lanes of each k-half (xor butterfly: fixed order), then the 8
+    // waves' rows are combined in a fixed order
+    float* red = reinterpret_cast<float*>(smem + C::LDS_MAIN);   // [8][2][BNT]
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int cmp = 0; cmp < 2; ++cmp) {
+          float a1 = s1[j][q][cmp], a2 = s2[j][q][cmp];
+#pragma unroll
+          for (int d = 1; d < 32; d <<= 1) {
+            a1 += __shfl_xor(a1, d, 64);
+            a2 += __shfl_xor(a2, d, 64);
+          }
+          if ((lane & 31) == 0) {
+            const int ch = j * 32 + 8 * (q >> 1) + 4 * khalf + 2 * (q & 1) + cmp;
+            red[(wave * 2 + 0) * BNT + ch] = a1;
+            red[(wave * 2 + 1) * BNT + ch] = a2;
+          }
+        }
+    __syncthreads();
+    if (tid < 2 * BNT) {
+      const int which = tid / BNT, n = tid % BNT;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * 2 + which) * BNT + n];
+      p.stats[((size_t)blockIdx.x * 2 + which) * p.Cout + n] = v;
+    }
+  }
+  PH_TRACE(5);
+  PH_TRACE_ACC_T(6, cyc_m, 0); PH_TRACE_ACC_T(3, cyc_e, 0); PH_TRACE_ACC_T(8, cyc_b, 0);
+#ifdef PH_TRACE_FINE
+  PH_TRACE_ACC_T(4, cyc_e1, 256); PH_TRACE_ACC_T(9, cyc_e2, 256); PH_TRACE_ACC_T(7, cyc_e3, 256);   // group 1's store phase: issue / epilogue / wait
+#else
+  PH_TRACE_ACC_T(4, cyc_m, 256); PH_TRACE_ACC_T(9, cyc_e, 256); PH_TRACE_ACC_T(7, cyc_b, 256);   // group 1
+#endif
+  (void)cyc_e1; (void)cyc_e2; (void)cyc_e3;
+  PH_TRACE_ACC(10, PH_CLK() - ql0_); PH_TRACE_ACC(11, (unsigned long long)K);
+  (void)cyc_m; (void)cyc_e; (void)cyc_b;
+}
+
+int launch_l1(const PhTapConv& p, hipStream_t st) {
+  using C = L1Cfg;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tapconv2_l1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess)
+      return PH_ELAUNCH;
+    attr_done = true;
+  }
+  const int total = cdiv(p.OHt, C::TH) * cdiv(p.OWt, C::TW) * p.B;
+  const int resident = ph_num_cus();
+  dim3 grid(total < resident ? total : resident);
+  void* tok = nullptr;
+  if (ph_prof_on())
+    ph_prof_begin(PH_CLS_TAPCONV2_RES, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
+  hipLaunchKernelGGL(tapconv2_l1_kernel, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
+  ph_prof_end(tok, st);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
 template <int WM, int WN, int FM, bool RES>
 int launch2(const PhTapConv& p, hipStream_t st) {
   using C = Tap2Cfg<WM, WN, FM, RES>;
@@ -559,7 +1035,11 @@ int ph_tapconv2_stat_parts(const PhTapConv* p) {
 
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
   if (p->Cout % 128 == 0) return launch2<2, 2, 4, false>(*p, st);
-  return launch2<4, 1, 2, true>(*p, st);   // Cin = Cout = 64: resident weights
+#ifdef PH_L1_ONE_GROUP   // A/B build: the one-wave-per-SIMD resident-weights configuration
+  return launch2<4, 1, 2, true>(*p, st);
+#else
+  return launch_l1(*p, st);   // Cin = Cout = 64: resident weights, two wave groups
+#endif
 }
 
 #ifdef PH_TAP_TRACE

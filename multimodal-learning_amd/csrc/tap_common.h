@@ -25,8 +25,14 @@
     const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                   \
     if (threadIdx.x == 0 && wg_ < PH_TRACE_WGS) ph_tap_trace[(size_t)wg_ * 12 + (k)] = (v);                \
   } while (0)
+#define PH_TRACE_ACC_T(k, v, thr)                                                                          \
+  do {                                                                                                     \
+    const unsigned wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                   \
+    if (threadIdx.x == (thr) && wg_ < PH_TRACE_WGS) ph_tap_trace[(size_t)wg_ * 12 + (k)] = (v);            \
+  } while (0)
 #define PH_CLK() clock64()
 #else
+#define PH_TRACE_ACC_T(k, v, thr)
 #define PH_TRACE(k)
 #define PH_TRACE_HWID()
 #define PH_TRACE_ACC(k, v)

@@ -46,6 +46,16 @@ for name, Cin, Cout, H in shapes:
     ns = np.median(buf[:, 11].astype(np.float64))
     loop = np.median(buf[:, 10].astype(np.float64))
     med = lambda k: np.median(buf[:, k].astype(np.float64))
+    if Cin == 64 and Cout == 64 and not os.environ.get("PH_L1_ONE_GROUP"):
+        # two-group layer-1 kernel: slot 11 = tiles of the workgroup; per group: MFMA phases, store phases, barrier waits
+        K = ns
+        print(f"{name}: span {span:.1f} us ({fl / span / 1e6:.0f} TFLOP/s), workgroup life {np.median(life):.1f} us, prologue "
+              f"{np.median(prol):.2f} us, {K:.0f} tiles/workgroup, loop {loop:.0f} cyc ({loop / np.median(life - prol) / 1e3:.2f} GHz) "
+              f"= {loop / (K + 1):.0f} per half-phase")
+        print(f"    group 0 per tile: MFMA phase {med(6) / (K / 2):.0f} (floor 4608), store phase {med(3) / (K / 2):.0f}, barrier wait {med(8) / (K / 2):.0f};"
+              f"  group 1: MFMA {med(4) / (K / 2):.0f}, store {med(9) / (K / 2):.0f}, barrier wait {med(7) / (K / 2):.0f}"
+              "   (build with EXTRA=-DPH_TRACE_FINE: slots 4/9/7 = group 0's store phase split into DMA issue / epilogue / vmcnt wait)")
+        continue
     ntile = max(ns / (9 * Cin / 64), 1)
     print(f"{name}: Cin {Cin} Cout {Cout} HW {H}: span {span:.1f} us ({fl / span / 1e6:.0f} TFLOP/s), workgroup life {np.median(life):.1f} us, "
           f"prologue {np.median(prol):.2f} us, {ns:.0f} stages/workgroup")
