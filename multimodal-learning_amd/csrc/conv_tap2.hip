@@ -261,12 +261,15 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     }
     __syncthreads();
   };
-  auto epilogue = [&](const TileCtx& tc, auto fullc) {
+  // FULL (tile inside the output) and RM (0: no residual, 1: + res_g, 2: + res_g masked by res_a > 0) are compile-time:
+  // as a run-time test inside the unrolled loops the residual cost a taken branch per stored word.
+  auto epilogue = [&](const TileCtx& tc, auto fullc, auto rmc) {
     constexpr bool FULL = decltype(fullc)::value;   // the tile lies completely inside the output: no masking
+    constexpr int RM = decltype(rmc)::value;
     const int r0 = tc.r0, c0 = tc.c0, n0 = tc.n0;
     T* out = reinterpret_cast<T*>(p.out) + (size_t)tc.b * p.OH * p.OW * p.Cout;
-    const T* resg = p.res_g ? reinterpret_cast<const T*>(p.res_g) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
-    const T* resa = p.res_a ? reinterpret_cast<const T*>(p.res_a) + (size_t)tc.b * p.OH * p.OW * p.Cout : nullptr;
+    const T* resg = reinterpret_cast<const T*>(p.res_g) + (size_t)tc.b * p.OH * p.OW * p.Cout;
+    const T* resa = reinterpret_cast<const T*>(p.res_a) + (size_t)tc.b * p.OH * p.OW * p.Cout;
     // byte selector of v_perm_b32 {neighbour's packed pair, own packed pair}: even lanes build [own lo | neighbour lo],
     // odd lanes [neighbour hi | own hi]
     const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
           o[m] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + (nrow[0] & ~1);
         }
         bf16x2 rg[8][FN], ra[8][FN];
-        if (resg) {
+        if constexpr (RM > 0) {
 #pragma unroll
           for (int m = 0; m < 8; ++m)
 #pragma unroll
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
               ra[m][j] = bf16x2{(bf16)1.f, (bf16)1.f};
               if (mine[m]) {
                 rg[m][j] = *reinterpret_cast<const bf16x2*>(resg + o[m] + j * 32);
-                if (resa) ra[m][j] = *reinterpret_cast<const bf16x2*>(resa + o[m] + j * 32);
+                if constexpr (RM > 1) ra[m][j] = *reinterpret_cast<const bf16x2*>(resa + o[m] + j * 32);
               }
             }
         }
@@ -319,9 +322,9 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
             const unsigned x = __builtin_bit_cast(unsigned, own);
             const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
             bf16x2 w = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(y, x, psel));
-            if (resg) {
-              w[0] = (bf16)((float)w[0] + ((float)ra[m][j][0] > 0.f ? (float)rg[m][j][0] : 0.f));
-              w[1] = (bf16)((float)w[1] + ((float)ra[m][j][1] > 0.f ? (float)rg[m][j][1] : 0.f));
+            if constexpr (RM > 0) {
+              w[0] = (bf16)((float)w[0] + ((RM < 2 || (float)ra[m][j][0] > 0.f) ? (float)rg[m][j][0] : 0.f));
+              w[1] = (bf16)((float)w[1] + ((RM < 2 || (float)ra[m][j][1] > 0.f) ? (float)rg[m][j][1] : 0.f));
             }
 #ifdef PH_ABL_NOSTORE   // timing ablation only
             asm volatile("" ::"v"(w));
@@ -333,6 +336,18 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       }
       ep_w += PH_CLK() - e0_;
     }
+  };
+
+  const int rmode = p.res_g ? (p.res_a ? 2 : 1) : 0;
+  auto epilogue_any = [&](const TileCtx& tc) {
+    const bool full = (tc.r0 + TH <= p.OHt) && (tc.c0 + TW <= p.OWt);
+    auto with_full = [&](auto fullc) {
+      if (rmode == 0) epilogue(tc, fullc, std::integral_constant<int, 0>{});
+      else if (rmode == 1) epilogue(tc, fullc, std::integral_constant<int, 1>{});
+      else epilogue(tc, fullc, std::integral_constant<int, 2>{});
+    };
+    if (full) with_full(std::true_type{});
+    else with_full(std::false_type{});
   };
 
   // ---- the tap stream.  Tile (outer loop) -> 64-channel slice -> 9 taps (fully unrolled: tap offsets, the piece of
@@ -491,8 +506,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     if constexpr (RES) PH_BARRIER();   // no per-tap barrier in this configuration: all waves are done with the A buffer
     const unsigned long long q3_ = PH_CLK();
     cyc_b += q3_ - q2b_;
-    if ((tcur.r0 + TH <= p.OHt) && (tcur.c0 + TW <= p.OWt)) epilogue(tcur, std::true_type{});
-    else epilogue(tcur, std::false_type{});
+    epilogue_any(tcur);
     if (p.stats && (!nvalid || tnext.n0 != tcur.n0)) flush_stats(tcur.n0, smem + (acur ^ 1) * C::A_BYTES);
     zero_acc();
     cyc_e += PH_CLK() - q3_;

@@ -4,7 +4,7 @@
 VAR=${1:-libpathomic_hip_oldl1.so}
 cd multimodal-learning_amd
 cp libpathomic_hip.so /tmp/lib_new.so
-show='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["roofline"])'
+show='import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], [(k["kernel"][:28], k["total_ms"]) for k in d["roofline"]["all_kernels"]])'
 for r in 1 2; do
   cp /tmp/lib_new.so libpathomic_hip.so; echo "== current"
   (cd .. && python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "$show")
