@@ -331,11 +331,66 @@ __global__ void pack_all_kernel(PhPackAll t, bf16* __restrict__ packed, int npla
   }
 }
 
+// The same, tiled through LDS: one workgroup per (conv, 32 output channels, 32 input channels), all taps.  The
+// element-per-thread kernel above writes the dgrad layout [tap][I][O] as 2-byte words scattered with a stride of O
+// elements (110 us for the 11 M weights of a ResNet-18, twice per step); here the OIHW rows are read as contiguous
+// runs of 32*NT floats and both layouts leave as 64-byte runs.
+struct PackTiles { int tstart[21]; };
+template <int NP>
+__global__ __launch_bounds__(256) void pack_all_tiled_kernel(PhPackAll t, PackTiles pt, bf16* __restrict__ packed) {
+  __shared__ bf16 sh[NP][32][32 * 9 + 2];
+  int u = 0;
+#pragma unroll 1
+  while (u + 1 < t.n && (int)blockIdx.x >= pt.tstart[u + 1]) ++u;
+  const int O = t.O[u], I = t.I[u], NT = t.NT[u];
+  const int tile = (int)blockIdx.x - pt.tstart[u];
+  const int itiles = I >> 5;
+  const int o0 = (tile / itiles) << 5, i0 = (tile % itiles) << 5;
+  const size_t n = (size_t)NT * O * I;
+  const int run = 32 * NT;   // contiguous floats per output-channel row of the tile
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int o = idx / run, r = idx - o * run;
+    const float v = t.w[u][((size_t)(o0 + o) * I + i0) * NT + r];
+    if constexpr (NP == 1) {
+      sh[0][o][r] = (bf16)v;
+    } else {
+      bf16 a, b, c;
+      split3_bf16(v, a, b, c);
+      sh[0][o][r] = a; sh[1][o][r] = b; sh[2][o][r] = c;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int x = idx & 31, y = (idx >> 5) & 31, tp = idx >> 10;
+    // forward layout [tap][O][I]: x = input channel (fastest), y = output channel
+    const size_t fdst = t.dst_fwd[u] + ((size_t)tp * O + o0 + y) * I + i0 + x;
+    // dgrad layout [tap][I][O]: x = output channel (fastest), y = input channel
+    const size_t ddst = t.dst_dg[u] + ((size_t)tp * I + i0 + y) * O + o0 + x;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      packed[fdst + pl * n] = sh[pl][y][x * NT + tp];
+      packed[ddst + pl * n] = sh[pl][x][y * NT + tp];
+    }
+  }
+}
+
 }  // namespace
 
 int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_t st) {
-  hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, st, *t, (bf16*)packed,
-                     nplanes);
+  bool tiled = t->n <= 20;
+  PackTiles pt;
+  pt.tstart[0] = 0;
+  for (int u = 0; u < t->n && tiled; ++u) {
+    if ((t->O[u] & 31) || (t->I[u] & 31) || t->NT[u] > 9) tiled = false;
+    pt.tstart[u + 1] = pt.tstart[u] + (t->O[u] >> 5) * (t->I[u] >> 5);
+  }
+  if (tiled && nplanes == 1)
+    hipLaunchKernelGGL(pack_all_tiled_kernel<1>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (bf16*)packed);
+  else if (tiled && nplanes == 3)
+    hipLaunchKernelGGL(pack_all_tiled_kernel<3>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (bf16*)packed);
+  else
+    hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, st, *t, (bf16*)packed,
+                       nplanes);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -51,6 +51,29 @@ class FlatParams:
         return [tuple(s) for s in segs]
 
 
+class PinnedRing:
+    """Host staging for small per-step values that are uploaded with an asynchronous copy while the device still
+    works on earlier steps: a ring of pinned rows, each guarded by an event recorded after its copy (a single pinned
+    buffer would be overwritten by the host, which runs steps ahead of the device, before the copy has executed)."""
+
+    def __init__(self, shape, dtype, depth=16):
+        self.buf = torch.zeros((depth,) + tuple(shape), dtype=dtype).pin_memory()
+        self.events = [None] * depth
+        self.k = 0
+
+    def upload(self, dst, values):
+        i = self.k % len(self.events)
+        self.k += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        row = self.buf[i]
+        row.copy_(torch.as_tensor(values, dtype=row.dtype).reshape(row.shape))
+        dst.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[i] = ev
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (L2-in-grad weight decay, bias correction, eps outside the sqrt) as one
     HIP kernel over flat parameter / gradient / state buffers (ph_adam_ema_step)."""
@@ -79,7 +102,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._v = torch.zeros_like(self._flat.flat)
             self._segs = self._flat.segments(lambda t: t.requires_grad)
             self._hyper = torch.zeros(4, device=ps[0].device, dtype=torch.float32)
-            self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._hyper_host = PinnedRing((4,), torch.float32)
             ops.bump_weight_epoch()
         return self._flat
 
@@ -91,11 +114,8 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1
         b1, b2 = g["betas"]
-        self._hyper_host[0] = g["lr"]
-        self._hyper_host[1] = 1.0 - b1 ** self._step
-        self._hyper_host[2] = math.sqrt(1.0 - b2 ** self._step)
-        self._hyper_host[3] = self.ema_alpha if self.ema_alpha is not None else 0.0
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._hyper_host.upload(self._hyper, [g["lr"], 1.0 - b1 ** self._step, math.sqrt(1.0 - b2 ** self._step),
+                                              self.ema_alpha if self.ema_alpha is not None else 0.0])
         self._prepared = True
 
     @property
@@ -270,6 +290,7 @@ class DistillStep:
         self.iter_num = opt.global_step
         self._want_graph = False
         self._static = None
+        self._slots = None
         self._side_stream = torch.cuda.Stream(device=self.device) if getattr(opt, "overlap_teachers", True) else None
         self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
         # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
@@ -457,49 +478,93 @@ class DistillStep:
             out = self._device_body(x_path, ema_x_path, x_omic, grade, index, sample_idx, bnorm, e, r1, r2)
             self.iter_num += 1
             return out
-        # ---- graph path: static input buffers, per-step scalars in device memory
-        st = getattr(self, "_static", None)
-        key = (tuple(x_path.shape), tuple(x_omic.shape), tuple(sample_idx.shape))
-        if st is None or st["key"] != key:
-            mk = lambda t, dt=None: torch.empty(t.shape, device=dev, dtype=dt or t.dtype)
-            st = dict(key=key, x_path=mk(x_path), ema_x_path=mk(ema_x_path), x_omic=mk(x_omic), grade=mk(grade),
-                      index=mk(index), sample_idx=mk(sample_idx),
-                      r=[None if r is None else torch.empty(r.shape, device=dev, dtype=torch.int32) for r in rk],
-                      graph=None, out=None)
-            self._static = st
-        for name, src in (("x_path", x_path), ("ema_x_path", ema_x_path), ("x_omic", x_omic), ("grade", grade),
-                          ("index", index), ("sample_idx", sample_idx)):
-            if src.data_ptr() != st[name].data_ptr():
-                st[name].copy_(src, non_blocking=True)
-        for dst, src in zip(st["r"], rk):
+        # ---- graph path: per-step scalars in device memory, inputs at fixed addresses.  A captured graph reads its
+        # inputs from the addresses it was captured with.  If the caller hands over DEVICE tensors (a loader's ring of
+        # resident batch buffers), up to two such input sets are adopted as they are - one captured graph each, sharing
+        # one memory pool - and replayed without any copy; anything else (host tensors, more than two sets) is staged
+        # into the first set's buffers by device-to-device / host-to-device copies (2 x 76 us for two 201 MB views).
+        given = dict(zip(self._IN_NAMES, (x_path, ema_x_path, x_omic, grade, index, sample_idx)))
+        st = self._ensure_slot(given, rk, bnorm, e)
+        if st is None:                       # capture failed: eager from now on
+            out = self._device_body(*[given[k].to(dev) for k in self._IN_NAMES], bnorm, e,
+                                    *[None if r is None else r.to(dev) for r in rk])
+            self.iter_num += 1
+            return out
+        self._static = st
+        for name in self._IN_NAMES:
+            if given[name].data_ptr() != st[name].data_ptr():
+                st[name].copy_(given[name], non_blocking=True)
+        for j, (dst, src) in enumerate(zip(st["r"], rk)):
             if dst is not None:
-                dst.copy_(src, non_blocking=True)
+                ring = st.setdefault("r_ring", {}).get(j)
+                if ring is None:
+                    ring = st["r_ring"][j] = PinnedRing(tuple(dst.shape), torch.int32)
+                ring.upload(dst, src)
         self.optimizer.prepare_step()
+        self.optimizer._prepared = False
+        st["graph"].replay()
+        self.iter_num += 1
+        return st["out"]
+
+    _IN_NAMES = ("x_path", "ema_x_path", "x_omic", "grade", "index", "sample_idx")
+
+    def _ensure_slot(self, given, r_like, bnorm, e):
+        """The input set (static buffers + captured graph) that serves `given`; captures its graph if needed."""
+        dev = self.device
+        names = self._IN_NAMES
+        on_dev = all(t.is_cuda and t.is_contiguous() for t in given.values())
+        ptrs = tuple(t.data_ptr() for t in given.values()) if on_dev else None
+        shapes = (tuple(given["x_path"].shape), tuple(given["x_omic"].shape), tuple(given["sample_idx"].shape))
+        slots = getattr(self, "_slots", None)
+        if slots is None or (slots and slots[0]["key"] != shapes):
+            slots = self._slots = []
+        st = next((q for q in slots if ptrs is not None and q["ptrs"] == ptrs), None)
+        if st is None and (not slots or (on_dev and len(slots) < 2)):
+            if on_dev:
+                bufs = dict(given)                    # adopted: the caller refills these tensors in place
+            else:
+                bufs = {k: torch.empty(t.shape, device=dev, dtype=t.dtype) for k, t in given.items()}
+            st = dict(key=shapes, ptrs=tuple(bufs[k].data_ptr() for k in names), graph=None, out=None,
+                      r=[None if r is None else torch.empty(tuple(r.shape), device=dev, dtype=torch.int32) for r in r_like],
+                      **bufs)
+            slots.append(st)
+        if st is None:
+            st = slots[0]
         if st["graph"] is None:
             lib().ph_prof_enable(0)          # event timing is an eager-mode facility
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
+            pool = next((q["graph"].pool() for q in slots if q["graph"] is not None), None)
+            was_prepared = self.optimizer._prepared
             try:
-                with torch.cuda.graph(g):
-                    self.optimizer._prepared = True
+                with torch.cuda.graph(g, pool=pool):
+                    self.optimizer._prepared = True       # the step scalars are read from device memory at replay
                     st["out"] = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"],
                                                   st["index"], st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
                 st["graph"] = g
-                # capture does not execute: the prepared scalars are still pending for the first replay
+                self.optimizer._prepared = was_prepared   # capture does not execute anything
             except Exception as exc:     # e.g. a collective that cannot be captured on this stack: stay eager
                 import warnings
                 warnings.warn("HIP graph capture of the distill step failed (%r); continuing with eager launches" % (exc,))
                 torch.cuda.synchronize()
                 self._want_graph = False
                 self._static = None
-                out = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"], st["index"],
-                                        st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
-                self.iter_num += 1
-                return out
-        self.optimizer._prepared = False
-        st["graph"].replay()
-        self.iter_num += 1
-        return st["out"]
+                self._slots = None
+                self.optimizer._prepared = was_prepared
+                return None
+        return st
+
+    def precapture(self, batch, epoch=0):
+        """Capture the graph for another resident input set without running a step (e.g. the second buffer of a
+        loader's two-deep ring, so that its first use does not pay the capture).  Needs one graph step done before."""
+        slots = getattr(self, "_slots", None)
+        if not slots or slots[0]["graph"] is None:
+            raise RuntimeError("precapture: run a graph-mode step first")
+        (x_path, ema_x_path), _, x_omic, _, _, grade, index, sample_idx = batch
+        given = dict(zip(self._IN_NAMES, (x_path, ema_x_path, x_omic, grade, index, sample_idx)))
+        bnorm = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))
+        e = getattr(self, "_e_dev", None) if self.variant != "miccai2022" else epoch / self.opt.niter_decay
+        return self._ensure_slot(given, slots[0]["r"], bnorm, e) is not None
 
     # ------------------------------------------------------------------ checkpoint / resume (SURVEY row f-3)
     def state_dict(self):
@@ -540,6 +605,7 @@ class DistillStep:
                 mod.rng_step.copy_(sd["teacher_rng_steps"][name])
         ops.bump_weight_epoch()      # packed MFMA weight images are rebuilt from the loaded parameters
         self._static = None          # a captured graph keeps pointing at valid buffers, but is rebuilt to be safe
+        self._slots = None
 
     def static_inputs(self):
         """The graph path's resident input buffers (fill them in place to skip the device-to-device copy)."""

@@ -398,3 +398,42 @@ def test_mia2023_variant_steps_vs_reference_golden(golden_dir):
         assert float(out["w1"].max()) == 1.0, "the re-weighting switch is a device scalar: replay must follow the epoch"
     finally:
         m.set_precision("bf16")
+
+
+def test_graph_replay_on_resident_input_sets_matches_staged_inputs():
+    """Device-resident batches are adopted in place as the captured graphs' input sets (two sets, one graph each,
+    DistillStep._ensure_slot / precapture): the trajectory must be bit-identical to feeding the same batches from the
+    host through the staging copies, and no staging copy may be left (the adopted tensors ARE the static buffers)."""
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt, synthetic_batch
+    m.set_precision("bf16")
+    opt = default_opt()
+    bts = [synthetic_batch(8, 64, seed=40 + i) for i in range(2)]
+    rng = np.random.RandomState(3)
+    ranks = [[rng.choice(np.arange(30, 100), 20, replace=False) for _ in range(2)] for _ in range(7)]
+
+    def run(resident):
+        step = _mk_step(opt, 1024, seed=0)
+        step.enable_graph()
+        if resident:
+            feeds = [tuple(tuple(u.cuda() for u in t) if isinstance(t, tuple) else t.cuda() for t in _tuple(bt)) for bt in bts]
+        else:
+            feeds = [_tuple(bt) for bt in bts]
+        for i in range(7):
+            if resident and i == 3:
+                assert step.precapture(feeds[1], epoch=1)
+                assert len(step._slots) == 2 and all(q["graph"] is not None for q in step._slots)
+            out = step.step(feeds[i % 2], epoch=1, ranks=ranks[i])
+        torch.cuda.synchronize()
+        if resident:
+            assert step._static["x_path"].data_ptr() == feeds[0][0][0].data_ptr(), "inputs were staged, not adopted"
+            assert len(step._slots) == 2
+        else:
+            assert len(step._slots) == 1
+        return out["loss"].item(), step.model.state_dict()["fc_new2.weight"].clone(), \
+            step.ema_model.state_dict()["conv1.weight"].clone(), step.criterion_kd.contrast.memory_v1.clone()
+
+    a, b = run(False), run(True)
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
