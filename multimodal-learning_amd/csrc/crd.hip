@@ -70,22 +70,31 @@ __global__ __launch_bounds__(256) void crd_score_kernel(const float* __restrict_
 
 // one block per sample.  sel[b][0..P2) = positive columns, sel[b][P2..P2+K2) = negative columns (absolute
 // column numbers in [0, P+K)); xs/xt = gathered raw exp scores.
-__global__ __launch_bounds__(256) void crd_select_kernel(const float* __restrict__ diff,
+__global__ __launch_bounds__(1024) void crd_select_kernel(const float* __restrict__ diff,
                                                          const float* __restrict__ out1,
                                                          const float* __restrict__ out2,
                                                          const int* __restrict__ ranks, int* __restrict__ sel,
                                                          float* __restrict__ xs, float* __restrict__ xt, int P, int K,
                                                          int P2, int K2, int select_neg, int select_pos) {
-  extern __shared__ float sd[];   // [P+K] discrepancies, then int rank_to_col[P]
+  extern __shared__ __attribute__((aligned(16))) float sd[];   // [P+K] discrepancies, then int rank_to_col[P]
   const int b = blockIdx.x, PK = P + K, S2 = P2 + K2;
   int* r2c = reinterpret_cast<int*>(sd + PK);
   for (int i = threadIdx.x; i < PK; i += blockDim.x) sd[i] = diff[(size_t)b * PK + i];
   __syncthreads();
   // positives: rank in DEscending order of diff[0..P)  (memory_new.py:303)
+  // (rank by counting; the list is read from LDS four values at a time - one ds_read_b128 per four comparisons)
+  const int P4 = P & ~3;
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
     const float v = sd[i];
     int r = 0;
-    for (int q = 0; q < P; ++q) { const float w = sd[q]; r += (w > v) || (w == v && q < i); }
+    for (int q = 0; q < P4; q += 4) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(sd + q);
+      r += (w[0] > v) || (w[0] == v && q < i);
+      r += (w[1] > v) || (w[1] == v && q + 1 < i);
+      r += (w[2] > v) || (w[2] == v && q + 2 < i);
+      r += (w[3] > v) || (w[3] == v && q + 3 < i);
+    }
+    for (int q = P4; q < P; ++q) { const float w = sd[q]; r += (w > v) || (w == v && q < i); }
     r2c[r] = i;
   }
   __syncthreads();
@@ -103,7 +112,15 @@ __global__ __launch_bounds__(256) void crd_select_kernel(const float* __restrict
     if (select_neg) {
       const float v = sd[P + i];
       r = 0;
-      for (int q = 0; q < K; ++q) { const float w = sd[P + q]; r += (w < v) || (w == v && q < i); }
+      const int K4 = (P & 3) ? 0 : (K & ~3);   // 16-byte aligned only when P is a multiple of 4
+      for (int q = 0; q < K4; q += 4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sd + P + q);
+        r += (w[0] < v) || (w[0] == v && q < i);
+        r += (w[1] < v) || (w[1] == v && q + 1 < i);
+        r += (w[2] < v) || (w[2] == v && q + 2 < i);
+        r += (w[3] < v) || (w[3] == v && q + 3 < i);
+      }
+      for (int q = K4; q < K; ++q) { const float w = sd[P + q]; r += (w < v) || (w == v && q < i); }
     } else {
       r = i;
     }
@@ -322,7 +339,9 @@ int ph_crd_select(const float* diff, const float* out1, const float* out2, const
                   float* xt, int B, int P, int K, int P2, int K2, int select_neg, int select_pos, hipStream_t st) {
   if (P2 > P || K2 > K || (!select_pos && P2 != P)) return PH_EINVAL;
   const size_t lds = (size_t)(P + K) * 4 + (size_t)P * 4;
-  hipLaunchKernelGGL(crd_select_kernel, dim3(B), dim3(256), lds, st, diff, out1, out2, ranks, sel, xs, xt, P, K, P2,
+  // 1024 threads per sample: the rank counting is instruction-bound (P^2 + K^2 comparisons), 256 threads left one wave
+  // per SIMD on B of the 256 CUs (76 us at B = 64, P + K = 1000)
+  hipLaunchKernelGGL(crd_select_kernel, dim3(B), dim3(1024), lds, st, diff, out1, out2, ranks, sel, xs, xt, P, K, P2,
                      K2, select_neg, select_pos);
   PH_LAUNCH_CHECK();
   return PH_OK;

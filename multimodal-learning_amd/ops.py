@@ -67,7 +67,7 @@ def linear_fwd(x, w, b, act=ACT_NONE):
     N = w.shape[0]
     y = torch.empty(Bn, N, device=x.device, dtype=torch.float32)
     if K >= 4096 and Bn * N <= 256 * 256:
-        nsplit = 32
+        nsplit = 128 if K >= 8192 else 32     # 64-256 workgroups: a 16641-deep K in 5 LDS steps per workgroup instead of 17
         part = torch.empty(nsplit * Bn * N, device=x.device, dtype=torch.float32)
         check(lib().ph_sgemm_splitk(ptr(x), ptr(w), ptr(b), ptr(y), ptr(part), nsplit, Bn, N, K, K, 1, 1, K, N, act,
                                     stream()), "ph_sgemm_splitk")
