@@ -27,7 +27,7 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
              "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
              "stem_wgrad_kernel<bf16>",
              "tapconv2_kernel<2,2,4,false> (3x3 stride-1 fwd+dgrad, Cout>=128)",
-             "tapconv2_kernel<4,1,2,true> (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1)"]
+             "tapconv2_l1_kernel (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1, two wave groups)"]
 NCLS = len(CLS_NAMES)
 
 

@@ -25,7 +25,9 @@ def short(k):
 def cls_of(name):
     """kernel name -> class index of ph_prof_summary / bench.py CLS_NAMES"""
     n = name
-    if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel: <2,2,4,false> = Cout >= 128, <4,1,2,true> = layer 1
+    if "tapconv2_l1_kernel" in n:   # layer 1 (Cin = Cout = 64): two wave groups, resident weights
+        return 7
+    if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel, Cout >= 128
         return 7 if ("4, 1, 2" in n or "Li4ELi1ELi2E" in n) else 6
     if "tapconv_kernel" in n:
         if "Li2ELi8ELi128" in n or ", 2, 8, 128" in n:
