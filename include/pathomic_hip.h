@@ -206,6 +206,10 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
  * reference: this is the tensor-nuclear-norm proximal operator, see csrc/tsvd.hip): adj, aux are [V][B][B] (view-major),
  * V in {2,4,6,8}, B <= 64; tnn[0] = (1/V) sum over frequency slices of the nuclear norm of the thresholded slice.
  * ---------------------------------------------------------------------------------------------- */
+/* Orthogonality loss of the stage-1 trainer (reference MICCAI-2022/CL_utils/orthogonal_loss.py:18-32): rows scaled by
+ * a DETACHED 1/(||x||+eps) (:24-28); the D x D cross-correlation and its mean square are ph_sgemm + ph_sqdiff_sum. */
+int ph_row_invnorm_scale(const float* x, float* y, float* inv /* [B] */, int B, int D, float eps, ph_stream_t stream);
+int ph_row_scale(const float* x, const float* r /* [B] */, float* y, int B, int D, ph_stream_t stream);
 int ph_sqdiff_sum(const float* a, const float* b, float* out, size_t n, float scale, ph_stream_t stream);
 int ph_scaled_diff(const float* a, const float* b, const float* gscalar, float alpha, float* out, size_t n,
                    ph_stream_t stream);

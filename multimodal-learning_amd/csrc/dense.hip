@@ -480,6 +480,26 @@ __global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict
   for (int d = lane; d < D; d += 64) y[(size_t)row * D + d] = x[(size_t)row * D + d] / n;
   if (lane == 0) nrm[row] = n;
 }
+// y = x / (||x||_2 + eps) per row with the norm treated as a constant (orthogonal_loss.py:24-28: `.detach()` on the
+// norm), inv[row] = 1 / (||x|| + eps) kept for the backward (a plain row scaling)
+__global__ void row_invnorm_scale_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv,
+                                         int B, int D, float eps) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = x[(size_t)row * D + d]; s += v * v; }
+  s = wave_sum(s);
+  const float r = 1.f / (sqrtf(s) + eps);
+  for (int d = lane; d < D; d += 64) y[(size_t)row * D + d] = x[(size_t)row * D + d] * r;
+  if (lane == 0) inv[row] = r;
+}
+__global__ void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ r, float* __restrict__ y, int B,
+                                 int D) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const float f = r[row];
+  for (int d = lane; d < D; d += 64) y[(size_t)row * D + d] = x[(size_t)row * D + d] * f;
+}
 __global__ void l2norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                   const float* __restrict__ nrm, float* __restrict__ dx, int B, int D) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -726,6 +746,16 @@ int ph_conf_discrepancy(const float* logit_s, const float* logit_t, const int64_
 }
 int ph_l2norm_fwd(const float* x, float* y, float* nrm, int B, int D, hipStream_t st) {
   hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, y, nrm, B, D);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_row_invnorm_scale(const float* x, float* y, float* inv, int B, int D, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(row_invnorm_scale_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, y, inv, B, D, eps);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_row_scale(const float* x, const float* r, float* y, int B, int D, hipStream_t st) {
+  hipLaunchKernelGGL(row_scale_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, x, r, y, B, D);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

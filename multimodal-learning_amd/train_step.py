@@ -616,8 +616,9 @@ class DistillStep:
 class TeacherStage1Step:
     """The batch body of the stage-1 mean-teacher trainer (MICCAI-2022/train_test_MT.py:121-230) for the
     grading task: student PathomicNet forward/backward, EMA PathomicNet forward, three-branch NLL (:208-212),
-    `pred_KD_loss` consistency (CL_utils/KD_losses.py:12-36; --num_teachers 1/2/3, :180-201), Adam, EMA update.
-    CRD / SP / orthogonality terms of that trainer (--CRD_distill, --SP_distill, --orth_loss) are not wired here."""
+    `pred_KD_loss` consistency (CL_utils/KD_losses.py:12-36; --num_teachers 1/2/3, :180-201), the optional vanilla
+    CRD term on the fused features (--CRD_distill 1, CL_utils/CRD_criterion.py) and orthogonality term (--orth_loss
+    True, CL_utils/orthogonal_loss.py), Adam, EMA update.  (--SP_distill names a class the reference never imports.)"""
 
     def __init__(self, opt, device="cuda", k=1, models=None):
         from .networks_new import define_net, define_optimizer, define_scheduler
@@ -632,7 +633,30 @@ class TeacherStage1Step:
             self.model, self.ema_model = models
         for p in self.ema_model.parameters():
             p.detach_()                                                             # train_test_MT.py:74-76
-        self.optimizer = define_optimizer(opt, self.model)                          # :86
+        # optional terms: vanilla CRD between the student's and the EMA teacher's fused features (:74-76,157-165; the
+        # reference builds three criteria, appends all six embed heads to the optimiser and uses the `fuse` one) and the
+        # orthogonality loss between the path and omic features (:79,216-218)
+        self.crd_on = getattr(opt, "CRD_distill", 0) == 1
+        self.orth_on = getattr(opt, "orth_loss", "False") == "True"
+        if getattr(opt, "SP_distill", 0) == 1:
+            raise NotImplementedError("--SP_distill: the reference's stage-1 trainer cannot run it either (its `Similarity` "
+                                      "import is commented out, train_test_MT.py:27,169)")
+        module_list = nn.ModuleList([self.model])
+        if self.crd_on:
+            from .CL_utils.CRD_criterion import CRDLoss as CRDLossV0
+            self.CRD_criterion_path = CRDLossV0(opt).to(self.device)
+            self.CRD_criterion_omic = CRDLossV0(opt).to(self.device)
+            self.CRD_criterion_fuse = CRDLossV0(opt).to(self.device)
+            for c in (self.CRD_criterion_path, self.CRD_criterion_omic, self.CRD_criterion_fuse):
+                c.contrast.verbose = False
+            # :84-90 appends all six heads to the optimiser, but only the `fuse` pair ever receives a gradient and
+            # torch's Adam skips parameters whose .grad is None: the other four never change.  The flat fused Adam has
+            # no "None" gradients (it would apply weight decay to them), so they are simply left out.
+            module_list.append(self.CRD_criterion_fuse.embed_s); module_list.append(self.CRD_criterion_fuse.embed_t)
+        if self.orth_on:
+            from .CL_utils.orthogonal_loss import OrthLoss
+            self.Orth_loss = OrthLoss()
+        self.optimizer = define_optimizer(opt, module_list if self.crd_on else self.model)      # :86-94
         self.scheduler = define_scheduler(opt, self.optimizer)
         self.iter_num = opt.global_step
         self.model.train(); self.ema_model.train()
@@ -641,7 +665,9 @@ class TeacherStage1Step:
             if hasattr(mod, "_get_packed"):
                 mod._follow_epoch = True
         self.optimizer.ema_flat = self.ema_flat
-        self.optimizer.ema_range = (0, self.optimizer.flat.numel)
+        n_model = len(list(self.model.parameters()))
+        flat = self.optimizer.flat
+        self.optimizer.ema_range = (0, flat.offsets[n_model] if n_model < len(flat.offsets) else flat.numel)
 
     @staticmethod
     def pred_KD_loss(p_s, p_t):
@@ -649,8 +675,10 @@ class TeacherStage1Step:
         kernel at T = 1 (log_softmax of a log-probability vector is the vector itself)."""
         return ops.KLFn.apply(p_s, p_t.detach(), 1.0, float(p_s.shape[0]))
 
-    def step(self, batch):
+    def step(self, batch, epoch=0):
         opt = self.opt
+        if epoch >= 15:
+            opt.CRD_weight = 0.01                                                                # train_test_MT.py:118-119
         (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
         dev = self.device
         x_path, ema_x_path = x_path.to(dev, non_blocking=True), ema_x_path.to(dev, non_blocking=True)
@@ -660,8 +688,12 @@ class TeacherStage1Step:
         fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
             x_path=x_path, x_omic=x_omic)                                                        # :137
         with torch.no_grad():
-            _, _, _, _, _, ema_pred, ema_pred_path, ema_pred_omic, _, _, _ = self.ema_model(
+            ema_fuse_feat, _, _, _, _, ema_pred, ema_pred_path, ema_pred_omic, _, _, _ = self.ema_model(
                 x_path=ema_x_path, x_omic=x_omic)                                                # :143-145
+        loss_CRD = torch.zeros((), device=dev)
+        if self.crd_on:                                                                          # :157-165
+            loss_CRD = opt.CRD_weight * self.CRD_criterion_fuse(
+                fuse_feat, ema_fuse_feat.detach(), index.to(dev), sample_idx.to(dev)).reshape(())
         kd = self.pred_KD_loss
         if getattr(opt, "pred_distill", 1) == 1:
             nt = opt.num_teachers
@@ -681,10 +713,15 @@ class TeacherStage1Step:
             loss_pred_KD = torch.zeros((), device=dev)
         nll = lambda p: ops.NLLFn.apply(p, grade, B)
         loss_nll = nll(pred_path) + nll(pred_omic) + nll(pred)                                  # :208-212
-        loss = opt.lambda_nll * loss_nll + loss_pred_KD                                         # :214 (reg_type none)
+        loss = opt.lambda_nll * loss_nll + loss_CRD + loss_pred_KD                              # :214 (reg_type none)
+        loss_orth = torch.zeros((), device=dev)
+        if self.orth_on:
+            loss_orth = self.Orth_loss(path_feat, omic_feat)                                    # :216-218
+            loss = loss + loss_orth
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()                                                                   # + EMA (:229) fused
         self.iter_num += 1
         return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),
+                    loss_CRD=loss_CRD.detach(), loss_orth=loss_orth.detach(),
                     pred=pred.detach(), pred_path=pred_path.detach(), pred_omic=pred_omic.detach())

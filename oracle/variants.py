@@ -76,6 +76,43 @@ def crd_v3_loss(st, sample_weights, f_s, f_t, y, idx):
         _contrast_loss_weighted(sample_weights, out_v2, st.n_data)
 
 
+# ------------------------------------------------------------------------------------------------ stage-1 terms
+def orth_loss(x1, x2):
+    """OrthLoss.forward (MICCAI-2022/CL_utils/orthogonal_loss.py:18-32): rows divided by their DETACHED L2 norm + 1e-6,
+    mean square of the D x D cross-correlation."""
+    b = x1.size(0)
+    x1 = x1.view(b, -1); x2 = x2.view(b, -1)
+    a = x1 / (torch.norm(x1, p=2, dim=1, keepdim=True).detach() + 1e-6)
+    c = x2 / (torch.norm(x2, p=2, dim=1, keepdim=True).detach() + 1e-6)
+    return torch.mean((a.t().mm(c)).pow(2))
+
+
+def crd_v0_loss(st, f_s, f_t, y, idx):
+    """CRDLoss.forward of MICCAI-2022/CL_utils/CRD_criterion.py:167-189 (stage-1 trainer): the vanilla bank of
+    crd_v3_loss with unit sample weights and the two-layer heads Linear-ReLU-Linear + L2 norm (:219-234).
+    st.embed_s / st.embed_t hold linear.0.* and linear.2.* tensors."""
+    def head(x, d):
+        h = F.relu(F.linear(x.view(x.shape[0], -1), d["linear.0.weight"], d["linear.0.bias"]))
+        h = F.linear(h, d["linear.2.weight"], d["linear.2.bias"])
+        return h / h.pow(2).sum(1, keepdim=True).pow(0.5)
+    v1, v2 = head(f_s, st.embed_s), head(f_t, st.embed_t)
+    K = int(st.params[0].item()); T = st.params[1].item()
+    B, D = v1.shape
+    n_out = st.memory_v1.size(0)
+    w1 = torch.index_select(st.memory_v1, 0, idx.view(-1)).detach().view(B, K + 1, D)
+    out_v2 = torch.exp(torch.bmm(w1, v2.view(B, D, 1)) / T)
+    w2 = torch.index_select(st.memory_v2, 0, idx.view(-1)).detach().view(B, K + 1, D)
+    out_v1 = torch.exp(torch.bmm(w2, v1.view(B, D, 1)) / T)
+    if st.params[2].item() < 0:
+        st.params[2] = out_v1.mean().detach() * n_out
+    if st.params[3].item() < 0:
+        st.params[3] = out_v2.mean().detach() * n_out
+    out_v1 = out_v1 / st.params[2].item()
+    out_v2 = out_v2 / st.params[3].item()
+    _bank_update(st, v1, v2, y)
+    return _contrast_loss_weighted(1.0, out_v1, st.n_data) + _contrast_loss_weighted(1.0, out_v2, st.n_data)
+
+
 def momentum_aekd_loss(main_loss, feat_s, loss_t_list, mo_scale, grads_m=0.9, grads_thresh="False", thresh=0.0,
                        ce_grads=True):
     """momentum_AEKD_loss (train_test_path_multi_distill_v2.py:89-132): cosine Gram WITHOUT the x len(list)

@@ -327,3 +327,44 @@ def test_tsvd_state_step_runs_and_schedules_mu():
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(f.grad).all() for f in feats)
     assert abs(st.mu - 1.1e-5) < 1e-12 and st.tnn is not None
+
+
+@pytest.mark.gpu
+def test_stage1_orth_and_vanilla_crd_vs_reference_golden(golden_dir):
+    """Row f-1 optional terms through the C-ABI: OrthLoss (row scaling kernels + fp32 GEMMs) and the stage-1 vanilla CRD
+    criterion (two-layer heads over the fused CRD bank kernels) against the reference's own outputs."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.CL_utils.orthogonal_loss import OrthLoss
+    from multimodal_learning_amd.CL_utils.CRD_criterion import CRDLoss
+    from oracle.variants import CRDv3State
+    from types import SimpleNamespace
+    from tests.test_oracle_variants import _embed2_state
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "stage1_terms.npz"))
+    R = Report("stage-1 optional terms vs REFERENCE golden")
+    x1 = torch.as_tensor(g["orth_x1"]).cuda().requires_grad_(True); x2 = torch.as_tensor(g["orth_x2"]).cuda().requires_grad_(True)
+    lo = OrthLoss()(x1, x2)
+    g1, g2 = torch.autograd.grad(lo, [x1, x2])
+    R.close(g["orth_loss"], lo, 1e-9, 1e-4, "orth loss"); R.close(g["orth_g1"], g1, 1e-9, 1e-3, "orth d/dx1")
+    R.close(g["orth_g2"], g2, 1e-9, 1e-3, "orth d/dx2")
+    opt = SimpleNamespace(s_dim=128, t_dim=128, feat_dim=128, nce_k=int(g["K"]), nce_t=0.07, nce_m=0.5, n_data=int(g["n_data"]))
+    crd = CRDLoss(opt).cuda()
+    crd.contrast.verbose = False
+    crd.embed_s.load_state_dict(_embed2_state(70)); crd.embed_t.load_state_dict(_embed2_state(71))
+    st = CRDv3State(opt.n_data, K=opt.nce_k, seed=80)
+    crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).cuda().requires_grad_(True)
+        idx = torch.as_tensor(g[f"index{it}"]).cuda()
+        loss = crd(f_s, torch.as_tensor(g[f"f_t{it}"]).cuda(), idx, torch.as_tensor(g[f"sidx{it}"]).cuda())
+        gs = torch.autograd.grad(loss.sum(), [f_s, crd.embed_s.linear[0].weight, crd.embed_s.linear[2].weight,
+                                              crd.embed_t.linear[2].bias])
+        R.close(g[f"loss{it}"], loss, 1e-4, 1e-5, f"CRD loss call {it}")
+        R.close(g[f"g_fs{it}"], gs[0], 1e-6, 2e-3, f"d/df_s call {it}")
+        R.close(g[f"g_w0{it}"], gs[1], 1e-6, 2e-3, f"d/d embed_s.linear.0.weight call {it}")
+        R.close(g[f"g_w2{it}"], gs[2], 1e-6, 2e-3, f"d/d embed_s.linear.2.weight call {it}")
+        R.close(g[f"g_tb2{it}"], gs[3], 1e-6, 2e-3, f"d/d embed_t.linear.2.bias call {it}")
+        R.close(g[f"params{it}"], crd.contrast.params, 1e-2, 1e-5, "params / Z")
+        R.close(g[f"bank_v1_rows{it}"], crd.contrast.memory_v1[idx], 1e-5, 0, f"bank v1 rows call {it}")
+        R.close(g[f"bank_v2_rows{it}"], crd.contrast.memory_v2[idx], 1e-5, 0, f"bank v2 rows call {it}")
+    R.finish()

@@ -437,3 +437,65 @@ def test_graph_replay_on_resident_input_sets_matches_staged_inputs():
     assert a[0] == b[0], (a[0], b[0])
     for x, y in zip(a[1:], b[1:]):
         assert torch.equal(x, y)
+
+
+def test_stage1_step_with_crd_and_orth_terms_vs_reference_golden(golden_dir):
+    """Row f-1 with --CRD_distill 1 --orth_loss True: two steps of train_test_MT.py:121-230 (vanilla CRD between the
+    student's and the EMA teacher's fused features, six projection heads in the optimiser, orthogonality loss between
+    the path and omic features) against the reference's own modules (tests/golden/make_golden_stage1_terms.py)."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import synthetic_batch
+    from oracle.variants import CRDv3State
+    from tests.test_oracle_variants import _embed2_state
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "stage1_terms_step_b4_h64.npz"))
+    K, n_data = int(g["K"]), int(g["n_data"])
+    m.set_precision("bf16x6")
+    try:
+        opt = m.stage2_opt(dropout_rate=0.0, batch_size=4, cut_fuse_grad=False, num_teachers=2)
+        opt.pred_distill, opt.KD_weight = 1, float(g["KD_weight"])
+        opt.CRD_distill, opt.CRD_weight, opt.orth_loss, opt.SP_distill = 1, float(g["CRD_weight"]), "True", 0
+        opt.nce_k, opt.n_data = K, n_data
+        model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+        sd = W.make_state_dict(W.teacher_shapes(320), 3)
+        model.load_state_dict(sd); ema.load_state_dict(sd)
+        st = m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda()))
+        for i, c in enumerate((st.CRD_criterion_path, st.CRD_criterion_omic, st.CRD_criterion_fuse)):
+            c.embed_s.load_state_dict(_embed2_state(90 + 2 * i)); c.embed_t.load_state_dict(_embed2_state(91 + 2 * i))
+            bank = CRDv3State(n_data, K=K, seed=100 + i)
+            c.contrast.memory_v1.copy_(bank.memory_v1); c.contrast.memory_v2.copy_(bank.memory_v2)
+        ops_lr = float(opt.lr)
+        R = Report("2 stage-1 steps with CRD + orthogonality terms vs REFERENCE golden (B=4, 64x64)")
+        for it in range(2):
+            bt = synthetic_batch(4, 64, n_data=n_data, P=1, K=K, seed=60 + it)
+            z = torch.zeros(4)
+            batch = ((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"])
+            out = st.step(batch, epoch=it)
+            rt = 1e-3 if it == 0 else 5e-2
+            sc = lambda k: np.asarray(g[k]).reshape(())      # (the reference's CRD term has shape [1])
+            R.close(sc(f"loss{it}"), out["loss"].reshape(()), 0, rt, f"loss step {it}")
+            R.close(sc(f"loss_nll{it}"), out["loss_nll"].reshape(()), 0, rt, f"loss_nll step {it}")
+            R.close(sc(f"loss_CRD{it}"), out["loss_CRD"].reshape(()), 0, rt, f"loss_CRD step {it}")
+            R.close(sc(f"loss_orth{it}"), out["loss_orth"].reshape(()), 1e-6 if it == 0 else 1e-4, rt, f"loss_orth step {it}")
+            R.close(g[f"pred{it}"], out["pred"], 10 * rt, 0, f"pred step {it}")
+            R.close(g[f"bank_v1_rows{it}"], st.CRD_criterion_fuse.contrast.memory_v1[bt["index"].cuda()],
+                    1e-4 if it == 0 else 2e-2, 0, f"fuse bank rows step {it}")
+            if it == 0:
+                msd = st.model.state_dict()
+                for key in g.files:
+                    if key.startswith("w0_") and not key.startswith("w0_embed"):
+                        name = key[3:]
+                        upd_ref = g[key] - sd[name].numpy()
+                        upd = msd[name].cpu().numpy() - sd[name].numpy()
+                        frac_bad = float((np.abs(upd - upd_ref) > 0.2 * ops_lr).mean())
+                        assert frac_bad < 0.02, (name, frac_bad)
+                # the projection heads are in the optimiser: the used one follows its gradient, the unused ones only decay
+                e0 = _embed2_state(94)["linear.2.weight"].numpy()
+                upd_ref = g["w0_embed_s_fuse"] - e0
+                upd = st.CRD_criterion_fuse.embed_s.linear[2].weight.detach().cpu().numpy() - e0
+                assert float((np.abs(upd - upd_ref) > 0.2 * ops_lr).mean()) < 0.02
+                R.close(g["w0_embed_s_path"], st.CRD_criterion_path.embed_s.linear[0].weight, 2e-6, 0, "unused head after step 0")
+        R.finish()
+    finally:
+        m.set_precision("bf16")

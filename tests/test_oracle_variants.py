@@ -131,3 +131,35 @@ def test_tsvd_update_aux_prox_properties():
         pert = yf + 1e-3 * (rng.standard_normal(yf.shape) + 1j * rng.standard_normal(yf.shape))
         assert fobj(pert) >= best - 1e-9
     assert np.isfinite(base) and np.isfinite(obj(y))
+
+
+def _embed2_state(seed):
+    """Seed recipe of tests/golden/make_golden_stage1_terms.py for the two-layer projection heads."""
+    g = torch.Generator().manual_seed(seed)
+    return {"linear.0.weight": torch.randn(128, 128, generator=g) * 0.08, "linear.0.bias": torch.randn(128, generator=g) * 0.02,
+            "linear.2.weight": torch.randn(128, 128, generator=g) * 0.08, "linear.2.bias": torch.randn(128, generator=g) * 0.02}
+
+
+def test_stage1_orth_and_vanilla_crd_vs_reference_golden(golden_dir):
+    """Stage-1 optional terms (row f-1): OrthLoss and the vanilla CRD criterion with two-layer heads."""
+    from oracle.variants import orth_loss, crd_v0_loss
+    g = np.load(os.path.join(golden_dir, "stage1_terms.npz"))
+    x1 = torch.as_tensor(g["orth_x1"]).requires_grad_(True); x2 = torch.as_tensor(g["orth_x2"]).requires_grad_(True)
+    lo = orth_loss(x1, x2)
+    g1, g2 = torch.autograd.grad(lo, [x1, x2])
+    _close(g["orth_loss"], lo, 1e-9, 1e-5); _close(g["orth_g1"], g1, 1e-9, 1e-4); _close(g["orth_g2"], g2, 1e-9, 1e-4)
+    st = CRDv3State(int(g["n_data"]), K=int(g["K"]), seed=80, embed_s=_embed2_state(70), embed_t=_embed2_state(71))
+    for d in (st.embed_s, st.embed_t):
+        for v in d.values():
+            v.requires_grad_(True)
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).requires_grad_(True)
+        idx = torch.as_tensor(g[f"index{it}"])
+        loss = crd_v0_loss(st, f_s, torch.as_tensor(g[f"f_t{it}"]), idx, torch.as_tensor(g[f"sidx{it}"]))
+        gs = torch.autograd.grad(loss.sum(), [f_s, st.embed_s["linear.0.weight"], st.embed_s["linear.2.weight"],
+                                              st.embed_t["linear.2.bias"]])
+        _close(g[f"loss{it}"], loss, 1e-5, 1e-5)
+        _close(g[f"g_fs{it}"], gs[0], 1e-6, 1e-3); _close(g[f"g_w0{it}"], gs[1], 1e-6, 1e-3)
+        _close(g[f"g_w2{it}"], gs[2], 1e-6, 1e-3); _close(g[f"g_tb2{it}"], gs[3], 1e-6, 1e-3)
+        _close(g[f"params{it}"], st.params, 1e-2, 1e-5)
+        _close(g[f"bank_v1_rows{it}"], st.memory_v1[idx], 1e-6); _close(g[f"bank_v2_rows{it}"], st.memory_v2[idx], 1e-6)
