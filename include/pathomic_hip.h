@@ -206,6 +206,16 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
  * reference: this is the tensor-nuclear-norm proximal operator, see csrc/tsvd.hip): adj, aux are [V][B][B] (view-major),
  * V in {2,4,6,8}, B <= 64; tnn[0] = (1/V) sum over frequency slices of the nuclear norm of the thresholded slice.
  * ---------------------------------------------------------------------------------------------- */
+/* On-device contrast-index sampler (reference MICCAI-2022/data_loaders_MT.py:229-249 and the neg_mode
+ * variants of "MIA 2023/stage2_unimodal_student/data_loaders_MT.py":205-238).  out[b] = [positives | K negatives]:
+ * pos_mode 0 'exact' (the query), 1 'relax' (one same-class row), 2 'multi_pos' (P distinct same-class rows, slot 0 :=
+ * the query); neg_mode 0 'diff_class' (rows of the other classes), 1 'all_others' (every row but the query); with
+ * replacement exactly when K exceeds the candidate list.  cls_pos / cls_neg: the per-class row lists concatenated,
+ * *_off[c] .. *_off[c+1] delimiting class c.  `step` (device counter, may be NULL) and `seed` select the draw. */
+int ph_contrast_sampler(const int64_t* index, const int64_t* grade, const int* cls_pos, const int* cls_pos_off,
+                        const int* cls_neg, const int* cls_neg_off, int n_data, int B, int P, int K, int pos_mode,
+                        int neg_mode, uint64_t seed, const uint64_t* step, int64_t* out, ph_stream_t stream);
+
 /* Orthogonality loss of the stage-1 trainer (reference MICCAI-2022/CL_utils/orthogonal_loss.py:18-32): rows scaled by
  * a DETACHED 1/(||x||+eps) (:24-28); the D x D cross-correlation and its mean square are ph_sgemm + ph_sqdiff_sum. */
 int ph_row_invnorm_scale(const float* x, float* y, float* inv /* [B] */, int B, int D, float eps, ph_stream_t stream);

@@ -20,6 +20,8 @@ from .train_step import (AEKD_loss, momentum_AEKD_loss, update_ema_variables, Di
                          TeacherStage1Step)
 from . import dist
 from . import mia2023
+from . import sampler
+from .sampler import ContrastIndexSampler
 from . import tsvd
 from .options import stage2_opt
 

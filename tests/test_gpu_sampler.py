@@ -1,0 +1,110 @@
+"""On-device contrast-index sampler (row f-2) through the C-ABI: the structural rules of the reference's draw
+(data_loaders_MT.py:229-249) hold exactly; the distribution of every column matches the numpy restatement."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _labels(n, seed=0):
+    return np.random.RandomState(seed).randint(0, 3, n)
+
+
+@pytest.mark.parametrize("pos_mode,neg_mode,P,K,n", [("multi_pos", "diff_class", 300, 700, 1024), ("exact", "diff_class", 1, 512, 4096),
+                                                     ("relax", "all_others", 1, 4096, 65536), ("multi_pos", "all_others", 6, 4096, 3000)])
+def test_sampler_rules(pos_mode, neg_mode, P, K, n):
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.sampler import ContrastIndexSampler
+    labels = _labels(n)
+    opt = SimpleNamespace(nce_p=P, nce_k=K, pos_mode=pos_mode, neg_mode=neg_mode, label_dim=3)
+    s = ContrastIndexSampler(opt, labels, seed=7)
+    g = torch.Generator().manual_seed(1)
+    B = 64
+    index = torch.randperm(n, generator=g)[:B]
+    grade = torch.as_tensor(labels[index.numpy()])
+    a = s(index, grade).cpu().numpy()
+    npos = P if pos_mode == "multi_pos" else 1
+    assert a.shape == (B, npos + K) and a.min() >= 0 and a.max() < n
+    for b in range(B):
+        own, gb = int(index[b]), int(grade[b])
+        pos, neg = a[b, :npos], a[b, npos:]
+        if pos_mode in ("exact", "multi_pos"):
+            assert pos[0] == own                                             # :231, :239
+        assert (labels[pos] == gb).all()                                     # same class
+        if pos_mode == "multi_pos":
+            assert len(set(pos[1:].tolist())) == npos - 1                    # replace=False (:238)
+        if neg_mode == "diff_class":
+            assert (labels[neg] != gb).all()
+            nlist = int((labels != gb).sum())
+        else:
+            assert (neg != own).all()
+            nlist = n - 1
+        if K <= nlist:
+            assert len(set(neg.tolist())) == K                               # replace only when K exceeds the list (:243)
+    # the draw is a pure function of (seed, step, query): repeatable, and different at the next step
+    s2 = ContrastIndexSampler(opt, labels, seed=7)
+    assert np.array_equal(s2(index, grade).cpu().numpy(), a)
+    assert not np.array_equal(s2(index, grade).cpu().numpy(), a)
+    assert int(s2.step) == 2
+
+
+def test_sampler_distribution_matches_numpy_rule():
+    """Column marginals: over many steps every candidate of a query's list is drawn equally often, for the GPU sampler as
+    for the numpy restatement of the reference rule (chi-square per query against the uniform law)."""
+    from multimodal_learning_amd.sampler import ContrastIndexSampler
+    from oracle.sampler import class_lists, sample_item
+    n, P, K = 600, 20, 64
+    labels = _labels(n, 3)
+    opt = SimpleNamespace(nce_p=P, nce_k=K, pos_mode="multi_pos", neg_mode="diff_class", label_dim=3)
+    s = ContrastIndexSampler(opt, labels, seed=11)
+    index = torch.tensor([5, 77, 300]); grade = torch.as_tensor(labels[index.numpy()])
+    T = 4000
+    draws = torch.stack([s(index, grade) for _ in range(T)]).cpu().numpy()          # [T, 3, P+K]
+    cp, cn = class_lists(labels, 3)
+    rng = np.random.RandomState(0)
+    ref = np.stack([[sample_item(rng, int(index[b]), int(grade[b]), cp, cn, n, P, K) for b in range(3)] for _ in range(T)])
+    for b in range(3):
+        gb = int(grade[b])
+        for name, arr in (("gpu", draws), ("numpy rule", ref)):
+            neg = arr[:, b, P:].reshape(-1)
+            cnt = np.bincount(neg, minlength=n)[cn[gb]]
+            exp = neg.size / len(cn[gb])
+            chi2 = ((cnt - exp) ** 2 / exp).sum()
+            dof = len(cn[gb]) - 1
+            # without replacement the counts are under-dispersed: chi2/dof < 1; a biased sampler gives >> 1
+            assert chi2 / dof < 1.3, (name, b, chi2 / dof)
+            pos = arr[:, b, 1:P].reshape(-1)
+            cntp = np.bincount(pos, minlength=n)[cp[gb]]
+            expp = pos.size / len(cp[gb])
+            chi2p = ((cntp - expp) ** 2 / expp).sum() / (len(cp[gb]) - 1)
+            assert chi2p < 1.3, (name, b, chi2p)
+        # slot-position marginal: a fixed slot is uniform over the list too (no positional bias of the permutation)
+        slot = draws[:, b, P + 3]
+        cnt = np.bincount(slot, minlength=n)[cn[gb]]
+        exp = T / len(cn[gb])
+        assert ((cnt - exp) ** 2 / exp).sum() / (len(cn[gb]) - 1) < 1.3
+
+
+def test_sampler_feeds_the_crd_bank():
+    """Integration: the sampled columns drive the DC-Distill CRD criterion (shapes, slot 0 = query)."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.sampler import ContrastIndexSampler
+    from multimodal_learning_amd.CL_utils import CRDLoss
+    opt = m.stage2_opt()
+    n = 1024
+    labels = _labels(n, 5)
+    opt.pos_mode = "multi_pos"
+    s = ContrastIndexSampler(opt, labels, seed=3)
+    crd = CRDLoss(opt, n).cuda()
+    crd.contrast.verbose = False
+    g = torch.Generator().manual_seed(2)
+    index = torch.randperm(n, generator=g)[:16]
+    idx = s(index, torch.as_tensor(labels[index.numpy()]))
+    assert idx.shape == (16, opt.nce_p + opt.nce_k) and torch.equal(idx[:, 0].cpu(), index)
+    f = torch.randn(16, 128, generator=g).relu_().cuda().requires_grad_(True)
+    loss = crd(0.1, f, torch.randn(16, 128, generator=g).relu_().cuda(), index.cuda(), idx)
+    loss.backward()
+    assert torch.isfinite(loss).item() and torch.isfinite(f.grad).all().item()

@@ -163,3 +163,19 @@ def test_stage1_orth_and_vanilla_crd_vs_reference_golden(golden_dir):
         _close(g[f"g_w2{it}"], gs[2], 1e-6, 1e-3); _close(g[f"g_tb2{it}"], gs[3], 1e-6, 1e-3)
         _close(g[f"params{it}"], st.params, 1e-2, 1e-5)
         _close(g[f"bank_v1_rows{it}"], st.memory_v1[idx], 1e-6); _close(g[f"bank_v2_rows{it}"], st.memory_v2[idx], 1e-6)
+
+
+def test_sampler_rule_restatement_properties():
+    """oracle/sampler.py (numpy restatement of data_loaders_MT.py:187-249): structural rules of one draw."""
+    from oracle.sampler import class_lists, sample_item
+    labels = np.random.RandomState(1).randint(0, 3, 500)
+    cp, cn = class_lists(labels, 3)
+    assert sum(len(c) for c in cp) == 500 and all(len(cn[i]) == 500 - len(cp[i]) for i in range(3))
+    rng = np.random.RandomState(2)
+    for index in (0, 17, 499):
+        g = int(labels[index])
+        s = sample_item(rng, index, g, cp, cn, 500, 20, 64)
+        assert s.shape == (84,) and s[0] == index and (labels[s[:20]] == g).all() and (labels[s[20:]] != g).all()
+        assert len(set(s[1:20].tolist())) == 19 and len(set(s[20:].tolist())) == 64
+        s2 = sample_item(rng, index, g, cp, cn, 500, 20, 700, neg_mode="all_others")       # K > list: with replacement
+        assert (s2[20:] != index).all() and len(set(s2[20:].tolist())) < 700
