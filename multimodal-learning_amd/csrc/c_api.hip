@@ -68,6 +68,24 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
   return PH_OK;
 }
 
+int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* res_g, const void* res_a, int B, int Cin,
+                        int IH, int IW, int Cout, int KS, int pad, int prec, void* ws_, hipStream_t st) {
+  if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
+  const size_t plane = (size_t)KS * KS * Cin * Cout;
+  bf16* hi = reinterpret_cast<bf16*>(ws_);
+  int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
+  if (rc) return rc;
+  const int OH = IH + 2 * pad - KS + 1, OW = IW + 2 * pad - KS + 1;
+  PhTapConv t{};
+  t.in = dy; t.w = hi; t.wplane = plane; t.out = dx; t.res_g = res_g; t.res_a = res_a;
+  t.B = B; t.IH = OH; t.IW = OW; t.Cin = Cout; t.Cout = Cin; t.OH = IH; t.OW = IW;
+  t.OHt = IH; t.OWt = IW; t.os = 1; t.iy0 = -(KS - 1 - pad); t.ix0 = t.iy0; t.ntaps = KS * KS;
+  for (int k = 0; k < t.ntaps; ++k) {
+    t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = (KS - 1 - k / KS) * KS + (KS - 1 - k % KS);
+  }
+  return ph_tapconv_launch(&t, 1, prec, st);
+}
+
 int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, int IH, int IW, int Cout, int KS,
                     int stride, int pad, int prec, void* ws_, hipStream_t st) {
   if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;

@@ -744,18 +744,19 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
       const int r = tc.r0 + (wm * FM + i) * 2 + pfr, c = tc.c0 + pcc;
       const bool mine = FULL || (r < p.OHt && c < p.OWt);
       const unsigned o = (unsigned)(((r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout) + 8 * khalf;
-      u32x4 rg[FN][2], ra[FN][2];
+      unsigned rg[FN][2][4], ra[FN][2][4];   // residual words: 8 channels = 4 packed pairs per (j, gp)
       if constexpr (RM > 0) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
           for (int gp = 0; gp < 2; ++gp) {
-            rg[j][gp] = u32x4{0u, 0u, 0u, 0u};
-            ra[j][gp] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            u32x4 tg = {0u, 0u, 0u, 0u}, ta = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
             if (mine) {
-              rg[j][gp] = *reinterpret_cast<const u32x4*>(resg + o + j * 32 + gp * 16);
-              if constexpr (RM > 1) ra[j][gp] = *reinterpret_cast<const u32x4*>(resa + o + j * 32 + gp * 16);
+              tg = *reinterpret_cast<const u32x4*>(resg + o + j * 32 + gp * 16);
+              if constexpr (RM > 1) ta = *reinterpret_cast<const u32x4*>(resa + o + j * 32 + gp * 16);
             }
+            rg[j][gp][0] = tg[0]; rg[j][gp][1] = tg[1]; rg[j][gp][2] = tg[2]; rg[j][gp][3] = tg[3];
+            ra[j][gp][0] = ta[0]; ra[j][gp][1] = ta[1]; ra[j][gp][2] = ta[2]; ra[j][gp][3] = ta[3];
           }
       }
 #pragma unroll
@@ -792,17 +793,21 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
           // lanes < 32 give their upper group to, and take the lower group from, lane + 32 (same pixel, other k-half)
           const auto a0 = __builtin_amdgcn_permlane32_swap(P[2 * gp][0], P[2 * gp + 1][0], false, false);
           const auto a1 = __builtin_amdgcn_permlane32_swap(P[2 * gp][1], P[2 * gp + 1][1], false, false);
-          u32x4 w = {a0[0], a1[0], a0[1], a1[1]};   // 8 consecutive channels from j*32 + gp*16 + 8*khalf
+          unsigned ww[4] = {(unsigned)a0[0], (unsigned)a1[0], (unsigned)a0[1], (unsigned)a1[1]};   // 8 consecutive channels
           if constexpr (RM > 0) {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-              bf16x2 wb = __builtin_bit_cast(bf16x2, w[d]);
-              const bf16x2 gb = __builtin_bit_cast(bf16x2, rg[j][gp][d]), ab = __builtin_bit_cast(bf16x2, ra[j][gp][d]);
-              wb[0] = (bf16)((float)wb[0] + ((RM < 2 || (float)ab[0] > 0.f) ? (float)gb[0] : 0.f));
-              wb[1] = (bf16)((float)wb[1] + ((RM < 2 || (float)ab[1] > 0.f) ? (float)gb[1] : 0.f));
-              w[d] = __builtin_bit_cast(unsigned, wb);
+              // bf16 pairs handled as bits: low half = even channel, high half = odd channel
+              const float w0 = __builtin_bit_cast(float, ww[d] << 16), w1 = __builtin_bit_cast(float, ww[d] & 0xffff0000u);
+              const float g0 = __builtin_bit_cast(float, rg[j][gp][d] << 16), g1 = __builtin_bit_cast(float, rg[j][gp][d] & 0xffff0000u);
+              const float a0f = __builtin_bit_cast(float, ra[j][gp][d] << 16), a1f = __builtin_bit_cast(float, ra[j][gp][d] & 0xffff0000u);
+              bf16x2 wb;
+              wb[0] = (bf16)(w0 + ((RM < 2 || a0f > 0.f) ? g0 : 0.f));
+              wb[1] = (bf16)(w1 + ((RM < 2 || a1f > 0.f) ? g1 : 0.f));
+              ww[d] = __builtin_bit_cast(unsigned, wb);
             }
           }
+          const u32x4 w = {ww[0], ww[1], ww[2], ww[3]};
 #ifdef PH_ABL_NOSTORE
           asm volatile("" ::"v"(w));
 #else

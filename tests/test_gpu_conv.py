@@ -109,3 +109,43 @@ def test_tapconv2_multitile_stream(case):
     dx = torch.full((B, H, H, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
     check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx), B, Cin, H, H, Cout, 3, 1, 1, 0, ptr(ws), stream()), "dgrad")
     assert_close(dx_ref, nchw_cpu(dx), 1e-6, 1.0 / 128, "multi-tile conv dgrad")
+
+
+RES_CASES = [  # Cin (= dgrad output channels), Cout, H, B
+    (64, 64, 32, 8),        # layer-1 kernel (two wave groups), full tiles
+    (64, 64, 40, 12),       # layer-1 kernel, partial tiles, several tiles per group
+    (128, 128, 24, 6),      # <2,2,4,false>, partial tiles
+    (256, 256, 16, 4),
+]
+
+
+@pytest.mark.parametrize("mode", ["masked", "plain"])
+@pytest.mark.parametrize("case", RES_CASES)
+def test_tapconv2_dgrad_with_fused_residual(case, mode):
+    """The BasicBlock backward fuses d_x = dgrad(conv1) + d_out * (out > 0) into the dgrad epilogue (res_g / res_a of
+    PhTapConv; resnet_plan.hip: conv_dgrad).  Perf mode: like-for-like against F.conv_transpose2d with the same rounding
+    points (the dgrad is rounded to bf16, the residual is added in fp32, the sum is rounded again)."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, B = case
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + H + B)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5)
+    dy = torch.randn(B, Cout, H, H, generator=g).bfloat16().float()
+    res_g = torch.randn(B, Cin, H, H, generator=g).bfloat16().float()
+    res_a = torch.randn(B, Cin, H, H, generator=g).relu_().bfloat16().float()      # about half the entries are zero
+    torch.set_num_threads(8)
+    core = F.conv_transpose2d(dy, w.bfloat16().float(), None, 1, 1).bfloat16().float()
+    ref = (core + (res_g * (res_a > 0) if mode == "masked" else res_g)).bfloat16().float()
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 1, 1), device="cuda", dtype=torch.uint8)
+    dx = torch.full((B, H, H, Cin), float("nan"), device="cuda", dtype=torch.bfloat16)
+    gd, ad = nhwc(res_g, torch.bfloat16), nhwc(res_a, torch.bfloat16)
+    dyd, wd = nhwc(dy, torch.bfloat16), w.cuda()      # (named: a temporary would be freed - and reused - before the launch)
+    check(L.ph_conv2d_dgrad_res(ptr(dyd), ptr(wd), ptr(dx), ptr(gd),
+                                ptr(ad) if mode == "masked" else None, B, Cin, H, H, Cout, 3, 1, 0, ptr(ws), stream()),
+          "dgrad_res")
+    got = nchw_cpu(dx)
+    # the residual term is exact; the dgrad term carries the usual bf16 noise (summation order + one rounding)
+    assert_close(ref, got, 1e-6, 1.0 / 64, "dgrad + residual")
+    if mode == "masked":
+        mask = res_a == 0
+        assert_close(core[mask], got[mask], 1e-6, 1.0 / 128, "masked-out positions carry the plain dgrad")

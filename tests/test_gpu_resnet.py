@@ -200,3 +200,48 @@ def test_dropout_backward_uses_the_forward_mask():
             b = -a * ap * 0.25
             dropped = torch.isclose(y, torch.full_like(y, a * ap + b), atol=1e-6)
             assert torch.allclose(x.grad, (~dropped).float() * a, atol=1e-6)
+
+
+def test_student_backward_perf_mode_matches_parity_mode_on_ragged_tiles():
+    """The perf-mode (bf16) backward runs different kernels from the parity mode that is pinned to the reference: the
+    second-generation tap-convs with the residual add / ReLU mask fused into their dgrad epilogues (conv_tap2.hip,
+    including the two-group layer-1 kernel), on partial tiles here (160 -> 40 / 20 / 10 / 5 pixel maps: none is a
+    multiple of the 16 x 16 tile).  On this untrained train-mode-BN network bf16 arithmetic alone decorrelates the
+    gradients to cosine ~0.82-0.89 against fp32 (the CPU oracle's own bf16 emulation shows 0.84-0.89 against its fp32
+    run for the same loss), uniformly over the depth.  Asserted: every conv / linear weight gradient keeps cosine >= 0.70
+    with the parity-mode gradient and none falls more than 0.12 below the median (BN scale / shift vectors: >= 0.50) - a wrong residual term in the layer-1 dgrad
+    epilogue (found with this test) put layer1.0 at 0.15 and conv1 at 0.05 while the later layers stayed at 0.83.
+    Like-for-like kernel parity of that epilogue: test_gpu_conv.py::test_tapconv2_dgrad_with_fused_residual."""
+    import multimodal_learning_amd as m
+    from oracle.step import synthetic_batch
+    bt = synthetic_batch(8, 160, seed=9)
+    wf = torch.linspace(0.5, 1.5, 128).cuda()
+    grads = {}
+    try:
+        for mode in ("bf16x6", "bf16"):
+            m.set_precision(mode)
+            net = _student()
+            net.train()
+            f3, feat, hazard, pred, _ = net(x_path=bt["x_path"].cuda())
+            loss = (feat * wf).sum() + (hazard * torch.tensor([1.0, -2.0, 0.5]).cuda()).sum() + 0.1 * f3.sum()
+            loss.backward()
+            grads[mode] = {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None}
+    finally:
+        m.set_precision("bf16")
+    cosines = {}
+    for k, gp in grads["bf16x6"].items():
+        gq = grads["bf16"][k]
+        denom = gp.norm().item()
+        # (a bias in front of a train-mode BN has a mathematically zero gradient: whatever is there is rounding noise)
+        if k == "fc_new1.0.bias" or denom < 1e-6 or gp.numel() < 64:
+            continue
+        cosines[k] = torch.dot(gp.flatten(), gq.flatten()).item() / (denom * gq.norm().item() + 1e-30)
+    big = {k: v for k, v in cosines.items() if grads["bf16"][k].numel() >= 4096}      # conv / linear weights
+    small = {k: v for k, v in cosines.items() if k not in big}                        # BN scale / shift (64-512 values)
+    vals = sorted(big.values())
+    med = vals[len(vals) // 2]
+    worst, worst_s = min(big, key=big.get), min(small, key=small.get)
+    print(f"\nperf-mode vs parity-mode gradients: {len(big)} weight tensors median cosine {med:.4f}, worst {big[worst]:.4f} at {worst}; "
+          f"{len(small)} BN tensors worst {small[worst_s]:.4f} at {worst_s}")
+    assert big[worst] >= 0.70 and big[worst] >= med - 0.12, (worst, big[worst], med)
+    assert small[worst_s] >= 0.50, (worst_s, small[worst_s])
