@@ -656,6 +656,19 @@ class TeacherStage1Step:
         if self.orth_on:
             from .CL_utils.orthogonal_loss import OrthLoss
             self.Orth_loss = OrthLoss()
+        # t-SVD low-rank constraint of the MIA-2022 stage-1 trainer ("MIA 2022/train_test_tSVD.py":161-181,299-431):
+        # adjacency tensors over n_views feature views per modality, auxiliary tensors from the tensor-nuclear-norm prox
+        self.tsvd_on = getattr(opt, "tSVD_loss", "False") == "True"
+        if self.tsvd_on:
+            if opt.n_views not in (2, 4):
+                raise NotImplementedError("n_views %d: the mixed-feature views of :334-363 are not wired (2 and 4 are)" % opt.n_views)
+            if opt.tSVD_mode not in ("path", "omic", "pathomic"):
+                raise ValueError(opt.tSVD_mode)
+            self.mu = float(opt.mu)                                                              # :161 (never reset per epoch)
+            z = lambda: [torch.zeros(opt.batch_size, opt.batch_size, device=self.device) for _ in range(opt.n_views)]
+            self.adj_tensor1, self.aux_tensor1, self.adj_tensor2, self.aux_tensor2 = z(), z(), z(), z()   # :165-177
+            self.path_TNN = self.omic_TNN = None
+            self._batch_idx = 0
         self.optimizer = define_optimizer(opt, module_list if self.crd_on else self.model)      # :86-94
         self.scheduler = define_scheduler(opt, self.optimizer)
         self.iter_num = opt.global_step
@@ -675,7 +688,11 @@ class TeacherStage1Step:
         kernel at T = 1 (log_softmax of a log-probability vector is the vector itself)."""
         return ops.KLFn.apply(p_s, p_t.detach(), 1.0, float(p_s.shape[0]))
 
-    def step(self, batch, epoch=0):
+    def start_epoch(self):
+        """The t-SVD auxiliary update runs every opt.aux_iter batches of an epoch (:375): reset the batch counter."""
+        self._batch_idx = 0
+
+    def step(self, batch, epoch=0, batch_idx=None):
         opt = self.opt
         if epoch >= 15:
             opt.CRD_weight = 0.01                                                                # train_test_MT.py:118-119
@@ -688,7 +705,7 @@ class TeacherStage1Step:
         fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
             x_path=x_path, x_omic=x_omic)                                                        # :137
         with torch.no_grad():
-            ema_fuse_feat, _, _, _, _, ema_pred, ema_pred_path, ema_pred_omic, _, _, _ = self.ema_model(
+            ema_fuse_feat, ema_path_feat, ema_omic_feat, _, _, ema_pred, ema_pred_path, ema_pred_omic, _, _, _ = self.ema_model(
                 x_path=ema_x_path, x_omic=x_omic)                                                # :143-145
         loss_CRD = torch.zeros((), device=dev)
         if self.crd_on:                                                                          # :157-165
@@ -718,10 +735,39 @@ class TeacherStage1Step:
         if self.orth_on:
             loss_orth = self.Orth_loss(path_feat, omic_feat)                                    # :216-218
             loss = loss + loss_orth
+        loss_tsvd = torch.zeros((), device=dev)
+        if self.tsvd_on:                                                                        # train_test_tSVD.py:299-431
+            from . import tsvd as T
+            if opt.n_views == 4:
+                feats1 = [fuse_feat.detach(), ema_fuse_feat, path_feat, ema_path_feat]          # :311-313
+                feats2 = [fuse_feat.detach(), ema_fuse_feat, omic_feat, ema_omic_feat]
+            else:
+                feats1 = [path_feat, ema_path_feat]                                             # :320-322
+                feats2 = [omic_feat, ema_omic_feat]
+            self.adj_tensor1 = T.update_adj_tensor(self.adj_tensor1, feats1)                    # :365-366
+            self.adj_tensor2 = T.update_adj_tensor(self.adj_tensor2, feats2)
+            bidx = self._batch_idx if batch_idx is None else batch_idx
+            if bidx % opt.aux_iter == 0:
+                # `if opt.tSVD_mode == "path" or "pathomic":` (:378, :398) is always true: both tensors are updated
+                for adj, name in ((self.adj_tensor1, "1"), (self.adj_tensor2, "2")):
+                    stack = torch.stack([a.detach() for a in adj], dim=2)
+                    aux, tnn = T.update_aux(stack, opt.Lambda_global / self.mu)                 # :382, :402
+                    setattr(self, "aux_tensor" + name, [aux[:, :, v].contiguous() for v in range(opt.n_views)])
+                    if name == "1":
+                        self.path_TNN = tnn
+                    else:
+                        self.omic_TNN = tnn
+                self.mu = min(self.mu * opt.pho, opt.max_mu)                                    # :413
+            self._batch_idx = bidx + 1
+            if opt.tSVD_mode in ("path", "pathomic"):                                           # :418-431
+                loss_tsvd = loss_tsvd + T.tsvd_penalty(self.adj_tensor1, self.aux_tensor1, self.mu)
+            if opt.tSVD_mode in ("omic", "pathomic"):
+                loss_tsvd = loss_tsvd + T.tsvd_penalty(self.adj_tensor2, self.aux_tensor2, self.mu)
+            loss = loss + loss_tsvd
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()                                                                   # + EMA (:229) fused
         self.iter_num += 1
         return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),
-                    loss_CRD=loss_CRD.detach(), loss_orth=loss_orth.detach(),
+                    loss_CRD=loss_CRD.detach(), loss_orth=loss_orth.detach(), loss_tsvd=loss_tsvd.detach(),
                     pred=pred.detach(), pred_path=pred_path.detach(), pred_omic=pred_omic.detach())

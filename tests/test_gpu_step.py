@@ -499,3 +499,54 @@ def test_stage1_step_with_crd_and_orth_terms_vs_reference_golden(golden_dir):
         R.finish()
     finally:
         m.set_precision("bf16")
+
+
+def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir):
+    """Row a16 end to end (BASELINE cfg 4's computation at a small size): two stage-1 steps with the t-SVD constraint
+    ("MIA 2022/train_test_tSVD.py":199-470: adjacency tensors over 4 views per modality, auxiliary update at every batch,
+    mu schedule, Frobenius penalty) against the reference's modules driven in the trainer's order; the absent
+    `update_aux` is our proximal operator on both sides (parity unpinned for that one function)."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import synthetic_batch
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "tsvd_step_b8_h64.npz"))
+    B = int(g["B"])
+    m.set_precision("bf16x6")
+    try:
+        opt = m.stage2_opt(dropout_rate=0.0, batch_size=B, cut_fuse_grad=bool(int(g["cut_fuse_grad"])), num_teachers=2)
+        opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, float(g["KD_weight"]), 0, 0, "False"
+        opt.tSVD_loss, opt.tSVD_mode, opt.n_views, opt.aux_iter = "True", "pathomic", int(g["n_views"]), 1
+        opt.mu, opt.pho, opt.max_mu, opt.Lambda_global = float(g["mu"]), float(g["pho"]), float(g["max_mu"]), float(g["Lambda_global"])
+        opt.lr = float(g["lr"])
+        model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+        sd = W.make_state_dict(W.teacher_shapes(320), 3)
+        model.load_state_dict(sd); ema.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 4))
+        st = m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda()))
+        R = Report("2 stage-1 steps with the t-SVD constraint vs the reference trainer's logic (B=8, 64x64)")
+        sc = lambda k: np.asarray(g[k]).reshape(())
+        for it in range(2):
+            bt = synthetic_batch(B, 64, seed=70 + it)
+            z = torch.zeros(B)
+            out = st.step(((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"]))
+            rt = 1e-3 if it == 0 else 5e-2
+            R.close(sc(f"loss{it}"), out["loss"].reshape(()), 0, rt, f"loss step {it}")
+            R.close(sc(f"loss_nll{it}"), out["loss_nll"].reshape(()), 0, rt, f"loss_nll step {it}")
+            R.close(sc(f"loss_tsvd{it}"), out["loss_tsvd"].reshape(()), 1e-5, 2 * rt, f"loss_tsvd step {it}")
+            R.close(sc(f"mu{it}"), torch.tensor(st.mu), 1e-9, 1e-6, f"mu after step {it}")
+            R.close(g[f"adj1_2_{it}"], st.adj_tensor1[2], 1e-4 if it == 0 else 2e-2, 0, f"adjacency path view 2 step {it}")
+            R.close(g[f"adj2_3_{it}"], st.adj_tensor2[3], 1e-4 if it == 0 else 2e-2, 0, f"adjacency omic view 3 step {it}")
+            R.close(g[f"aux1_2_{it}"], st.aux_tensor1[2], 2e-4 if it == 0 else 2e-2, 0, f"aux path view 2 step {it}")
+            R.close(g[f"aux2_0_{it}"], st.aux_tensor2[0], 2e-4 if it == 0 else 2e-2, 0, f"aux omic view 0 step {it}")
+            R.close(sc(f"path_TNN{it}"), st.path_TNN.reshape(()), 1e-3 if it == 0 else 5e-2, 1e-3, f"path TNN step {it}")
+            if it == 0:
+                msd = st.model.state_dict()
+                for key in g.files:
+                    if key.startswith("w0_"):
+                        name = key[3:]
+                        upd_ref = g[key] - sd[name].numpy()
+                        upd = msd[name].cpu().numpy() - sd[name].numpy()
+                        assert float((np.abs(upd - upd_ref) > 0.2 * opt.lr).mean()) < 0.02, name
+        R.finish()
+    finally:
+        m.set_precision("bf16")
