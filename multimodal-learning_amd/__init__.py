@@ -21,6 +21,7 @@ from .train_step import (AEKD_loss, momentum_AEKD_loss, update_ema_variables, Di
 from . import dist
 from . import mia2023
 from . import sampler
+from . import distiller_zoo
 from .sampler import ContrastIndexSampler
 from . import tsvd
 from .options import stage2_opt

@@ -368,3 +368,23 @@ def test_stage1_orth_and_vanilla_crd_vs_reference_golden(golden_dir):
         R.close(g[f"bank_v1_rows{it}"], crd.contrast.memory_v1[idx], 1e-5, 0, f"bank v1 rows call {it}")
         R.close(g[f"bank_v2_rows{it}"], crd.contrast.memory_v2[idx], 1e-5, 0, f"bank v2 rows call {it}")
     R.finish()
+
+
+@pytest.mark.gpu
+def test_distiller_zoo_sp_and_feats_kl_vs_reference_golden(golden_dir):
+    """Row f-4 (part): Similarity (SP) and feats_KL against the reference's own classes."""
+    from multimodal_learning_amd.distiller_zoo import Similarity, feats_KL
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "zoo_sp_featskl.npz"))
+    R = Report("distiller-zoo losses vs REFERENCE golden")
+    for B in (8, 64):
+        f_s = torch.as_tensor(g[f"f_s{B}"]).cuda().requires_grad_(True)
+        f_t = torch.as_tensor(g[f"f_t{B}"]).cuda()
+        l1 = Similarity()(f_s, f_t)
+        g1, = torch.autograd.grad(l1.sum(), f_s)
+        R.close(g[f"sp{B}"], l1, 1e-8, 1e-4, f"SP loss B={B}"); R.close(g[f"sp_g{B}"], g1, 1e-9, 2e-3, f"SP grad B={B}")
+        l2 = feats_KL()(f_s, f_t)
+        g2, = torch.autograd.grad(l2, f_s)
+        R.close(np.asarray(g[f"fkl{B}"]).reshape(()), l2.reshape(()), 1e-6, 1e-4, f"feats_KL loss B={B}")
+        R.close(g[f"fkl_g{B}"], g2, 1e-8, 1e-3, f"feats_KL grad B={B}")
+    R.finish()
