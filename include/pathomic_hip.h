@@ -195,11 +195,12 @@ int ph_conv2d_fwd(const void* x, const float* w_oihw, void* y, float* ch_sum /* 
                   void* ws, ph_stream_t stream);
 int ph_conv2d_dgrad(const void* dy, const float* w_oihw, void* dx, int B, int Cin, int IH, int IW, int Cout, int KS,
                     int stride, int pad, int prec, void* ws, ph_stream_t stream);
-/* stride-1 dgrad with the residual term of a BasicBlock backward fused into its epilogue, as the trunk backward uses it
+/* dgrad with the residual term of a BasicBlock backward fused into its epilogue, as the trunk backward uses it (stride 1: the
+ * identity shortcut; stride 2: the downsample path accumulates in place, res_g == dx, a parity class no tap reaches keeps dx)
  * (reference resnets.py:58-74 backward: d_x = dgrad(conv1) + d_out * (out > 0)):
  * dx = round(dgrad) + (res_a == NULL || res_a > 0 ? res_g : 0); res_g / res_a: [B][IH][IW][Cin] in the activation type. */
 int ph_conv2d_dgrad_res(const void* dy, const float* w_oihw, void* dx, const void* res_g, const void* res_a, int B, int Cin,
-                        int IH, int IW, int Cout, int KS, int pad, int prec, void* ws, ph_stream_t stream);
+                        int IH, int IW, int Cout, int KS, int stride, int pad, int prec, void* ws, ph_stream_t stream);
 int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Cin, int IH, int IW, int Cout, int KS,
                     int stride, int pad, int prec, void* ws, ph_stream_t stream);
 

@@ -69,21 +69,45 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
 }
 
 int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* res_g, const void* res_a, int B, int Cin,
-                        int IH, int IW, int Cout, int KS, int pad, int prec, void* ws_, hipStream_t st) {
-  if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
+                        int IH, int IW, int Cout, int KS, int stride, int pad, int prec, void* ws_, hipStream_t st) {
+  if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return PH_EINVAL;
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws_);
   int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
-  const int OH = IH + 2 * pad - KS + 1, OW = IW + 2 * pad - KS + 1;
+  const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
   t.in = dy; t.w = hi; t.wplane = plane; t.out = dx; t.res_g = res_g; t.res_a = res_a;
   t.B = B; t.IH = OH; t.IW = OW; t.Cin = Cout; t.Cout = Cin; t.OH = IH; t.OW = IW;
-  t.OHt = IH; t.OWt = IW; t.os = 1; t.iy0 = -(KS - 1 - pad); t.ix0 = t.iy0; t.ntaps = KS * KS;
-  for (int k = 0; k < t.ntaps; ++k) {
-    t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = (KS - 1 - k / KS) * KS + (KS - 1 - k % KS);
+  if (stride == 1) {
+    t.OHt = IH; t.OWt = IW; t.os = 1; t.iy0 = -(KS - 1 - pad); t.ix0 = t.iy0; t.ntaps = KS * KS;
+    for (int k = 0; k < t.ntaps; ++k) {
+      t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = (KS - 1 - k / KS) * KS + (KS - 1 - k % KS);
+    }
+    return ph_tapconv_launch(&t, 1, prec, st);
   }
-  return ph_tapconv_launch(&t, 1, prec, st);
+  // stride 2, as resnet_plan.hip:conv_dgrad: one launch per output parity class; a class no tap reaches keeps what
+  // dx already holds (the in-place residual res_g == dx of the downsample path)
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      int nk = 0, khs[3], dhs[3], nw = 0, kws[3], dws[3];
+      for (int kh = 0; kh < KS; ++kh)
+        if (((a + pad - kh) & 1) == 0) { khs[nk] = kh; dhs[nk] = (a + pad - kh) / 2; ++nk; }
+      for (int kw = 0; kw < KS; ++kw)
+        if (((b + pad - kw) & 1) == 0) { kws[nw] = kw; dws[nw] = (b + pad - kw) / 2; ++nw; }
+      t.OHt = (IH - a + 1) / 2; t.OWt = (IW - b + 1) / 2;
+      if (t.OHt <= 0 || t.OWt <= 0) continue;
+      t.os = 2; t.oa_h = a; t.oa_w = b; t.iy0 = 0; t.ix0 = 0; t.ntaps = nk * nw;
+      if (t.ntaps == 0) continue;
+      int q = 0;
+      for (int i = 0; i < nk; ++i)
+        for (int j = 0; j < nw; ++j) {
+          if (dhs[i] < 0 || dws[j] < 0 || dhs[i] > 2 || dws[j] > 2) return PH_EINVAL;
+          t.dy[q] = dhs[i]; t.dx[q] = dws[j]; t.wtap[q] = khs[i] * KS + kws[j]; ++q;
+        }
+      if ((rc = ph_tapconv_launch(&t, 1, prec, st))) return rc;
+    }
+  return PH_OK;
 }
 
 int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, int IH, int IW, int Cout, int KS,

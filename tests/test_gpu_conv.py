@@ -141,7 +141,7 @@ def test_tapconv2_dgrad_with_fused_residual(case, mode):
     gd, ad = nhwc(res_g, torch.bfloat16), nhwc(res_a, torch.bfloat16)
     dyd, wd = nhwc(dy, torch.bfloat16), w.cuda()      # (named: a temporary would be freed - and reused - before the launch)
     check(L.ph_conv2d_dgrad_res(ptr(dyd), ptr(wd), ptr(dx), ptr(gd),
-                                ptr(ad) if mode == "masked" else None, B, Cin, H, H, Cout, 3, 1, 0, ptr(ws), stream()),
+                                ptr(ad) if mode == "masked" else None, B, Cin, H, H, Cout, 3, 1, 1, 0, ptr(ws), stream()),
           "dgrad_res")
     got = nchw_cpu(dx)
     # the residual term is exact; the dgrad term carries the usual bf16 noise (summation order + one rounding)
@@ -149,3 +149,34 @@ def test_tapconv2_dgrad_with_fused_residual(case, mode):
     if mode == "masked":
         mask = res_a == 0
         assert_close(core[mask], got[mask], 1e-6, 1.0 / 128, "masked-out positions carry the plain dgrad")
+
+
+@pytest.mark.parametrize("prec", [1, 0])
+@pytest.mark.parametrize("case", [(64, 128, 32, 1, 0, 3), (128, 256, 18, 1, 0, 2), (64, 128, 32, 3, 1, 2)])
+def test_stride2_dgrad_accumulates_in_place(case, prec):
+    """The downsample path of a BasicBlock backward adds its 1x1 / stride-2 dgrad INTO the gradient buffer that already
+    holds the main path's dgrad (resnet_plan.hip: conv_dgrad(..., gnext, gnext, nullptr)): res_g == dx, one launch per
+    output parity class, classes no tap reaches untouched.  Both precisions, first-generation kernels."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, KS, pad, B = case
+    g = torch.Generator().manual_seed(Cin + Cout + H + KS)
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) * (2.0 / (Cin * KS * KS)) ** 0.5
+    OH = (H + 2 * pad - KS) // 2 + 1
+    dy = torch.randn(B, Cout, OH, OH, generator=g)
+    base = torch.randn(B, Cin, H, H, generator=g)
+    dt = torch.float32 if prec == 1 else torch.bfloat16
+    if prec == 0:
+        dy = dy.bfloat16().float(); base = base.bfloat16().float(); w_r = w.bfloat16().float()
+    else:
+        w_r = w
+    core = F.conv_transpose2d(dy, w_r, None, 2, pad, output_padding=H - ((OH - 1) * 2 - 2 * pad + KS))
+    if prec == 0:
+        core = core.bfloat16().float()
+    ref = core + base
+    dx = nhwc(base, dt).clone()
+    dyd, wd = nhwc(dy, dt), w.cuda()
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, KS, 2, pad), device="cuda", dtype=torch.uint8)
+    check(L.ph_conv2d_dgrad_res(ptr(dyd), ptr(wd), ptr(dx), ptr(dx), None, B, Cin, H, H, Cout, KS, 2, pad, prec, ptr(ws),
+                                stream()), "dgrad_res s2")
+    assert_close(ref, nchw_cpu(dx), 1e-5, 2e-5 if prec == 1 else 1.0 / 64, "stride-2 dgrad accumulated in place")
