@@ -245,3 +245,76 @@ def test_student_backward_perf_mode_matches_parity_mode_on_ragged_tiles():
           f"{len(small)} BN tensors worst {small[worst_s]:.4f} at {worst_s}")
     assert big[worst] >= 0.70 and big[worst] >= med - 0.12, (worst, big[worst], med)
     assert small[worst_s] >= 0.50, (worst_s, small[worst_s])
+
+
+def test_perf_mode_forward_stage_by_stage():
+    """Perf mode like for like, one stage at a time: every stage's reference is computed in fp32 torch from the GPU's OWN
+    input to that stage (read out of the plan workspace through ph_resnet_tensor_info), so no error is carried from stage
+    to stage and each kernel family is held to bf16 rounding: stem conv (the register-prefetch / packed-store path of
+    conv_stem.hip), fused BN + ReLU + max-pool, the layer-1 tap-conv (two-group kernel) with its in-kernel BatchNorm
+    statistics, BN apply, and the residual BN apply.  160 x 160 input: partial tiles everywhere."""
+    import ctypes as C
+    import torch.nn.functional as F
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd._lib import lib, check
+    from oracle.step import synthetic_batch
+    m.set_precision("bf16")
+    net = _student()
+    net.train()
+    B, H = 6, 160
+    x = synthetic_batch(B, H, seed=4)["x_path"].cuda()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    f3, feat, hazard, pred, _ = net(x_path=x)            # requires grad -> the workspace persists until backward
+    plan = net._get_plan(B, H, H)
+    ws = f3.grad_fn.ws                                   # the trunk's autograd node keeps the workspace of this forward
+    assert ws is not None and ws.numel() == plan.ws_bytes
+
+    def tensor(what, idx):
+        off = C.c_size_t(0)
+        dims = (C.c_int * 4)()
+        check(lib().ph_resnet_tensor_info(plan.h, what, idx, C.byref(off), dims), "tensor_info")
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        t = ws[off.value: off.value + 2 * n].view(torch.bfloat16).view(dims[0], dims[1], dims[2], dims[3])
+        return t.float().permute(0, 3, 1, 2).contiguous()            # NCHW fp32 copy
+
+    def rel(ref, got):
+        return ((ref - got).abs().max() / ref.abs().max()).item()
+
+    def bn(z, wkey, bkey):   # train-mode BatchNorm with the batch statistics of z
+        mu = z.mean(dim=(0, 2, 3), keepdim=True)
+        var = z.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+        return (z - mu) / torch.sqrt(var + 1e-5) * sd[wkey].view(1, -1, 1, 1) + sd[bkey].view(1, -1, 1, 1)
+
+    rb = lambda t: t.bfloat16().float()
+    # stem conv: bf16 operands, fp32 accumulate, bf16 store
+    y0 = tensor(0, 0)
+    y0_ref = F.conv2d(rb(x), rb(sd["conv1.weight"]), None, 2, 3)
+    assert rel(y0_ref, y0) <= 1.0 / 128, ("stem conv", rel(y0_ref, y0))
+    # BN + ReLU + maxpool from the stored y0
+    p0 = tensor(3, 0)
+    p0_ref = F.max_pool2d(F.relu(bn(y0, "bn1.weight", "bn1.bias")), 3, 2, 1)
+    assert rel(p0_ref, p0) <= 1.0 / 64, ("stem bn+relu+maxpool", rel(p0_ref, p0))
+    # layer1.0: conv1 (unit 1) from the pooled map, BN + ReLU -> a1, conv2 (unit 2), BN + residual + ReLU -> block output
+    y1 = tensor(0, 1)
+    y1_ref = F.conv2d(p0, rb(sd["layer1.0.conv1.weight"]), None, 1, 1)
+    assert rel(y1_ref, y1) <= 1.0 / 128, ("layer1.0.conv1", rel(y1_ref, y1))
+    a1 = tensor(2, 0)
+    a1_ref = F.relu(bn(y1, "layer1.0.bn1.weight", "layer1.0.bn1.bias"))
+    assert rel(a1_ref, a1) <= 1.0 / 64, ("layer1.0 bn1+relu", rel(a1_ref, a1))
+    y2 = tensor(0, 2)
+    y2_ref = F.conv2d(a1, rb(sd["layer1.0.conv2.weight"]), None, 1, 1)
+    assert rel(y2_ref, y2) <= 1.0 / 128, ("layer1.0.conv2", rel(y2_ref, y2))
+    o0 = tensor(1, 0)
+    o0_ref = F.relu(bn(y2, "layer1.0.bn2.weight", "layer1.0.bn2.bias") + p0)
+    assert rel(o0_ref, o0) <= 1.0 / 64, ("layer1.0 bn2+residual+relu", rel(o0_ref, o0))
+    # a stride-2 block with a downsample path: layer2.0 (block 2)
+    units = {"layer2.0.conv1": None}
+    o1 = tensor(1, 1)                                    # layer1.1 output = layer2.0 input
+    nunits = lib().ph_resnet_num_units(plan.h)
+    # unit order: stem, then per block conv1, conv2, (downsample); layer1 has 2 blocks x 2 convs -> layer2.0.conv1 is unit 5
+    y5 = tensor(0, 5)
+    y5_ref = F.conv2d(o1, rb(sd["layer2.0.conv1.weight"]), None, 2, 1)
+    assert y5.shape == y5_ref.shape and nunits == 20
+    assert rel(y5_ref, y5) <= 1.0 / 128, ("layer2.0.conv1 (stride 2)", rel(y5_ref, y5))
+    print("\nperf-mode stages: stem conv %.4f, stem pool %.4f, l1 conv %.4f, bn+relu %.4f, conv2 %.4f, bn+res %.4f, s2 conv %.4f"
+          % (rel(y0_ref, y0), rel(p0_ref, p0), rel(y1_ref, y1), rel(a1_ref, a1), rel(y2_ref, y2), rel(o0_ref, o0), rel(y5_ref, y5)))
