@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the step from a captured HIP graph")
+    ap.add_argument("--generic-loss-head", action="store_true",
+                    help="A/B: per-loss autograd graphs + GK-Refine by five small backward passes instead of loss_head.py")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
                     "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
     args = ap.parse_args()
@@ -100,6 +102,7 @@ def main():
         sync = m.dist.ReplicaSync()
     m.set_precision("bf16")
     opt = m.stage2_opt(dropout_rate=0.1, batch_size=args.batch)
+    opt.fused_loss_head = not args.generic_loss_head
     n_data = 1024
     torch.manual_seed(0)
     np.random.seed(2019 + rank)

@@ -13,11 +13,12 @@ from .. import ops
 from .._lib import lib, check, ptr, stream, require_cuda
 
 
-class _CRDCoreFn(torch.autograd.Function):
-    """(v1, v2) -> NCE loss (s_loss + t_loss of CRD_loss.py:172-174) with analytic gradients."""
-
-    @staticmethod
-    def forward(ctx, v1, v2, mem, y, idx, ranks, per_sample=False):
+def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None):
+    """The fused CRD step on normalised embeddings: scores against the PRE-update banks, pair selection, first-call Z,
+    NCE loss, analytic gradients, bank momentum update.  Returns (loss, dv1, dv2) with dv = d loss / d v for a unit
+    upstream gradient (per_sample: row b of dv belongs to loss[b]).  `loss_out`: optional 0-d destination of the summed
+    loss.  No autograd here: _CRDCoreFn wraps it, the fused loss head of DistillStep calls it directly."""
+    if True:
         v1, v2 = ops._f32(v1), ops._f32(v2)
         B, D = v1.shape
         P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
@@ -67,7 +68,7 @@ class _CRDCoreFn(torch.autograd.Function):
         if per_sample:
             loss = lossp       # [B] per-sample losses (each already divided by the batch normaliser)
         else:
-            loss = torch.empty((), device=dev, dtype=torch.float32)
+            loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
             check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
         # momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica
         # applies the update of the whole global batch
@@ -77,9 +78,18 @@ class _CRDCoreFn(torch.autograd.Function):
             yy, vv1, vv2 = y, v1.detach(), v2.detach()
         check(L.ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
                               yy.shape[0], D, st), "ph_crd_update")
+        mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
+        return loss, dv1, dv2
+
+
+class _CRDCoreFn(torch.autograd.Function):
+    """(v1, v2) -> NCE loss (s_loss + t_loss of CRD_loss.py:172-174) with analytic gradients."""
+
+    @staticmethod
+    def forward(ctx, v1, v2, mem, y, idx, ranks, per_sample=False):
+        loss, dv1, dv2 = crd_core(v1, v2, mem, y, idx, ranks, per_sample)
         ctx.save_for_backward(dv1, dv2)
         ctx.per_sample = per_sample
-        mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
         return loss
 
     @staticmethod

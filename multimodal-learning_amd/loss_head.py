@@ -1,0 +1,147 @@
+"""Fused loss head of the MICCAI-2022 stage-2 step (train_test_path_multi_distill.py:262-313 + AEKD_loss :41-70).
+
+The generic path builds the five loss terms as separate autograd graphs and lets GK-Refine differentiate each of them
+w.r.t. the student feature (five small backward passes), then back-propagates the weighted sum a sixth time: ~125
+kernels of 3-6 us, a third of them torch scalar glue, 1.3 ms of a 14 ms step.  Everything in that block is a function of
+ONE differentiable tensor - the student feature [B,128] - through three tiny linear maps (fc_new2 and the two CRD
+student heads), so the per-loss gradients are computed once, in closed form, with the same kernels:
+
+    d KL_k / d feat   = kl_bwd(logits, teacher_k) @ W2            (k = fused teacher, EMA teacher)
+    d CE   / d feat   = log_softmax_bwd(nll_bwd) @ W2
+    d CRD_k / d feat  = l2norm_bwd(d CRD_k / d v1) @ W_embed_s,k  (d CRD / d v is produced by the CRD loss kernel)
+
+GK-Refine's weights are the row sums of the cosine Gram of these five vectors (scale-invariant, so the alpha / beta
+factors are applied afterwards); the gradient of the final loss is their weighted sum - no second pass through the
+losses.  Values equal the generic path's up to fp32 summation order (tests/test_gpu_step.py)."""
+import torch
+
+from . import ops
+from ._lib import lib, check, ptr, stream
+from .CL_utils.memory_new import crd_core
+
+_ORDER_INT = (0, 1, 4, 2, 3)      # external [div1, div2, kd1, kd2, CE] -> internal [div1, div2, CE, kd1, kd2] position
+
+
+class LossHeadCtx:
+    """Non-differentiable inputs of one step (plain container)."""
+
+    def __init__(self, step, grade, t_logit, ema_logit, fuse_feat, ema_feat, index, sample_idx, r1, r2, bnorm):
+        self.step, self.grade, self.t_logit, self.ema_logit = step, grade, t_logit, ema_logit
+        self.fuse_feat, self.ema_feat, self.index, self.sample_idx = fuse_feat, ema_feat, index, sample_idx
+        self.r1, self.r2, self.bnorm = r1, r2, bnorm
+        self.out = None
+
+
+def _const(step, name, values, dtype=torch.float32):
+    cache = step.__dict__.setdefault("_lh_const", {})
+    key = (name, tuple(values))
+    if key not in cache:
+        cache[key] = torch.tensor(list(values), device=step.device, dtype=dtype)
+    return cache[key]
+
+
+def _grad_dst(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+class FusedDistillLossFn(torch.autograd.Function):
+    """loss = lambda_nll * CE + sum_i scale_i * KD_i as a function of the student feature; TERMINAL: backward ignores the
+    incoming gradient value (it is the 1.0 of loss.backward()) and writes the gradients of fc_new2 and of the four CRD
+    projection heads straight into their .grad buffers (zeroed by optimizer.zero_grad() just before)."""
+
+    @staticmethod
+    def forward(ctx, feat, H):
+        step = H.step
+        opt, model = step.opt, step.model
+        L = lib()
+        st = stream()
+        feat = ops._f32(feat).contiguous()
+        B, D = feat.shape
+        dev = feat.device
+        W2, b2 = model.fc_new2.weight, model.fc_new2.bias
+        Cc = W2.shape[0]
+        inv = 1.0 / H.bnorm
+        T = float(opt.kd_T)
+        one = _const(step, "one", (1.0,))
+        logits = ops.linear_fwd(feat, W2, b2)
+        pred = torch.empty_like(logits)
+        check(L.ph_log_softmax(ptr(logits), ptr(pred), B, Cc, st), "ph_log_softmax")
+        Lb = torch.empty(5, device=dev, dtype=torch.float32)      # unscaled losses, internal order
+        dl = torch.empty(3, B, Cc, device=dev, dtype=torch.float32)   # d loss / d logits for div1, div2, CE
+        for k, yt in enumerate((H.t_logit, H.ema_logit)):
+            yt = ops._f32(yt).contiguous()
+            check(L.ph_kl_fwd(ptr(logits), ptr(yt), ptr(Lb[k]), B, Cc, T, inv, st), "ph_kl_fwd")
+            check(L.ph_kl_bwd(ptr(one), ptr(logits), ptr(yt), ptr(dl[k]), B, Cc, T, inv, st), "ph_kl_bwd")
+        grade = H.grade.contiguous()
+        check(L.ph_nll_fwd(ptr(pred), ptr(grade), ptr(Lb[2]), B, Cc, inv, st), "ph_nll_fwd")
+        dpred = torch.empty_like(pred)
+        check(L.ph_nll_bwd(ptr(one), ptr(grade), ptr(dpred), B, Cc, inv, st), "ph_nll_bwd")
+        check(L.ph_log_softmax_bwd(ptr(dpred), ptr(pred), ptr(dl[2]), B, Cc, st), "ph_log_softmax_bwd")
+        G = torch.empty(5, B, D, device=dev, dtype=torch.float32)
+        ops.sgemm(dl, W2, None, G, 3 * B, D, Cc, Cc, 1, D, 1)          # rows 0..2: d{div1, div2, CE}/d feat = dlogit @ W2
+        crd_saved = []
+        for k, (crd, tf, rk) in enumerate(((step.criterion_kd, H.fuse_feat, H.r1), (step.criterion_kd_path, H.ema_feat, H.r2))):
+            tf = ops._f32(tf).contiguous()
+            es, et = crd.embed_s.linear, crd.embed_t.linear
+            v1 = torch.empty(B, es.weight.shape[0], device=dev, dtype=torch.float32); n1 = torch.empty(B, device=dev)
+            v2 = torch.empty_like(v1); n2 = torch.empty_like(n1)
+            pre_s = ops.linear_fwd(feat, es.weight, es.bias)
+            check(L.ph_l2norm_fwd(ptr(pre_s), ptr(v1), ptr(n1), B, v1.shape[1], st), "ph_l2norm_fwd")
+            pre_t = ops.linear_fwd(tf, et.weight, et.bias)
+            check(L.ph_l2norm_fwd(ptr(pre_t), ptr(v2), ptr(n2), B, v2.shape[1], st), "ph_l2norm_fwd")
+            _, dv1, dv2 = crd_core(v1, v2, crd.contrast, H.index, H.sample_idx, rk, False, loss_out=Lb[3 + k])
+            dps = torch.empty_like(v1)
+            check(L.ph_l2norm_bwd(ptr(dv1), ptr(v1), ptr(n1), ptr(dps), B, v1.shape[1], st), "ph_l2norm_bwd")
+            Do = es.weight.shape[0]
+            ops.sgemm(dps, es.weight, None, G[3 + k], B, D, Do, Do, 1, D, 1)      # d CRD_k / d feat
+            crd_saved.append((dps, dv2, v2, n2, tf))
+        gram = torch.empty(25, device=dev, dtype=torch.float32)
+        check(L.ph_gram(ptr(G), ptr(gram), 5, B * D, st), "ph_gram")
+        if step.sync is not None:
+            step.sync.all_reduce_sum(gram)
+        scale_int = torch.empty(5, device=dev, dtype=torch.float32)
+        check(L.ph_gk_scale(ptr(gram), None, 5, 0, 4.0, ptr(scale_int), None, st), "ph_gk_scale")     # x len(KD list) (:61)
+        a, b, lam = float(opt.alpha), float(opt.beta), float(opt.lambda_nll)
+        w = torch.addcmul(_const(step, "lam", (0, 0, lam, 0, 0)), scale_int, _const(step, "coef", (a, a, 0, b, b)))
+        total = torch.dot(w, Lb)
+        scaled = Lb * _const(step, "logc", (a, a, 1, b, b))
+        H.out = dict(loss_cls=scaled[2], loss_div1=scaled[0], loss_div2=scaled[1], loss_kd1=scaled[3], loss_kd2=scaled[4],
+                     scale=scale_int.index_select(0, _const(step, "perm", (0, 1, 3, 4, 2), torch.int64)),
+                     logit_path=logits, pred_path=pred)
+        ctx.H, ctx.feat, ctx.dl, ctx.G, ctx.w, ctx.crd_saved = H, feat, dl, G, w, crd_saved
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        H, feat, dl, G, w = ctx.H, ctx.feat, ctx.dl, ctx.G, ctx.w
+        step = H.step
+        model = step.model
+        L = lib()
+        st = stream()
+        B, D = feat.shape
+        dev = feat.device
+        Cc = dl.shape[2]
+        dfeat = torch.empty(B, D, device=dev, dtype=torch.float32)
+        ops.sgemm(w, G, None, dfeat, 1, B * D, 5, 5, 1, B * D, 1)                       # sum_i w_i G_i
+        dlt = torch.empty(B, Cc, device=dev, dtype=torch.float32)
+        ops.sgemm(w, dl, None, dlt, 1, B * Cc, 3, 3, 1, B * Cc, 1)                      # w[0:3] . {dl_div1, dl_div2, dl_CE}
+        ones = ops._ones(B, dev)
+        ops.sgemm(dlt, feat, None, _grad_dst(model.fc_new2.weight), Cc, D, B, 1, Cc, D, 1)      # dW2 = dlogit^T feat
+        ops.sgemm(ones, dlt, None, _grad_dst(model.fc_new2.bias), 1, Cc, B, 0, 1, Cc, 1)
+        for k, (crd, (dps, dv2, v2, n2, tf)) in enumerate(zip((step.criterion_kd, step.criterion_kd_path), ctx.crd_saved)):
+            wk = w[3 + k:4 + k]
+            es, et = crd.embed_s.linear, crd.embed_t.linear
+            Do = es.weight.shape[0]
+            gs = dps * wk
+            ops.sgemm(gs, feat, None, _grad_dst(es.weight), Do, D, B, 1, Do, D, 1)
+            ops.sgemm(ones, gs, None, _grad_dst(es.bias), 1, Do, B, 0, 1, Do, 1)
+            dpt = torch.empty_like(v2)
+            check(L.ph_l2norm_bwd(ptr(dv2), ptr(v2), ptr(n2), ptr(dpt), B, v2.shape[1], st), "ph_l2norm_bwd")
+            gt = dpt * wk
+            Dt = tf.shape[1]
+            ops.sgemm(gt, tf, None, _grad_dst(et.weight), Do, Dt, B, 1, Do, Dt, 1)
+            ops.sgemm(ones, gt, None, _grad_dst(et.bias), 1, Do, B, 0, 1, Do, 1)
+        ctx.crd_saved = None
+        return dfeat, None

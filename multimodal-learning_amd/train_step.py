@@ -329,6 +329,22 @@ class DistillStep:
             with torch.no_grad():
                 _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
                 fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
+        if self._fused_head_ok():
+            # :262-313 as one function of the student feature (loss_head.py): same values, ~50 launches instead of ~125
+            from .loss_head import FusedDistillLossFn, LossHeadCtx
+            Hc = LossHeadCtx(self, grade, logits[-1].detach(), ema_logit_path.detach(), fuse_feat.detach(),
+                             ema_path_feat.detach(), index, sample_idx, r1, r2, bnorm)
+            loss = FusedDistillLossFn.apply(path_feat, Hc)
+            self.optimizer.zero_grad()                                                                      # :326
+            loss.backward()                                                                                 # :327
+            if self.sync is not None:
+                self.sync.all_reduce_grads(self.optimizer.flat)
+            self.optimizer.step()                                                                           # :328 (+ :329 fused)
+            o = Hc.out
+            return dict(loss=loss.detach(), loss_cls=o["loss_cls"], loss_div1=o["loss_div1"], loss_div2=o["loss_div2"],
+                        loss_kd1=o["loss_kd1"], loss_kd2=o["loss_kd2"], scale=o["scale"], logit_path=o["logit_path"],
+                        pred_path=o["pred_path"], path_feat=path_feat.detach(), ema_logit=ema_logit_path,
+                        fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat)
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
         if self.variant == "mia2023":
             return self._mia2023_tail(e, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path,
@@ -367,6 +383,15 @@ class DistillStep:
                     scale=scale, logit_path=logit_path.detach(), pred_path=pred_path.detach(),
                     path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
                     fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+
+    def _fused_head_ok(self):
+        """The closed-form loss head covers the shipped MICCAI stage-2 command: two teachers, CRD, GK-Refine with the CE
+        gradient, a log-softmax grading head.  `opt.fused_loss_head = False` selects the generic autograd path."""
+        opt = self.opt
+        return (self.variant == "miccai2022" and getattr(opt, "fused_loss_head", True) and opt.assign_weights == "True"
+                and bool(opt.CE_grads) and opt.num_teachers == 2 and opt.distill == "crd"
+                and isinstance(getattr(self.model, "fc_new2", None), nn.Linear)
+                and isinstance(getattr(self.model, "act", None), nn.LogSoftmax))
 
     def _mia2023_tail(self, rw, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path, ema_path_feat,
                       ema_logit_path, fuse_feat, logits):

