@@ -159,7 +159,7 @@ __global__ void crd_setz_kernel(float* params, const float* sums, float count, f
 //   loss_s = -(1/Bn) [ sum_p log(x/(x+c)) / P2 + sum_n log(mPn/(x+c)) ],  x = xs/Z_v1, c = K2/n_data + eps
 //   d loss_s / d dot_j = -(1/(Bn P2)) (c/(x+c))/T  (positives) ;  +(1/Bn) (x/(x+c))/T  (negatives)
 //   dv1[b] = sum_j coef_s[j] mem2[idx[b][sel_j]] ; dv2[b] = sum_j coef_t[j] mem1[idx[b][sel_j]]
-__global__ __launch_bounds__(256) void crd_loss_grad_kernel(const float* __restrict__ xs,
+__global__ __launch_bounds__(1024) void crd_loss_grad_kernel(const float* __restrict__ xs,
                                                             const float* __restrict__ xt,
                                                             const int* __restrict__ sel,
                                                             const int64_t* __restrict__ idx,
@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void crd_loss_grad_kernel(const float* __restr
   const float mPn = (float)K2 / n_data, c = mPn + 1e-7f;
   f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
   float ls = 0.f;
-  for (int j = hw; j < S2; j += 8) {
+  // 32 half-waves per sample: the loop is a chain of dependent gathers (sel -> idx -> bank row), latency-bound; with 8
+  // half-waves (256 threads) it took 54 us at B = 64, P2 + K2 = 532
+  constexpr int NHW = 32;
+  for (int j = hw; j < S2; j += NHW) {
     const float x1 = xs[(size_t)b * S2 + j] / Z1, x2 = xt[(size_t)b * S2 + j] / Z2;
     float c1, c2;
     if (j < P2) {
@@ -200,22 +203,22 @@ __global__ __launch_bounds__(256) void crd_loss_grad_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 4; ++k) { g1[k] += c1 * m2[k]; g2[k] += c2 * m1[k]; }
   }
-  __shared__ float sh[8][2][D];
-  __shared__ float shl[8];
+  __shared__ float sh[NHW][2][D];
+  __shared__ float shl[NHW];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { sh[hw][0][l * 4 + k] = g1[k]; sh[hw][1][l * 4 + k] = g2[k]; }
   if (l == 0) shl[hw] = ls;
   __syncthreads();
-  {
+  if (threadIdx.x < 2 * D) {
     const int which = threadIdx.x >> 7, d = threadIdx.x & 127;
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) t += sh[q][which][d];
+    for (int q = 0; q < NHW; ++q) t += sh[q][which][d];
     (which ? dv2 : dv1)[(size_t)b * D + d] = t;
   }
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int q = 0; q < 8; ++q) t += shl[q];
+    for (int q = 0; q < NHW; ++q) t += shl[q];
     lossp[b] = -t * inv_bnorm;
   }
 }
@@ -362,7 +365,7 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
                      const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
                      int feat_dim, float n_data, float inv_bnorm, hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
-  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B), dim3(256), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
+  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B), dim3(1024), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
                      posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, n_data, inv_bnorm);
   PH_LAUNCH_CHECK();
   return PH_OK;
