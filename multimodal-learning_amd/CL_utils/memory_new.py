@@ -18,68 +18,67 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None):
     NCE loss, analytic gradients, bank momentum update.  Returns (loss, dv1, dv2) with dv = d loss / d v for a unit
     upstream gradient (per_sample: row b of dv belongs to loss[b]).  `loss_out`: optional 0-d destination of the summed
     loss.  No autograd here: _CRDCoreFn wraps it, the fused loss head of DistillStep calls it directly."""
-    if True:
-        v1, v2 = ops._f32(v1), ops._f32(v2)
-        B, D = v1.shape
-        P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
-        PK, S2 = P + K, P2 + K2
-        dev = v1.device
-        idx = require_cuda(idx).contiguous()
-        y = require_cuda(y).contiguous()
-        if idx.dtype != torch.int64 or y.dtype != torch.int64 or idx.shape != (B, PK):
-            raise RuntimeError("contrast_idx must be int64 [B, nce_p+nce_k] and idx int64 [B]")
-        out1 = torch.empty(B, PK, device=dev, dtype=torch.float32)
-        out2 = torch.empty_like(out1)
-        diff = torch.empty_like(out1)
-        L = lib()
-        st = stream()
-        T = mem.T
-        idx2 = getattr(mem, "_idx_bank2", None)          # MIA-2023 v10: bank-specific positive rows
-        posw_s = getattr(mem, "_posw_s", None)
-        posw_t = getattr(mem, "_posw_t", None)
-        check(L.ph_crd_score(ptr(v1), ptr(v2), ptr(idx), ptr(idx2), ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(out1),
-                             ptr(out2), ptr(diff), B, PK, D, T, st), "ph_crd_score")
-        sel = torch.empty(B, S2, device=dev, dtype=torch.int32)
-        xs = torch.empty(B, S2, device=dev, dtype=torch.float32)
-        xt = torch.empty_like(xs)
-        check(L.ph_crd_select(ptr(diff), ptr(out1), ptr(out2), ptr(ranks), ptr(sel), ptr(xs), ptr(xt), B, P, K, P2, K2,
-                              1 if mem.select_neg_pairs == "True" else 0,
-                              1 if getattr(mem, "select_pos_pairs", False) is True else 0, st), "ph_crd_select")
-        if not mem._z_set:
-            sums = torch.empty(2, device=dev, dtype=torch.float32)
-            check(L.ph_crd_zsum(ptr(xs), ptr(xt), ptr(sums), B * S2, st), "ph_crd_zsum")
-            count = float(B * S2)
-            if mem.sync is not None:
-                count = mem.sync.all_reduce_z(sums, count)
-            check(L.ph_crd_setz(ptr(mem.params), ptr(sums), count, float(mem.nLem), st), "ph_crd_setz")
-            mem._z_set = True
-            if mem.verbose:   # the reference prints Z once (memory_new.py:371,375); costs one host sync
-                z = mem.params[2:4].tolist()
-                print("normalization constant Z_v1 is set to {:.1f}".format(z[0]))
-                print("normalization constant Z_v2 is set to {:.1f}".format(z[1]))
-        lossp = torch.empty(B, device=dev, dtype=torch.float32)
-        dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
-        dv2 = torch.empty_like(dv1)
-        bnorm = float(mem.batch_norm_size or B)
-        check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(posw_s), ptr(posw_t),
-                                 ptr(mem.memory_v1), ptr(mem.memory_v2),
-                                 ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, PK, P2, K2, D, float(mem.nLem),
-                                 1.0 / bnorm, st), "ph_crd_loss_grad")
-        if per_sample:
-            loss = lossp       # [B] per-sample losses (each already divided by the batch normaliser)
-        else:
-            loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
-            check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
-        # momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica
-        # applies the update of the whole global batch
+    v1, v2 = ops._f32(v1), ops._f32(v2)
+    B, D = v1.shape
+    P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
+    PK, S2 = P + K, P2 + K2
+    dev = v1.device
+    idx = require_cuda(idx).contiguous()
+    y = require_cuda(y).contiguous()
+    if idx.dtype != torch.int64 or y.dtype != torch.int64 or idx.shape != (B, PK):
+        raise RuntimeError("contrast_idx must be int64 [B, nce_p+nce_k] and idx int64 [B]")
+    out1 = torch.empty(B, PK, device=dev, dtype=torch.float32)
+    out2 = torch.empty_like(out1)
+    diff = torch.empty_like(out1)
+    L = lib()
+    st = stream()
+    T = mem.T
+    idx2 = getattr(mem, "_idx_bank2", None)          # MIA-2023 v10: bank-specific positive rows
+    posw_s = getattr(mem, "_posw_s", None)
+    posw_t = getattr(mem, "_posw_t", None)
+    check(L.ph_crd_score(ptr(v1), ptr(v2), ptr(idx), ptr(idx2), ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(out1),
+                         ptr(out2), ptr(diff), B, PK, D, T, st), "ph_crd_score")
+    sel = torch.empty(B, S2, device=dev, dtype=torch.int32)
+    xs = torch.empty(B, S2, device=dev, dtype=torch.float32)
+    xt = torch.empty_like(xs)
+    check(L.ph_crd_select(ptr(diff), ptr(out1), ptr(out2), ptr(ranks), ptr(sel), ptr(xs), ptr(xt), B, P, K, P2, K2,
+                          1 if mem.select_neg_pairs == "True" else 0,
+                          1 if getattr(mem, "select_pos_pairs", False) is True else 0, st), "ph_crd_select")
+    if not mem._z_set:
+        sums = torch.empty(2, device=dev, dtype=torch.float32)
+        check(L.ph_crd_zsum(ptr(xs), ptr(xt), ptr(sums), B * S2, st), "ph_crd_zsum")
+        count = float(B * S2)
         if mem.sync is not None:
-            yy, vv1, vv2 = mem.sync.all_gather_rows(y, v1.detach(), v2.detach())
-        else:
-            yy, vv1, vv2 = y, v1.detach(), v2.detach()
-        check(L.ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
-                              yy.shape[0], D, st), "ph_crd_update")
-        mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
-        return loss, dv1, dv2
+            count = mem.sync.all_reduce_z(sums, count)
+        check(L.ph_crd_setz(ptr(mem.params), ptr(sums), count, float(mem.nLem), st), "ph_crd_setz")
+        mem._z_set = True
+        if mem.verbose:   # the reference prints Z once (memory_new.py:371,375); costs one host sync
+            z = mem.params[2:4].tolist()
+            print("normalization constant Z_v1 is set to {:.1f}".format(z[0]))
+            print("normalization constant Z_v2 is set to {:.1f}".format(z[1]))
+    lossp = torch.empty(B, device=dev, dtype=torch.float32)
+    dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
+    dv2 = torch.empty_like(dv1)
+    bnorm = float(mem.batch_norm_size or B)
+    check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(posw_s), ptr(posw_t),
+                             ptr(mem.memory_v1), ptr(mem.memory_v2),
+                             ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, PK, P2, K2, D, float(mem.nLem),
+                             1.0 / bnorm, st), "ph_crd_loss_grad")
+    if per_sample:
+        loss = lossp       # [B] per-sample losses (each already divided by the batch normaliser)
+    else:
+        loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
+        check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
+    # momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica
+    # applies the update of the whole global batch
+    if mem.sync is not None:
+        yy, vv1, vv2 = mem.sync.all_gather_rows(y, v1.detach(), v2.detach())
+    else:
+        yy, vv1, vv2 = y, v1.detach(), v2.detach()
+    check(L.ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
+                          yy.shape[0], D, st), "ph_crd_update")
+    mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
+    return loss, dv1, dv2
 
 
 class _CRDCoreFn(torch.autograd.Function):
