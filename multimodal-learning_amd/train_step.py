@@ -266,6 +266,7 @@ class DistillStep:
             raise ValueError("variant must be 'miccai2022', 'mia2022' or 'mia2023'")
         self.variant = variant
         self._mo_state = None     # momentum GK-Refine weights (mia2022), updated in place on the device
+        self.sampler = None       # optional ContrastIndexSampler: draws sample_idx when the batch carries None
         self._mo_init = None
         self.opt = opt
         self.device = torch.device(device)
@@ -472,6 +473,15 @@ class DistillStep:
             raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd)")
         (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
         dev = self.device
+        if sample_idx is None:
+            # the loader's contrast-index draw (data_loaders_MT.py:229-249) on the device: set `step.sampler` to a
+            # ContrastIndexSampler built from the training labels; one launch per step, outside the captured graph
+            if getattr(self, "sampler", None) is None:
+                raise ValueError("the batch carries no sample_idx and no step.sampler (ContrastIndexSampler) is set")
+            buf = getattr(self, "_sample_idx_buf", None)
+            if buf is None or buf.shape[0] != index.shape[0]:
+                buf = self._sample_idx_buf = torch.empty(index.shape[0], self.sampler.width, device=dev, dtype=torch.int64)
+            sample_idx = self.sampler(index, grade, out=buf)
         bnorm = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))
         self.criterion_div.batch_norm_size = bnorm
         self.criterion_kd.contrast.batch_norm_size = bnorm

@@ -108,3 +108,36 @@ def test_sampler_feeds_the_crd_bank():
     loss = crd(0.1, f, torch.randn(16, 128, generator=g).relu_().cuda(), index.cuda(), idx)
     loss.backward()
     assert torch.isfinite(loss).item() and torch.isfinite(f.grad).all().item()
+
+
+def test_distill_step_draws_its_contrast_indices_on_the_device():
+    """A batch without sample_idx: DistillStep asks its ContrastIndexSampler (one launch per step into a persistent
+    buffer that the captured graph reads).  The trajectory must be repeatable and must differ from step to step."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.sampler import ContrastIndexSampler
+    from oracle.step import default_opt, synthetic_batch
+    from tests.test_gpu_step import _mk_step
+    m.set_precision("bf16")
+    opt = default_opt()
+    opt.pos_mode, opt.neg_mode = "multi_pos", "diff_class"
+    n = 1024
+    labels = _labels(n, 2)
+
+    def run():
+        step = _mk_step(opt, n, seed=0)
+        step.sampler = ContrastIndexSampler(opt, labels, seed=5)
+        step.enable_graph()
+        losses, idxs = [], []
+        for it in range(5):
+            bt = synthetic_batch(8, 64, seed=30 + it)
+            grade = torch.as_tensor(labels[bt["index"].numpy()])
+            z = torch.zeros(8)
+            out = step.step(((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, grade, bt["index"], None), epoch=1,
+                            ranks=[np.arange(30, 50), np.arange(40, 60)])
+            losses.append(out["loss"].item())
+            idxs.append(step._sample_idx_buf.clone())
+        return losses, idxs
+    (l1, i1), (l2, i2) = run(), run()
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(i1, i2))
+    assert all(np.isfinite(l1)) and not torch.equal(i1[0][:, 1:], i1[1][:, 1:])
+    assert int(i1[0].shape[1]) == opt.nce_p + opt.nce_k
