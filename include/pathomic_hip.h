@@ -168,6 +168,15 @@ int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, co
 int ph_gram(const float* G /* [ng][n] */, float* gram /* [ng*ng] */, int ng, int n, ph_stream_t stream);
 int ph_gk_scale(const float* gram, const float* const* losses /* device array of nl device scalars */, int ng, int nl,
                 float mult, float* scale, float* total, ph_stream_t stream);
+/* Fused forms used by the closed-form loss head of the stage-2 step (multimodal_learning_amd/loss_head.py; reference
+ * train_test_path_multi_distill.py:262-313 and AEKD_loss :41-70).  ph_logit_losses: log-softmax, the two DistillKL terms
+ * and the NLL of one logit matrix plus d(each loss)/d(logits) for a unit upstream gradient (losses[3], dl[3][B][C]).
+ * ph_gk_finish: GK-Refine weights of five gradients in the order [div1, div2, CE, kd1, kd2] from their Gram matrix,
+ * w = add + scale * coef, total = w . losses, scaled = losses * logc, scale_ext = scale as [div1, div2, kd1, kd2, CE]. */
+int ph_logit_losses(const float* ys, const float* yt1, const float* yt2, const int64_t* grade, float* pred, float* losses,
+                    float* dl, int B, int C, float T, float inv_bnorm, ph_stream_t stream);
+int ph_gk_finish(const float* gram, const float* losses, const float* coef, const float* add, const float* logc, float mult,
+                 float* scale_int, float* w, float* total, float* scaled, float* scale_ext, ph_stream_t stream);
 /* momentum_AEKD_loss ("MIA 2022/train_test_path_multi_distill_v2.py":89-132): cosine Gram row sums without the
  * x len(list) factor, optional > thresh binarisation (:114-115), EMA of the weights (:121-124; *mo_init == 0 on the
  * first call, set to 1 by the kernel) */

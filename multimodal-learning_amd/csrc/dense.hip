@@ -415,6 +415,69 @@ __global__ void kl_bwd_kernel(const float* __restrict__ gs, const float* __restr
     dys[b * C + c] = k * (expf(ys[b * C + c] / T - ms) / ss - expf(yt[b * C + c] / T - mt) / st);
 }
 
+// The logit-level part of the stage-2 loss block in ONE launch (loss_head.py): log-softmax of the student logits, the
+// two DistillKL terms and the NLL, and d(each loss)/d(logits) for a unit upstream gradient - the same arithmetic, row
+// by row and in the same order, as log_softmax / kl_fwd / kl_bwd / nll_fwd / nll_bwd / log_softmax_bwd above (which it
+// replaces inside DistillStep: 8 dependent launches of ~5 us).  losses[0..2] = KL(t1), KL(t2), NLL; dl = [3][B][C].
+__global__ __launch_bounds__(256) void logit_losses_kernel(const float* __restrict__ ys, const float* __restrict__ yt1,
+                                                           const float* __restrict__ yt2,
+                                                           const int64_t* __restrict__ grade, float* __restrict__ pred,
+                                                           float* __restrict__ losses, float* __restrict__ dl, int B, int C,
+                                                           float T, float inv_bnorm) {
+  __shared__ float sh[16];
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const float kk = T * inv_bnorm;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* y = ys + (size_t)b * C;
+    // log-softmax of the raw logits (log_softmax_kernel)
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, y[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(y[c] - mx);
+    const float l = mx + logf(se);
+    const int gb = (int)grade[b];
+    for (int c = 0; c < C; ++c) pred[(size_t)b * C + c] = y[c] - l;
+    s3 -= y[gb] - l;                                            // nll_fwd
+    // d NLL / d logits = log_softmax_bwd(nll_bwd): g - exp(pred) * sum(g), g = -inv_bnorm at the label
+    const float gsum = -inv_bnorm;
+    for (int c = 0; c < C; ++c)
+      dl[((size_t)2 * B + b) * C + c] = (c == gb ? -inv_bnorm : 0.f) - expf(y[c] - l) * gsum;
+    // temperature softmax of the student (kl_*_kernel)
+    float ms = -INFINITY;
+    for (int c = 0; c < C; ++c) ms = fmaxf(ms, y[c] / T);
+    float ss = 0.f;
+    for (int c = 0; c < C; ++c) ss += expf(y[c] / T - ms);
+    const float ls = ms + logf(ss);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float* t = (k ? yt2 : yt1) + (size_t)b * C;
+      float mt = -INFINITY;
+      for (int c = 0; c < C; ++c) mt = fmaxf(mt, t[c] / T);
+      float st = 0.f;
+      for (int c = 0; c < C; ++c) st += expf(t[c] / T - mt);
+      const float lt = mt + logf(st);
+      float acc = 0.f;
+      for (int c = 0; c < C; ++c) {
+        const float lpt = t[c] / T - lt, lps = y[c] / T - ls;
+        const float pt = expf(lpt);
+        if (pt > 0.f) acc += pt * (lpt - lps);
+        dl[((size_t)k * B + b) * C + c] = kk * (expf(y[c] / T - ms) / ss - expf(t[c] / T - mt) / st);
+      }
+      if (k) s2 += acc; else s1 += acc;
+    }
+  }
+  s1 = block_sum(s1, sh);
+  __syncthreads();
+  s2 = block_sum(s2, sh);
+  __syncthreads();
+  s3 = block_sum(s3, sh);
+  if (threadIdx.x == 0) {
+    losses[0] = s1 * T * T * inv_bnorm;
+    losses[1] = s2 * T * T * inv_bnorm;
+    losses[2] = s3 * inv_bnorm;
+  }
+}
+
 // MIA-2023 DistillKL ("MIA 2023/stage2_unimodal_student/KD_loss.py":14-20): per-sample KL rows
 __global__ void kl_rows_fwd_kernel(const float* __restrict__ ys, const float* __restrict__ yt,
                                    float* __restrict__ sample_loss, int B, int C, float T) {
@@ -713,6 +776,13 @@ int ph_nll_fwd(const float* pred, const int64_t* grade, float* loss, int B, int 
 }
 int ph_nll_bwd(const float* gs, const int64_t* grade, float* dpred, int B, int C, float inv_bnorm, hipStream_t st) {
   hipLaunchKernelGGL(nll_bwd_kernel, dim3(nblk((size_t)B * C)), dim3(256), 0, st, gs, grade, dpred, B, C, inv_bnorm);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_logit_losses(const float* ys, const float* yt1, const float* yt2, const int64_t* grade, float* pred, float* losses,
+                    float* dl, int B, int C, float T, float inv_bnorm, hipStream_t st) {
+  if (C > 64) return PH_EINVAL;
+  hipLaunchKernelGGL(logit_losses_kernel, dim3(1), dim3(256), 0, st, ys, yt1, yt2, grade, pred, losses, dl, B, C, T, inv_bnorm);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

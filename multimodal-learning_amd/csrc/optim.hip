@@ -57,6 +57,32 @@ __global__ void gk_scale_kernel(const float* __restrict__ gram, const float* con
   if (total) *total = t;
 }
 
+// GK-Refine tail of loss_head.py in one launch: scale_i (as gk_scale_kernel) from the Gram matrix of the five gradients
+// in the order [div1, div2, CE, kd1, kd2]; w = scale * coef + add (the per-term factors alpha / beta and lambda_nll);
+// total = w . losses; scaled = losses * logc (the values the trainer logs); scale_ext = scale in the reference's order
+// [div1, div2, kd1, kd2, CE].
+__global__ void gk_finish_kernel(const float* __restrict__ gram, const float* __restrict__ losses,
+                                 const float* __restrict__ coef, const float* __restrict__ add,
+                                 const float* __restrict__ logc, float mult, float* __restrict__ scale_int,
+                                 float* __restrict__ w, float* __restrict__ total, float* __restrict__ scaled,
+                                 float* __restrict__ scale_ext) {
+  if (threadIdx.x != 0) return;
+  const int ng = 5;
+  float t = 0.f, sc[5];
+  for (int i = 0; i < ng; ++i) {
+    float s = 0.f;
+    for (int j = 0; j < ng; ++j) s += gram[i * ng + j] * mult / (sqrtf(gram[i * ng + i]) * sqrtf(gram[j * ng + j]));
+    sc[i] = s;
+    scale_int[i] = s;
+    const float wi = add[i] + s * coef[i];
+    w[i] = wi;
+    t += wi * losses[i];
+    scaled[i] = losses[i] * logc[i];
+  }
+  *total = t;
+  scale_ext[0] = sc[0]; scale_ext[1] = sc[1]; scale_ext[2] = sc[3]; scale_ext[3] = sc[4]; scale_ext[4] = sc[2];
+}
+
 // Adam (torch.optim.Adam semantics) + optional EMA of the parameters, 4 elements per thread.
 //   g' = g + wd*p ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 //   ema = alpha*ema + (1-alpha)*p_new
@@ -231,6 +257,14 @@ int ph_gram(const float* G, float* gram, int ng, int n, hipStream_t st) {
 int ph_gk_scale(const float* gram, const float* const* losses, int ng, int nl, float mult, float* scale, float* total,
                 hipStream_t st) {
   hipLaunchKernelGGL(gk_scale_kernel, dim3(1), dim3(64), 0, st, gram, losses, ng, nl, mult, scale, total);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_gk_finish(const float* gram, const float* losses, const float* coef, const float* add, const float* logc, float mult,
+                 float* scale_int, float* w, float* total, float* scaled, float* scale_ext, hipStream_t st) {
+  hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(64), 0, st, gram, losses, coef, add, logc, mult, scale_int, w, total,
+                     scaled, scale_ext);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

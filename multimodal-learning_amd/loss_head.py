@@ -64,21 +64,13 @@ class FusedDistillLossFn(torch.autograd.Function):
         Cc = W2.shape[0]
         inv = 1.0 / H.bnorm
         T = float(opt.kd_T)
-        one = _const(step, "one", (1.0,))
         logits = ops.linear_fwd(feat, W2, b2)
         pred = torch.empty_like(logits)
-        check(L.ph_log_softmax(ptr(logits), ptr(pred), B, Cc, st), "ph_log_softmax")
-        Lb = torch.empty(5, device=dev, dtype=torch.float32)      # unscaled losses, internal order
+        Lb = torch.empty(5, device=dev, dtype=torch.float32)      # unscaled losses, internal order [div1, div2, CE, kd1, kd2]
         dl = torch.empty(3, B, Cc, device=dev, dtype=torch.float32)   # d loss / d logits for div1, div2, CE
-        for k, yt in enumerate((H.t_logit, H.ema_logit)):
-            yt = ops._f32(yt).contiguous()
-            check(L.ph_kl_fwd(ptr(logits), ptr(yt), ptr(Lb[k]), B, Cc, T, inv, st), "ph_kl_fwd")
-            check(L.ph_kl_bwd(ptr(one), ptr(logits), ptr(yt), ptr(dl[k]), B, Cc, T, inv, st), "ph_kl_bwd")
-        grade = H.grade.contiguous()
-        check(L.ph_nll_fwd(ptr(pred), ptr(grade), ptr(Lb[2]), B, Cc, inv, st), "ph_nll_fwd")
-        dpred = torch.empty_like(pred)
-        check(L.ph_nll_bwd(ptr(one), ptr(grade), ptr(dpred), B, Cc, inv, st), "ph_nll_bwd")
-        check(L.ph_log_softmax_bwd(ptr(dpred), ptr(pred), ptr(dl[2]), B, Cc, st), "ph_log_softmax_bwd")
+        yt1, yt2, grade = ops._f32(H.t_logit).contiguous(), ops._f32(H.ema_logit).contiguous(), H.grade.contiguous()
+        check(L.ph_logit_losses(ptr(logits), ptr(yt1), ptr(yt2), ptr(grade), ptr(pred), ptr(Lb), ptr(dl), B, Cc, T, inv, st),
+              "ph_logit_losses")
         G = torch.empty(5, B, D, device=dev, dtype=torch.float32)
         ops.sgemm(dl, W2, None, G, 3 * B, D, Cc, Cc, 1, D, 1)          # rows 0..2: d{div1, div2, CE}/d feat = dlogit @ W2
         crd_saved = []
@@ -101,15 +93,15 @@ class FusedDistillLossFn(torch.autograd.Function):
         check(L.ph_gram(ptr(G), ptr(gram), 5, B * D, st), "ph_gram")
         if step.sync is not None:
             step.sync.all_reduce_sum(gram)
-        scale_int = torch.empty(5, device=dev, dtype=torch.float32)
-        check(L.ph_gk_scale(ptr(gram), None, 5, 0, 4.0, ptr(scale_int), None, st), "ph_gk_scale")     # x len(KD list) (:61)
         a, b, lam = float(opt.alpha), float(opt.beta), float(opt.lambda_nll)
-        w = torch.addcmul(_const(step, "lam", (0, 0, lam, 0, 0)), scale_int, _const(step, "coef", (a, a, 0, b, b)))
-        total = torch.dot(w, Lb)
-        scaled = Lb * _const(step, "logc", (a, a, 1, b, b))
+        fin = torch.empty(21, device=dev, dtype=torch.float32)    # scale_int[5] | w[5] | total | scaled[5] | scale_ext[5]
+        check(L.ph_gk_finish(ptr(gram), ptr(Lb), ptr(_const(step, "coef", (a, a, 0, b, b))),
+                             ptr(_const(step, "lam", (0, 0, lam, 0, 0))), ptr(_const(step, "logc", (a, a, 1, b, b))), 4.0,
+                             ptr(fin[0:5]), ptr(fin[5:10]), ptr(fin[10:11]), ptr(fin[11:16]), ptr(fin[16:21]), st),
+              "ph_gk_finish")                                     # x len(KD list) = 4 (:61)
+        w, total, scaled = fin[5:10], fin[10], fin[11:16]
         H.out = dict(loss_cls=scaled[2], loss_div1=scaled[0], loss_div2=scaled[1], loss_kd1=scaled[3], loss_kd2=scaled[4],
-                     scale=scale_int.index_select(0, _const(step, "perm", (0, 1, 3, 4, 2), torch.int64)),
-                     logit_path=logits, pred_path=pred)
+                     scale=fin[16:21], logit_path=logits, pred_path=pred)
         ctx.H, ctx.feat, ctx.dl, ctx.G, ctx.w, ctx.crd_saved = H, feat, dl, G, w, crd_saved
         return total
 
