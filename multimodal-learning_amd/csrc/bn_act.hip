@@ -376,6 +376,62 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dpo
   }
 }
 
+// BatchNorm-backward sums of the stem taken over POOLED pixels: every pooling window sends its gradient to exactly one
+// input pixel (its argmax), so  sum_pixels dz = sum_windows [relu] dpool  and  sum_pixels dz * xhat = sum_windows [relu]
+// dpool * xhat(argmax pixel)  - one 16-byte gradient load, one 8-byte code load and eight 2-byte gathers of the conv
+// output per window-vector instead of four window gathers per input pixel.  Same partial-row layout as the kernel above
+// (a block walks STEM_ROWS / 2 pooled rows).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __restrict__ dpool,
+                                                                     const uint8_t* __restrict__ idx,
+                                                                     const T* __restrict__ y,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     float* __restrict__ parts, int B, int H, int W) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const int cg = threadIdx.x & 7, wl = threadIdx.x >> 3, c = cg * 8;
+  float sc[8], sf[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean[c + k]; is[k] = invstd[c + k];
+    s1[k] = 0.f; s2[k] = 0.f;
+  }
+  constexpr int PROWS = STEM_ROWS / 2;
+  const int row0 = blockIdx.x * PROWS, row1 = min(B * OH, row0 + PROWS);
+  for (int prow = row0; prow < row1; ++prow) {
+    const size_t b = prow / OH;
+    const int ph = prow - (int)b * OH;
+    for (int pw = wl; pw < OW; pw += 32) {
+      const size_t o8 = ((size_t)prow * OW + pw) * 8 + cg;
+      float g8[8];
+      load8(dpool + o8 * 8, g8);
+      const uint64_t packed = *reinterpret_cast<const uint64_t*>(idx + o8 * 8);
+      const T* ybase = y + (((size_t)b * H + (2 * ph - 1)) * W + (2 * pw - 1)) * 64 + c;   // window origin (may lie outside:
+#pragma unroll                                                                            //  the argmax never does)
+      for (int k = 0; k < 8; ++k) {
+        const unsigned code = (unsigned)(packed >> (8 * k)) & 0xffu;
+        const unsigned kh = (code * 171u) >> 9, kw = code - 3u * kh;
+        const float z = ldf(ybase + ((size_t)kh * W + kw) * 64 + k);
+        const float dz = (z * sc[k] + sf[k]) > 0.f ? g8[k] : 0.f;
+        s1[k] += dz;
+        s2[k] += dz * ((z - mu[k]) * is[k]);
+      }
+    }
+  }
+  __shared__ float sh[2][256][9];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+    float t = 0.f;
+    for (int q = 0; q < 32; ++q) t += sh[which][q * 8 + (ch >> 3)][ch & 7];
+    parts[((size_t)blockIdx.x * 2 + which) * 64 + ch] = t;
+  }
+}
+
 inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -499,6 +555,18 @@ int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void*
                               int W, int C, int prec, hipStream_t st) {
   if (C != 64) return PH_EINVAL;
   const int nb = ph_stem_bwd_parts(B, H);
+#ifdef PH_STEM_BWD_POOLED
+  if (H % 2 == 0) {   // (the block -> pooled-row mapping reuses the partial-row count of the per-pixel kernel)
+    if (prec == PH_PREC_BF16)
+      hipLaunchKernelGGL((stem_bwd_reduce_pooled_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx,
+                         (const bf16*)y0, scale, shift, mean, invstd, parts, B, H, W);
+    else
+      hipLaunchKernelGGL((stem_bwd_reduce_pooled_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dpool, idx,
+                         (const float*)y0, scale, shift, mean, invstd, parts, B, H, W);
+    PH_LAUNCH_CHECK();
+    return PH_OK;
+  }
+#endif
   if (prec == PH_PREC_BF16)
     hipLaunchKernelGGL((stem_bwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx, (const bf16*)y0,
                        scale, shift, mean, invstd, nullptr, nullptr, nullptr, parts, (bf16*)nullptr, B, H, W);
