@@ -555,7 +555,7 @@ int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void*
                               int W, int C, int prec, hipStream_t st) {
   if (C != 64) return PH_EINVAL;
   const int nb = ph_stem_bwd_parts(B, H);
-#ifdef PH_STEM_BWD_POOLED
+#ifndef PH_STEM_BWD_PER_PIXEL   // (A/B switch: the per-input-pixel form of the reduction, 246 us against 190 us)
   if (H % 2 == 0) {   // (the block -> pooled-row mapping reuses the partial-row count of the per-pixel kernel)
     if (prec == PH_PREC_BF16)
       hipLaunchKernelGGL((stem_bwd_reduce_pooled_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx,
