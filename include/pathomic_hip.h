@@ -219,7 +219,7 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
  *   out[0] = scale * sum (a - b)^2 ;  gradient out = gscalar[0] * alpha * (a - b).
  * ph_tsvd_update_aux replaces update_aux(adj, Lambda_global / mu) called at :382-391 (its source is absent from the
  * reference: this is the tensor-nuclear-norm proximal operator, see csrc/tsvd.hip): adj, aux are [V][B][B] (view-major),
- * V in {2,4,6,8}, B <= 64; tnn[0] = (1/V) sum over frequency slices of the nuclear norm of the thresholded slice.
+ * V in {2,4,6,8}, B <= 128 (B <= 64: Jacobi on the embedding of X^H X; above: one-sided Jacobi on the slice); tnn[0] = (1/V) sum over frequency slices of the nuclear norm of the thresholded slice.
  * ---------------------------------------------------------------------------------------------- */
 /* On-device contrast-index sampler (reference MICCAI-2022/data_loaders_MT.py:229-249 and the neg_mode
  * variants of "MIA 2023/stage2_unimodal_student/data_loaders_MT.py":205-238).  out[b] = [positives | K negatives]:
@@ -238,6 +238,8 @@ int ph_row_scale(const float* x, const float* r /* [B] */, float* y, int B, int 
 int ph_sqdiff_sum(const float* a, const float* b, float* out, size_t n, float scale, ph_stream_t stream);
 int ph_scaled_diff(const float* a, const float* b, const float* gscalar, float alpha, float* out, size_t n,
                    ph_stream_t stream);
+/* the mixed-feature views of n_views = 6 / 8 (:305-307, :334-363): out = wa * a / max(a) + wb * b / max(b) over n elements */
+int ph_maxnorm_mix(const float* a, const float* b, float* out, size_t n, float wa, float wb, ph_stream_t stream);
 size_t ph_tsvd_workspace_bytes(int V, int B);
 int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn /* may be NULL */, int V, int B, float tau,
                        void* workspace, ph_stream_t stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ph_row_scale": (i32, [vp, vp, vp, i32, i32, vp]),
     "ph_sqdiff_sum": (i32, [vp, vp, vp, sz, f32, vp]),
     "ph_scaled_diff": (i32, [vp, vp, vp, f32, vp, sz, vp]),
+    "ph_maxnorm_mix": (i32, [vp, vp, vp, sz, f32, f32, vp]),
     "ph_tsvd_workspace_bytes": (sz, [i32, i32]),
     "ph_tsvd_update_aux": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
     "ph_crd_score": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),

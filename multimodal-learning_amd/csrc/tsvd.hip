@@ -11,7 +11,7 @@
 // real symmetric 2B x 2B matrix [[Re, -Im], [Im, Re]] (every eigenvalue twice; a matrix function of the embedding
 // is the embedding of the matrix function) and diagonalised in LDS by parallel cyclic Jacobi rotations (round-robin
 // pairing: n/2 disjoint rotations per step).  One workgroup per frequency slice k = 0 .. V/2 (the others are
-// complex conjugates).  B <= 64.
+// complex conjugates).  B <= 64; larger batches (up to 128) use the one-sided Jacobi kernel below.
 #include "ph_common.h"
 #include "ph_kernels.h"
 
@@ -40,6 +40,25 @@ __global__ void scaled_diff_kernel(const float* __restrict__ a, const float* __r
                                    const float* __restrict__ gscalar, float alpha, float* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = gscalar[0] * alpha * (a[i] - b[i]);
+}
+
+// mixed-feature views of n_views = 6 / 8 (train_test_tSVD.py:305-307,334-363): out = wa * a / max(a) + wb * b / max(b)
+__global__ __launch_bounds__(1024) void maxnorm_mix_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, size_t n, float wa, float wb) {
+  __shared__ float ra[1024], rb[1024];
+  float ma = -INFINITY, mb = -INFINITY;
+  for (size_t i = threadIdx.x; i < n; i += 1024) { ma = fmaxf(ma, a[i]); mb = fmaxf(mb, b[i]); }
+  ra[threadIdx.x] = ma; rb[threadIdx.x] = mb;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      ra[threadIdx.x] = fmaxf(ra[threadIdx.x], ra[threadIdx.x + o]);
+      rb[threadIdx.x] = fmaxf(rb[threadIdx.x], rb[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  ma = ra[0]; mb = rb[0];
+  for (size_t i = threadIdx.x; i < n; i += 1024) out[i] = wa * (a[i] / ma) + wb * (b[i] / mb);
 }
 
 // frequency slice k of the DFT along the view axis: X_k[i][j] = sum_v adj[v][i][j] * exp(-2 pi i k v / V)
@@ -206,6 +225,151 @@ __global__ __launch_bounds__(256) void tsvd_slice_kernel(const float* __restrict
   }
 }
 
+// ---- B up to 128: one-sided (Hestenes) Jacobi on the complex slice itself.  The 2B x 2B embedding above needs 2 x 263 KB
+// at B = 128; the slice is 128 KB.  Column pairs (p, q) of A (initially X) are rotated until all columns are mutually
+// orthogonal: A = X V = U Sigma, so sigma_j = ||a_j|| and the thresholded slice is
+//   Y = U max(Sigma - tau, 0) V^H = A diag(f_j / sigma_j^2) A^H X,   f_j = max(1 - tau / sigma_j, 0),
+// which needs neither V nor U explicitly.  A lives in LDS column-major; X, T = A^H X and Y go through the workspace.
+// One workgroup (1024 threads = 64 teams of 16 lanes, one team per column pair) per frequency slice.
+constexpr int TB_MAXB = 128, TB_LD = TB_MAXB + 1, TB_ROWS = TB_MAXB / 16;
+
+__global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __restrict__ adj, float* __restrict__ yre,
+                                                              float* __restrict__ yim, float* __restrict__ tre,
+                                                              float* __restrict__ tim, float* __restrict__ tnn_k, int V,
+                                                              int B, float tau) {
+  extern __shared__ float sm[];
+  float* Are = sm;                       // [n][TB_LD]  column-major: Are[col * TB_LD + row]
+  float* Aim = sm + TB_MAXB * TB_LD;
+  __shared__ float dj[TB_MAXB], red[1024];
+  __shared__ int rotated;
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int n = B + (B & 1);             // an odd B gets a zero column that never rotates
+  const size_t bb = (size_t)B * B;
+  float* Xre = yre + (size_t)k * bb;     // the slice, row-major; overwritten by Y at the end
+  float* Xim = yim + (size_t)k * bb;
+  float* Tre = tre + (size_t)k * bb;
+  float* Tim = tim + (size_t)k * bb;
+  float part = 0.f;
+  for (int e = tid; e < n * B; e += 1024) {
+    const int i = e / n, b = e % n;
+    float re = 0.f, im = 0.f;
+    if (b < B) {
+      dft_elem(adj, V, bb, (size_t)i * B + b, k, re, im);
+      Xre[(size_t)i * B + b] = re;
+      Xim[(size_t)i * B + b] = im;
+    }
+    Are[b * TB_LD + i] = re;
+    Aim[b * TB_LD + i] = im;
+    part += re * re + im * im;
+  }
+  red[tid] = part;
+  if (tid == 0) rotated = 0;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float nrm2 = red[0];
+  const float col_floor = 1e-14f * nrm2;  // columns below the rounding noise of the slice are left alone (and dropped)
+  __syncthreads();
+  const int team = tid >> 4, l = tid & 15, half = n / 2;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    for (int step = 0; step < n - 1; ++step) {
+      if (team < half) {
+        const int j1 = n - 1 - team;
+        const int p = team == 0 ? n - 1 : (step + team - 1) % (n - 1);
+        const int q = (step + j1 - 1) % (n - 1);
+        float ar[TB_ROWS], ai[TB_ROWS], br[TB_ROWS], bi[TB_ROWS];
+        float al = 0.f, be = 0.f, gr = 0.f, gi = 0.f;
+#pragma unroll
+        for (int m = 0; m < TB_ROWS; ++m) {
+          const int r = l + 16 * m;
+          const bool in = r < B;
+          ar[m] = in ? Are[p * TB_LD + r] : 0.f; ai[m] = in ? Aim[p * TB_LD + r] : 0.f;
+          br[m] = in ? Are[q * TB_LD + r] : 0.f; bi[m] = in ? Aim[q * TB_LD + r] : 0.f;
+          al += ar[m] * ar[m] + ai[m] * ai[m];
+          be += br[m] * br[m] + bi[m] * bi[m];
+          gr += ar[m] * br[m] + ai[m] * bi[m];     // conj(a_p) . a_q
+          gi += ar[m] * bi[m] - ai[m] * br[m];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          al += __shfl_xor(al, o, 16); be += __shfl_xor(be, o, 16);
+          gr += __shfl_xor(gr, o, 16); gi += __shfl_xor(gi, o, 16);
+        }
+        const float g2 = gr * gr + gi * gi;
+        if (fminf(al, be) > col_floor && g2 > 1e-12f * al * be) {
+          const float g = sqrtf(g2), er = gr / g, ei = gi / g;
+          const float ze = (be - al) / (2.f * g);
+          const float t = copysignf(1.f, ze) / (fabsf(ze) + sqrtf(1.f + ze * ze));
+          const float c = 1.f / sqrtf(1.f + t * t), s = c * t;
+#pragma unroll
+          for (int m = 0; m < TB_ROWS; ++m) {
+            const int r = l + 16 * m;
+            if (r < B) {
+              // a_p' = c a_p - s e^{-i phi} a_q ;  a_q' = s e^{i phi} a_p + c a_q
+              Are[p * TB_LD + r] = c * ar[m] - s * (er * br[m] + ei * bi[m]);
+              Aim[p * TB_LD + r] = c * ai[m] - s * (er * bi[m] - ei * br[m]);
+              Are[q * TB_LD + r] = s * (er * ar[m] - ei * ai[m]) + c * br[m];
+              Aim[q * TB_LD + r] = s * (er * ai[m] + ei * ar[m]) + c * bi[m];
+            }
+          }
+          if (l == 0) rotated = 1;
+        }
+      }
+      __syncthreads();
+    }
+    const int any = rotated;
+    __syncthreads();
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    if (!any) break;
+  }
+  // sigma_j = ||a_j||;  d_j = f_j / sigma_j^2;  nuclear norm of the thresholded slice
+  part = 0.f;
+  if (tid < n) {
+    float a2 = 0.f;
+    for (int r = 0; r < B; ++r) a2 += Are[tid * TB_LD + r] * Are[tid * TB_LD + r] + Aim[tid * TB_LD + r] * Aim[tid * TB_LD + r];
+    const float sig = sqrtf(a2);
+    const bool keep = a2 > 100.f * col_floor && sig > tau;
+    dj[tid] = keep ? (1.f - tau / sig) / a2 : 0.f;
+    part = keep ? sig - tau : 0.f;
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) tnn_k[k] = red[0];
+  // T = A^H X
+  for (int e = tid; e < B * B; e += 1024) {
+    const int j = e / B, b = e % B;
+    float tr = 0.f, ti = 0.f;
+    for (int i = 0; i < B; ++i) {
+      const float ar = Are[j * TB_LD + i], ai = Aim[j * TB_LD + i], xr = Xre[(size_t)i * B + b], xi = Xim[(size_t)i * B + b];
+      tr += ar * xr + ai * xi;
+      ti += ar * xi - ai * xr;
+    }
+    Tre[e] = tr * dj[j];
+    Tim[e] = ti * dj[j];
+  }
+  __threadfence_block();
+  __syncthreads();
+  // Y = A (D T)
+  for (int e = tid; e < B * B; e += 1024) {
+    const int i = e / B, b = e % B;
+    float yr = 0.f, yi = 0.f;
+    for (int j = 0; j < B; ++j) {
+      const float ar = Are[j * TB_LD + i], ai = Aim[j * TB_LD + i], tr = Tre[(size_t)j * B + b], ti = Tim[(size_t)j * B + b];
+      yr += ar * tr - ai * ti;
+      yi += ar * ti + ai * tr;
+    }
+    Xre[e] = yr;
+    Xim[e] = yi;
+  }
+}
+
 // inverse DFT along the view axis from the slices 0 .. V/2 (slice V-k = conj(slice k)), and the tensor nuclear norm
 __global__ void tsvd_idft_kernel(const float* __restrict__ yre, const float* __restrict__ yim,
                                  const float* __restrict__ tnn_k, float* __restrict__ aux, float* __restrict__ tnn,
@@ -233,10 +397,17 @@ __global__ void tsvd_idft_kernel(const float* __restrict__ yre, const float* __r
 
 #include "pathomic_hip.h"
 
-size_t ph_tsvd_workspace_bytes(int V, int B) { return ((size_t)(V / 2 + 1) * 2 * B * B + 16) * sizeof(float); }
+size_t ph_tsvd_workspace_bytes(int V, int B) { return ((size_t)(V / 2 + 1) * 4 * B * B + 16) * sizeof(float); }
 
 int ph_sqdiff_sum(const float* a, const float* b, float* out, size_t n, float scale, hipStream_t st) {
   hipLaunchKernelGGL(sqdiff_sum_kernel, dim3(1), dim3(1024), 0, st, a, b, out, n, scale);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_maxnorm_mix(const float* a, const float* b, float* out, size_t n, float wa, float wb, hipStream_t st) {
+  if (!a || !b || !out || n == 0) return PH_EINVAL;
+  hipLaunchKernelGGL(maxnorm_mix_kernel, dim3(1), dim3(1024), 0, st, a, b, out, n, wa, wb);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -249,12 +420,29 @@ int ph_scaled_diff(const float* a, const float* b, const float* gscalar, float a
 }
 
 int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn, int V, int B, float tau, void* ws_, hipStream_t st) {
-  if (!adj || !aux || !ws_ || V < 2 || V > 8 || (V & 1) || B < 1 || B > TS_MAXB) return PH_EINVAL;
+  if (!adj || !aux || !ws_ || V < 2 || V > 8 || (V & 1) || B < 1 || B > TB_MAXB) return PH_EINVAL;
   float* ws = reinterpret_cast<float*>(ws_);
   const size_t bb = (size_t)B * B;
   float* yre = ws;
   float* yim = ws + (size_t)(V / 2 + 1) * bb;
-  float* tk = yim + (size_t)(V / 2 + 1) * bb;
+  float* tre = yim + (size_t)(V / 2 + 1) * bb;
+  float* tim = tre + (size_t)(V / 2 + 1) * bb;
+  float* tk = tim + (size_t)(V / 2 + 1) * bb;
+  if (B > TS_MAXB) {
+    const int ldsb = 2 * TB_MAXB * TB_LD * (int)sizeof(float);
+    static bool attr_big = false;
+    if (!attr_big) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tsvd_slice_big_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) != hipSuccess)
+        return PH_ELAUNCH;
+      attr_big = true;
+    }
+    hipLaunchKernelGGL(tsvd_slice_big_kernel, dim3(V / 2 + 1), dim3(1024), ldsb, st, adj, yre, yim, tre, tim, tk, V, B, tau);
+    PH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tsvd_idft_kernel, dim3((unsigned)((bb * V + 255) / 256)), dim3(256), 0, st, yre, yim, tk, aux, tnn, V, B);
+    PH_LAUNCH_CHECK();
+    return PH_OK;
+  }
   const int lds = 2 * TS_MAXN * TS_LD * (int)sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {

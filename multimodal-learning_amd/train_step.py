@@ -695,8 +695,8 @@ class TeacherStage1Step:
         # adjacency tensors over n_views feature views per modality, auxiliary tensors from the tensor-nuclear-norm prox
         self.tsvd_on = getattr(opt, "tSVD_loss", "False") == "True"
         if self.tsvd_on:
-            if opt.n_views not in (2, 4):
-                raise NotImplementedError("n_views %d: the mixed-feature views of :334-363 are not wired (2 and 4 are)" % opt.n_views)
+            if opt.n_views not in (2, 4, 6, 8):
+                raise ValueError("n_views %d (train_test_tSVD.py:309-363 builds 2, 4, 6 or 8 views)" % opt.n_views)
             if opt.tSVD_mode not in ("path", "omic", "pathomic"):
                 raise ValueError(opt.tSVD_mode)
             self.mu = float(opt.mu)                                                              # :161 (never reset per epoch)
@@ -773,12 +773,16 @@ class TeacherStage1Step:
         loss_tsvd = torch.zeros((), device=dev)
         if self.tsvd_on:                                                                        # train_test_tSVD.py:299-431
             from . import tsvd as T
-            if opt.n_views == 4:
-                feats1 = [fuse_feat.detach(), ema_fuse_feat, path_feat, ema_path_feat]          # :311-313
-                feats2 = [fuse_feat.detach(), ema_fuse_feat, omic_feat, ema_omic_feat]
-            else:
+            if opt.n_views == 2:
                 feats1 = [path_feat, ema_path_feat]                                             # :320-322
                 feats2 = [omic_feat, ema_omic_feat]
+            else:
+                feats1 = [fuse_feat.detach(), ema_fuse_feat, path_feat, ema_path_feat]          # :311-313
+                feats2 = [fuse_feat.detach(), ema_fuse_feat, omic_feat, ema_omic_feat]
+                # n_views 6 / 8 add mixtures of the max-normalised mean-teacher features (:305-307, :341-363)
+                for wa in (0.9, 0.8, 0.7, 0.6)[:opt.n_views - 4]:
+                    feats1.append(T.maxnorm_mix(ema_path_feat, ema_omic_feat, wa, 1.0 - wa))
+                    feats2.append(T.maxnorm_mix(ema_omic_feat, ema_path_feat, wa, 1.0 - wa))
             self.adj_tensor1 = T.update_adj_tensor(self.adj_tensor1, feats1)                    # :365-366
             self.adj_tensor2 = T.update_adj_tensor(self.adj_tensor2, feats2)
             bidx = self._batch_idx if batch_idx is None else batch_idx

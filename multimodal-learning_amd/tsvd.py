@@ -23,6 +23,15 @@ def update_adj_tensor(adj_tensor, feats):
     return adj_tensor
 
 
+def maxnorm_mix(a, b, wa, wb):
+    """wa * a / max(a) + wb * b / max(b): the mixed-feature views of n_views = 6 / 8 (train_test_tSVD.py:305-307,
+    :334-363; both operands are mean-teacher features, no gradient)."""
+    a, b = ops._f32(a.detach()), ops._f32(b.detach())
+    out = torch.empty_like(a)
+    check(lib().ph_maxnorm_mix(ptr(a), ptr(b), ptr(out), a.numel(), float(wa), float(wb), stream()), "ph_maxnorm_mix")
+    return out
+
+
 def update_aux(adj, tau, print_bool=False):
     """adj: [B, B, n_views] detached adjacency stack, tau = Lambda_global / mu.  Returns (aux [B, B, n_views], TNN)
     like the call at train_test_tSVD.py:382; TNN is a 0-d device tensor (no host sync)."""

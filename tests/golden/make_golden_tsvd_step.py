@@ -4,7 +4,8 @@ shape of the computation at a small size): the reference's own modules ("MIA 202
 driven in the order of train_test_tSVD.py:199-470 with `update_adj_tensor` compiled from that file.  The trainer's
 `update_aux` lives in my_utils/TSVD_update_aux.py, which is NOT in the reference repository ("parity unpinned"): the
 tensor-nuclear-norm proximal operator of oracle/variants.py stands in at exactly that call site (:382, :402).
-Build container only.  Writes tests/golden/tsvd_step_b8_h64.npz."""
+Build container only.  Writes tests/golden/tsvd_step_b8_h64.npz (4 views) or, with the argument `8`,
+tsvd_step_b8_h64_v8.npz (8 views: the mixed-feature views of :341-363)."""
 import contextlib
 import io
 import os
@@ -22,7 +23,7 @@ sys.path.insert(0, HERE)
 REF = "/root/reference/MIA 2022"
 
 
-def main():
+def main(n_views=4, out_name="tsvd_step_b8_h64.npz"):
     from make_golden import install_shims, npz
     install_shims()
     sys.path.insert(0, REF)
@@ -32,7 +33,7 @@ def main():
     from oracle.variants import update_aux
     sys.argv = ["x", "--model_name", "golden", "--reg_type", "none", "--beta1", "0.9", "--input_size_omic", "320",
                 "--dropout_rate", "0", "--gpu_ids", "-1", "--checkpoints_dir", tempfile.mkdtemp(), "--batch_size", "8",
-                "--tSVD_loss", "True", "--tSVD_mode", "pathomic", "--n_views", "4", "--mu", "0.01", "--pho", "1.5",
+                "--tSVD_loss", "True", "--tSVD_mode", "pathomic", "--n_views", str(n_views), "--mu", "0.01", "--pho", "1.5",
                 "--Lambda_global", "0.05", "--aux_iter", "1"]
     with contextlib.redirect_stdout(io.StringIO()):
         import options
@@ -77,6 +78,12 @@ def main():
         # ---- :299-431
         feats1 = [fuse_feat.detach(), ema_fuse_feat, path_feat, ema_path_feat]
         feats2 = [fuse_feat.detach(), ema_fuse_feat, omic_feat, ema_omic_feat]
+        if nv > 4:      # :305-307, :341-363: mixtures of the max-normalised mean-teacher features
+            norm_path_feat = ema_path_feat / torch.max(ema_path_feat)
+            norm_omic_feat = ema_omic_feat / torch.max(ema_omic_feat)
+            for wa in (0.9, 0.8, 0.7, 0.6)[:nv - 4]:
+                feats1.append(wa * norm_path_feat + (1 - wa) * norm_omic_feat)
+                feats2.append(wa * norm_omic_feat + (1 - wa) * norm_path_feat)
         adj1 = update_adj_tensor(adj1, feats1)
         adj2 = update_adj_tensor(adj2, feats2)
         if it % opt.aux_iter == 0:
@@ -101,14 +108,18 @@ def main():
         iter_num += 1
         rec.update({f"loss{it}": loss, f"loss_nll{it}": loss_nll, f"loss_kd{it}": loss_kd, f"loss_tsvd{it}": loss_tsvd,
                     f"mu{it}": mu, f"adj1_2_{it}": adj1[2], f"aux1_2_{it}": aux1[2], f"adj2_3_{it}": adj2[3],
-                    f"aux2_0_{it}": aux2[0], f"pred{it}": pred})
+                    f"aux2_0_{it}": aux2[0], f"pred{it}": pred, f"adj1_last_{it}": adj1[nv - 1],
+                    f"aux2_last_{it}": aux2[nv - 1]})
         sd = model.state_dict()
         for k in ("omic_net.encoder.0.0.weight", "fusion.encoder2.0.weight", "path_net.fc_new1.0.weight"):
             rec[f"w{it}_{k}"] = sd[k].clone()
-    np.savez_compressed(os.path.join(HERE, "tsvd_step_b8_h64.npz"), **npz(rec))
-    print("wrote tsvd_step_b8_h64.npz", [round(float(rec[f"loss{i}"]), 5) for i in range(2)],
+    np.savez_compressed(os.path.join(HERE, out_name), **npz(rec))
+    print("wrote", out_name, [round(float(rec[f"loss{i}"]), 5) for i in range(2)],
           [round(float(rec[f"loss_tsvd{i}"]), 6) for i in range(2)])
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "8":
+        main(8, "tsvd_step_b8_h64_v8.npz")
+    else:
+        main()

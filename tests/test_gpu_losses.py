@@ -297,9 +297,11 @@ def test_tsvd_adjacency_penalty_golden(golden_dir):
         assert np.abs(grads[v].cpu().numpy() - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-3)
 
 
-@pytest.mark.parametrize("B,V,tau", [(16, 4, 0.05), (64, 4, 0.3), (24, 2, 0.1), (32, 8, 0.02), (8, 6, 0.5)])
+@pytest.mark.parametrize("B,V,tau", [(16, 4, 0.05), (64, 4, 0.3), (24, 2, 0.1), (32, 8, 0.02), (8, 6, 0.5),
+                                     (128, 4, 0.3), (65, 2, 0.1), (96, 6, 0.05), (128, 8, 0.02), (127, 4, 0.5)])
 def test_tsvd_update_aux_vs_oracle(B, V, tau):
-    """ph_tsvd_update_aux (Jacobi eigen-solver in LDS) vs the float64 numpy proximal operator of the oracle.  The
+    """ph_tsvd_update_aux (B <= 64: Jacobi eigen-solver of X^H X in LDS; 64 < B <= 128, BASELINE config 4: one-sided
+    Jacobi on the slice) vs the float64 numpy proximal operator of the oracle.  The
     algorithm itself is OUR reading of the absent `update_aux` (parity unpinned vs the reference)."""
     import multimodal_learning_amd as m
     from oracle import variants as OV

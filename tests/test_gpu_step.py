@@ -501,16 +501,18 @@ def test_stage1_step_with_crd_and_orth_terms_vs_reference_golden(golden_dir):
         m.set_precision("bf16")
 
 
-def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir):
+@pytest.mark.parametrize("fixture", ["tsvd_step_b8_h64.npz", "tsvd_step_b8_h64_v8.npz"])
+def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir, fixture):
     """Row a16 end to end (BASELINE cfg 4's computation at a small size): two stage-1 steps with the t-SVD constraint
     ("MIA 2022/train_test_tSVD.py":199-470: adjacency tensors over 4 views per modality, auxiliary update at every batch,
     mu schedule, Frobenius penalty) against the reference's modules driven in the trainer's order; the absent
-    `update_aux` is our proximal operator on both sides (parity unpinned for that one function)."""
+    `update_aux` is our proximal operator on both sides (parity unpinned for that one function).  The
+    second fixture has n_views = 8: four more views mixed from the max-normalised mean-teacher features (:341-363)."""
     import multimodal_learning_amd as m
     from oracle import weights as W
     from oracle.step import synthetic_batch
     from tests.gpu_util import Report
-    g = np.load(os.path.join(golden_dir, "tsvd_step_b8_h64.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
     B = int(g["B"])
     m.set_precision("bf16x6")
     try:
@@ -539,6 +541,8 @@ def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir):
             R.close(g[f"aux1_2_{it}"], st.aux_tensor1[2], 2e-4 if it == 0 else 2e-2, 0, f"aux path view 2 step {it}")
             R.close(g[f"aux2_0_{it}"], st.aux_tensor2[0], 2e-4 if it == 0 else 2e-2, 0, f"aux omic view 0 step {it}")
             R.close(sc(f"path_TNN{it}"), st.path_TNN.reshape(()), 1e-3 if it == 0 else 5e-2, 1e-3, f"path TNN step {it}")
+            R.close(g[f"adj1_last_{it}"], st.adj_tensor1[-1], 1e-4 if it == 0 else 2e-2, 0, f"adjacency path last view step {it}")
+            R.close(g[f"aux2_last_{it}"], st.aux_tensor2[-1], 2e-4 if it == 0 else 2e-2, 0, f"aux omic last view step {it}")
             if it == 0:
                 msd = st.model.state_dict()
                 for key in g.files:
@@ -550,6 +554,34 @@ def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir):
         R.finish()
     finally:
         m.set_precision("bf16")
+
+
+def test_tsvd_stage1_step_at_config4_batch():
+    """BASELINE config 4's batch (128) through the stage-1 step with the t-SVD constraint: the auxiliary tensors the step
+    leaves behind are the oracle's proximal operator of the adjacency tensors it computed (one-sided Jacobi kernel,
+    64 < B <= 128), and the step is finite."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle import variants as OV
+    from oracle.step import synthetic_batch
+    B = 128
+    opt = m.stage2_opt(dropout_rate=0.0, batch_size=B, cut_fuse_grad=True, num_teachers=2)
+    opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, 1.0, 0, 0, "False"
+    opt.tSVD_loss, opt.tSVD_mode, opt.n_views, opt.aux_iter = "True", "pathomic", 4, 1
+    opt.mu, opt.pho, opt.max_mu, opt.Lambda_global = 0.01, 1.5, 1.0, 0.05
+    model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+    model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3)); ema.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 4))
+    st = m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda()))
+    bt = synthetic_batch(B, 64, seed=5)
+    z = torch.zeros(B)
+    out = st.step(((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"]))
+    assert torch.isfinite(out["loss"]).all() and torch.isfinite(out["loss_tsvd"]).all()
+    for adj, aux, tnn in ((st.adj_tensor1, st.aux_tensor1, st.path_TNN), (st.adj_tensor2, st.aux_tensor2, st.omic_TNN)):
+        stack = torch.stack([a.detach().cpu() for a in adj], dim=2)
+        ref, tnn_ref = OV.update_aux(stack, opt.Lambda_global / opt.mu)
+        got = torch.stack([a.cpu() for a in aux], dim=2).numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
+        assert abs(float(tnn) - tnn_ref) <= 1e-4 * max(abs(tnn_ref), 1.0)
 
 
 def test_fused_loss_head_equals_generic_autograd_path():
