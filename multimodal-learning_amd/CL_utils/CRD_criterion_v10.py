@@ -91,8 +91,9 @@ class CRDLoss(nn.Module):
         rows = _CRDCoreFn.apply(v1, v2, mem, idx, idx1, None, True)          # [B]: (s + t) sample losses / bsz
         mem.last.update(nb1=nb1, nb2=nb2, sim1=sim1, sim2=sim2)
         w = sample_weights.to(dev).reshape(-1) if torch.is_tensor(sample_weights) else float(sample_weights)
-        sample_loss = w * rows * B                                           # the reference's per-sample values
-        return sample_loss.sum(0) / B, sample_loss
+        bn = float(mem.batch_norm_size or B)                                 # global batch under data parallelism
+        sample_loss = w * rows * bn                                          # the reference's per-sample values
+        return sample_loss.sum(0) / bn, sample_loss
 
 
 class ContrastLoss_v2(nn.Module):

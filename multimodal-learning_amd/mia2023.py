@@ -33,10 +33,11 @@ class DistillKL(nn.Module):
     def __init__(self, T):
         super().__init__()
         self.T = T
+        self.batch_norm_size = None    # global batch under data parallelism
 
     def forward(self, y_s, y_t):
         sample_loss = _KLRowsFn.apply(y_s, y_t.detach(), float(self.T))
-        return sample_loss.sum() / y_s.shape[0], sample_loss
+        return sample_loss.sum() / float(self.batch_norm_size or y_s.shape[0]), sample_loss
 
 
 def assign_sample_weights(pred_s, pred_t, gt, discrep_scale, max_discrep, from_logits=False):
@@ -52,9 +53,12 @@ def assign_sample_weights(pred_s, pred_t, gt, discrep_scale, max_discrep, from_l
     return out
 
 
-def GK_refine_thresh(opt, optimizer, main_loss, feat_s, loss_t_list):
+def GK_refine_thresh(opt, optimizer, main_loss, feat_s, loss_t_list, batch_norm_size=None, sync=None):
     """train_test_path_multi_distill.py:81-128: per-sample gradient-agreement weights.  The reference loops over
-    the batch on the host with sklearn; here one wave per sample (ph_gk_rows).  Returns (scale[n], total_KD_loss)."""
+    the batch on the host with sklearn; here one wave per sample (ph_gk_rows).  Returns (scale[n], total_KD_loss).
+    The weights are per sample (a cosine between rows of this replica's gradients: nothing to exchange under data
+    parallelism); `batch_norm_size` is the global batch the total is averaged over, `sync` averages the reported
+    mean weights over the replicas."""
     losses = [l.sum() for l in loss_t_list] + ([main_loss] if opt.CE_grads else [])
     grads = [torch.autograd.grad(l, feat_s, retain_graph=True)[0] for l in losses]
     ng = len(grads)
@@ -63,5 +67,8 @@ def GK_refine_thresh(opt, optimizer, main_loss, feat_s, loss_t_list):
     all_scale = torch.empty(B, ng, device=G.device, dtype=torch.float32)
     check(lib().ph_gk_rows(ptr(G), ng, B, D, 1 if opt.use_grads_thresh == "True" else 0, float(opt.grads_thresh),
                            ptr(all_scale), stream()), "ph_gk_rows")
-    total = torch.sum(all_scale[:, :-1].transpose(0, 1) * torch.stack(list(loss_t_list))) / B
-    return all_scale.mean(0), total
+    total = torch.sum(all_scale[:, :-1].transpose(0, 1) * torch.stack(list(loss_t_list))) / float(batch_norm_size or B)
+    mean_scale = all_scale.mean(0)
+    if sync is not None:
+        mean_scale = sync.all_reduce_sum(mean_scale) / sync.world_size
+    return mean_scale, total

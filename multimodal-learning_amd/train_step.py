@@ -258,9 +258,6 @@ class DistillStep:
             from .mia2023 import DistillKL
             if train_class_idx is None:
                 raise ValueError("variant 'mia2023' needs train_class_idx (CRD_criterion_v10.py:25)")
-            if sync is not None:
-                raise NotImplementedError("variant 'mia2023' is single-GPU: its per-sample loss normalisation is not "
-                                          "wired for data parallelism")
             CRDLoss = lambda o, n: _CRDv10(o, n, train_class_idx)    # noqa: E731
         else:
             raise ValueError("variant must be 'miccai2022', 'mia2022' or 'mia2023'")
@@ -413,13 +410,16 @@ class DistillStep:
         if opt.assign_weights == "True":
             if getattr(opt, "loss_weighting", "GK_refine") != "GK_refine":
                 raise NotImplementedError("loss_weighting '%s' (the shipped command uses GK_refine)" % opt.loss_weighting)
-            scale, loss_KD = GK_refine_thresh(opt, self.optimizer, loss_cls, path_feat, KD_loss_list)        # :422
+            scale, loss_KD = GK_refine_thresh(opt, self.optimizer, loss_cls, path_feat, KD_loss_list,        # :422
+                                              batch_norm_size=self.criterion_div.batch_norm_size, sync=self.sync)
         else:
             scale = None
             loss_KD = opt.alpha * (loss_div1 + loss_div2) + opt.beta * (loss_kd1 + loss_kd2)                # :427
         loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :431
         self.optimizer.zero_grad()
         loss.backward()
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self.optimizer.flat)
         self.optimizer.step()                                                                               # :446-447 fused
         return dict(loss=loss.detach(), loss_cls=loss_cls.detach(), loss_div1=loss_div1.detach(),
                     loss_div2=loss_div2.detach(), loss_kd1=loss_kd1.detach(), loss_kd2=loss_kd2.detach(),

@@ -1,0 +1,186 @@
+"""Two data-parallel replicas of the distillation step emulated on ONE GPU: two DistillStep
+objects, one thread each, exchanging through `LocalSync` - an in-process stand-in with the interface of
+`multimodal_learning_amd.dist.ReplicaSync` (bucketed gradient all-reduce, CRD row all-gather, Gram / Z reductions).
+The real RCCL run is the driver's; what is pinned here is that the replicated step with global-batch normalisers
+computes the same thing as one process on the whole batch, wherever that is defined:
+
+  * BatchNorm keeps per-replica statistics (the DataParallel semantics of the reference), so the batch is built with
+    the second shard's images and omic vectors equal to the first shard's: the forward statistics of a shard then equal
+    those of the whole batch, while labels, bank indices and contrast indices differ per sample.
+  * everything downstream of the student feature that couples samples only through normalisers / collectives must
+    match the single process: the losses (summed over replicas), the GK-Refine weights, the all-reduced gradients of
+    the grading head and of the four CRD embedding heads, and the updated bank rows.
+  * the all-reduced flat gradient and the updated parameters are bitwise equal on the two replicas."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class LocalGroup:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=180)
+        self.slots = [None] * world
+
+
+class LocalSync:
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world_size = group, rank, group.world
+
+    def _exchange(self, t):
+        self.g.slots[self.rank] = t
+        self.g.barrier.wait()
+        parts = list(self.g.slots)
+        self.g.barrier.wait()
+        return parts
+
+    def _sum(self, t):
+        parts = self._exchange(t.clone())
+        tot = parts[0].clone()
+        for p in parts[1:]:
+            tot += p                       # rank order on every replica: bitwise identical results
+        t.copy_(tot)
+        return t
+
+    def all_reduce_grads(self, flat):
+        return self._sum(flat if torch.is_tensor(flat) else flat.grad)
+
+    def all_reduce_sum(self, t):
+        return self._sum(t)
+
+    def all_reduce_z(self, sums, count):
+        self._sum(sums)
+        return count * self.world_size
+
+    def all_gather_rows(self, y, v1, v2):
+        ys, a, b = self._exchange(y.clone()), self._exchange(v1.clone()), self._exchange(v2.clone())
+        return torch.cat(ys, 0), torch.cat(a, 0), torch.cat(b, 0)
+
+    def attach(self, step):
+        for crd in (step.criterion_kd, step.criterion_kd_path):
+            crd.contrast.sync = self
+
+
+def _build(variant, sync, B, n_data, labels):
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt
+    kw = dict(batch_size=B)
+    if variant == "miccai2022":
+        opt = default_opt(**kw)
+        step = m.DistillStep(opt, n_data, device="cuda", sync=sync)
+    elif variant == "mia2022":
+        opt = default_opt(nce_k=512, grads_m=0.9, grads_thresh="False", thresh=0.1, **kw)
+        step = m.DistillStep(opt, n_data, device="cuda", sync=sync, variant="mia2022")
+    else:
+        opt = default_opt(nce_k=512, nce_p=4, pos_extra="neighbors", neg_mode="all_others", start_reweight=0,
+                          discrep_scale=1, max_discrep=2.0, use_grads_thresh="True", grads_thresh=0.0,
+                          loss_weighting="GK_refine", **kw)
+        class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+        step = m.DistillStep(opt, n_data, device="cuda", sync=sync, variant="mia2023", train_class_idx=class_idx)
+    step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+    step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+    step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+    g = torch.Generator().manual_seed(77)
+    for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+        crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 10 + 2 * i))
+        crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 11 + 2 * i))
+        for bank in (crd.contrast.memory_v1, crd.contrast.memory_v2):
+            bank.copy_((torch.rand(bank.shape, generator=g) * 2 - 1) * 0.15)
+        crd.contrast.verbose = False
+    return step, opt
+
+
+def _batch(variant, B, H, n_data, labels):
+    from oracle.step import synthetic_batch
+    P, K = (300, 700) if variant == "miccai2022" else (1, 512)
+    bt = synthetic_batch(B, H, n_data=n_data, P=P, K=K, seed=900)
+    h = B // 2
+    for k in ("x_path", "ema_x_path", "x_omic"):
+        bt[k][h:] = bt[k][:h]              # per-shard BatchNorm statistics == whole-batch statistics
+    if variant == "mia2023":
+        bt["grade"] = labels[bt["index"]]
+    z = torch.zeros(B)
+    return ((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"])
+
+
+def _head_grads(step):
+    out = {}
+    for name in ("fc_new2.weight", "fc_new2.bias"):
+        out[name] = dict(step.model.named_parameters())[name].grad.detach().clone()
+    for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+        for e in ("embed_s", "embed_t"):
+            for pn, p in getattr(crd, e).named_parameters():
+                out[f"crd{i}.{e}.{pn}"] = p.grad.detach().clone()
+    return out
+
+
+@pytest.mark.parametrize("variant", ["miccai2022", "mia2022", "mia2023"])
+def test_two_replicas_equal_one_process_on_the_global_batch(variant):
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.dist import shard_batch
+    B, H, n_data = 8, 64, 1024
+    labels = torch.randint(0, 3, (n_data,), generator=torch.Generator().manual_seed(5))
+    m.set_precision("bf16x6")
+    try:
+        batch = _batch(variant, B, H, n_data, labels)
+        single, _ = _build(variant, None, B, n_data, labels)
+        # the host-RNG rank draw of memory_new.py:311 is shared by the whole batch: the same list on every replica
+        ranks = [np.arange(30, 50), np.arange(45, 65)] if variant == "miccai2022" else None
+        o1 = single.step(batch, epoch=3, ranks=ranks)
+        torch.cuda.synchronize()
+        g1 = _head_grads(single)
+        idx = batch[6].cuda()
+        banks1 = [crd.contrast.memory_v1[idx].clone() for crd in (single.criterion_kd, single.criterion_kd_path)] + \
+                 [crd.contrast.memory_v2[idx].clone() for crd in (single.criterion_kd, single.criterion_kd_path)]
+
+        group = LocalGroup(2)
+        reps = [_build(variant, LocalSync(group, r), B // 2, n_data, labels)[0] for r in range(2)]
+        outs, errs = [None, None], []
+
+        def run(r):
+            try:
+                torch.cuda.set_device(0)
+                outs[r] = reps[r].step(shard_batch(batch, r, 2), epoch=3, ranks=ranks)
+                torch.cuda.synchronize()
+            except BaseException as e:      # noqa: BLE001 - re-raised in the main thread
+                errs.append(e)
+                group.barrier.abort()
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(300)
+        if errs:
+            raise errs[0]
+        # replicas agree bitwise
+        f0, f1 = reps[0].optimizer.flat, reps[1].optimizer.flat
+        assert torch.equal(f0.grad, f1.grad) and torch.equal(f0.flat, f1.flat)
+        assert torch.equal(reps[0].ema_flat.flat, reps[1].ema_flat.flat)
+        # ... and equal the single process where that is defined
+        for k in ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2"):
+            tot = sum(float(o[k]) for o in outs)
+            ref = float(o1[k])
+            assert abs(tot - ref) <= 2e-4 * max(abs(ref), 1e-2), (k, tot, ref)
+        if o1.get("scale") is not None:
+            s1, s2 = o1["scale"].cpu().numpy(), outs[0]["scale"].cpu().numpy()
+            assert np.abs(s1 - s2).max() <= 2e-4 * np.abs(s1).max(), (s1, s2)
+            assert torch.equal(outs[0]["scale"], outs[1]["scale"])
+        g2 = _head_grads(reps[0])
+        gmax = max(float(v.abs().max()) for v in g1.values())
+        for k, v in g1.items():
+            err = float((g2[k] - v).abs().max())
+            assert err <= 1e-3 * float(v.abs().max()) + 1e-6 * gmax, (k, err, float(v.abs().max()))
+        banks2 = [crd.contrast.memory_v1[idx].clone() for crd in (reps[0].criterion_kd, reps[0].criterion_kd_path)] + \
+                 [crd.contrast.memory_v2[idx].clone() for crd in (reps[0].criterion_kd, reps[0].criterion_kd_path)]
+        for a, b in zip(banks1, banks2):
+            assert float((a - b).abs().max()) <= 1e-5
+        for c0, c1 in zip((reps[0].criterion_kd, reps[0].criterion_kd_path), (reps[1].criterion_kd, reps[1].criterion_kd_path)):
+            assert torch.equal(c0.contrast.memory_v1, c1.contrast.memory_v1)
+            assert torch.equal(c0.contrast.params, c1.contrast.params)
+    finally:
+        m.set_precision("bf16")
