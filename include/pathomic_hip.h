@@ -65,6 +65,12 @@ int ph_resnet_forward(const PhResnetPlan* plan, const void* const* params, const
 int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
                        const float* g_f3 /* may be NULL */, const float* g_f4, void* const* grads,
                        ph_stream_t stream);
+/* The same backward in two calls for a data-parallel caller: part 0 = layers 4 and 3 (afterwards the gradients of
+ * layers 3-4, 93 % of the trunk's parameter bytes, are final and their all-reduce can start), part 1 = layers 2, 1 and
+ * the stem; part -1 = everything (== ph_resnet_backward).  The reference's DataParallel reduces after the whole
+ * backward (utils.py:257-260). */
+int ph_resnet_backward_part(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
+                            const float* g_f3, const float* g_f4, void* const* grads, int part, ph_stream_t stream);
 int ph_resnet_tensor_info(const PhResnetPlan* plan, int what, int id, size_t* byte_off, int* dims4);
 
 /* ------------------------------------------------------------------------------------------------

@@ -380,7 +380,17 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
 // matching ph_resnet_forward left in `ws`.
 int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
                        const float* g_f3, const float* g_f4, void* const* grads, hipStream_t st) {
-  if (!P || !params || !packed || !ws_ || !g_f4 || !grads) return PH_EINVAL;
+  return ph_resnet_backward_part(P, params, packed, ws_, g_f3, g_f4, grads, -1, st);
+}
+
+// part -1: everything; part 0: layers 4 and 3 (blocks 7..4); part 1: layers 2 and 1 (blocks 3..0) and the stem.  After
+// part 0 every gradient of layers 3-4 (93 % of the trunk's parameter bytes) is final: a data-parallel caller starts
+// their all-reduce there and overlaps it with part 1.  An even number of blocks per part keeps the ping-pong buffers
+// of the block gradient where the next part expects them.
+int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
+                            const float* g_f3, const float* g_f4, void* const* grads, int part, hipStream_t st) {
+  if (!P || !params || !packed || !ws_ || !g_f4 || !grads || part < -1 || part > 1) return PH_EINVAL;
+  const int bi_hi = part == 1 ? 3 : 7, bi_lo = part == 0 ? 4 : 0;
   Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0};
   unsigned char* ws = c.ws;
   unsigned char* gcur = ws + P->g0_off;
@@ -388,12 +398,12 @@ int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const v
   unsigned char* dyb = ws + P->dy_off;
   unsigned char* dab = ws + P->da_off;
   int rc;
-  if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
-  {
+  if (part != 1) {
+    if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
     const Block& b = P->blocks[7];
     if ((rc = ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st))) return rc;
   }
-  for (int bi = 7; bi >= 0; --bi) {
+  for (int bi = bi_hi; bi >= bi_lo; --bi) {
     const Block& b = P->blocks[bi];
     if (bi == 5 && g_f3)
       if ((rc = ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st))) return rc;
@@ -418,7 +428,7 @@ int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const v
     }
     unsigned char* t = gcur; gcur = gnext; gnext = t;
   }
-  {  // stem: d_pool -> (maxpool, relu, bn) backward -> wgrad.  No dgrad: the image needs no gradient.
+  if (part != 0) {  // stem: d_pool -> (maxpool, relu, bn) backward -> wgrad.  No dgrad: the image needs no gradient.
     const Unit& u = P->units[0];
     const size_t npix = (size_t)P->B * u.OH * u.OW;
     float* parts = reinterpret_cast<float*>(ws + P->bparts_off);

@@ -98,8 +98,19 @@ class _TrunkFn(torch.autograd.Function):
         g4 = g4.contiguous().float()
         g3 = g3.contiguous().float() if g3 is not None else None
         grads, gptrs = net._alloc_trunk_grads()
-        check(lib().ph_resnet_backward(plan.h, ctx.table, ptr(ctx.packed), ptr(ctx.ws), ptr(g3), ptr(g4),
-                                       ops.void_array(gptrs), stream()), "ph_resnet_backward")
+        hook = getattr(net, "_grad_ready_hook", None)
+        if hook is None:
+            check(lib().ph_resnet_backward(plan.h, ctx.table, ptr(ctx.packed), ptr(ctx.ws), ptr(g3), ptr(g4),
+                                           ops.void_array(gptrs), stream()), "ph_resnet_backward")
+        else:
+            # data parallelism: after layers 4 and 3 the bulk of the gradient bytes is final; the hook starts their
+            # all-reduce, which then overlaps the backward of layers 2, 1 and the stem
+            ga = ops.void_array(gptrs)
+            for part in (0, 1):
+                check(lib().ph_resnet_backward_part(plan.h, ctx.table, ptr(ctx.packed), ptr(ctx.ws), ptr(g3), ptr(g4),
+                                                    ga, part, stream()), "ph_resnet_backward_part")
+                if part == 0:
+                    hook()
         ctx.ws = None
         return (None, None) + tuple(grads)
 

@@ -304,6 +304,12 @@ class DistillStep:
         self.optimizer.ema_range = (0, end)
         if sync is not None:
             sync.attach(self)
+            if hasattr(sync, "begin_grad_slice") and getattr(opt, "overlap_grad_allreduce", True):
+                # everything from layer3.0.conv1.weight to the end of the flat buffer (layers 3-4, heads, CRD embeddings)
+                # is final once the trunk backward has passed layer 3: its all-reduce starts there (dist.begin_grad_slice)
+                first = self.model.layer3[0].conv1.weight
+                lo = next(o for t, o in zip(flat.tensors, flat.offsets) if t is first)
+                self.model._grad_ready_hook = lambda: self.sync.begin_grad_slice(self.optimizer.flat, lo)
 
     # ------------------------------------------------------------------ one step
     def _device_body(self, x_path, ema_x_path, x_omic, grade, index, sample_idx, bnorm, e, r1, r2):

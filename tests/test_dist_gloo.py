@@ -54,6 +54,26 @@ def test_bucketed_grad_allreduce():
         assert s == expect.sum().item() and e == expect[1234].item()
 
 
+def _grads_two_phase(rank, world):
+    from multimodal_learning_amd.dist import ReplicaSync
+    sync = ReplicaSync(bucket_bytes=4096)
+    g = torch.arange(5000, dtype=torch.float32) * (rank + 1)
+    g[:1700] = -1.0                                # "not final yet" when the tail slice starts its all-reduce
+    sync.begin_grad_slice(g, 1700)                 # the trunk backward has passed layer 3
+    g[:1700] = torch.arange(1700, dtype=torch.float32) * (rank + 1)   # ... layers 2, 1 and the stem finish
+    sync.all_reduce_grads(g)
+    again = g.clone()
+    sync.all_reduce_grads(again)                   # no slice pending: the whole buffer is reduced
+    return g.clone(), again
+
+
+def test_grad_allreduce_in_two_phases_equals_one():
+    out = _run(_grads_two_phase)
+    expect = torch.arange(5000, dtype=torch.float32) * 3
+    for g, again in out:
+        assert torch.equal(g, expect) and torch.equal(again, expect * 2)
+
+
 def _gather(rank, world):
     from multimodal_learning_amd.dist import ReplicaSync
     sync = ReplicaSync()

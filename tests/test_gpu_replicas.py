@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 class LocalGroup:
     def __init__(self, world):
         self.world = world
-        self.barrier = threading.Barrier(world, timeout=180)
+        self.barrier = threading.Barrier(world, timeout=60)
         self.slots = [None] * world
 
 
@@ -46,8 +46,22 @@ class LocalSync:
         t.copy_(tot)
         return t
 
+    def begin_grad_slice(self, flat, lo):
+        # Called in the middle of the trunk backward (layers 3-4 done).  The real ReplicaSync launches the asynchronous
+        # all-reduce of the slice here; this stand-in snapshots the slice (what an all-reduce launched now would see) and
+        # exchanges it later from the replica's own thread - both replicas' backward passes run on the ONE autograd
+        # worker thread of the device, so blocking here would deadlock the emulation.
+        g = flat if torch.is_tensor(flat) else flat.grad
+        self.pending = (lo, g[lo:].clone())
+
     def all_reduce_grads(self, flat):
-        return self._sum(flat if torch.is_tensor(flat) else flat.grad)
+        g = flat if torch.is_tensor(flat) else flat.grad
+        pend, self.pending = getattr(self, "pending", None), None
+        assert pend is not None and 0 < pend[0] < g.numel(), "the trunk backward did not announce its finished slice"
+        lo, snap = pend
+        assert torch.equal(snap, g[lo:]), "gradients behind the announced offset changed after the announcement"
+        self._sum(g[lo:])
+        return self._sum(g[:lo])
 
     def all_reduce_sum(self, t):
         return self._sum(t)
@@ -184,3 +198,31 @@ def test_two_replicas_equal_one_process_on_the_global_batch(variant):
             assert torch.equal(c0.contrast.params, c1.contrast.params)
     finally:
         m.set_precision("bf16")
+
+
+def test_split_trunk_backward_is_bitwise_the_single_call():
+    """ph_resnet_backward_part (layers 4-3, then layers 2-1 + stem, with a hook in between) writes bitwise the gradients
+    of ph_resnet_backward; at the hook the gradients of layers 3-4 already hold their final values."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt
+    opt = default_opt()
+    x = (torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)) * 2 - 1).cuda()
+    res = []
+    for split in (False, True):
+        net = m.define_net(opt, 1, path_only=True).cuda()
+        net.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+        net.train()
+        seen = {}
+        if split:
+            l4 = net.layer4[1].conv2.weight
+            net._grad_ready_hook = lambda: seen.update(at_hook="called")
+        out = net(x_path=x)
+        (out[1].square().sum() + out[0].sum()).backward()
+        torch.cuda.synchronize()
+        if split:
+            assert seen.get("at_hook") == "called"
+        res.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert res[0].keys() == res[1].keys() and len(res[0]) > 60
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k
