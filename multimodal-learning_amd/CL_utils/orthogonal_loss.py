@@ -12,7 +12,7 @@ class _OrthFn(torch.autograd.Function):
     (orthogonal_loss.py:24-30): row scaling kernels + fp32 GEMMs + a squared-sum reduction."""
 
     @staticmethod
-    def forward(ctx, x1, x2):
+    def forward(ctx, x1, x2, sync=None):
         x1, x2 = ops._f32(x1), ops._f32(x2)
         B, D1 = x1.shape
         D2 = x2.shape[1]
@@ -22,6 +22,8 @@ class _OrthFn(torch.autograd.Function):
         check(lib().ph_row_invnorm_scale(ptr(x2), ptr(b), ptr(i2), B, D2, 1e-6, stream()), "ph_row_invnorm_scale")
         m = torch.empty(D1, D2, device=x1.device, dtype=torch.float32)
         ops.sgemm(a, b, None, m, D1, D2, B, 1, D1, D2, 1)                  # M = A^T B
+        if sync is not None:
+            sync.all_reduce_sum(m)            # data parallel: M sums over the global batch; the row gradients stay local
         zero = torch.zeros_like(m)
         out = torch.empty(1, device=x1.device, dtype=torch.float32)
         check(lib().ph_sqdiff_sum(ptr(m), ptr(zero), ptr(out), m.numel(), 1.0 / m.numel(), stream()), "ph_sqdiff_sum")
@@ -49,12 +51,14 @@ class _OrthFn(torch.autograd.Function):
             ops.sgemm(a, gm, None, db, B, D2, D1, D1, 1, D2, 1)            # dB = A dM
             d2 = torch.empty_like(b)
             check(lib().ph_row_scale(ptr(db), ptr(i2), ptr(d2), B, D2, stream()), "ph_row_scale")
-        return d1, d2
+        return d1, d2, None
 
 
 class OrthLoss(nn.Module):
     """orthogonal_loss.py:11-32."""
 
+    sync = None   # a ReplicaSync under data parallelism
+
     def forward(self, input1, input2):
         bsz = input1.size(0)
-        return _OrthFn.apply(input1.reshape(bsz, -1), input2.reshape(bsz, -1))
+        return _OrthFn.apply(input1.reshape(bsz, -1), input2.reshape(bsz, -1), self.sync)

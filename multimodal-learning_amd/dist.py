@@ -66,15 +66,25 @@ class ReplicaSync:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
         return count * self.world_size
 
+    def all_gather_cat(self, t):
+        """Rows of every replica, rank-ordered (the feature views of the t-SVD adjacency, train_test_tSVD.py:57-70)."""
+        parts = [torch.empty_like(t) for _ in range(self.world_size)]
+        dist.all_gather(parts, t.contiguous(), group=self.group)
+        return torch.cat(parts, dim=0)
+
     def attach(self, step):
         """Wire the CRD memories of a DistillStep to this group and make every replica start identical."""
-        for crd in (step.criterion_kd, step.criterion_kd_path):
+        self.attach_parts((step.criterion_kd, step.criterion_kd_path), (step.optimizer.flat.flat, step.ema_flat.flat),
+                          (step.fix_model, step.model, step.ema_model))
+
+    def attach_parts(self, crds, flats, modules):
+        for crd in crds:
             crd.contrast.sync = self
             for b in (crd.contrast.memory_v1, crd.contrast.memory_v2, crd.contrast.params):
                 dist.broadcast(b, src=0, group=self.group)
-        for t in (step.optimizer.flat.flat, step.ema_flat.flat):
+        for t in flats:
             dist.broadcast(t, src=0, group=self.group)
-        for m in (step.fix_model, step.model, step.ema_model):
+        for m in modules:
             for t in list(m.parameters()) + list(m.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
 

@@ -654,6 +654,22 @@ class DistillStep:
         return None if st is None else {k: st[k] for k in ("x_path", "ema_x_path", "x_omic", "grade", "index", "sample_idx")}
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """All-gather of feature rows with a local backward: forward returns the rows of every replica (rank order),
+    backward returns the gradient of THIS replica's rows.  Every replica evaluates the same function of the gathered
+    rows (the t-SVD penalty), so the partial derivative with respect to its own rows is complete as it stands; the
+    gradient all-reduce then adds the replicas' parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, sync):
+        ctx.lo, ctx.n = sync.rank * x.shape[0], x.shape[0]
+        return sync.all_gather_cat(x.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.lo:ctx.lo + ctx.n].contiguous(), None
+
+
 class TeacherStage1Step:
     """The batch body of the stage-1 mean-teacher trainer (MICCAI-2022/train_test_MT.py:121-230) for the
     grading task: student PathomicNet forward/backward, EMA PathomicNet forward, three-branch NLL (:208-212),
@@ -661,10 +677,16 @@ class TeacherStage1Step:
     CRD term on the fused features (--CRD_distill 1, CL_utils/CRD_criterion.py) and orthogonality term (--orth_loss
     True, CL_utils/orthogonal_loss.py), Adam, EMA update.  (--SP_distill names a class the reference never imports.)"""
 
-    def __init__(self, opt, device="cuda", k=1, models=None):
+    def __init__(self, opt, device="cuda", k=1, models=None, sync=None):
+        """`sync`: a dist.ReplicaSync for data parallelism (one process per GPU, `opt.batch_size` tiles each).  Loss
+        normalisers use the global batch, the vanilla CRD bank is updated identically on every replica, the
+        cross-correlation of the orthogonality loss is all-reduced, and the t-SVD adjacency tensors are built over the
+        global batch from all-gathered feature views (every replica computes the same auxiliary tensors; the penalty's
+        gradient reaches this replica's rows only, the gradient all-reduce adds the replicas up)."""
         from .networks_new import define_net, define_optimizer, define_scheduler
         self.opt = opt
         self.device = torch.device(device)
+        self.sync = sync
         if opt.task != "grad":
             raise NotImplementedError("stage-1 step implements the grading task (survival/Cox is out of scope)")
         if models is None:
@@ -706,7 +728,8 @@ class TeacherStage1Step:
             if opt.tSVD_mode not in ("path", "omic", "pathomic"):
                 raise ValueError(opt.tSVD_mode)
             self.mu = float(opt.mu)                                                              # :161 (never reset per epoch)
-            z = lambda: [torch.zeros(opt.batch_size, opt.batch_size, device=self.device) for _ in range(opt.n_views)]
+            gb = opt.batch_size * (sync.world_size if sync is not None else 1)
+            z = lambda: [torch.zeros(gb, gb, device=self.device) for _ in range(opt.n_views)]
             self.adj_tensor1, self.aux_tensor1, self.adj_tensor2, self.aux_tensor2 = z(), z(), z(), z()   # :165-177
             self.path_TNN = self.omic_TNN = None
             self._batch_idx = 0
@@ -722,12 +745,18 @@ class TeacherStage1Step:
         n_model = len(list(self.model.parameters()))
         flat = self.optimizer.flat
         self.optimizer.ema_range = (0, flat.offsets[n_model] if n_model < len(flat.offsets) else flat.numel)
+        if sync is not None:
+            crds = (self.CRD_criterion_path, self.CRD_criterion_omic, self.CRD_criterion_fuse) if self.crd_on else ()
+            sync.attach_parts(crds, (flat.flat, self.ema_flat.flat), (self.model, self.ema_model))
+            if self.orth_on:
+                self.Orth_loss.sync = sync
 
     @staticmethod
-    def pred_KD_loss(p_s, p_t):
+    def pred_KD_loss(p_s, p_t, bnorm=None):
         """KD_losses.py:27-29 (grading, sample_KD False): sum(kl_div(p_s, exp(p_t))) / B on log-probabilities - the KL
-        kernel at T = 1 (log_softmax of a log-probability vector is the vector itself)."""
-        return ops.KLFn.apply(p_s, p_t.detach(), 1.0, float(p_s.shape[0]))
+        kernel at T = 1 (log_softmax of a log-probability vector is the vector itself).  `bnorm`: the global batch
+        under data parallelism."""
+        return ops.KLFn.apply(p_s, p_t.detach(), 1.0, float(bnorm or p_s.shape[0]))
 
     def start_epoch(self):
         """The t-SVD auxiliary update runs every opt.aux_iter batches of an epoch (:375): reset the batch counter."""
@@ -741,7 +770,7 @@ class TeacherStage1Step:
         dev = self.device
         x_path, ema_x_path = x_path.to(dev, non_blocking=True), ema_x_path.to(dev, non_blocking=True)
         x_omic, grade = x_omic.to(dev, non_blocking=True), grade.to(dev, non_blocking=True)
-        B = float(x_path.shape[0])
+        B = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))   # global batch
         self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)
         fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
             x_path=x_path, x_omic=x_omic)                                                        # :137
@@ -750,9 +779,10 @@ class TeacherStage1Step:
                 x_path=ema_x_path, x_omic=x_omic)                                                # :143-145
         loss_CRD = torch.zeros((), device=dev)
         if self.crd_on:                                                                          # :157-165
+            self.CRD_criterion_fuse.contrast.batch_norm_size = B
             loss_CRD = opt.CRD_weight * self.CRD_criterion_fuse(
                 fuse_feat, ema_fuse_feat.detach(), index.to(dev), sample_idx.to(dev)).reshape(())
-        kd = self.pred_KD_loss
+        kd = lambda p_s, p_t: self.pred_KD_loss(p_s, p_t, B)      # noqa: E731
         if getattr(opt, "pred_distill", 1) == 1:
             nt = opt.num_teachers
             kd_fuse = kd(pred, ema_pred)
@@ -779,6 +809,12 @@ class TeacherStage1Step:
         loss_tsvd = torch.zeros((), device=dev)
         if self.tsvd_on:                                                                        # train_test_tSVD.py:299-431
             from . import tsvd as T
+            if self.sync is not None:
+                # the adjacency tensors span the global batch: gather every feature view (rank-ordered rows); the
+                # backward of the gather hands this replica's rows their gradient
+                fuse_feat, path_feat, omic_feat = (_GatherRowsFn.apply(t, self.sync) for t in (fuse_feat, path_feat, omic_feat))
+                ema_fuse_feat, ema_path_feat, ema_omic_feat = (self.sync.all_gather_cat(t) for t in
+                                                               (ema_fuse_feat, ema_path_feat, ema_omic_feat))
             if opt.n_views == 2:
                 feats1 = [path_feat, ema_path_feat]                                             # :320-322
                 feats2 = [omic_feat, ema_omic_feat]
@@ -811,6 +847,8 @@ class TeacherStage1Step:
             loss = loss + loss_tsvd
         self.optimizer.zero_grad()
         loss.backward()
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self.optimizer.flat)
         self.optimizer.step()                                                                   # + EMA (:229) fused
         self.iter_num += 1
         return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),

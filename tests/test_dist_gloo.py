@@ -74,6 +74,18 @@ def test_grad_allreduce_in_two_phases_equals_one():
         assert torch.equal(g, expect) and torch.equal(again, expect * 2)
 
 
+def _gather_cat(rank, world):
+    from multimodal_learning_amd.dist import ReplicaSync
+    sync = ReplicaSync()
+    t = torch.full((3, 4), float(rank + 1))
+    return sync.all_gather_cat(t)
+
+
+def test_feature_view_allgather_is_rank_ordered():
+    for out in _run(_gather_cat):
+        assert out.shape == (6, 4) and torch.equal(out[:3], torch.ones(3, 4)) and torch.equal(out[3:], torch.full((3, 4), 2.0))
+
+
 def _gather(rank, world):
     from multimodal_learning_amd.dist import ReplicaSync
     sync = ReplicaSync()

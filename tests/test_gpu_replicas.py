@@ -28,8 +28,9 @@ class LocalGroup:
 
 
 class LocalSync:
-    def __init__(self, group, rank):
+    def __init__(self, group, rank, expect_slice=True):
         self.g, self.rank, self.world_size = group, rank, group.world
+        self.expect_slice = expect_slice      # DistillStep announces the layer 3-4 slice; the stage-1 step does not
 
     def _exchange(self, t):
         self.g.slots[self.rank] = t
@@ -57,6 +58,9 @@ class LocalSync:
     def all_reduce_grads(self, flat):
         g = flat if torch.is_tensor(flat) else flat.grad
         pend, self.pending = getattr(self, "pending", None), None
+        if not self.expect_slice:
+            assert pend is None
+            return self._sum(g)
         assert pend is not None and 0 < pend[0] < g.numel(), "the trunk backward did not announce its finished slice"
         lo, snap = pend
         assert torch.equal(snap, g[lo:]), "gradients behind the announced offset changed after the announcement"
@@ -74,8 +78,15 @@ class LocalSync:
         ys, a, b = self._exchange(y.clone()), self._exchange(v1.clone()), self._exchange(v2.clone())
         return torch.cat(ys, 0), torch.cat(a, 0), torch.cat(b, 0)
 
+    def all_gather_cat(self, t):
+        return torch.cat(self._exchange(t.clone()), 0)
+
     def attach(self, step):
         for crd in (step.criterion_kd, step.criterion_kd_path):
+            crd.contrast.sync = self
+
+    def attach_parts(self, crds, flats, modules):
+        for crd in crds:
             crd.contrast.sync = self
 
 
@@ -226,3 +237,84 @@ def test_split_trunk_backward_is_bitwise_the_single_call():
     assert res[0].keys() == res[1].keys() and len(res[0]) > 60
     for k in res[0]:
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+def test_two_stage1_replicas_with_tsvd_orth_crd_equal_one_process():
+    """TeacherStage1Step under data parallelism (BASELINE configs 4 / 5 run their stage-1 trainers on several GPUs): the
+    t-SVD adjacency / auxiliary tensors span the global batch (all-gathered feature views), the orthogonality loss sees
+    the all-reduced cross-correlation, the vanilla CRD bank and the loss normalisers use the global batch."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.dist import shard_batch
+    from oracle import weights as W
+    from oracle.step import synthetic_batch
+    B, H, n_data, K = 8, 64, 1024, 256
+
+    def build(bs, sync):
+        opt = m.stage2_opt(dropout_rate=0.0, batch_size=bs, cut_fuse_grad=True, num_teachers=2)
+        opt.pred_distill, opt.KD_weight, opt.SP_distill = 1, 1.0, 0
+        opt.CRD_distill, opt.CRD_weight, opt.nce_k, opt.n_data = 1, 0.1, K, n_data
+        opt.orth_loss = "True"
+        opt.tSVD_loss, opt.tSVD_mode, opt.n_views, opt.aux_iter = "True", "pathomic", 4, 1
+        opt.mu, opt.pho, opt.max_mu, opt.Lambda_global = 0.01, 1.5, 1.0, 0.05
+        model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+        model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3)); ema.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 4))
+        st = m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda()), sync=sync)
+        g = torch.Generator().manual_seed(11)
+        for crd in (st.CRD_criterion_path, st.CRD_criterion_omic, st.CRD_criterion_fuse):
+            for i, e in enumerate((crd.embed_s, crd.embed_t)):
+                for p in e.parameters():
+                    p.data.copy_((torch.rand(p.shape, generator=g) - 0.5) * 0.1)
+            for bank in (crd.contrast.memory_v1, crd.contrast.memory_v2):
+                bank.copy_((torch.rand(bank.shape, generator=g) * 2 - 1) * 0.15)
+            crd.contrast.verbose = False
+        return st
+
+    heads = ("classifier.0.weight", "path_net.fc_new2.weight", "omic_net.classifier.0.weight")
+    m.set_precision("bf16x6")
+    try:
+        bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=950)
+        for k in ("x_path", "ema_x_path", "x_omic"):
+            bt[k][B // 2:] = bt[k][:B // 2]
+        z = torch.zeros(B)
+        batch = ((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"])
+        single = build(B, None)
+        names = dict(single.model.named_parameters())
+        assert all(h in names for h in heads), [n for n in names if "classifier" in n or "fc_new2" in n]
+        o1 = single.step(batch)
+        g1 = {h: names[h].grad.clone() for h in heads}
+        group = LocalGroup(2)
+        reps = [build(B // 2, LocalSync(group, r, expect_slice=False)) for r in range(2)]
+        outs, errs = [None, None], []
+
+        def run(r):
+            try:
+                outs[r] = reps[r].step(shard_batch(batch, r, 2))
+                torch.cuda.synchronize()
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                group.barrier.abort()
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(300)
+        if errs:
+            raise errs[0]
+        f0, f1 = reps[0].optimizer.flat, reps[1].optimizer.flat
+        assert torch.equal(f0.grad, f1.grad) and torch.equal(f0.flat, f1.flat)
+        for k in ("loss_tsvd", "loss_orth"):          # functions of the global batch: the same value everywhere
+            assert torch.equal(outs[0][k], outs[1][k])
+            assert abs(float(outs[0][k]) - float(o1[k])) <= 2e-4 * max(abs(float(o1[k])), 1e-3), (k, float(outs[0][k]), float(o1[k]))
+        for k in ("loss_nll", "loss_pred_KD", "loss_CRD"):      # partial sums over the replica's rows
+            tot = sum(float(o[k]) for o in outs)
+            assert abs(tot - float(o1[k])) <= 2e-4 * max(abs(float(o1[k])), 1e-3), (k, tot, float(o1[k]))
+        for v in range(4):
+            assert float((reps[0].aux_tensor1[v] - single.aux_tensor1[v]).abs().max()) <= 2e-5
+            assert float((reps[0].adj_tensor2[v] - single.adj_tensor2[v]).abs().max()) <= 2e-5
+            assert torch.equal(reps[0].aux_tensor2[v], reps[1].aux_tensor2[v])
+        n0 = dict(reps[0].model.named_parameters())
+        for h in heads:
+            err = float((n0[h].grad - g1[h]).abs().max())
+            assert err <= 1e-3 * float(g1[h].abs().max()) + 1e-7, (h, err)
+    finally:
+        m.set_precision("bf16")
