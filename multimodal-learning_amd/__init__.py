@@ -24,6 +24,7 @@ from . import sampler
 from . import distiller_zoo
 from .sampler import ContrastIndexSampler
 from . import tsvd
+from . import evaluate
 from .options import stage2_opt
 
 __all__ = ["build", "lib", "set_precision", "get_precision", "init_net", "init_max_weights", "count_parameters",

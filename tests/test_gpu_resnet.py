@@ -318,3 +318,49 @@ def test_perf_mode_forward_stage_by_stage():
     assert rel(y5_ref, y5) <= 1.0 / 128, ("layer2.0.conv1 (stride 2)", rel(y5_ref, y5))
     print("\nperf-mode stages: stem conv %.4f, stem pool %.4f, l1 conv %.4f, bn+relu %.4f, conv2 %.4f, bn+res %.4f, s2 conv %.4f"
           % (rel(y0_ref, y0), rel(p0_ref, p0), rel(y1_ref, y1), rel(a1_ref, a1), rel(y2_ref, y2), rel(o0_ref, o0), rel(y5_ref, y5)))
+
+
+def test_evaluation_loop_vs_reference_test_function(golden_dir):
+    """Row f-3: evaluate.test() (eval-mode forwards of the student and the frozen teacher, NLL, accuracy, ROC-AUC / AP /
+    F1 through sklearn) against the reference's own test() run over the same three synthetic batches
+    (tests/golden/make_golden_eval_loop.py)."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    g = np.load(os.path.join(golden_dir, "eval_loop_b6_h64.npz"))
+    nb, B, H = int(g["nb"]), int(g["B"]), int(g["H"])
+
+    class Loader(list):
+        dataset = range(nb * B)
+    loader = Loader()
+    for i in range(nb):
+        bt = synthetic_batch(B, H, seed=500 + i)
+        z = torch.zeros(B)
+        loader.append((bt["x_path"], z, bt["x_omic"], z, z, bt["grade"]))
+    m.set_precision("bf16x6")
+    try:
+        opt = default_opt(dropout_rate=0.25)
+        student = m.define_net(opt, 1, path_only=True); teacher = m.define_net(opt, 1)
+        student.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+        teacher.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+        out = m.evaluate.test(opt, teacher.cuda(), student.cuda(), loader, "cuda")
+        loss_test, cidx, pval, sacc, acc, metrics, pred_test, grads_test, feats_test = out
+        assert cidx is None and pval is None and sacc is None
+        assert abs(loss_test - float(g["loss_test"])) <= 1e-3 * max(abs(float(g["loss_test"])), 1.0)
+        assert abs(acc - float(g["grad_path_test"])) < 1e-12
+        assert np.array_equal(pred_test[8], g["gt_all"]) and pred_test[8].dtype == g["gt_all"].dtype
+        for got, key in ((pred_test[5], "probs_all"), (pred_test[6], "probs_path"), (feats_test[1], "feat_path_all")):
+            ref = g[key]
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1.0), key
+        # The ranking metrics are step functions of the scores (this fixture's random-weight networks saturate: many
+        # log-probabilities tie to within rounding, and one swapped pair moves the micro AUC by 1/(18*36)).  So: the
+        # metric function on the REFERENCE's scores reproduces the reference's metrics exactly; end to end the metrics
+        # agree to a few pair swaps; accuracy / micro-F1 (argmax only) exactly.
+        from sklearn.preprocessing import LabelBinarizer
+        onehot = LabelBinarizer().fit(g["gt_all"]).transform(g["gt_all"])
+        on_ref_scores = m.evaluate.grading_metrics(onehot, g["probs_path"])
+        assert np.allclose(np.asarray(on_ref_scores, dtype=np.float64), g["metrics"], atol=1e-12)
+        got = np.asarray(metrics, dtype=np.float64)
+        assert np.abs(got - g["metrics"]).max() <= 0.02 and abs(got[2] - g["metrics"][2]) < 1e-12, (got, g["metrics"])
+    finally:
+        m.set_precision("bf16")
