@@ -227,6 +227,19 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
  * reference: this is the tensor-nuclear-norm proximal operator, see csrc/tsvd.hip): adj, aux are [V][B][B] (view-major),
  * V in {2,4,6,8}, B <= 128 (B <= 64: Jacobi on the embedding of X^H X; above: one-sided Jacobi on the slice); tnn[0] = (1/V) sum over frequency slices of the nuclear norm of the thresholded slice.
  * ---------------------------------------------------------------------------------------------- */
+/* Relational distillation baselines of the distiller zoo (`--distill pkt|rkd`,
+ * "MIA 2022/train_test_path_multi_distill_v2.py":339-342).  Each entry returns the loss AND its gradient with respect
+ * to the student rows f_s [B, D] (the teacher rows f_t are constants), fixed summation order.
+ * ph_pkt_loss_grad: "MIA 2022/distiller_zoo/PKT.py":17-46 (cosine-similarity probabilities, KL, eps 1e-7).
+ * ph_rkd_loss_grad: "MIA 2022/distiller_zoo/RKD.py":15-58 (w_d * smooth-L1 of mean-normalised pairwise distances +
+ * w_a * smooth-L1 of the B^3 angles); B <= 128, D <= 512. */
+size_t ph_pkt_workspace_bytes(int B, int D);
+int ph_pkt_loss_grad(const float* f_s, const float* f_t, float* loss, float* dx, int B, int D, void* workspace,
+                     ph_stream_t stream);
+size_t ph_rkd_workspace_bytes(int B, int D);
+int ph_rkd_loss_grad(const float* f_s, const float* f_t, float* loss, float* dx, int B, int D, float w_d, float w_a,
+                     void* workspace, ph_stream_t stream);
+
 /* On-device contrast-index sampler (reference MICCAI-2022/data_loaders_MT.py:229-249 and the neg_mode
  * variants of "MIA 2023/stage2_unimodal_student/data_loaders_MT.py":205-238).  out[b] = [positives | K negatives]:
  * pos_mode 0 'exact' (the query), 1 'relax' (one same-class row), 2 'multi_pos' (P distinct same-class rows, slot 0 :=

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Golden vectors for the two distiller-zoo losses that are built: the reference's own classes, loaded
-from their files ("MIA 2022/distiller_zoo/SP.py", "feats_KL.py"; the package __init__ imports dgl, which is absent).
+"""Golden vectors for the distiller-zoo losses that are built (SP, feats_KL, RKD, PKT): the reference's own classes, loaded
+from their files ("MIA 2022/distiller_zoo/SP.py", "feats_KL.py", "RKD.py", "PKT.py"; the package __init__ imports dgl, which is absent).
 Build container only.  Writes tests/golden/zoo_sp_featskl.npz."""
 import importlib.util
 import os
@@ -34,6 +34,15 @@ def main():
         l2 = fk(f_s, f_t)
         g2, = torch.autograd.grad(l2, f_s)
         rec.update({f"f_s{B}": f_s, f"f_t{B}": f_t, f"sp{B}": l1, f"sp_g{B}": g1, f"fkl{B}": l2, f"fkl_g{B}": g2})
+    rkd, pkt = load("RKD").RKDLoss(), load("PKT").PKT()
+    for B in (8, 64, 128):
+        f_s = torch.randn(B, 128, generator=g).relu_().requires_grad_(True)
+        f_t = torch.randn(B, 128, generator=g).relu_()
+        l3 = rkd(f_s, f_t)
+        g3, = torch.autograd.grad(l3, f_s)
+        l4 = pkt(f_s, f_t)
+        g4, = torch.autograd.grad(l4, f_s)
+        rec.update({f"r_f_s{B}": f_s, f"r_f_t{B}": f_t, f"rkd{B}": l3, f"rkd_g{B}": g3, f"pkt{B}": l4, f"pkt_g{B}": g4})
     np.savez_compressed(os.path.join(HERE, "zoo_sp_featskl.npz"), **npz(rec))
     print("wrote zoo_sp_featskl.npz", float(rec["sp8"]), float(rec["fkl8"]))
 

@@ -390,3 +390,24 @@ def test_distiller_zoo_sp_and_feats_kl_vs_reference_golden(golden_dir):
         R.close(np.asarray(g[f"fkl{B}"]).reshape(()), l2.reshape(()), 1e-6, 1e-4, f"feats_KL loss B={B}")
         R.close(g[f"fkl_g{B}"], g2, 1e-8, 1e-3, f"feats_KL grad B={B}")
     R.finish()
+
+
+def test_distiller_zoo_rkd_and_pkt_vs_reference_golden(golden_dir):
+    """Row f-4: RKDLoss and PKT (closed-form loss + gradient kernels, csrc/zoo.hip) against the reference's own classes
+    at B = 8, 64 and 128; a loss scaled by a constant scales the gradient (the backward multiplies the stored gradient)."""
+    from multimodal_learning_amd.distiller_zoo import RKDLoss, PKT
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "zoo_sp_featskl.npz"))
+    R = Report("RKD / PKT vs REFERENCE golden")
+    for B in (8, 64, 128):
+        f_s = torch.as_tensor(g[f"r_f_s{B}"]).cuda().requires_grad_(True)
+        f_t = torch.as_tensor(g[f"r_f_t{B}"]).cuda()
+        l3 = RKDLoss()(f_s, f_t)
+        g3, = torch.autograd.grad(3.0 * l3, f_s)
+        R.close(np.asarray(g[f"rkd{B}"]).reshape(()), l3.reshape(()), 1e-7, 1e-4, f"RKD loss B={B}")
+        R.close(3.0 * g[f"rkd_g{B}"], g3, 1e-8, 2e-3, f"RKD grad B={B}")
+        l4 = PKT()(f_s, f_t)
+        g4, = torch.autograd.grad(l4, f_s)
+        R.close(np.asarray(g[f"pkt{B}"]).reshape(()), l4.reshape(()), 1e-9, 2e-3, f"PKT loss B={B}")
+        R.close(g[f"pkt_g{B}"], g4, 1e-10, 5e-3, f"PKT grad B={B}")
+    R.finish()
