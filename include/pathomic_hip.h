@@ -240,6 +240,16 @@ size_t ph_rkd_workspace_bytes(int B, int D);
 int ph_rkd_loss_grad(const float* f_s, const float* f_t, float* loss, float* dx, int B, int D, float w_d, float w_a,
                      void* workspace, ph_stream_t stream);
 
+/* Superpixel attention masks of the MIA-2023 stage-1 trainer (SURVEY row f-4;
+ * "MIA 2023/stage1_multi_modal_teacher/train_test_MT_SP_Masking.py":77-98), the part after the input gradients exist:
+ * ph_superpixel_mask: grad_nchw [B,C,H,W] f32, sp_mask [B,H,W] labels in [0,N) -> mean gradient per superpixel
+ * (sum over channels and pixels / (area + 1e-9); mean_out [B,N] may be NULL) and mask [B,H,W] = union of the K
+ * superpixels with the largest mean (:88-93).  N <= 2048.  The reference does the aggregation on the HOST (:84-86).
+ * ph_topk_threshold_mask: mask[b][i] = x[b][i] >= (K-th largest of row b)  (:96). */
+int ph_superpixel_mask(const float* grad_nchw, const int64_t* sp_mask, float* mask, float* mean_out, int B, int C, int H,
+                       int W, int N, int K, ph_stream_t stream);
+int ph_topk_threshold_mask(const float* x, float* mask, int B, int D, int K, ph_stream_t stream);
+
 /* On-device contrast-index sampler (reference MICCAI-2022/data_loaders_MT.py:229-249 and the neg_mode
  * variants of "MIA 2023/stage2_unimodal_student/data_loaders_MT.py":205-238).  out[b] = [positives | K negatives]:
  * pos_mode 0 'exact' (the query), 1 'relax' (one same-class row), 2 'multi_pos' (P distinct same-class rows, slot 0 :=

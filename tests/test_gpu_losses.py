@@ -411,3 +411,29 @@ def test_distiller_zoo_rkd_and_pkt_vs_reference_golden(golden_dir):
         R.close(np.asarray(g[f"pkt{B}"]).reshape(()), l4.reshape(()), 1e-9, 2e-3, f"PKT loss B={B}")
         R.close(g[f"pkt_g{B}"], g4, 1e-10, 5e-3, f"PKT grad B={B}")
     R.finish()
+
+
+def test_superpixel_attention_masks_vs_reference_golden(golden_dir):
+    """Row f-4: the tail of the MIA-2023 stage-1 `superpixel_attention_mask` (per-superpixel mean of the image gradient,
+    top-Path_K superpixel mask, top-Omic_K omic mask) against the reference's own statements run on the same synthetic
+    gradients (tests/golden/make_golden_superpixel.py).  Masks are integer work: exact."""
+    import types
+    import multimodal_learning_amd as m
+    g = np.load(os.path.join(golden_dir, "superpixel_masks.npz"))
+    for tag in ("a", "b"):
+        grad = torch.as_tensor(g[f"{tag}_x_path_grad"]).cuda()
+        og = torch.as_tensor(g[f"{tag}_x_omic_grad"]).cuda()
+        sp = torch.as_tensor(g[f"{tag}_sp_mask"]).cuda()
+        PK, OK = int(g[f"{tag}_Path_K"]), int(g[f"{tag}_Omic_K"])
+        mask, mean = m.superpixel.superpixel_topk_mask(grad, sp, PK, return_mean=True)
+        ref_mean = g[f"{tag}_mean"]
+        assert mean.shape == ref_mean.shape
+        assert np.abs(mean.cpu().numpy() - ref_mean).max() <= 2e-5 * np.abs(ref_mean).max()
+        assert np.array_equal(mask.cpu().numpy(), g[f"{tag}_path_mask"]), tag
+        assert np.array_equal(m.superpixel.omic_topk_mask(og, OK).cpu().numpy(), g[f"{tag}_omic_mask"]), tag
+        opt = types.SimpleNamespace(Path_K=PK, Omic_K=OK)
+        pm, om = m.superpixel.masks_from_input_gradients(opt, grad, og, sp, num_superpixels=ref_mean.shape[1])
+        assert torch.equal(pm, mask) and om.shape == og.shape
+        # bitwise reproducible (order-independent fixed-point accumulation)
+        mask2, mean2 = m.superpixel.superpixel_topk_mask(grad, sp, PK, return_mean=True)
+        assert torch.equal(mean, mean2) and torch.equal(mask, mask2)
