@@ -71,6 +71,14 @@ int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, cons
  * backward (utils.py:257-260). */
 int ph_resnet_backward_part(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
                             const float* g_f3, const float* g_f4, void* const* grads, int part, ph_stream_t stream);
+/* Gradient with respect to the image [B,3,H,W] f32 of an EVAL-mode forward (flags bit1; BatchNorm backward is then
+ * gamma * invstd * dz, no parameter gradients).  The reference needs it for the MIA-2023 stage-1 superpixel attention
+ * masks ("MIA 2023/stage1_multi_modal_teacher/train_test_MT_SP_Masking.py":62-75: model.eval(); cost.backward();
+ * x_path.grad).  ph_stem_dgrad is its last step (input gradient of the 7x7/2 conv; dy NHWC of the mode's type). */
+int ph_resnet_backward_input(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
+                             const float* g_f3 /* may be NULL */, const float* g_f4, float* dx_nchw, ph_stream_t stream);
+int ph_stem_dgrad(const void* dy_nhwc, const float* w_oihw, float* dx_nchw, int B, int H, int W, int prec,
+                  ph_stream_t stream);
 int ph_resnet_tensor_info(const PhResnetPlan* plan, int what, int id, size_t* byte_off, int* dims4);
 
 /* ------------------------------------------------------------------------------------------------
@@ -89,6 +97,10 @@ int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y,
 /* eval mode (module.eval(): running statistics), used by the reference's test() (train_test_path_multi_distill.py:409-411) */
 int ph_bn1d_eval(const float* x, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float* y, int B, int C, float eps, int relu, ph_stream_t stream);
+/* backward of the eval-mode form (a fixed per-channel scale): needed when a gradient flows THROUGH an eval-mode net to its
+ * input (train_test_MT_SP_Masking.py:62-75) */
+int ph_bn1d_eval_bwd(const float* g, const float* y, const float* gamma, const float* running_var, float* dx, int B, int C,
+                     float eps, int relu, ph_stream_t stream);
 int ph_bn1d_bwd(const float* g, const float* y, const float* x, const float* mean, const float* invstd,
                 const float* gamma, float* dx, float* dgamma, float* dbeta, int B, int C, int relu,
                 ph_stream_t stream);

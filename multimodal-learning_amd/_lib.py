@@ -25,6 +25,9 @@ SIGNATURES = {
     "ph_resnet_pack_weights": (i32, [vp, vp, vp, vp]),
     "ph_resnet_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ph_resnet_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ph_bn1d_eval_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),
+    "ph_resnet_backward_input": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ph_stem_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_resnet_backward_part": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ph_resnet_tensor_info": (i32, [vp, i32, i32, vp, vp]),
     "ph_sgemm": (i32, [vp, vp, vp, vp, i32, i32, i32, lng, lng, lng, lng, lng, i32, i32, vp]),

@@ -169,3 +169,9 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, in
   if (rc) return rc;
   return ph_wgrad_reduce_launch(g.slab, dw, g.nchunks, KS, Cout, Cin, st);
 }
+
+int ph_stem_dgrad(const void* dy_nhwc, const float* w_oihw, float* dx_nchw, int B, int H, int W, int prec, hipStream_t st) {
+  if (!dy_nhwc || !w_oihw || !dx_nchw || B < 1 || H < 2 || W < 2 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X6))
+    return PH_EINVAL;
+  return ph_stem_dgrad_launch(dy_nhwc, w_oihw, dx_nchw, B, H, W, prec, st);
+}

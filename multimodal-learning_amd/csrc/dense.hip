@@ -6,6 +6,17 @@
 
 namespace {
 
+// nn.BatchNorm1d in eval mode is y = x * gamma / sqrt(running_var + eps) + const: dx = g * (y > 0 if relu) * gamma * rsqrt(var + eps)
+__global__ void bn1d_eval_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ gamma,
+                                     const float* __restrict__ var, float* __restrict__ dx, size_t n, int C, float eps, int relu) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float s = gamma[c] * rsqrtf(var[c] + eps);
+  dx[i] = (relu && !(y[i] > 0.f)) ? 0.f : g[i] * s;
+}
+
+
 // ------------------------------------------------------------------ generic strided SGEMM
 // C[m][n] (ldc) = act( sum_k A(m,k) * B(k,n) + bias[n] ) (+ C if accumulate)
 //   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
@@ -745,6 +756,16 @@ int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y,
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
+int ph_bn1d_eval_bwd(const float* g, const float* y, const float* gamma, const float* running_var, float* dx, int B, int C,
+                     float eps, int relu, hipStream_t st) {
+  if (!g || !y || !gamma || !running_var || !dx || B < 1 || C < 1) return PH_EINVAL;
+  const size_t n = (size_t)B * C;
+  hipLaunchKernelGGL(bn1d_eval_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, y, gamma, running_var, dx, n,
+                     C, eps, relu);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
 int ph_bn1d_eval(const float* x, const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float* y, int B, int C, float eps, int relu, hipStream_t st) {
   hipLaunchKernelGGL(bn1d_eval_kernel, dim3(nblk((size_t)B * C)), dim3(256), 0, st, x, gamma, beta, running_mean,

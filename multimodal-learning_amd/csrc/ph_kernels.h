@@ -79,6 +79,8 @@ struct PhStemWgrad {
   int nchunks, tiles_per_chunk;
 };
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st);
+// input gradient of the 7x7/2 stem conv: dy [B][H/2][W/2][64] (type of the mode) -> dx [B][3][H][W] f32 (stem_dgrad.hip)
+int ph_stem_dgrad_launch(const void* dy, const float* w_oihw, float* dx_nchw, int B, int H, int W, int prec, hipStream_t st);
 int ph_stem_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, hipStream_t st);
 
 // weight packing (OIHW fp32 -> MFMA-friendly bf16, 3 split planes of `plane` elements each)

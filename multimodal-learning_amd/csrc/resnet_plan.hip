@@ -454,6 +454,58 @@ int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, co
   return PH_OK;
 }
 
+// Gradient with respect to the IMAGE of an eval-mode forward (flags bit1): BatchNorm is a fixed per-channel scale, so
+// its backward is gamma * invstd * dz - the training kernel with zero correction terms - and no parameter gradient is
+// produced.  Used by the MIA-2023 stage-1 superpixel attention masks
+// ("MIA 2023/stage1_multi_modal_teacher/train_test_MT_SP_Masking.py":62-75: model.eval(), cost.backward(), x_path.grad).
+int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
+                             const float* g_f3, const float* g_f4, float* dx_nchw, hipStream_t st) {
+  if (!P || !params || !packed || !ws_ || !g_f4 || !dx_nchw) return PH_EINVAL;
+  Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0, 1};
+  unsigned char* ws = c.ws;
+  unsigned char* gcur = ws + P->g0_off;
+  unsigned char* gnext = ws + P->g1_off;
+  unsigned char* dyb = ws + P->dy_off;
+  unsigned char* dab = ws + P->da_off;
+  float* c1 = reinterpret_cast<float*>(ws + P->cc_off);
+  float* c2 = c1 + 512;
+  int rc;
+  if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
+  if (hipMemsetAsync(c1, 0, 1024 * sizeof(float), st) != hipSuccess) return PH_ELAUNCH;
+  auto bn_eval_bwd = [&](int ui, const void* g, const void* a, void* dy) -> int {
+    const Unit& u = P->units[ui];
+    return ph_bn_bwd_apply_launch(g, a, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), (const float*)params[ui * 6 + 1], c1, c2,
+                                  dy, (size_t)P->B * u.OH * u.OW, u.Cout, P->prec, st);
+  };
+  {
+    const Block& b = P->blocks[7];
+    if ((rc = ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st))) return rc;
+  }
+  for (int bi = 7; bi >= 0; --bi) {
+    const Block& b = P->blocks[bi];
+    if (bi == 5 && g_f3)
+      if ((rc = ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st))) return rc;
+    const void* out = ws + b.out_off;
+    const void* a1 = ws + b.a1_off;
+    if ((rc = bn_eval_bwd(b.u2, gcur, out, dyb))) return rc;
+    if ((rc = conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr))) return rc;
+    if ((rc = bn_eval_bwd(b.u1, dab, a1, dyb))) return rc;
+    if (b.uds < 0) {
+      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, gcur, out))) return rc;
+    } else {
+      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, nullptr, nullptr))) return rc;
+      if ((rc = bn_eval_bwd(b.uds, gcur, out, dyb))) return rc;
+      if ((rc = conv_dgrad(c, b.uds, dyb, gnext, gnext, nullptr))) return rc;
+    }
+    unsigned char* t = gcur; gcur = gnext; gnext = t;
+  }
+  const Unit& u = P->units[0];
+  if ((rc = ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
+                                     c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64, P->prec, st)))
+    return rc;
+  return ph_stem_dgrad_launch(dyb, (const float*)params[0], dx_nchw, P->B, P->H, P->W, P->prec, st);
+}
+
 // debug / test access: byte offset + dims of an intermediate activation in the workspace
 //   what: 0 = unit raw output y (id = unit), 1 = block output (id = block), 2 = block a1, 3 = pooled stem
 int ph_resnet_tensor_info(const PhResnetPlan* P, int what, int id, size_t* byte_off, int* dims4) {

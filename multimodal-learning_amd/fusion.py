@@ -47,6 +47,8 @@ class BilinearFusion(nn.Module):
 
     def _bn_relu(self, x, bn):
         if not self.training:
+            if torch.is_grad_enabled() and x.requires_grad:
+                return ops.BN1dEvalFn.apply(x, bn, True)      # a gradient flows through the eval-mode net to its inputs
             return ops.bn1d_eval(x, bn, relu=True)
         return ops.BN1dFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                 True, True)

@@ -251,6 +251,28 @@ def bn1d_eval(x, bn, relu):
     return y
 
 
+class BN1dEvalFn(torch.autograd.Function):
+    """bn1d_eval with a backward to the input (eval-mode BatchNorm1d is a fixed per-channel scale): used when a
+    gradient flows through an eval-mode network to its inputs (MIA-2023 superpixel attention masks)."""
+
+    @staticmethod
+    def forward(ctx, x, bn, relu):
+        y = bn1d_eval(x, bn, relu)
+        ctx.save_for_backward(y)
+        ctx.bn, ctx.relu = bn, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        bn = ctx.bn
+        g = _f32(g)
+        dx = torch.empty_like(y)
+        check(lib().ph_bn1d_eval_bwd(ptr(g), ptr(y), ptr(bn.weight), ptr(bn.running_var), ptr(dx), y.shape[0], y.shape[1],
+                                     bn.eps, int(ctx.relu), stream()), "ph_bn1d_eval_bwd")
+        return dx, None, None
+
+
 class LogSoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -78,13 +78,18 @@ class _TrunkFn(torch.autograd.Function):
         plan = net._get_plan(B, H, W)
         packed = net._get_packed(plan)
         table = net._param_table()
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        want_dx = ctx.needs_input_grad[0]
+        if want_dx and net.training:
+            raise NotImplementedError("gradient with respect to the image in train mode (the reference only takes it "
+                                      "through an eval-mode net: train_test_MT_SP_Masking.py:62-75)")
+        need_grad = torch.is_grad_enabled() and (want_dx or any(p.requires_grad for p in params))
         ws = net._get_workspace(plan, persistent=need_grad)
         f3 = torch.empty(B, 256, device=x.device, dtype=torch.float32)
         f4 = torch.empty(B, 512, device=x.device, dtype=torch.float32)
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4),
                                       1 if net.training else 2, stream()), "ph_resnet_forward")
         ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table
+        ctx.input_only = not net.training      # eval mode: the backward produces the image gradient only
         ctx.set_materialize_grads(False)
         ctx.nparams = len(params)
         return f3, f4
@@ -97,6 +102,16 @@ class _TrunkFn(torch.autograd.Function):
             g4 = torch.zeros(plan.key[0], 512, device=dev, dtype=torch.float32)
         g4 = g4.contiguous().float()
         g3 = g3.contiguous().float() if g3 is not None else None
+        if ctx.input_only:
+            if not ctx.needs_input_grad[0]:
+                ctx.ws = None
+                return (None, None) + (None,) * ctx.nparams
+            B, H, W = plan.key[0], plan.key[1], plan.key[2]
+            dx = torch.empty(B, 3, H, W, device=dev, dtype=torch.float32)
+            check(lib().ph_resnet_backward_input(plan.h, ctx.table, ptr(ctx.packed), ptr(ctx.ws), ptr(g3), ptr(g4), ptr(dx),
+                                                 stream()), "ph_resnet_backward_input")
+            ctx.ws = None
+            return (dx, None) + (None,) * ctx.nparams
         grads, gptrs = net._alloc_trunk_grads()
         hook = getattr(net, "_grad_ready_hook", None)
         if hook is None:
@@ -252,9 +267,21 @@ class ResNet(nn.Module):
     # ------------------------------------------------------------------ reference API
     def _forward_impl(self, x):
         lin, bn = self.fc_new1[0], self.fc_new1[1]
+        if not self.training and torch.is_grad_enabled() and x.requires_grad:
+            # eval-mode net with a gradient to the IMAGE (MIA-2023 superpixel attention, train_test_MT_SP_Masking.py:62-75)
+            f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())
+            h = ops.LinearFn.apply(f4, lin.weight, lin.bias)
+            features = ops.BN1dEvalFn.apply(h, bn, True)
+            hazard = ops.LinearFn.apply(features, self.fc_new2.weight, self.fc_new2.bias)
+            pred = None
+            if self.act is not None:
+                if not isinstance(self.act, nn.LogSoftmax):
+                    raise NotImplementedError("only act_type 'LSM' (grading task) is on the hot path")
+                pred = ops.LogSoftmaxFn.apply(hazard)
+            return f3, features, hazard, pred, None
         if not self.training:
             # eval mode (the reference's test(), train_test_path_multi_distill.py:409-431): BatchNorm uses the running
-            # statistics.  Forward only - the reference never back-propagates through an eval-mode net.
+            # statistics.  Forward only.
             with torch.no_grad():
                 f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())
                 h = ops.linear_fwd(f4, lin.weight, lin.bias)

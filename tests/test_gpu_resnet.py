@@ -364,3 +364,56 @@ def test_evaluation_loop_vs_reference_test_function(golden_dir):
         assert np.abs(got - g["metrics"]).max() <= 0.02 and abs(got[2] - g["metrics"][2]) < 1e-12, (got, g["metrics"])
     finally:
         m.set_precision("bf16")
+
+
+def test_eval_mode_image_gradient_vs_oracle_autograd():
+    """ph_resnet_backward_input + ph_stem_dgrad: the gradient of an eval-mode student's loss with respect to the IMAGE
+    (train_test_MT_SP_Masking.py:62-75 takes it for the superpixel attention masks) against torch autograd through the
+    oracle's eval-mode forward on the CPU.  Parity mode; a ragged size exercises the tile edges of the stem dgrad."""
+    import multimodal_learning_amd as m
+    import torch.nn.functional as F
+    from oracle import weights as W
+    from oracle.step import default_opt
+
+    def eval_forward(sd, x):      # plain PyTorch fp32 restatement of the eval-mode student (resnets.py:217-253)
+        def bn(t, p):
+            return F.batch_norm(t, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.1, 1e-5)
+        t = F.max_pool2d(F.relu(bn(F.conv2d(x, sd["conv1.weight"], None, 2, 3), "bn1")), 3, 2, 1)
+        for li in range(1, 5):
+            for bi in range(2):
+                p = f"layer{li}.{bi}"
+                stride = 2 if (li > 1 and bi == 0) else 1
+                idt = t
+                o = F.relu(bn(F.conv2d(t, sd[p + ".conv1.weight"], None, stride, 1), p + ".bn1"))
+                o = bn(F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
+                if p + ".downsample.0.weight" in sd:
+                    idt = bn(F.conv2d(t, sd[p + ".downsample.0.weight"], None, stride, 0), p + ".downsample.1")
+                t = F.relu(o + idt)
+        f4 = t.mean((2, 3))
+        h = F.linear(f4, sd["fc_new1.0.weight"], sd["fc_new1.0.bias"])
+        feat = F.relu(F.batch_norm(h, sd["fc_new1.1.running_mean"], sd["fc_new1.1.running_var"], sd["fc_new1.1.weight"],
+                                   sd["fc_new1.1.bias"], False, 0.1, 1e-5))
+        return F.log_softmax(F.linear(feat, sd["fc_new2.weight"], sd["fc_new2.bias"]), dim=1)
+    m.set_precision("bf16x6")
+    try:
+        sd = W.make_state_dict(W.student_shapes(), 1)
+        net = m.define_net(default_opt(), 1, path_only=True)
+        net.load_state_dict(sd)
+        net = net.cuda().eval()
+        for B, H in ((2, 64), (3, 72)):
+            g = torch.Generator().manual_seed(B)
+            x = torch.rand(B, 3, H, H, generator=g) * 2 - 1
+            grade = torch.randint(0, 3, (B,), generator=g)
+            xg = x.clone().cuda().requires_grad_(True)
+            out = net(x_path=xg)
+            loss = m.ops.NLLFn.apply(out[3], grade.cuda(), float(B))
+            loss.backward()
+            xr = x.clone().requires_grad_(True)
+            ref_loss = F.nll_loss(eval_forward(sd, xr), grade)
+            ref_loss.backward()
+            assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(abs(float(ref_loss)), 1.0)
+            err = float((xg.grad.cpu() - xr.grad).abs().max()); mx = float(xr.grad.abs().max())
+            assert err <= 2e-4 * mx, (B, H, err, mx)
+            assert all(p.grad is None for n_, p in net.named_parameters() if n_.startswith(("layer", "conv1", "bn1")))
+    finally:
+        m.set_precision("bf16")
