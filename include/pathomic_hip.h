@@ -261,6 +261,8 @@ int ph_rkd_loss_grad(const float* f_s, const float* f_t, float* loss, float* dx,
 int ph_superpixel_mask(const float* grad_nchw, const int64_t* sp_mask, float* mask, float* mean_out, int B, int C, int H,
                        int W, int N, int K, ph_stream_t stream);
 int ph_topk_threshold_mask(const float* x, float* mask, int B, int D, int K, ph_stream_t stream);
+/* out[b][c][p] = x[b][c][p] * (1 - mask[b][p])  (:201-202, the masked views; C = 1 for the omic vector) */
+int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, size_t P, ph_stream_t stream);
 
 /* On-device contrast-index sampler (reference MICCAI-2022/data_loaders_MT.py:229-249 and the neg_mode
  * variants of "MIA 2023/stage2_unimodal_student/data_loaders_MT.py":205-238).  out[b] = [positives | K negatives]:

@@ -94,6 +94,15 @@ __global__ void topk_threshold_mask_kernel(const float* __restrict__ x, float* _
   }
 }
 
+// out[b][c][p] = x[b][c][p] * (1 - mask[b][p])   (train_test_MT_SP_Masking.py:201-202: the masked views of the inputs)
+__global__ void apply_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
+                                  size_t n, int C, size_t P) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t b = i / (C * P), p = i % P;
+  out[i] = x[i] * (1.f - mask[b * P + p]);
+}
+
 }  // namespace
 
 #include "pathomic_hip.h"
@@ -111,6 +120,14 @@ int ph_superpixel_mask(const float* grad_nchw, const int64_t* sp_mask, float* ma
 int ph_topk_threshold_mask(const float* x, float* mask, int B, int D, int K, hipStream_t st) {
   if (!x || !mask || B < 1 || D < 1 || K < 1 || K > D || D > 16384) return PH_EINVAL;
   hipLaunchKernelGGL(topk_threshold_mask_kernel, dim3(B), dim3(256), (size_t)D * sizeof(float), st, x, mask, B, D, K);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, size_t P, hipStream_t st) {
+  if (!x || !mask || !out || B < 1 || C < 1 || P < 1) return PH_EINVAL;
+  const size_t n = (size_t)B * C * P;
+  hipLaunchKernelGGL(apply_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, mask, out, n, C, P);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -82,7 +82,11 @@ class _TrunkFn(torch.autograd.Function):
         if want_dx and net.training:
             raise NotImplementedError("gradient with respect to the image in train mode (the reference only takes it "
                                       "through an eval-mode net: train_test_MT_SP_Masking.py:62-75)")
-        need_grad = torch.is_grad_enabled() and (want_dx or any(p.requires_grad for p in params))
+        # One workspace per network serves forward and backward (grad mode is off inside Function.forward, so this was
+        # always the cached one).  A trainer that runs the SAME network several times before one backward (the MIA-2023
+        # masked views, train_test_MT_SP_Masking.py:204-208) sets `net._multi_forward`: every taped forward then keeps a
+        # workspace of its own.
+        need_grad = any(ctx.needs_input_grad) and getattr(net, "_multi_forward", False)
         ws = net._get_workspace(plan, persistent=need_grad)
         f3 = torch.empty(B, 256, device=x.device, dtype=torch.float32)
         f4 = torch.empty(B, 512, device=x.device, dtype=torch.float32)

@@ -37,6 +37,43 @@ def omic_topk_mask(x_omic_grad, omic_k):
     return mask
 
 
+def apply_mask(x, mask):
+    """x * (1 - mask) with the mask broadcast over the channel axis (:201-202): x [B, C, H, W] with mask [B, H, W], or
+    x [B, D] with mask [B, D]."""
+    x = ops._f32(require_cuda(x, "x")).contiguous()
+    mask = ops._f32(mask.to(x.device)).contiguous()
+    B = x.shape[0]
+    C = x.shape[1] if x.dim() == 4 else 1
+    P = mask[0].numel()
+    out = torch.empty_like(x)
+    check(lib().ph_apply_mask(ptr(x), ptr(mask), ptr(out), B, C, P, stream()), "ph_apply_mask")
+    return out
+
+
 def masks_from_input_gradients(opt, x_path_grad, x_omic_grad, sp_mask, num_superpixels=None):
     """The tail of superpixel_attention_mask (:77-101): returns (x_path_super_mask, x_omic_super_mask), both float."""
     return (superpixel_topk_mask(x_path_grad, sp_mask, opt.Path_K, num_superpixels), omic_topk_mask(x_omic_grad, opt.Omic_K))
+
+
+def superpixel_attention_mask(opt, optimizer, model, x_path, x_grph, x_omic, sp_mask, grade, device, num_superpixels=None):
+    """The reference's function, same signature (:42-102): switch `model` to eval mode, take the gradient of the fused
+    branch's NLL with respect to the image and the omic vector (eval-mode backward of the trunk down to the image:
+    `ph_resnet_backward_input`), build the two masks, switch back to train mode.  Unlike the reference this does not
+    leave the eval-mode cost's parameter gradients in `.grad` (the trainer zeroes them before its own backward)."""
+    dev = torch.device(device)
+    x_path_adv = ops._f32(x_path.detach().to(dev)).clone().requires_grad_(True)            # :46-49
+    x_omic_adv = ops._f32(x_omic.detach().to(dev)).clone().requires_grad_(True)
+    grade = grade.to(dev)
+    model.eval()                                                                           # :62
+    try:
+        out = model(x_path=x_path_adv, x_grph=x_grph, x_omic=x_omic_adv)                  # :63
+        pred = out[5]
+        if not pred.requires_grad:
+            raise RuntimeError("the fused prediction does not depend on the inputs (cut_fuse_grad?): the reference's "
+                               "gradient hooks would never fire either")
+        cost = ops.NLLFn.apply(pred, grade, float(pred.shape[0]))                          # :66
+        x_path_grad, x_omic_grad = torch.autograd.grad(cost, [x_path_adv, x_omic_adv])     # :67-75
+        masks = masks_from_input_gradients(opt, x_path_grad, x_omic_grad, sp_mask, num_superpixels)
+    finally:
+        model.train()                                                                      # :99
+    return masks

@@ -766,12 +766,36 @@ class TeacherStage1Step:
         opt = self.opt
         if epoch >= 15:
             opt.CRD_weight = 0.01                                                                # train_test_MT.py:118-119
-        (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
+        views, x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
+        sp_mask = x_path_m_v1 = x_path_m_v2 = None
+        if len(views) == 6:      # the MIA-2023 loader (train_test_MT_SP_Masking.py:185): superpixel maps and two masked views
+            x_path, sp_mask, ema_x_path, _, x_path_m_v1, x_path_m_v2 = views
+        else:
+            x_path, ema_x_path = views
         dev = self.device
         x_path, ema_x_path = x_path.to(dev, non_blocking=True), ema_x_path.to(dev, non_blocking=True)
         x_omic, grade = x_omic.to(dev, non_blocking=True), grade.to(dev, non_blocking=True)
         B = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))   # global batch
         self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)
+        loss_masking = torch.zeros((), device=dev)
+        if getattr(opt, "masking", 0) and epoch > opt.start_epoch:                              # MIA-2023 :198-220
+            # superpixel attention: mask the Path_K superpixels / Omic_K genes the fused prediction is most sensitive to
+            # and ask the two masked views to agree with the mean teacher's predictions on the loader's masked views
+            from . import superpixel as SPX
+            if sp_mask is None:
+                raise ValueError("opt.masking needs the 6-view loader tuple (x_path, sp_mask, ema_x_path, ema_sp_mask, "
+                                 "x_path_m_v1, x_path_m_v2)")
+            for mod in self.model.modules():
+                if hasattr(mod, "_get_workspace"):
+                    mod._multi_forward = True     # three taped forwards of the same trunk before one backward
+            pm, om = SPX.superpixel_attention_mask(opt, self.optimizer, self.model, x_path, x_grph, x_omic, sp_mask, grade,
+                                                   dev, getattr(opt, "num_superpixels_max", None))
+            pred_m1 = self.model(x_path=SPX.apply_mask(x_path, pm), x_omic=x_omic)[5]            # :204-205
+            pred_m2 = self.model(x_path=x_path, x_omic=SPX.apply_mask(x_omic, om))[5]            # :207-208
+            with torch.no_grad():
+                ema_m1 = self.ema_model(x_path=x_path_m_v1.to(dev), x_omic=x_omic)[5]             # :211-215
+                ema_m2 = self.ema_model(x_path=x_path_m_v2.to(dev), x_omic=x_omic)[5]
+            loss_masking = self.pred_KD_loss(pred_m1, ema_m1, B) + self.pred_KD_loss(pred_m2, ema_m2, B)   # :217-220
         fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
             x_path=x_path, x_omic=x_omic)                                                        # :137
         with torch.no_grad():
@@ -801,7 +825,7 @@ class TeacherStage1Step:
             loss_pred_KD = torch.zeros((), device=dev)
         nll = lambda p: ops.NLLFn.apply(p, grade, B)
         loss_nll = nll(pred_path) + nll(pred_omic) + nll(pred)                                  # :208-212
-        loss = opt.lambda_nll * loss_nll + loss_CRD + loss_pred_KD                              # :214 (reg_type none)
+        loss = opt.lambda_nll * loss_nll + loss_CRD + loss_pred_KD + loss_masking               # :214 (reg_type none); MIA-2023 :303-304
         loss_orth = torch.zeros((), device=dev)
         if self.orth_on:
             loss_orth = self.Orth_loss(path_feat, omic_feat)                                    # :216-218
@@ -853,4 +877,5 @@ class TeacherStage1Step:
         self.iter_num += 1
         return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),
                     loss_CRD=loss_CRD.detach(), loss_orth=loss_orth.detach(), loss_tsvd=loss_tsvd.detach(),
+                    loss_pred_KD_masking=loss_masking.detach(),
                     pred=pred.detach(), pred_path=pred_path.detach(), pred_omic=pred_omic.detach())

@@ -437,3 +437,50 @@ def test_superpixel_attention_masks_vs_reference_golden(golden_dir):
         # bitwise reproducible (order-independent fixed-point accumulation)
         mask2, mean2 = m.superpixel.superpixel_topk_mask(grad, sp, PK, return_mean=True)
         assert torch.equal(mean, mean2) and torch.equal(mask, mask2)
+
+
+def test_superpixel_attention_mask_end_to_end_vs_reference_function(golden_dir):
+    """Row f-4 end to end: superpixel.superpixel_attention_mask (eval-mode PathomicNet forward, gradient of the fused NLL
+    down to the image and the omic vector, aggregation, top-K masks) against the reference's own function run on the
+    reference's network (tests/golden/make_golden_sp_attention.py).  Gradients at 1e-3 of their maximum (parity mode);
+    the masks equal the reference's wherever the ranking is not decided by a margin below that tolerance."""
+    import types
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    g = np.load(os.path.join(golden_dir, "sp_attention_b4_h64.npz"))
+    B, H = int(g["B"]), int(g["H"])
+    m.set_precision("bf16x6")
+    try:
+        opt = default_opt(dropout_rate=float(g["dropout_rate"]), cut_fuse_grad=False)
+        model = m.define_net(opt, 1)
+        model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+        model = model.cuda().train()
+        bt = synthetic_batch(B, H, seed=620)
+        sp = torch.as_tensor(g["sp_mask"])
+        o = types.SimpleNamespace(Path_K=int(g["Path_K"]), Omic_K=int(g["Omic_K"]))
+        # the gradients themselves
+        model.eval()
+        xp = bt["x_path"].cuda().requires_grad_(True); xo = bt["x_omic"].cuda().requires_grad_(True)
+        pred = model(x_path=xp, x_grph=None, x_omic=xo)[5]
+        cost = m.ops.NLLFn.apply(pred, bt["grade"].cuda(), float(B))
+        gp, go = torch.autograd.grad(cost, [xp, xo])
+        assert abs(float(cost) - float(g["cost"])) <= 1e-3 * abs(float(g["cost"]))
+        for got, key in ((gp, "x_path_grad"), (go, "x_omic_grad")):
+            ref = g[key]
+            assert np.abs(got.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), key
+        model.train()
+        pm, om = m.superpixel.superpixel_attention_mask(o, None, model, bt["x_path"], torch.zeros(B), bt["x_omic"], sp,
+                                                        bt["grade"], "cuda")
+        assert model.training
+        # masks: exact unless a rank is decided within the gradient tolerance
+        _, mean_ref = m.superpixel.superpixel_topk_mask(torch.as_tensor(g["x_path_grad"]).cuda(), sp.cuda(), o.Path_K, return_mean=True)
+        for b in range(B):
+            if not np.array_equal(pm[b].cpu().numpy(), g["path_mask"][b]):
+                srt = np.sort(mean_ref[b].cpu().numpy())[::-1]
+                margin = srt[o.Path_K - 1] - srt[o.Path_K]
+                assert margin <= 2e-3 * np.abs(srt).max(), (b, margin)
+        assert (pm.cpu().numpy() != g["path_mask"]).mean() < 0.05
+        assert (om.cpu().numpy() != g["omic_mask"]).mean() < 0.01
+    finally:
+        m.set_precision("bf16")

@@ -624,3 +624,56 @@ def test_fused_loss_head_equals_generic_autograd_path():
         print(f"\nfused vs generic loss head: worst relative gradient difference {worst[1]:.2e} at {worst[0]}")
     finally:
         m.set_precision("bf16")
+
+
+def test_stage1_step_with_superpixel_masking_terms():
+    """MIA-2023 stage-1 batch body (train_test_MT_SP_Masking.py:185-330): with opt.masking the step adds the two
+    masked-view consistency terms.  Every component is pinned against the reference on its own (the attention masks
+    end to end, pred_KD_loss, the network forwards); here the wiring: the term equals an independent evaluation of
+    :198-220 through the module-level API on a copy of the model, three taped forwards of one trunk back-propagate
+    (gradients differ from the step without masking), epoch <= start_epoch switches the term off."""
+    import copy
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import synthetic_batch
+    from tests.golden.make_golden_superpixel import label_map
+    B, H = 4, 64
+    m.set_precision("bf16x6")
+    try:
+        def build():
+            opt = m.stage2_opt(dropout_rate=0.0, batch_size=B, cut_fuse_grad=False, num_teachers=2)
+            opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, 1.0, 0, 0, "False"
+            opt.masking, opt.start_epoch, opt.Path_K, opt.Omic_K = 1, 1, 5, 8
+            model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+            model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3)); ema.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 4))
+            return m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda())), opt
+        bt = synthetic_batch(B, H, seed=630)
+        gen = torch.Generator().manual_seed(41)
+        sp = label_map(B, H, H, 6, gen)
+        v1 = bt["x_path"] * (torch.rand(B, 1, H, H, generator=gen) > 0.2)
+        v2 = bt["x_path"] * (torch.rand(B, 1, H, H, generator=gen) > 0.2)
+        z = torch.zeros(B)
+        batch = ((bt["x_path"], sp, bt["ema_x_path"], sp, v1, v2), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"])
+        st, opt = build()
+        # independent evaluation of :198-220 on a copy (the step updates running statistics and weights)
+        ref_model, ref_ema = copy.deepcopy(st.model), copy.deepcopy(st.ema_model)
+        xp, xo = bt["x_path"].cuda(), bt["x_omic"].cuda()
+        pm, om = m.superpixel.superpixel_attention_mask(opt, None, ref_model, xp, z, xo, sp, bt["grade"], "cuda")
+        with torch.no_grad():
+            p1 = ref_model(x_path=m.superpixel.apply_mask(xp, pm), x_omic=xo)[5]
+            p2 = ref_model(x_path=xp, x_omic=m.superpixel.apply_mask(xo, om))[5]
+            e1 = ref_ema(x_path=v1.cuda(), x_omic=xo)[5]; e2 = ref_ema(x_path=v2.cuda(), x_omic=xo)[5]
+            expect = m.TeacherStage1Step.pred_KD_loss(p1, e1) + m.TeacherStage1Step.pred_KD_loss(p2, e2)
+        assert float(pm.sum()) > 0 and float(om.sum()) == B * 8
+        out = st.step(batch, epoch=2)
+        assert torch.isfinite(out["loss"]) and float(out["loss_pred_KD_masking"]) > 0
+        assert abs(float(out["loss_pred_KD_masking"]) - float(expect)) <= 1e-4 * max(abs(float(expect)), 1e-3)
+        g_mask = st.optimizer.flat.grad.clone()
+        st0, _ = build()
+        out0 = st0.step(batch, epoch=1)                      # epoch <= start_epoch: term off
+        assert float(out0["loss_pred_KD_masking"]) == 0.0
+        assert abs(float(out["loss"]) - float(out0["loss"]) - float(out["loss_pred_KD_masking"])) <= 1e-3 * abs(float(out["loss"]))
+        g0 = st0.optimizer.flat.grad
+        assert torch.isfinite(g_mask).all() and float((g_mask - g0).abs().max()) > 1e-6 * float(g0.abs().max())
+    finally:
+        m.set_precision("bf16")
