@@ -26,6 +26,7 @@ from .sampler import ContrastIndexSampler
 from . import tsvd
 from . import evaluate
 from . import superpixel
+from . import augment
 from .options import stage2_opt
 
 __all__ = ["build", "lib", "set_precision", "get_precision", "init_net", "init_max_weights", "count_parameters",

@@ -1,0 +1,184 @@
+// On-device input pipeline of the training loader (reference MICCAI-2022/data_loaders_MT.py:168-175,
+// 51-53: TransformTwice(Compose([RandomHorizontalFlip, RandomVerticalFlip, RandomCrop(input_size_path),
+// ColorJitter(0.1, 0.1, 0.05, 0.01), ToTensor, Normalize(0.5, 0.5)])) run by PIL in four DataLoader workers).
+// Source images stay uint8 [B][SH][SW][3] in HBM; one launch draws the per-(image, view) parameters, one computes the
+// grey mean the contrast step needs, one writes both fp32 NCHW views.  Byte work, HBM-bound: 0.8 MB read + 3 MB written
+// per 512 x 512 view.
+//
+// torchvision / PIL are not in this image, so the colour arithmetic is RESTATED from their documented algorithms and is
+// "parity unpinned" (see oracle/augment.py, which states the same arithmetic in numpy and is what the tests compare
+// against): PIL ImageEnhance = Image.blend(degenerate, image, factor) on uint8 with truncation; brightness blends with
+// black, contrast with the rounded mean of the ITU-R 601-2 luma, saturation with the per-pixel luma; the four steps run
+// in a random order; hue shifts H in a float HSV round trip.
+#include "ph_common.h"
+#include "ph_kernels.h"
+
+namespace {
+
+constexpr int AP = 16;   // floats per (image, view) parameter row:
+// 0 flipH 1 flipV 2 top 3 left 4 brightness 5 contrast 6 saturation 7 hue 8..11 order (0 b, 1 c, 2 s, 3 h) 12 grey mean
+
+__device__ __forceinline__ uint64_t amix(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t h) { return (float)(h >> 40) * (1.0f / 16777216.0f); }
+
+__global__ void augment_params_kernel(float* __restrict__ params, int n, uint64_t seed, const uint64_t* __restrict__ step,
+                                      int SH, int SW, int S, float jb, float jc, float js, float jh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (image, view)
+  if (i >= n) return;
+  const uint64_t st = step ? step[0] : 0;
+  const uint64_t base = amix(seed ^ amix(st * 0x9E3779B97F4A7C15ull + (uint64_t)i + 1));
+  float* p = params + (size_t)i * AP;
+  p[0] = (amix(base ^ 1) >> 63) ? 1.f : 0.f;
+  p[1] = (amix(base ^ 2) >> 63) ? 1.f : 0.f;
+  p[2] = (float)(amix(base ^ 3) % (uint64_t)(SH - S + 1));
+  p[3] = (float)(amix(base ^ 4) % (uint64_t)(SW - S + 1));
+  p[4] = 1.f - jb + 2.f * jb * u01(amix(base ^ 5));
+  p[5] = 1.f - jc + 2.f * jc * u01(amix(base ^ 6));
+  p[6] = 1.f - js + 2.f * js * u01(amix(base ^ 7));
+  p[7] = -jh + 2.f * jh * u01(amix(base ^ 8));
+  int idx = (int)(amix(base ^ 9) % 24), pool[4] = {0, 1, 2, 3};
+  for (int k = 0, f = 6; k < 4; ++k) {   // factorial-base decode of one of the 24 orders
+    const int q = idx / f; idx %= f;
+    p[8 + k] = (float)pool[q];
+    for (int t = q; t < 3 - k; ++t) pool[t] = pool[t + 1];
+    if (k < 3) f /= (3 - k);
+  }
+  p[12] = 0.f; p[13] = p[14] = p[15] = 0.f;
+}
+
+__device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+// PIL ImagingBlend on one uint8 channel: degenerate d, image v, factor f
+__device__ __forceinline__ int blend8(int d, int v, float f) {
+  const float t = __fadd_rn((float)d, __fmul_rn(f, (float)(v - d)));
+  if (f >= 0.f && f <= 1.f) return (int)t;
+  return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
+}
+
+__device__ __forceinline__ void hue_shift(int& r, int& g, int& b, float hf) {
+  const float R = r / 255.f, G = g / 255.f, B = b / 255.f;
+  const float mx = fmaxf(R, fmaxf(G, B)), mn = fminf(R, fminf(G, B)), d = mx - mn;
+  float h = 0.f;
+  if (d > 0.f) {
+    if (mx == R) h = (G - B) / d;
+    else if (mx == G) h = 2.f + (B - R) / d;
+    else h = 4.f + (R - G) / d;
+    h /= 6.f;
+    h -= floorf(h);
+  }
+  const float s = mx > 0.f ? d / mx : 0.f, v = mx;
+  h += hf;
+  h -= floorf(h);
+  const float h6 = h * 6.f;
+  const int i = (int)floorf(h6) % 6;
+  const float fr = h6 - floorf(h6);
+  const float p = v * (1.f - s), q = v * (1.f - s * fr), t = v * (1.f - s * (1.f - fr));
+  float rr, gg, bb;
+  switch (i) {
+    case 0: rr = v; gg = t; bb = p; break;
+    case 1: rr = q; gg = v; bb = p; break;
+    case 2: rr = p; gg = v; bb = t; break;
+    case 3: rr = p; gg = q; bb = v; break;
+    case 4: rr = t; gg = p; bb = v; break;
+    default: rr = v; gg = p; bb = q; break;
+  }
+  r = min(255, max(0, (int)rintf(rr * 255.f)));
+  g = min(255, max(0, (int)rintf(gg * 255.f)));
+  b = min(255, max(0, (int)rintf(bb * 255.f)));
+}
+
+// the colour steps in their drawn order; stops in front of the contrast step when `until_contrast`
+__device__ __forceinline__ void jitter(int& r, int& g, int& b, const float* p, bool until_contrast) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int op = (int)p[8 + k];
+    if (op == 0) { r = blend8(0, r, p[4]); g = blend8(0, g, p[4]); b = blend8(0, b, p[4]); }
+    else if (op == 1) {
+      if (until_contrast) return;
+      const int m = (int)p[12];
+      r = blend8(m, r, p[5]); g = blend8(m, g, p[5]); b = blend8(m, b, p[5]);
+    } else if (op == 2) { const int l = luma(r, g, b); r = blend8(l, r, p[6]); g = blend8(l, g, p[6]); b = blend8(l, b, p[6]); }
+    else hue_shift(r, g, b, p[7]);
+  }
+}
+
+__device__ __forceinline__ void fetch(const uint8_t* __restrict__ src, const float* p, int b, int SH, int SW, int y, int x, int& r,
+                                      int& g, int& bl) {
+  int sy = (int)p[2] + y, sx = (int)p[3] + x;              // crop window of the flipped image ...
+  if (p[1] != 0.f) sy = SH - 1 - sy;                       // ... = mirrored coordinates of the source
+  if (p[0] != 0.f) sx = SW - 1 - sx;
+  const uint8_t* q = src + (((size_t)b * SH + sy) * SW + sx) * 3;
+  r = q[0]; g = q[1]; bl = q[2];
+}
+
+// grey mean (PIL: int(ImageStat.Stat(image.convert("L")).mean[0] + 0.5)) of the image as it enters the contrast step
+__global__ __launch_bounds__(1024) void augment_mean_kernel(const uint8_t* __restrict__ src, float* __restrict__ params, int SH,
+                                                            int SW, int S) {
+  __shared__ unsigned long long red[1024];
+  const int iv = blockIdx.x, b = iv >> 1;
+  float* p = params + (size_t)iv * AP;
+  unsigned long long s = 0;
+  for (int e = threadIdx.x; e < S * S; e += 1024) {
+    int r, g, bl;
+    fetch(src, p, b, SH, SW, e / S, e % S, r, g, bl);
+    jitter(r, g, bl, p, true);
+    s += (unsigned long long)luma(r, g, bl);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) p[12] = (float)(int)((double)red[0] / ((double)S * (double)S) + 0.5);
+}
+
+// both views: out_v[b][c][y][x] = (jittered / 255 - 0.5) / 0.5
+__global__ void augment_apply_kernel(const uint8_t* __restrict__ src, const float* __restrict__ params, float* __restrict__ out0,
+                                     float* __restrict__ out1, int B, int SH, int SW, int S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t per = (size_t)S * S;
+  if (i >= (size_t)B * 2 * per) return;
+  const int iv = (int)(i / per), b = iv >> 1, v = iv & 1;
+  const int e = (int)(i % per);
+  const float* p = params + (size_t)iv * AP;
+  int r, g, bl;
+  fetch(src, p, b, SH, SW, e / S, e % S, r, g, bl);
+  jitter(r, g, bl, p, false);
+  float* o = (v ? out1 : out0) + (size_t)b * 3 * per + e;
+  o[0] = ((float)r / 255.f - 0.5f) / 0.5f;
+  o[per] = ((float)g / 255.f - 0.5f) / 0.5f;
+  o[2 * per] = ((float)bl / 255.f - 0.5f) / 0.5f;
+}
+
+}  // namespace
+
+#include "pathomic_hip.h"
+
+extern "C" {
+
+int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step, int SH, int SW, int S, float brightness,
+                      float contrast, float saturation, float hue, hipStream_t st) {
+  if (!params || B < 1 || S < 1 || S > SH || S > SW) return PH_EINVAL;
+  hipLaunchKernelGGL(augment_params_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, params, 2 * B, seed, step, SH, SW, S,
+                     brightness, contrast, saturation, hue);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_augment_apply(const uint8_t* src, float* params, float* out0, float* out1, int B, int SH, int SW, int S, hipStream_t st) {
+  if (!src || !params || !out0 || !out1 || B < 1 || S < 1 || S > SH || S > SW) return PH_EINVAL;
+  hipLaunchKernelGGL(augment_mean_kernel, dim3(2 * B), dim3(1024), 0, st, src, params, SH, SW, S);
+  PH_LAUNCH_CHECK();
+  const size_t n = (size_t)B * 2 * S * S;
+  hipLaunchKernelGGL(augment_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, params, out0, out1, B, SH, SW, S);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+}  // extern "C"

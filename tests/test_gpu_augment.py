@@ -1,0 +1,89 @@
+"""On-device input pipeline against the numpy restatement of the loader's transform
+(oracle/augment.py; the colour arithmetic is parity-unpinned - torchvision / PIL are absent) and for the
+structural rules that do not depend on it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _src(B, SH, SW, seed):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randint(0, 256, (B, SH // 8, SW // 8, 3), generator=g, dtype=torch.uint8)
+    img = base.repeat_interleave(8, 1).repeat_interleave(8, 2).int() + torch.randint(-20, 21, (B, SH, SW, 3), generator=g)
+    return img.clamp(0, 255).to(torch.uint8)
+
+
+def _opt(S):
+    import types
+    return types.SimpleNamespace(input_size_path=S)
+
+
+def test_apply_equals_oracle_for_given_draws():
+    """All 24 step orders, both flips, crops at the corners, factors on both sides of 1: every output pixel equals the
+    oracle's (hue rounds a float HSV round trip: at most one grey level = 2/255 apart there)."""
+    import itertools
+    import multimodal_learning_amd as m
+    from oracle import augment as OA
+    B, SH, SW, S = 12, 96, 80, 64
+    src = _src(B, SH, SW, 1)
+    orders = list(itertools.permutations(range(4)))
+    rng = np.random.default_rng(0)
+    prm = torch.zeros(B, 2, 16)
+    dicts = {}
+    for b in range(B):
+        for v in range(2):
+            k = b * 2 + v
+            d = dict(flipH=int(k & 1), flipV=int((k >> 1) & 1), top=int([0, SH - S, rng.integers(0, SH - S + 1)][k % 3]),
+                     left=int([SW - S, 0, rng.integers(0, SW - S + 1)][k % 3]), S=S, b=float(np.float32(rng.uniform(0.9, 1.1))),
+                     c=float(np.float32(rng.uniform(0.9, 1.1))), s=float(np.float32(rng.uniform(0.95, 1.05))),
+                     h=float(np.float32(rng.uniform(-0.01, 0.01))), order=orders[k])
+            dicts[(b, v)] = d
+            prm[b, v, :12] = torch.tensor([d["flipH"], d["flipV"], d["top"], d["left"], d["b"], d["c"], d["s"], d["h"], *d["order"]])
+    aug = m.augment.DeviceAugment(_opt(S))
+    o0, o1 = aug(src.cuda(), params=prm)
+    outs = (o0.cpu().numpy(), o1.cpu().numpy())
+    worst = 0.0
+    for (b, v), d in dicts.items():
+        ref, mean = OA.one_view(src[b].numpy(), d)
+        assert int(aug.last_params[b, v, 12]) == mean, (b, v)
+        worst = max(worst, float(np.abs(outs[v][b] - ref).max()))
+        assert (np.abs(outs[v][b] - ref) > 1e-6).mean() < 0.02, (b, v)
+    assert worst <= 2.0 / 255 * 2 + 1e-6, worst
+
+
+def test_neutral_jitter_is_crop_flip_normalise_exactly():
+    import multimodal_learning_amd as m
+    B, SH, SW, S = 3, 72, 88, 48
+    src = _src(B, SH, SW, 2)
+    prm = torch.zeros(B, 2, 16)
+    prm[:, :, 4:7] = 1.0
+    prm[:, :, 8:12] = torch.tensor([2.0, 0.0, 3.0, 1.0])
+    prm[:, 0, 0] = 1; prm[:, 1, 1] = 1
+    prm[:, :, 2] = 5; prm[:, :, 3] = 11
+    o0, o1 = m.augment.DeviceAugment(_opt(S))(src.cuda(), params=prm)
+    f = src.float() / 255
+    v0 = f.flip(2)[:, 5:5 + S, 11:11 + S].permute(0, 3, 1, 2)
+    v1 = f.flip(1)[:, 5:5 + S, 11:11 + S].permute(0, 3, 1, 2)
+    assert torch.equal(o0.cpu(), (v0 - 0.5) / 0.5) and torch.equal(o1.cpu(), (v1 - 0.5) / 0.5)
+
+
+def test_device_draws_are_in_range_reproducible_and_spread():
+    import multimodal_learning_amd as m
+    B, SH, SW, S = 256, 40, 48, 32
+    src = _src(4, SH, SW, 3).repeat(64, 1, 1, 1).cuda()
+    a1 = m.augment.DeviceAugment(_opt(S), seed=7); a2 = m.augment.DeviceAugment(_opt(S), seed=7)
+    x1 = a1(src); p1 = a1.last_params.cpu(); x2 = a2(src); p2 = a2.last_params.cpu()
+    assert torch.equal(p1, p2) and torch.equal(x1[0], x2[0]) and torch.equal(x1[1], x2[1])
+    a1(src); p3 = a1.last_params.cpu()
+    assert not torch.equal(p1, p3)                                   # the step counter moves the stream
+    p = p1.reshape(-1, 16).numpy()
+    assert set(np.unique(p[:, 0])) <= {0.0, 1.0} and 0.35 < p[:, 0].mean() < 0.65 and 0.35 < p[:, 1].mean() < 0.65
+    assert p[:, 2].min() >= 0 and p[:, 2].max() <= SH - S and p[:, 3].max() <= SW - S and len(np.unique(p[:, 3])) > 8
+    for col, lo, hi in ((4, 0.9, 1.1), (5, 0.9, 1.1), (6, 0.95, 1.05), (7, -0.01, 0.01)):
+        assert p[:, col].min() >= lo - 1e-6 and p[:, col].max() <= hi + 1e-6 and p[:, col].std() > 0.2 * (hi - lo)
+    orders = {tuple(r) for r in p[:, 8:12].astype(int).tolist()}
+    assert all(sorted(o) == [0, 1, 2, 3] for o in orders) and len(orders) == 24
+    assert not torch.equal(x1[0], x1[1])                             # the two views are drawn independently
+    assert float(x1[0].min()) >= -1.0 and float(x1[0].max()) <= 1.0

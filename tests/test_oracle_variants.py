@@ -179,3 +179,22 @@ def test_sampler_rule_restatement_properties():
         assert len(set(s[1:20].tolist())) == 19 and len(set(s[20:].tolist())) == 64
         s2 = sample_item(rng, index, g, cp, cn, 500, 20, 700, neg_mode="all_others")       # K > list: with replacement
         assert (s2[20:] != index).all() and len(set(s2[20:].tolist())) < 700
+
+
+def test_augment_oracle_structure():
+    """oracle/augment.py (numpy restatement of the loader transform, parity unpinned for the colour arithmetic): neutral
+    factors reduce it to flip + crop + normalise exactly; a brightness factor scales with truncation; the contrast mean is
+    the rounded luma mean of the image as it enters that step."""
+    from oracle import augment as OA
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    base = dict(flipH=1, flipV=1, top=4, left=9, S=32, b=1.0, c=1.0, s=1.0, h=0.0, order=(0, 1, 2, 3))
+    out, mean = OA.one_view(src, base)
+    ref = src[::-1, ::-1][4:36, 9:41].astype(np.float32).transpose(2, 0, 1) / 255
+    assert np.abs(out - (ref - 0.5) / 0.5).max() <= 2.0 / 255 * 2     # (neutral hue: float HSV round trip, <= 1 level)
+    assert mean == int(OA.luma(src[::-1, ::-1][4:36, 9:41]).mean() + 0.5)
+    out_b, _ = OA.one_view(src, dict(base, b=0.5, order=(0, 2, 1, 3), h=0.0, flipH=0, flipV=0))
+    crop = src[4:36, 9:41].astype(np.int64)
+    half = (crop * 0.5).astype(np.int64)
+    got = np.rint((out_b * 0.5 + 0.5) * 255).astype(np.int64).transpose(1, 2, 0)
+    assert np.abs(got - half).max() <= 1
