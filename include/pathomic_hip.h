@@ -271,7 +271,7 @@ int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, s
  * ph_augment_params (counter RNG keyed by seed, *step, image, view) or supplied by the caller.  ph_augment_apply writes the
  * two views as f32 [B][3][S][S] in [-1, 1].  The colour arithmetic restates PIL / torchvision (absent here): parity
  * unpinned, see csrc/augment.hip and oracle/augment.py. */
-int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step /* device; may be NULL */, int SH, int SW,
+int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step /* device pointer or NULL */, int SH, int SW,
                       int S, float brightness, float contrast, float saturation, float hue, ph_stream_t stream);
 int ph_augment_apply(const uint8_t* src, float* params, float* out0, float* out1, int B, int SH, int SW, int S,
                      ph_stream_t stream);
