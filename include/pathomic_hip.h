@@ -268,7 +268,7 @@ int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, s
  * RandomHorizontalFlip, RandomVerticalFlip, RandomCrop(S), ColorJitter(b, c, s, h), ToTensor, Normalize(0.5, 0.5)]))).
  * src: uint8 [B][SH][SW][3].  params: [B][2 views][16] f32 rows {flipH, flipV, top, left, brightness, contrast,
  * saturation, hue, order[4] (0 b, 1 c, 2 s, 3 h), grey mean (filled by ph_augment_apply), pad[3]} - drawn on the device by
- * ph_augment_params (counter RNG keyed by seed, *step, image, view) or supplied by the caller.  ph_augment_apply writes the
+ * ph_augment_params - a counter RNG keyed by seed, *step, image and view - or supplied by the caller.  ph_augment_apply writes the
  * two views as f32 [B][3][S][S] in [-1, 1].  The colour arithmetic restates PIL / torchvision (absent here): parity
  * unpinned, see csrc/augment.hip and oracle/augment.py. */
 int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step /* device pointer or NULL */, int SH, int SW,
