@@ -267,7 +267,7 @@ int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, s
 /* On-device input pipeline (reference MICCAI-2022/data_loaders_MT.py:168-175 TransformTwice(Compose([
  * RandomHorizontalFlip, RandomVerticalFlip, RandomCrop(S), ColorJitter(b, c, s, h), ToTensor, Normalize(0.5, 0.5)]))).
  * src: uint8 [B][SH][SW][3].  params: [B][2 views][16] f32 rows {flipH, flipV, top, left, brightness, contrast,
- * saturation, hue, order[4] (0 b, 1 c, 2 s, 3 h), grey mean (filled by ph_augment_apply), pad[3]} - drawn on the device by
+ * saturation, hue, order[4] (0 b, 1 c, 2 s, 3 h), grey mean (filled by ph_augment_apply), pad, 64-bit grey-sum accumulator (zero on entry)} - drawn on the device by
  * ph_augment_params - a counter RNG keyed by seed, *step, image and view - or supplied by the caller.  ph_augment_apply writes the
  * two views as f32 [B][3][S][S] in [-1, 1].  The colour arithmetic restates PIL / torchvision (absent here): parity
  * unpinned, see csrc/augment.hip and oracle/augment.py. */

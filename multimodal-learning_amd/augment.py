@@ -37,6 +37,7 @@ class DeviceAugment:
             self.step += 1
         else:
             params = params.to(src.device).float().contiguous().clone()
+            params[..., 12:] = 0          # the grey-sum accumulator slot
         out0 = torch.empty(B, 3, S, S, device=src.device, dtype=torch.float32)
         out1 = torch.empty_like(out0)
         check(lib().ph_augment_apply(ptr(src), ptr(params), ptr(out0), ptr(out1), B, SH, SW, S, stream()), "ph_augment_apply")

@@ -17,6 +17,7 @@ namespace {
 
 constexpr int AP = 16;   // floats per (image, view) parameter row:
 // 0 flipH 1 flipV 2 top 3 left 4 brightness 5 contrast 6 saturation 7 hue 8..11 order (0 b, 1 c, 2 s, 3 h) 12 grey mean
+// 14..15: the 64-bit integer grey sum (must be zero on entry to ph_augment_apply)
 
 __device__ __forceinline__ uint64_t amix(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;
@@ -93,14 +94,14 @@ __device__ __forceinline__ void hue_shift(int& r, int& g, int& b, float hf) {
 }
 
 // the colour steps in their drawn order; stops in front of the contrast step when `until_contrast`
-__device__ __forceinline__ void jitter(int& r, int& g, int& b, const float* p, bool until_contrast) {
+__device__ __forceinline__ void jitter(int& r, int& g, int& b, const float* p, int mean, bool until_contrast) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int op = (int)p[8 + k];
     if (op == 0) { r = blend8(0, r, p[4]); g = blend8(0, g, p[4]); b = blend8(0, b, p[4]); }
     else if (op == 1) {
       if (until_contrast) return;
-      const int m = (int)p[12];
+      const int m = mean;
       r = blend8(m, r, p[5]); g = blend8(m, g, p[5]); b = blend8(m, b, p[5]);
     } else if (op == 2) { const int l = luma(r, g, b); r = blend8(l, r, p[6]); g = blend8(l, g, p[6]); b = blend8(l, b, p[6]); }
     else hue_shift(r, g, b, p[7]);
@@ -116,26 +117,34 @@ __device__ __forceinline__ void fetch(const uint8_t* __restrict__ src, const flo
   r = q[0]; g = q[1]; bl = q[2];
 }
 
-// grey mean (PIL: int(ImageStat.Stat(image.convert("L")).mean[0] + 0.5)) of the image as it enters the contrast step
-__global__ __launch_bounds__(1024) void augment_mean_kernel(const uint8_t* __restrict__ src, float* __restrict__ params, int SH,
-                                                            int SW, int S) {
-  __shared__ unsigned long long red[1024];
+// grey sum (PIL: int(ImageStat.Stat(image.convert("L")).mean[0] + 0.5)) of the image as it enters the contrast step:
+// MSPLIT workgroups per (image, view) add their exact integer partial sums to the 64-bit slot of the parameter row
+constexpr int MSPLIT = 16;
+__global__ __launch_bounds__(256) void augment_mean_kernel(const uint8_t* __restrict__ src, float* __restrict__ params, int SH,
+                                                           int SW, int S) {
+  __shared__ unsigned long long red[256];
   const int iv = blockIdx.x, b = iv >> 1;
   float* p = params + (size_t)iv * AP;
   unsigned long long s = 0;
-  for (int e = threadIdx.x; e < S * S; e += 1024) {
+  const int n = S * S, per = (n + MSPLIT - 1) / MSPLIT, lo = blockIdx.y * per, hi = min(n, lo + per);
+  for (int e = lo + threadIdx.x; e < hi; e += 256) {
     int r, g, bl;
     fetch(src, p, b, SH, SW, e / S, e % S, r, g, bl);
-    jitter(r, g, bl, p, true);
+    jitter(r, g, bl, p, 0, true);
     s += (unsigned long long)luma(r, g, bl);
   }
   red[threadIdx.x] = s;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) p[12] = (float)(int)((double)red[0] / ((double)S * (double)S) + 0.5);
+  if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(p + 14), red[0]);
+}
+
+__device__ __forceinline__ int grey_mean(const float* p, int S) {
+  const unsigned long long sum = *reinterpret_cast<const unsigned long long*>(p + 14);
+  return (int)((double)sum / ((double)S * (double)S) + 0.5);
 }
 
 // both views: out_v[b][c][y][x] = (jittered / 255 - 0.5) / 0.5
@@ -149,11 +158,16 @@ __global__ void augment_apply_kernel(const uint8_t* __restrict__ src, const floa
   const float* p = params + (size_t)iv * AP;
   int r, g, bl;
   fetch(src, p, b, SH, SW, e / S, e % S, r, g, bl);
-  jitter(r, g, bl, p, false);
+  jitter(r, g, bl, p, grey_mean(p, S), false);
   float* o = (v ? out1 : out0) + (size_t)b * 3 * per + e;
   o[0] = ((float)r / 255.f - 0.5f) / 0.5f;
   o[per] = ((float)g / 255.f - 0.5f) / 0.5f;
   o[2 * per] = ((float)bl / 255.f - 0.5f) / 0.5f;
+}
+
+__global__ void augment_publish_mean_kernel(float* __restrict__ params, int n, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) params[(size_t)i * AP + 12] = (float)grey_mean(params + (size_t)i * AP, S);
 }
 
 }  // namespace
@@ -173,7 +187,9 @@ int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step,
 
 int ph_augment_apply(const uint8_t* src, float* params, float* out0, float* out1, int B, int SH, int SW, int S, hipStream_t st) {
   if (!src || !params || !out0 || !out1 || B < 1 || S < 1 || S > SH || S > SW) return PH_EINVAL;
-  hipLaunchKernelGGL(augment_mean_kernel, dim3(2 * B), dim3(1024), 0, st, src, params, SH, SW, S);
+  hipLaunchKernelGGL(augment_mean_kernel, dim3(2 * B, MSPLIT), dim3(256), 0, st, src, params, SH, SW, S);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(augment_publish_mean_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, params, 2 * B, S);
   PH_LAUNCH_CHECK();
   const size_t n = (size_t)B * 2 * S * S;
   hipLaunchKernelGGL(augment_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, params, out0, out1, B, SH, SW, S);
