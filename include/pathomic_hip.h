@@ -266,15 +266,15 @@ int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, s
 
 /* On-device input pipeline (reference MICCAI-2022/data_loaders_MT.py:168-175 TransformTwice(Compose([
  * RandomHorizontalFlip, RandomVerticalFlip, RandomCrop(S), ColorJitter(b, c, s, h), ToTensor, Normalize(0.5, 0.5)]))).
- * src: uint8 [B][SH][SW][3].  params: [B][2 views][16] f32 rows {flipH, flipV, top, left, brightness, contrast,
+ * src: uint8 [n][SH][SW][3] tiles resident in HBM (the batch is rows[0..B) of it, or the first B tiles).  params: [B][2 views][16] f32 rows {flipH, flipV, top, left, brightness, contrast,
  * saturation, hue, order[4] (0 b, 1 c, 2 s, 3 h), grey mean (filled by ph_augment_apply), pad, 64-bit grey-sum accumulator (zero on entry)} - drawn on the device by
  * ph_augment_params - a counter RNG keyed by seed, *step, image and view - or supplied by the caller.  ph_augment_apply writes the
  * two views as f32 [B][3][S][S] in [-1, 1].  The colour arithmetic restates PIL / torchvision (absent here): parity
  * unpinned, see csrc/augment.hip and oracle/augment.py. */
 int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step /* device pointer or NULL */, int SH, int SW,
                       int S, float brightness, float contrast, float saturation, float hue, ph_stream_t stream);
-int ph_augment_apply(const uint8_t* src, float* params, float* out0, float* out1, int B, int SH, int SW, int S,
-                     ph_stream_t stream);
+int ph_augment_apply(const uint8_t* src, const int64_t* rows /* NULL - image b of the batch is src[b] - or src[rows[b]] */,
+                     float* params, float* out0, float* out1, int B, int SH, int SW, int S, ph_stream_t stream);
 
 /* On-device contrast-index sampler (reference MICCAI-2022/data_loaders_MT.py:229-249 and the neg_mode
  * variants of "MIA 2023/stage2_unimodal_student/data_loaders_MT.py":205-238).  out[b] = [positives | K negatives]:

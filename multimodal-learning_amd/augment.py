@@ -23,12 +23,17 @@ class DeviceAugment:
         self.step = torch.zeros(1, device=self.device, dtype=torch.int64)                      # device-side draw counter
         self.last_params = None
 
-    def __call__(self, src_u8, params=None):
+    def __call__(self, src_u8, params=None, rows=None):
+        """`rows` (int64 [B], device): take the batch straight out of a resident tile store src_u8 [n, SH, SW, 3] - no
+        gather copy of the 3 MB source tiles."""
         src = require_cuda(src_u8, "src_u8")
         if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[3] != 3:
             raise RuntimeError("src_u8 must be uint8 [B, SH, SW, 3]")
         src = src.contiguous()
-        B, SH, SW, _ = src.shape
+        _, SH, SW, _ = src.shape
+        if rows is not None:
+            rows = rows.to(src.device).long().contiguous()
+        B = src.shape[0] if rows is None else rows.shape[0]
         S = self.S
         if params is None:
             params = torch.empty(B, 2, NPARAM, device=src.device, dtype=torch.float32)
@@ -40,6 +45,29 @@ class DeviceAugment:
             params[..., 12:] = 0          # the grey-sum accumulator slot
         out0 = torch.empty(B, 3, S, S, device=src.device, dtype=torch.float32)
         out1 = torch.empty_like(out0)
-        check(lib().ph_augment_apply(ptr(src), ptr(params), ptr(out0), ptr(out1), B, SH, SW, S, stream()), "ph_augment_apply")
+        check(lib().ph_augment_apply(ptr(src), ptr(rows), ptr(params), ptr(out0), ptr(out1), B, SH, SW, S, stream()),
+              "ph_augment_apply")
         self.last_params = params
         return out0, out1
+
+
+class ResidentTileLoader:
+    """The training loader's batch tuple (data_loaders_MT.py:256) produced on the device: uint8 tiles, omic vectors and
+    labels live in HBM; a batch of row indices becomes ((x_path, ema_x_path), 0, x_omic, 0, 0, grade, index, sample_idx)
+    with both augmented views (DeviceAugment, straight from the store) and the contrast indices (ContrastIndexSampler)."""
+
+    def __init__(self, opt, tiles_u8, x_omic, grade, device="cuda", seed=0):
+        from .sampler import ContrastIndexSampler
+        self.device = torch.device(device)
+        self.tiles = require_cuda(tiles_u8, "tiles_u8").contiguous()
+        self.x_omic = x_omic.to(self.device).float().contiguous()
+        self.grade = grade.to(self.device).long().contiguous()
+        self.aug = DeviceAugment(opt, self.device, seed)
+        self.sampler = ContrastIndexSampler(opt, self.grade.cpu().numpy(), self.device, seed=seed)
+
+    def batch(self, index):
+        index = index.to(self.device).long().contiguous()
+        x_path, ema_x_path = self.aug(self.tiles, rows=index)
+        grade = self.grade[index]
+        z = torch.zeros(index.shape[0], device=self.device)
+        return ((x_path, ema_x_path), z, self.x_omic[index], z, z, grade, index, self.sampler(index, grade))

@@ -108,20 +108,20 @@ __device__ __forceinline__ void jitter(int& r, int& g, int& b, const float* p, i
   }
 }
 
-__device__ __forceinline__ void fetch(const uint8_t* __restrict__ src, const float* p, int b, int SH, int SW, int y, int x, int& r,
-                                      int& g, int& bl) {
+__device__ __forceinline__ void fetch(const uint8_t* __restrict__ src, const float* p, size_t b, int SH, int SW, int y, int x,
+                                      int& r, int& g, int& bl) {
   int sy = (int)p[2] + y, sx = (int)p[3] + x;              // crop window of the flipped image ...
   if (p[1] != 0.f) sy = SH - 1 - sy;                       // ... = mirrored coordinates of the source
   if (p[0] != 0.f) sx = SW - 1 - sx;
-  const uint8_t* q = src + (((size_t)b * SH + sy) * SW + sx) * 3;
+  const uint8_t* q = src + ((b * SH + sy) * SW + sx) * 3;
   r = q[0]; g = q[1]; bl = q[2];
 }
 
 // grey sum (PIL: int(ImageStat.Stat(image.convert("L")).mean[0] + 0.5)) of the image as it enters the contrast step:
 // MSPLIT workgroups per (image, view) add their exact integer partial sums to the 64-bit slot of the parameter row
 constexpr int MSPLIT = 16;
-__global__ __launch_bounds__(256) void augment_mean_kernel(const uint8_t* __restrict__ src, float* __restrict__ params, int SH,
-                                                           int SW, int S) {
+__global__ __launch_bounds__(256) void augment_mean_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ rows,
+                                                           float* __restrict__ params, int SH, int SW, int S) {
   __shared__ unsigned long long red[256];
   const int iv = blockIdx.x, b = iv >> 1;
   float* p = params + (size_t)iv * AP;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void augment_mean_kernel(const uint8_t* __rest
   const int n = S * S, per = (n + MSPLIT - 1) / MSPLIT, lo = blockIdx.y * per, hi = min(n, lo + per);
   for (int e = lo + threadIdx.x; e < hi; e += 256) {
     int r, g, bl;
-    fetch(src, p, b, SH, SW, e / S, e % S, r, g, bl);
+    fetch(src, p, rows ? (size_t)rows[b] : (size_t)b, SH, SW, e / S, e % S, r, g, bl);
     jitter(r, g, bl, p, 0, true);
     s += (unsigned long long)luma(r, g, bl);
   }
@@ -148,8 +148,9 @@ __device__ __forceinline__ int grey_mean(const float* p, int S) {
 }
 
 // both views: out_v[b][c][y][x] = (jittered / 255 - 0.5) / 0.5
-__global__ void augment_apply_kernel(const uint8_t* __restrict__ src, const float* __restrict__ params, float* __restrict__ out0,
-                                     float* __restrict__ out1, int B, int SH, int SW, int S) {
+__global__ void augment_apply_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ rows,
+                                     const float* __restrict__ params, float* __restrict__ out0, float* __restrict__ out1, int B,
+                                     int SH, int SW, int S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t per = (size_t)S * S;
   if (i >= (size_t)B * 2 * per) return;
@@ -157,7 +158,7 @@ __global__ void augment_apply_kernel(const uint8_t* __restrict__ src, const floa
   const int e = (int)(i % per);
   const float* p = params + (size_t)iv * AP;
   int r, g, bl;
-  fetch(src, p, b, SH, SW, e / S, e % S, r, g, bl);
+  fetch(src, p, rows ? (size_t)rows[b] : (size_t)b, SH, SW, e / S, e % S, r, g, bl);
   jitter(r, g, bl, p, grey_mean(p, S), false);
   float* o = (v ? out1 : out0) + (size_t)b * 3 * per + e;
   o[0] = ((float)r / 255.f - 0.5f) / 0.5f;
@@ -185,14 +186,15 @@ int ph_augment_params(float* params, int B, uint64_t seed, const uint64_t* step,
   return PH_OK;
 }
 
-int ph_augment_apply(const uint8_t* src, float* params, float* out0, float* out1, int B, int SH, int SW, int S, hipStream_t st) {
+int ph_augment_apply(const uint8_t* src, const int64_t* rows, float* params, float* out0, float* out1, int B, int SH, int SW,
+                     int S, hipStream_t st) {
   if (!src || !params || !out0 || !out1 || B < 1 || S < 1 || S > SH || S > SW) return PH_EINVAL;
-  hipLaunchKernelGGL(augment_mean_kernel, dim3(2 * B, MSPLIT), dim3(256), 0, st, src, params, SH, SW, S);
+  hipLaunchKernelGGL(augment_mean_kernel, dim3(2 * B, MSPLIT), dim3(256), 0, st, src, rows, params, SH, SW, S);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(augment_publish_mean_kernel, dim3((2 * B + 255) / 256), dim3(256), 0, st, params, 2 * B, S);
   PH_LAUNCH_CHECK();
   const size_t n = (size_t)B * 2 * S * S;
-  hipLaunchKernelGGL(augment_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, params, out0, out1, B, SH, SW, S);
+  hipLaunchKernelGGL(augment_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, rows, params, out0, out1, B, SH, SW, S);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -87,3 +87,22 @@ def test_device_draws_are_in_range_reproducible_and_spread():
     assert all(sorted(o) == [0, 1, 2, 3] for o in orders) and len(orders) == 24
     assert not torch.equal(x1[0], x1[1])                             # the two views are drawn independently
     assert float(x1[0].min()) >= -1.0 and float(x1[0].max()) <= 1.0
+
+
+def test_resident_loader_batches_straight_from_the_store():
+    """ResidentTileLoader: a batch drawn by row indices out of the resident uint8 store equals augmenting the gathered
+    tiles with the same draws; the tuple has the loader's layout and feeds DistillStep.step."""
+    import types
+    import multimodal_learning_amd as m
+    n, SH, S = 40, 96, 64
+    tiles = _src(n, SH, SH, 5).cuda()
+    labels = torch.arange(n) % 3
+    opt = types.SimpleNamespace(input_size_path=S, nce_p=4, nce_k=16, pos_mode="multi_pos", label_dim=3)
+    ld = m.augment.ResidentTileLoader(opt, tiles, torch.randn(n, 80), labels, seed=3)
+    idx = torch.tensor([7, 0, 33, 12, 12, 39])
+    (xa, xb), _, xo, _, _, gr, index, sidx = ld.batch(idx)
+    prm = ld.aug.last_params.clone()
+    ya, yb = m.augment.DeviceAugment(opt)(tiles[idx.cuda()], params=prm)
+    assert torch.equal(xa, ya) and torch.equal(xb, yb)
+    assert xa.shape == (6, 3, S, S) and xo.shape == (6, 80) and torch.equal(gr.cpu(), labels[idx]) and torch.equal(index.cpu(), idx)
+    assert sidx.shape == (6, 4 + 16) and torch.equal(sidx[:, 0].cpu(), idx)
