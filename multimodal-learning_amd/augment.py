@@ -23,7 +23,7 @@ class DeviceAugment:
         self.step = torch.zeros(1, device=self.device, dtype=torch.int64)                      # device-side draw counter
         self.last_params = None
 
-    def __call__(self, src_u8, params=None, rows=None):
+    def __call__(self, src_u8, params=None, rows=None, out=None):
         """`rows` (int64 [B], device): take the batch straight out of a resident tile store src_u8 [n, SH, SW, 3] - no
         gather copy of the 3 MB source tiles."""
         src = require_cuda(src_u8, "src_u8")
@@ -43,8 +43,14 @@ class DeviceAugment:
         else:
             params = params.to(src.device).float().contiguous().clone()
             params[..., 12:] = 0          # the grey-sum accumulator slot
-        out0 = torch.empty(B, 3, S, S, device=src.device, dtype=torch.float32)
-        out1 = torch.empty_like(out0)
+        if out is not None:          # caller-owned buffers (the resident input sets a captured step graph reads from)
+            out0, out1 = out
+            for t in (out0, out1):
+                if tuple(t.shape) != (B, 3, S, S) or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+                    raise RuntimeError("out must be two contiguous f32 [B, 3, S, S] device tensors")
+        else:
+            out0 = torch.empty(B, 3, S, S, device=src.device, dtype=torch.float32)
+            out1 = torch.empty_like(out0)
         check(lib().ph_augment_apply(ptr(src), ptr(rows), ptr(params), ptr(out0), ptr(out1), B, SH, SW, S, stream()),
               "ph_augment_apply")
         self.last_params = params
@@ -65,9 +71,19 @@ class ResidentTileLoader:
         self.aug = DeviceAugment(opt, self.device, seed)
         self.sampler = ContrastIndexSampler(opt, self.grade.cpu().numpy(), self.device, seed=seed)
 
-    def batch(self, index):
+    def batch(self, index, into=None):
+        """`into`: a previously returned batch tuple whose tensors are refilled in place (fixed addresses: a captured
+        step graph that adopted them replays without any staging copy)."""
         index = index.to(self.device).long().contiguous()
-        x_path, ema_x_path = self.aug(self.tiles, rows=index)
-        grade = self.grade[index]
-        z = torch.zeros(index.shape[0], device=self.device)
-        return ((x_path, ema_x_path), z, self.x_omic[index], z, z, grade, index, self.sampler(index, grade))
+        if into is None:
+            x_path, ema_x_path = self.aug(self.tiles, rows=index)
+            grade = self.grade[index]
+            z = torch.zeros(index.shape[0], device=self.device)
+            return ((x_path, ema_x_path), z, self.x_omic[index], z, z, grade, index, self.sampler(index, grade))
+        (x_path, ema_x_path), _, x_omic, _, _, grade, idx_buf, sample_idx = into
+        self.aug(self.tiles, rows=index, out=(x_path, ema_x_path))
+        torch.index_select(self.x_omic, 0, index, out=x_omic)
+        torch.index_select(self.grade, 0, index, out=grade)
+        idx_buf.copy_(index)
+        self.sampler(idx_buf, grade, out=sample_idx)
+        return into
