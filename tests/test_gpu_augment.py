@@ -106,3 +106,25 @@ def test_resident_loader_batches_straight_from_the_store():
     assert torch.equal(xa, ya) and torch.equal(xb, yb)
     assert xa.shape == (6, 3, S, S) and xo.shape == (6, 80) and torch.equal(gr.cpu(), labels[idx]) and torch.equal(index.cpu(), idx)
     assert sidx.shape == (6, 4 + 16) and torch.equal(sidx[:, 0].cpu(), idx)
+
+
+def test_resident_loader_refills_a_batch_in_place():
+    """batch(index, into=previous) rewrites the previous tuple's tensors at their addresses (what a captured step graph
+    that adopted them needs) with a new draw."""
+    import types
+    import multimodal_learning_amd as m
+    n, SH, S = 24, 64, 48
+    tiles = _src(n, SH, SH, 6).cuda()
+    labels = torch.arange(n) % 3
+    opt = types.SimpleNamespace(input_size_path=S, nce_p=3, nce_k=8, pos_mode="multi_pos", label_dim=3)
+    ld = m.augment.ResidentTileLoader(opt, tiles, torch.randn(n, 16), labels, seed=1)
+    bt = ld.batch(torch.tensor([1, 5, 9, 20]))
+    ptrs = [t.data_ptr() for t in (bt[0][0], bt[0][1], bt[2], bt[5], bt[6], bt[7])]
+    old = bt[0][0].clone()
+    idx2 = torch.tensor([2, 6, 10, 23])
+    bt2 = ld.batch(idx2, into=bt)
+    assert [t.data_ptr() for t in (bt2[0][0], bt2[0][1], bt2[2], bt2[5], bt2[6], bt2[7])] == ptrs
+    ya, yb = m.augment.DeviceAugment(opt)(tiles[idx2.cuda()], params=ld.aug.last_params.clone())
+    assert torch.equal(bt2[0][0], ya) and torch.equal(bt2[0][1], yb) and not torch.equal(bt2[0][0], old)
+    assert torch.equal(bt2[6].cpu(), idx2) and torch.equal(bt2[5].cpu(), labels[idx2]) and torch.equal(bt2[7][:, 0].cpu(), idx2)
+    assert torch.equal(bt2[2].cpu(), ld.x_omic[idx2.cuda()].cpu())
