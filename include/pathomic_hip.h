@@ -264,6 +264,11 @@ int ph_topk_threshold_mask(const float* x, float* mask, int B, int D, int K, ph_
 /* out[b][c][p] = x[b][c][p] * (1 - mask[b][p])  (:201-202, the masked views; C = 1 for the omic vector) */
 int ph_apply_mask(const float* x, const float* mask, float* out, int B, int C, size_t P, ph_stream_t stream);
 
+/* Batch indices of DataLoader(shuffle=True, drop_last=True) (the training loader's sampler): rows q..q+B-1 of the keyed
+ * permutation of epoch (*batch_no) / (n / B), q = ((*batch_no) % (n / B)) * B.  Distributional parity (host RNG stream). */
+int ph_shuffle_indices(int64_t* out, int n, int B, uint64_t seed, const uint64_t* batch_no /* device pointer or NULL */,
+                       ph_stream_t stream);
+
 /* On-device input pipeline (reference MICCAI-2022/data_loaders_MT.py:168-175 TransformTwice(Compose([
  * RandomHorizontalFlip, RandomVerticalFlip, RandomCrop(S), ColorJitter(b, c, s, h), ToTensor, Normalize(0.5, 0.5)]))).
  * src: uint8 [n][SH][SW][3] tiles resident in HBM (the batch is rows[0..B) of it, or the first B tiles).  params: [B][2 views][16] f32 rows {flipH, flipV, top, left, brightness, contrast,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ph_rkd_workspace_bytes": (sz, [i32, i32]),
     "ph_rkd_loss_grad": (i32, [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp]),
     "ph_superpixel_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "ph_shuffle_indices": (i32, [vp, i32, i32, u64, vp, vp]),
     "ph_augment_params": (i32, [vp, i32, u64, vp, i32, i32, i32, f32, f32, f32, f32, vp]),
     "ph_augment_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_apply_mask": (i32, [vp, vp, vp, i32, i32, sz, vp]),

@@ -70,20 +70,43 @@ class ResidentTileLoader:
         self.grade = grade.to(self.device).long().contiguous()
         self.aug = DeviceAugment(opt, self.device, seed)
         self.sampler = ContrastIndexSampler(opt, self.grade.cpu().numpy(), self.device, seed=seed)
+        self.row_to_tile = None       # optional int64 [n_rows]: dataset row -> tile of the store (several rows per tile)
+        self.batch_no = None
 
-    def batch(self, index, into=None):
+    def next(self, batch_size=None, into=None):
+        """The next batch of an endless shuffled run (DataLoader(shuffle=True, drop_last=True)): its row indices are
+        drawn on the device from a device-side batch counter, so the whole call - index draw, both augmented views,
+        gathers, contrast indices - is a fixed launch sequence that a HIP graph can capture and replay."""
+        from . import ops
+        if into is None:
+            B = int(batch_size)
+            index = torch.empty(B, device=self.device, dtype=torch.int64)
+        else:
+            index = into[6]
+            B = index.shape[0]
+        if getattr(self, "batch_no", None) is None:
+            self.batch_no = torch.zeros(1, device=self.device, dtype=torch.int64)
+        check(lib().ph_shuffle_indices(ptr(index), self.grade.shape[0], B, self.aug.seed, ptr(self.batch_no), stream()),
+              "ph_shuffle_indices")
+        ops.counter_inc(self.batch_no)
+        return self.batch(index, into=into, _index_in_place=into is not None)
+
+    def batch(self, index, into=None, _index_in_place=False):
         """`into`: a previously returned batch tuple whose tensors are refilled in place (fixed addresses: a captured
         step graph that adopted them replays without any staging copy)."""
         index = index.to(self.device).long().contiguous()
         if into is None:
-            x_path, ema_x_path = self.aug(self.tiles, rows=index)
+            rows = index if getattr(self, "row_to_tile", None) is None else self.row_to_tile[index]
+            x_path, ema_x_path = self.aug(self.tiles, rows=rows)
             grade = self.grade[index]
             z = torch.zeros(index.shape[0], device=self.device)
             return ((x_path, ema_x_path), z, self.x_omic[index], z, z, grade, index, self.sampler(index, grade))
         (x_path, ema_x_path), _, x_omic, _, _, grade, idx_buf, sample_idx = into
-        self.aug(self.tiles, rows=index, out=(x_path, ema_x_path))
+        rows = index if getattr(self, "row_to_tile", None) is None else self.row_to_tile[index]
+        self.aug(self.tiles, rows=rows, out=(x_path, ema_x_path))
         torch.index_select(self.x_omic, 0, index, out=x_omic)
         torch.index_select(self.grade, 0, index, out=grade)
-        idx_buf.copy_(index)
+        if not _index_in_place:
+            idx_buf.copy_(index)
         self.sampler(idx_buf, grade, out=sample_idx)
         return into

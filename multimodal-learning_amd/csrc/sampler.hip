@@ -81,7 +81,26 @@ __global__ __launch_bounds__(256) void contrast_sampler_kernel(SamplerArgs a) {
   }
 }
 
+// DataLoader(shuffle=True, drop_last=True) batch indices (train_cv_path_multi_MT.py / data_loaders_MT.py: the sampler of
+// the training loader): batch number `*batch_no` of an endless run takes rows q .. q+B-1 of its epoch's permutation of
+// [0, n); the permutation of epoch e is the keyed Feistel permutation perm_at(., n, key(seed, e)) - O(1) per index.
+__global__ void shuffle_indices_kernel(int64_t* __restrict__ out, int n, int B, uint64_t seed, const uint64_t* __restrict__ batch_no) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= B) return;
+  const uint64_t per_epoch = (uint64_t)(n / B);              // drop_last
+  const uint64_t bn = batch_no ? batch_no[0] : 0;
+  const uint64_t epoch = bn / per_epoch, q = (bn % per_epoch) * (uint64_t)B + (uint64_t)j;
+  out[j] = (int64_t)perm_at((unsigned)q, (unsigned)n, mix64(seed ^ mix64(epoch + 0x5bd1e995ull)));
+}
+
 }  // namespace
+
+extern "C" int ph_shuffle_indices(int64_t* out, int n, int B, uint64_t seed, const uint64_t* batch_no, hipStream_t st) {
+  if (!out || n < 1 || B < 1 || B > n) return PH_EINVAL;
+  hipLaunchKernelGGL(shuffle_indices_kernel, dim3((B + 255) / 256), dim3(256), 0, st, out, n, B, seed, batch_no);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
 
 extern "C" int ph_contrast_sampler(const int64_t* index, const int64_t* grade, const int* cls_pos, const int* cls_pos_off,
                                    const int* cls_neg, const int* cls_neg_off, int n_data, int B, int P, int K,

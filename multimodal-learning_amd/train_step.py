@@ -477,6 +477,23 @@ class DistillStep:
         opt = self.opt
         if opt.num_teachers != 2 or opt.distill != "crd":
             raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd)")
+        self._capture_pre = None
+        if batch is None:
+            # on-device input pipeline (augment.ResidentTileLoader, `step.loader = loader`): the batch is produced from the
+            # resident tile store.  In graph mode the loader's launches are captured IN FRONT of the step's own, so a
+            # replay is the whole iteration - shuffle indices, both augmented views, contrast indices, step - and the host
+            # launches nothing in between (eager launches between replays cost 1-4 ms per step on this runtime).
+            loader = getattr(self, "loader", None)
+            if loader is None:
+                raise ValueError("step(None) needs step.loader (augment.ResidentTileLoader)")
+            in_graph = getattr(self, "_want_graph", False) and self.iter_num - opt.global_step >= 2
+            if getattr(self, "_loader_bt", None) is None:
+                self._loader_bt = loader.next(opt.batch_size)          # allocates the resident input set
+            elif not in_graph:
+                loader.next(into=self._loader_bt)
+            batch = self._loader_bt
+            if in_graph:
+                self._capture_pre = lambda: loader.next(into=self._loader_bt)
         (x_path, ema_x_path), x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
         dev = self.device
         if sample_idx is None:
@@ -580,6 +597,8 @@ class DistillStep:
             try:
                 with torch.cuda.graph(g, pool=pool):
                     self.optimizer._prepared = True       # the step scalars are read from device memory at replay
+                    if getattr(self, "_capture_pre", None) is not None:
+                        self._capture_pre()               # the on-device input pipeline fills this input set first
                     st["out"] = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"],
                                                   st["index"], st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
                 st["graph"] = g

@@ -128,3 +128,36 @@ def test_resident_loader_refills_a_batch_in_place():
     assert torch.equal(bt2[0][0], ya) and torch.equal(bt2[0][1], yb) and not torch.equal(bt2[0][0], old)
     assert torch.equal(bt2[6].cpu(), idx2) and torch.equal(bt2[5].cpu(), labels[idx2]) and torch.equal(bt2[7][:, 0].cpu(), idx2)
     assert torch.equal(bt2[2].cpu(), ld.x_omic[idx2.cuda()].cpu())
+
+
+def test_distill_step_fed_by_the_resident_loader_inside_its_graph():
+    """step.loader = ResidentTileLoader; step.step(None): eager steps draw their batch eagerly, graph steps replay ONE
+    graph that contains the shuffle-index draw, both augmented views, the contrast indices and the step.  Every replay
+    consumes a new batch (the index buffer changes, an epoch of n/B batches visits every row once), losses stay finite."""
+    import types
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt
+    B, S, n_data = 8, 64, 96
+    opt = default_opt(batch_size=B, nce_p=30, nce_p2=8, nce_k=28, nce_k2=16, select_pos_mode="hard", n_data=n_data)
+    opt.input_size_path, opt.pos_mode, opt.label_dim = S, "multi_pos", 3
+    tiles = _src(16, 2 * S, 2 * S, 8).cuda()
+    labels = torch.arange(n_data) % 3          # three classes of 32 rows: nce_p = 30 positives exist without replacement
+    ld = m.augment.ResidentTileLoader(opt, tiles, torch.randn(n_data, 320), labels, seed=2)
+    ld.row_to_tile = torch.arange(n_data, device="cuda") % 16
+    step = m.DistillStep(opt, n_data, device="cuda")
+    for crd in (step.criterion_kd, step.criterion_kd_path):
+        crd.contrast.verbose = False
+    step.loader = ld
+    step.enable_graph()
+    seen, losses = [], []
+    for it in range(14):
+        out = step.step(None, epoch=1)
+        seen.append(step._loader_bt[6].clone())
+        losses.append(out["loss"].clone())
+    torch.cuda.synchronize()
+    assert step._slots and step._slots[0]["graph"] is not None, "the graph path was not taken"
+    assert all(torch.isfinite(l) for l in losses)
+    rows = torch.cat(seen[:12]).cpu()                    # 12 batches of 8 = one epoch of 96 rows
+    assert sorted(rows.tolist()) == list(range(n_data))
+    assert not torch.equal(seen[12].cpu(), seen[0].cpu())  # the next epoch uses another permutation
+    assert int(ld.batch_no.item()) == 14
