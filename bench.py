@@ -47,7 +47,7 @@ def make_batch(B, H, n_data, opt, device, seed):
     return ((d(x_path), d(ema_x_path)), d(z), d(x_omic), d(z), d(z), d(grade), d(index), d(sample_idx))
 
 
-def cpu_baseline(nsteps=2):
+def cpu_baseline(nsteps=10):
     """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/test_oracle_golden.py) timed on
     this host for BASELINE config 1 (B=16, 224x224), 3 fwd + 1 bwd ("minimal") mode.  Threads are capped at 16:
     at B=16 torch's CPU kernels stop scaling there (with all 256 host threads of the GPU box the same step takes
