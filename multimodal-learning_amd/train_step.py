@@ -283,6 +283,19 @@ class DistillStep:
         self.criterion_kd_path = CRDLoss(opt, n_data).to(self.device)              # :206
         self.module_list = nn.ModuleList([self.model, self.criterion_kd.embed_s, self.criterion_kd.embed_t,
                                           self.criterion_kd_path.embed_s, self.criterion_kd_path.embed_t])
+        # the other `--distill` choices of the MIA-2022 trainer (train_test_path_multi_distill_v2.py:316-342): one
+        # feature-level baseline criterion, no embedding heads in the optimiser
+        self.zoo_kd = None
+        if variant == "mia2022" and opt.distill != "crd":
+            from . import distiller_zoo as Z
+            zoo = {"kd": None, "feats_KL": Z.feats_KL, "rkd": Z.RKDLoss, "pkt": Z.PKT, "similarity": Z.Similarity}
+            if opt.distill not in zoo:
+                raise NotImplementedError("--distill %s (built: crd, kd, feats_KL, rkd, pkt, similarity)" % opt.distill)
+            if sync is not None and opt.distill in ("rkd", "pkt", "similarity"):
+                raise NotImplementedError("--distill %s relates the rows of ONE batch to each other: per-replica batches "
+                                          "would change the loss (single GPU only)" % opt.distill)
+            self.zoo_kd = zoo[opt.distill]() if zoo[opt.distill] is not None else False
+            self.module_list = nn.ModuleList([self.model])
         self.optimizer = define_optimizer(opt, self.module_list)                   # :211
         self.scheduler = define_scheduler(opt, self.optimizer)                     # :212
         self.iter_num = opt.global_step
@@ -353,6 +366,9 @@ class DistillStep:
         if self.variant == "mia2023":
             return self._mia2023_tail(e, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path,
                                       ema_path_feat, ema_logit_path, fuse_feat, logits)
+        if self.zoo_kd is not None:
+            return self._mia2022_baseline_tail(loss_cls, path_feat, logit_path, pred_path, ema_path_feat, ema_logit_path,
+                                               fuse_feat, logits)
         loss_div1 = self.criterion_div(logit_path, logits[-1].detach())                                     # :264
         loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
         if self.variant == "mia2022":
@@ -387,6 +403,48 @@ class DistillStep:
                     scale=scale, logit_path=logit_path.detach(), pred_path=pred_path.detach(),
                     path_feat=path_feat.detach(), ema_logit=ema_logit_path, fuse_logit=logits[-1],
                     fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+
+    def _mia2022_baseline_tail(self, loss_cls, path_feat, logit_path, pred_path, ema_path_feat, ema_logit_path, fuse_feat,
+                               logits):
+        """The `--distill kd | feats_KL | rkd | pkt | similarity` baselines of the MIA-2022 trainer
+        ("MIA 2022/train_test_path_multi_distill_v2.py":419-483): KL to one or two teachers plus one feature-level
+        criterion between the student feature and the fused teacher feature, summed with fixed weights alpha / beta
+        (GK-Refine needs the per-loss list, which the trainer only builds for crd and kd with two teachers)."""
+        opt = self.opt
+        z = torch.zeros((), device=self.device)
+        loss_div1 = loss_div2 = z
+        if opt.num_teachers == 2:                                                                           # :419-422
+            loss_div1 = self.criterion_div(logit_path, logits[-1].detach())
+            loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())
+        elif opt.num_teachers == 1 and opt.which_teacher == "fuse":
+            loss_div1 = self.criterion_div(logit_path, logits[-1].detach())
+        elif opt.num_teachers == 1 and opt.which_teacher == "self_EMA":
+            loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())
+        else:
+            raise NotImplementedError("num_teachers %r / which_teacher %r" % (opt.num_teachers, opt.which_teacher))
+        loss_div = loss_div1 + loss_div2
+        loss_kd = z if self.zoo_kd is False else self.zoo_kd(path_feat, fuse_feat.detach()).reshape(())     # :430-457
+        scale = None
+        if opt.assign_weights == "True":
+            if not (opt.distill == "kd" and opt.num_teachers == 2):
+                raise NotImplementedError("assign_weights with --distill %s: the trainer builds KD_loss_list only for crd and "
+                                          "kd with two teachers (:463-468)" % opt.distill)
+            KD_loss_list = [opt.alpha * loss_div1, opt.alpha * loss_div2]
+            scale, loss_KD = self._momentum_gk(loss_cls, path_feat, KD_loss_list)                           # :474
+            if opt.grads_thresh == "False":
+                loss_KD = loss_KD * len(KD_loss_list)
+        else:
+            loss_KD = opt.alpha * loss_div + opt.beta * loss_kd                                             # :482
+        loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :486
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self.optimizer.flat)
+        self.optimizer.step()
+        return dict(loss=loss.detach(), loss_cls=loss_cls.detach(), loss_div1=loss_div1.detach(), loss_div2=loss_div2.detach(),
+                    loss_kd1=(opt.beta * loss_kd).detach(), loss_kd2=z, scale=scale, logit_path=logit_path.detach(),
+                    pred_path=pred_path.detach(), path_feat=path_feat.detach(), ema_logit=ema_logit_path,
+                    fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat)
 
     def _fused_head_ok(self):
         """The closed-form loss head covers the shipped MICCAI stage-2 command: two teachers, CRD, GK-Refine with the CE
@@ -475,8 +533,9 @@ class DistillStep:
 
     def step(self, batch, epoch=0, ranks=None):
         opt = self.opt
-        if opt.num_teachers != 2 or opt.distill != "crd":
-            raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd)")
+        if self.zoo_kd is None and (opt.num_teachers != 2 or opt.distill != "crd"):
+            raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd); "
+                                      "variant 'mia2022' also runs the trainer's --distill baselines")
         self._capture_pre = None
         if batch is None:
             # on-device input pipeline (augment.ResidentTileLoader, `step.loader = loader`): the batch is produced from the

@@ -677,3 +677,43 @@ def test_stage1_step_with_superpixel_masking_terms():
         assert torch.isfinite(g_mask).all() and float((g_mask - g0).abs().max()) > 1e-6 * float(g0.abs().max())
     finally:
         m.set_precision("bf16")
+
+
+@pytest.mark.parametrize("distill", ["kd", "feats_KL", "rkd", "pkt", "similarity"])
+def test_mia2022_distill_baselines(distill):
+    """The other `--distill` choices of the MIA-2022 trainer (train_test_path_multi_distill_v2.py:419-486) through
+    DistillStep(variant="mia2022"): loss = lambda * CE + alpha * (KL terms) + beta * criterion(student feature, fused teacher
+    feature), the criterion being the reference-pinned zoo module; one and two teachers; `kd` also with GK-Refine."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd import distiller_zoo as Z
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    B, H, n_data = 8, 64, 256
+    crit = {"kd": None, "feats_KL": Z.feats_KL, "rkd": Z.RKDLoss, "pkt": Z.PKT, "similarity": Z.Similarity}[distill]
+    m.set_precision("bf16x6")
+    try:
+        for nt, which, aw in ((2, "fuse", "False"), (1, "self_EMA", "False")) + (((2, "fuse", "True"),) if distill == "kd" else ()):
+            opt = default_opt(batch_size=B, nce_k=64, distill=distill, num_teachers=nt, which_teacher=which, assign_weights=aw,
+                              grads_m=0.9, grads_thresh="False", thresh=0.1, alpha=1.0, beta=0.5)
+            step = m.DistillStep(opt, n_data, device="cuda", variant="mia2022")
+            step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+            step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+            step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+            assert len(step.module_list) == 1                      # no embedding heads in the optimiser
+            bt = synthetic_batch(B, H, n_data=n_data, P=1, K=64, seed=700)
+            z = torch.zeros(B)
+            out = step.step(((bt["x_path"], bt["ema_x_path"]), z, bt["x_omic"], z, z, bt["grade"], bt["index"], bt["sample_idx"]), epoch=2)
+            kd = float(crit()(out["path_feat"], out["fuse_feat"]).reshape(())) if crit is not None else 0.0
+            assert abs(float(out["loss_kd1"]) - opt.beta * kd) <= 1e-5 * max(abs(opt.beta * kd), 1e-4)
+            if nt == 1:
+                assert float(out["loss_div1"]) == 0.0 and float(out["loss_div2"]) > 0.0
+            if aw == "False":
+                expect = float(out["loss_cls"]) + opt.alpha * (float(out["loss_div1"]) + float(out["loss_div2"])) + opt.beta * kd
+                assert abs(float(out["loss"]) - expect) <= 1e-5 * abs(expect), (distill, nt)
+                assert out["scale"] is None
+            else:
+                assert out["scale"].shape == (3,) and torch.isfinite(out["scale"]).all()
+            g = step.optimizer.flat.grad
+            assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    finally:
+        m.set_precision("bf16")
