@@ -31,14 +31,20 @@ def grading_metrics(y_label, y_pred, avg="micro"):
     return rocauc, ap, f1_micro, f1_gradeIV
 
 
+def test_model(opt, model, test_loader, device):
+    """:530-611 - `test()` for the student alone (no frozen teacher): same 9-tuple, `probs_all` is None."""
+    return test(opt, None, model, test_loader, device)
+
+
 def test(opt, fix_model, model, test_loader, device):
     """:409-501 for the grading task.  Returns the reference's 9-tuple
     (loss_test, cindex_path, pvalue_test, surv_acc_test, grad_path_test, all_grad_metrics, pred_test, grads_test,
-    feats_test); the survival entries are None."""
+    feats_test); the survival entries are None.  `fix_model=None` gives `test_model()` (:530-611)."""
     if opt.task != "grad":
         raise NotImplementedError("evaluation of the survival (Cox) task is out of scope")
     from sklearn.preprocessing import LabelBinarizer
-    fix_model.eval()
+    if fix_model is not None:
+        fix_model.eval()
     model.eval()
     dev = torch.device(device)
     preds_path, preds_fuse, feats, grades, losses = [], [], [], [], []
@@ -49,14 +55,16 @@ def test(opt, fix_model, model, test_loader, device):
             x_omic = x_omic.to(dev, non_blocking=True)
             grade = grade.to(dev, non_blocking=True)
             _, feat_path, _, pred_path, _ = model(x_path=x_path, x_grph=x_grph, x_omic=x_omic)            # :427
-            _, _, _, _, _, pred, _, _, _, _, _ = fix_model(x_path=x_path, x_grph=x_grph, x_omic=x_omic)    # :431
+            pred = None
+            if fix_model is not None:
+                _, _, _, _, _, pred, _, _, _, _, _ = fix_model(x_path=x_path, x_grph=x_grph, x_omic=x_omic)  # :431
             loss_nll = ops.NLLFn.apply(pred_path, grade, float(pred_path.shape[0]))                        # :439
             losses.append((opt.lambda_nll * loss_nll + opt.lambda_reg * loss_reg).reshape(1))              # :441
             preds_path.append(pred_path); preds_fuse.append(pred); feats.append(feat_path); grades.append(grade)
     nb = len(losses)
     loss_test = float(torch.cat(losses).sum().item()) / len(test_loader)                                   # :442, :465
     probs_path = torch.cat(preds_path).cpu().numpy()
-    probs_all = torch.cat(preds_fuse).cpu().numpy()
+    probs_all = torch.cat(preds_fuse).cpu().numpy() if fix_model is not None else None
     feat_path_all = torch.cat(feats).cpu().numpy()
     gt = torch.cat(grades).cpu().numpy().reshape(-1)
     gt_all = gt.astype(np.float64)                                     # np.concatenate onto np.array([]) (:444)
@@ -64,9 +72,10 @@ def test(opt, fix_model, model, test_loader, device):
     enc = LabelBinarizer()
     enc.fit(gt_all)
     grad_gt = enc.transform(gt_all)                                                                        # :476-478
-    rocauc_fuse, ap_fuse, f1_micro_fuse, f1_gradeIV_fuse = grading_metrics(grad_gt, probs_all)             # :481
+    if fix_model is not None:
+        rocauc_fuse, ap_fuse, f1_micro_fuse, f1_gradeIV_fuse = grading_metrics(grad_gt, probs_all)         # :481
+        print("fixed fuse branch:", rocauc_fuse, ap_fuse, f1_micro_fuse, f1_gradeIV_fuse)
     rocauc_path, ap_path, f1_micro_path, f1_gradeIV_path = grading_metrics(grad_gt, probs_path)
-    print("fixed fuse branch:", rocauc_fuse, ap_fuse, f1_micro_fuse, f1_gradeIV_fuse)
     print("Path branch:", rocauc_path, ap_path, f1_micro_path, f1_gradeIV_path)
     all_grad_metrics = [rocauc_path, ap_path, f1_micro_path, f1_gradeIV_path]
     e = np.array([])

@@ -362,6 +362,10 @@ def test_evaluation_loop_vs_reference_test_function(golden_dir):
         assert np.allclose(np.asarray(on_ref_scores, dtype=np.float64), g["metrics"], atol=1e-12)
         got = np.asarray(metrics, dtype=np.float64)
         assert np.abs(got - g["metrics"]).max() <= 0.02 and abs(got[2] - g["metrics"][2]) < 1e-12, (got, g["metrics"])
+        # test_model(): the student alone - the same student-side results, no teacher probabilities
+        out2 = m.evaluate.test_model(opt, student, loader, "cuda")
+        assert out2[0] == loss_test and out2[4] == acc and out2[6][5] is None
+        assert np.array_equal(out2[6][6], pred_test[6]) and np.allclose(out2[5], metrics)
     finally:
         m.set_precision("bf16")
 
