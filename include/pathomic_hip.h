@@ -245,6 +245,10 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Ci
  * ph_pkt_loss_grad: "MIA 2022/distiller_zoo/PKT.py":17-46 (cosine-similarity probabilities, KL, eps 1e-7).
  * ph_rkd_loss_grad: "MIA 2022/distiller_zoo/RKD.py":15-58 (w_d * smooth-L1 of mean-normalised pairwise distances +
  * w_a * smooth-L1 of the B^3 angles); B <= 128, D <= 512. */
+/* Cox negative partial log-likelihood of the survival task (MICCAI-2022/utils.py:361-376): loss and d loss / d theta;
+ * dtheta may be NULL.  B <= 4096. */
+int ph_cox_loss_grad(const float* theta, const float* survtime, const float* censor, float* loss, float* dtheta, int B,
+                     ph_stream_t stream);
 size_t ph_pkt_workspace_bytes(int B, int D);
 int ph_pkt_loss_grad(const float* f_s, const float* f_t, float* loss, float* dx, int B, int D, void* workspace,
                      ph_stream_t stream);

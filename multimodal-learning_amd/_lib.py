@@ -57,6 +57,7 @@ SIGNATURES = {
     "ph_row_scale": (i32, [vp, vp, vp, i32, i32, vp]),
     "ph_sqdiff_sum": (i32, [vp, vp, vp, sz, f32, vp]),
     "ph_scaled_diff": (i32, [vp, vp, vp, f32, vp, sz, vp]),
+    "ph_cox_loss_grad": (i32, [vp, vp, vp, vp, vp, i32, vp]),
     "ph_pkt_workspace_bytes": (sz, [i32, i32]),
     "ph_pkt_loss_grad": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
     "ph_rkd_workspace_bytes": (sz, [i32, i32]),

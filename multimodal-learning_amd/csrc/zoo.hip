@@ -244,6 +244,38 @@ __global__ void rkd_gather_kernel(const float* __restrict__ dv, const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------ Cox
+// Negative partial log-likelihood of the survival task (MICCAI-2022/utils.py:361-376, after cox-nnet):
+//   S_i = sum_j [t_j >= t_i] exp(theta_j);  loss = -mean_i c_i (theta_i - log S_i)
+//   d loss / d theta_k = -(c_k - exp(theta_k) sum_i c_i [t_k >= t_i] / S_i) / B
+// The reference fills the B x B risk-set matrix with a Python double loop on the host; one workgroup here (B <= 4096).
+__global__ __launch_bounds__(1024) void cox_kernel(const float* __restrict__ theta, const float* __restrict__ t,
+                                                   const float* __restrict__ c, float* __restrict__ loss,
+                                                   float* __restrict__ dtheta, int B) {
+  extern __shared__ float sm[];
+  float* e = sm; float* tt = sm + B; float* w = tt + B;       // w_i = c_i / S_i
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < B; i += 1024) { e[i] = expf(theta[i]); tt[i] = t[i]; }
+  __syncthreads();
+  float l = 0.f;
+  for (int i = tid; i < B; i += 1024) {
+    float s = 0.f;
+    for (int j = 0; j < B; ++j) s += tt[j] >= tt[i] ? e[j] : 0.f;
+    w[i] = c[i] / s;
+    l += (theta[i] - logf(s)) * c[i];
+  }
+  l = block_sum(l, red);
+  if (tid == 0) loss[0] = -l / (float)B;
+  if (dtheta) {
+    for (int k = tid; k < B; k += 1024) {
+      float a = 0.f;
+      for (int i = 0; i < B; ++i) a += tt[k] >= tt[i] ? w[i] : 0.f;
+      dtheta[k] = -(c[k] - e[k] * a) / (float)B;
+    }
+  }
+}
+
 }  // namespace
 
 #include "pathomic_hip.h"
@@ -305,6 +337,14 @@ int ph_rkd_loss_grad(const float* f_s, const float* f_t, float* loss, float* dx,
   hipLaunchKernelGGL(rkd_angle_kernel, dim3(B), dim3(1024), lds, st, f_s, f_t, dv, part, B, D, w_a);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(rkd_gather_kernel, dim3(B), dim3(128), 0, st, dv, W, f_s, part, dx, loss, B, D);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_cox_loss_grad(const float* theta, const float* survtime, const float* censor, float* loss, float* dtheta, int B,
+                     hipStream_t st) {
+  if (!theta || !survtime || !censor || !loss || B < 1 || B > 4096) return PH_EINVAL;
+  hipLaunchKernelGGL(cox_kernel, dim3(1), dim3(1024), (size_t)3 * B * sizeof(float), st, theta, survtime, censor, loss, dtheta, B);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

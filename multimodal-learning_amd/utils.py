@@ -32,3 +32,31 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=[]):
 
 def count_parameters(model):
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+class _CoxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, theta, survtime, censor):
+        from . import ops
+        from ._lib import lib, check, ptr, stream
+        theta = ops._f32(theta).reshape(-1).contiguous()
+        t = ops._f32(survtime.to(theta.device)).reshape(-1).contiguous()
+        c = ops._f32(censor.to(theta.device)).reshape(-1).contiguous()
+        loss = torch.empty(1, device=theta.device, dtype=torch.float32)
+        d = torch.empty_like(theta)
+        check(lib().ph_cox_loss_grad(ptr(theta), ptr(t), ptr(c), ptr(loss), ptr(d), theta.shape[0], stream()), "ph_cox_loss_grad")
+        ctx.save_for_backward(d)
+        ctx.shape = None
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        return d * g, None, None
+
+
+def CoxLoss(survtime, censor, hazard_pred, device=None):
+    """utils.py:361-376 (same argument order): the Cox partial-likelihood loss of the survival task, one kernel instead of
+    a B x B host loop.  The survival TRAINERS are out of scope; this is the loss function alone."""
+    g = _CoxFn.apply(hazard_pred.reshape(-1), survtime, censor)
+    return g

@@ -484,3 +484,17 @@ def test_superpixel_attention_mask_end_to_end_vs_reference_function(golden_dir):
         assert (om.cpu().numpy() != g["omic_mask"]).mean() < 0.01
     finally:
         m.set_precision("bf16")
+
+
+def test_cox_loss_vs_reference_golden(golden_dir):
+    """utils.CoxLoss (one kernel: risk sets, log-sum, gradient) against the reference's own function and its autograd
+    gradient (tests/golden/make_golden_cox.py), tied survival times included."""
+    import multimodal_learning_amd as m
+    g = np.load(os.path.join(golden_dir, "cox_loss.npz"))
+    for B in (8, 64, 300):
+        theta = torch.as_tensor(g[f"theta{B}"]).cuda().requires_grad_(True)
+        loss = m.utils.CoxLoss(torch.as_tensor(g[f"t{B}"]), torch.as_tensor(g[f"c{B}"]), theta, "cuda")
+        gr, = torch.autograd.grad(2.0 * loss, theta)
+        assert abs(float(loss) - float(g[f"loss{B}"])) <= 1e-5 * abs(float(g[f"loss{B}"]))
+        ref = 2.0 * g[f"g{B}"]
+        assert gr.shape == ref.shape and np.abs(gr.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-8
