@@ -48,6 +48,7 @@ __global__ __launch_bounds__(1024) void superpixel_mask_kernel(const float* __re
   const float hi = ldexpf(1.f, ex > 126 ? 126 : ex), lo = ldexpf(1.f, ex > 126 ? ex - 126 : 0);   // scale = hi * lo
   for (int p = tid; p < HW; p += 1024) {
     const int n = (int)lab[p];
+    if (n < 0 || n >= N) continue;            // a label outside [0, N) belongs to no superpixel
     long long q = 0;
     for (int c = 0; c < C; ++c) q += (long long)rintf(g[(size_t)c * HW + p] * hi * lo);
     atomicAdd(reinterpret_cast<unsigned long long*>(&sums[n]), (unsigned long long)q);
@@ -77,7 +78,10 @@ __global__ __launch_bounds__(1024) void superpixel_mask_kernel(const float* __re
     if (tid == 0 && redi[0] != 0x7fffffff) sel[redi[0]] = 1;
     __syncthreads();
   }
-  for (int p = tid; p < HW; p += 1024) mask[(size_t)b * HW + p] = sel[(int)lab[p]] ? 1.f : 0.f;
+  for (int p = tid; p < HW; p += 1024) {
+    const int n = (int)lab[p];
+    mask[(size_t)b * HW + p] = (n >= 0 && n < N && sel[n]) ? 1.f : 0.f;
+  }
 }
 
 // mask[b][i] = 1 iff x[b][i] >= the K-th largest entry of row b  (fewer than K entries are strictly greater)
