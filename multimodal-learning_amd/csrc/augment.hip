@@ -113,6 +113,7 @@ __device__ __forceinline__ void fetch(const uint8_t* __restrict__ src, const flo
   int sy = (int)p[2] + y, sx = (int)p[3] + x;              // crop window of the flipped image ...
   if (p[1] != 0.f) sy = SH - 1 - sy;                       // ... = mirrored coordinates of the source
   if (p[0] != 0.f) sx = SW - 1 - sx;
+  sy = min(max(sy, 0), SH - 1); sx = min(max(sx, 0), SW - 1);   // caller-supplied windows cannot leave the tile
   const uint8_t* q = src + ((b * SH + sy) * SW + sx) * 3;
   r = q[0]; g = q[1]; bl = q[2];
 }
