@@ -498,3 +498,24 @@ def test_cox_loss_vs_reference_golden(golden_dir):
         assert abs(float(loss) - float(g[f"loss{B}"])) <= 1e-5 * abs(float(g[f"loss{B}"]))
         ref = 2.0 * g[f"g{B}"]
         assert gr.shape == ref.shape and np.abs(gr.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-8
+
+
+def test_tsvd_update_aux_degenerate_inputs():
+    """The proximal operator on degenerate stacks (both solvers): an all-zero stack stays zero, identical views collapse
+    onto slice 0 (the other frequency slices vanish), a threshold above every singular value returns zero - no NaNs."""
+    import multimodal_learning_amd as m
+    from oracle import variants as OV
+    for B in (32, 128):
+        z = torch.zeros(B, B, 4)
+        aux, tnn = m.tsvd.update_aux(z.cuda(), 0.1)
+        assert torch.equal(aux.cpu(), z) and float(tnn) == 0.0
+        g = torch.Generator().manual_seed(B)
+        a = torch.rand(B, B, generator=g)
+        same = a.unsqueeze(2).expand(B, B, 4).contiguous()
+        aux, tnn = m.tsvd.update_aux(same.cuda(), 0.05)
+        ref, tnn_ref = OV.update_aux(same, 0.05)
+        assert torch.isfinite(aux).all()
+        assert np.abs(aux.cpu().numpy() - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
+        assert abs(float(tnn) - tnn_ref) <= 1e-4 * max(abs(tnn_ref), 1.0)
+        aux, tnn = m.tsvd.update_aux(same.cuda(), 1e4)
+        assert float(aux.abs().max()) == 0.0 and float(tnn) == 0.0

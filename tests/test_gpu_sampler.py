@@ -141,3 +141,34 @@ def test_distill_step_draws_its_contrast_indices_on_the_device():
     assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(i1, i2))
     assert all(np.isfinite(l1)) and not torch.equal(i1[0][:, 1:], i1[1][:, 1:])
     assert int(i1[0].shape[1]) == opt.nce_p + opt.nce_k
+
+
+def test_shuffle_indices_walk_epochs_like_a_drop_last_loader():
+    """ph_shuffle_indices: DataLoader(shuffle=True, drop_last=True) - within an epoch of n // B batches no row repeats,
+    the tail rows that do not fill a batch are dropped, successive epochs use different permutations, and the draw is a
+    pure function of (seed, batch number)."""
+    from multimodal_learning_amd._lib import lib, check, ptr, stream
+    n, B = 1000, 96                      # 10 batches per epoch, 40 rows dropped
+    out = torch.empty(B, device="cuda", dtype=torch.int64)
+    cnt = torch.zeros(1, device="cuda", dtype=torch.int64)
+    epochs = []
+    for e in range(3):
+        rows = []
+        for b in range(n // B):
+            cnt.fill_(e * (n // B) + b)
+            check(lib().ph_shuffle_indices(ptr(out), n, B, 11, ptr(cnt), stream()), "ph_shuffle_indices")
+            rows.append(out.cpu().clone())
+        r = torch.cat(rows)
+        assert r.min() >= 0 and r.max() < n and len(set(r.tolist())) == (n // B) * B
+        epochs.append(r)
+    assert not torch.equal(epochs[0], epochs[1]) and not torch.equal(epochs[1], epochs[2])
+    cnt.fill_(7)
+    check(lib().ph_shuffle_indices(ptr(out), n, B, 11, ptr(cnt), stream()), "ph_shuffle_indices")
+    assert torch.equal(out.cpu(), epochs[0][7 * B:8 * B])
+    # every row is equally likely to lead a batch: first elements over many epochs spread over the range
+    firsts = []
+    for e in range(200):
+        cnt.fill_(e * (n // B))
+        check(lib().ph_shuffle_indices(ptr(out), n, B, 11, ptr(cnt), stream()), "ph_shuffle_indices")
+        firsts.append(int(out[0]))
+    assert len(set(firsts)) > 150 and 300 < np.mean(firsts) < 700
