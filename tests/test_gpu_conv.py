@@ -180,3 +180,25 @@ def test_stride2_dgrad_accumulates_in_place(case, prec):
     check(L.ph_conv2d_dgrad_res(ptr(dyd), ptr(wd), ptr(dx), ptr(dx), None, B, Cin, H, H, Cout, KS, 2, pad, prec, ptr(ws),
                                 stream()), "dgrad_res s2")
     assert_close(ref, nchw_cpu(dx), 1e-5, 2e-5 if prec == 1 else 1.0 / 64, "stride-2 dgrad accumulated in place")
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 33, 47), (2, 16, 16), (1, 130, 18)])
+def test_stem_dgrad_vs_conv_transpose(B, H, W):
+    """ph_stem_dgrad (input gradient of the 7x7 / stride 2 / pad 3 stem conv) against torch autograd, odd and tiny sizes."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd._lib import lib, check, ptr, stream
+    g = torch.Generator().manual_seed(H)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    x = torch.randn(B, 3, H, W, generator=g, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g)
+    ref, = torch.autograd.grad(y, x, dy, retain_graph=True)
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx = torch.empty(B, 3, H, W, device="cuda")
+    wc = w.cuda().contiguous()
+    check(lib().ph_stem_dgrad(ptr(dy_nhwc), ptr(wc), ptr(dx), B, H, W, 1, stream()), "ph_stem_dgrad")     # fp32 dy
+    assert float((dx.cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    dyb = dy_nhwc.bfloat16()
+    check(lib().ph_stem_dgrad(ptr(dyb), ptr(wc), ptr(dx), B, H, W, 0, stream()), "ph_stem_dgrad")         # bf16 dy
+    ref_b, = torch.autograd.grad(y, x, dyb.float().cpu().permute(0, 3, 1, 2))
+    assert float((dx.cpu() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
