@@ -245,15 +245,40 @@ __global__ __launch_bounds__(256) void crd_update_kernel(float* __restrict__ mem
 // the query's class with the largest cosine similarity to the query's OWN bank row.  One block per (query, bank);
 // every thread scans a strided slice keeping a private top-NP list, the lists are merged through LDS.  The
 // reference copies the whole bank to the host and calls sklearn per step; here the bank is read once from L2/HBM.
-constexpr int TOPK_MAX = 8;
+constexpr int TOPK_MAX = 8, TOPK_SPLIT = 32;
+
+// block-wide pick of the best (value desc, index asc) live candidate among n entries of (sv, si); every thread gets it
+__device__ __forceinline__ void block_argbest(const float* sv, const int* si, int n, float* rv, int* ri, int* rs, float& best,
+                                              int& besti, int& bestslot) {
+  const int tid = threadIdx.x;
+  float v = -INFINITY; int i = 0x7fffffff, sl = -1;
+  for (int e = tid; e < n; e += 256) {
+    const float ve = sv[e]; const int ie = si[e];
+    if (ie != 0x7fffffff && (ve > v || (ve == v && ie < i))) { v = ve; i = ie; sl = e; }
+  }
+  rv[tid] = v; ri[tid] = i; rs[tid] = sl;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      const float v2 = rv[tid + o]; const int i2 = ri[tid + o];
+      if (i2 != 0x7fffffff && (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid]))) { rv[tid] = v2; ri[tid] = i2; rs[tid] = rs[tid + o]; }
+    }
+    __syncthreads();
+  }
+  best = rv[0]; besti = ri[0]; bestslot = rs[0];
+  __syncthreads();
+}
+
+// stage 1: block (query b, bank, slice z) scans its slice of the bank; every thread keeps a private top list over its rows
+// (same per-row arithmetic and order as ever: the similarities are bitwise those of the single-block version), the block
+// picks its TOPK_MAX best by parallel arg-max rounds and leaves them in the workspace
 __global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restrict__ mem1,
                                                             const float* __restrict__ mem2,
                                                             const int* __restrict__ labels,
                                                             const int64_t* __restrict__ idx, int PK,
-                                                            const int64_t* __restrict__ batch_label, int n_data, int NP,
-                                                            int64_t* __restrict__ nb1, int64_t* __restrict__ nb2,
-                                                            float* __restrict__ sim1, float* __restrict__ sim2) {
-  const int b = blockIdx.x, bank = blockIdx.y;
+                                                            const int64_t* __restrict__ batch_label, int n_data,
+                                                            float* __restrict__ cand_v, int* __restrict__ cand_i) {
+  const int b = blockIdx.x, bank = blockIdx.y, z = blockIdx.z;
   const float* mem = bank ? mem2 : mem1;
   const int64_t qrow = idx[(size_t)b * PK];
   const int lab = (int)batch_label[b];
@@ -270,7 +295,8 @@ __global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restr
   float bv[TOPK_MAX]; int bi[TOPK_MAX];
 #pragma unroll
   for (int k = 0; k < TOPK_MAX; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
-  for (int j = threadIdx.x; j < n_data; j += blockDim.x) {
+  const int chunk = (n_data + TOPK_SPLIT - 1) / TOPK_SPLIT, lo = z * chunk, hi = min(n_data, lo + chunk);
+  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
     float v = 0.f;                                   // other classes are masked to similarity 0 (class_mask *)
     if (labels[j] == lab) {
       float dot = 0.f, nn = 0.f;
@@ -297,33 +323,62 @@ __global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restr
   }
   __shared__ float sv[256 * TOPK_MAX];
   __shared__ int si[256 * TOPK_MAX];
+  __shared__ float rv[256];
+  __shared__ int ri[256], rs[256];
 #pragma unroll
   for (int k = 0; k < TOPK_MAX; ++k) { sv[threadIdx.x * TOPK_MAX + k] = bv[k]; si[threadIdx.x * TOPK_MAX + k] = bi[k]; }
   __syncthreads();
-  if (threadIdx.x == 0) {   // serial merge of 256 sorted lists (NP <= 8 picks of 2048 candidates)
-    int head[1];
-    for (int pick = 0; pick < NP; ++pick) {
-      float best = -INFINITY; int besti = 0x7fffffff, bestslot = -1;
-      for (int e = 0; e < 256 * TOPK_MAX; ++e) {
-        const float v = sv[e]; const int i = si[e];
-        if (i != 0x7fffffff && (v > best || (v == best && i < besti))) { best = v; besti = i; bestslot = e; }
-      }
-      (void)head;
-      if (bestslot >= 0) si[bestslot] = 0x7fffffff;
+  const size_t base = (((size_t)b * 2 + bank) * TOPK_SPLIT + z) * TOPK_MAX;
+  for (int pick = 0; pick < TOPK_MAX; ++pick) {
+    float best; int besti, slot;
+    block_argbest(sv, si, 256 * TOPK_MAX, rv, ri, rs, best, besti, slot);
+    if (threadIdx.x == 0) {
+      if (slot >= 0) si[slot] = 0x7fffffff;
+      cand_v[base + pick] = best; cand_i[base + pick] = besti;
+    }
+    __syncthreads();
+  }
+}
+
+// stage 2: the NP best of the TOPK_SPLIT * TOPK_MAX candidates of a (query, bank)
+__global__ __launch_bounds__(256) void crd_bank_topk_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
+                                                                  int NP, int64_t* __restrict__ nb1, int64_t* __restrict__ nb2,
+                                                                  float* __restrict__ sim1, float* __restrict__ sim2) {
+  const int b = blockIdx.x, bank = blockIdx.y;
+  constexpr int NC = TOPK_SPLIT * TOPK_MAX;
+  __shared__ float sv[NC];
+  __shared__ int si[NC];
+  __shared__ float rv[256];
+  __shared__ int ri[256], rs[256];
+  const size_t base = ((size_t)b * 2 + bank) * NC;
+  for (int e = threadIdx.x; e < NC; e += 256) { sv[e] = cand_v[base + e]; si[e] = cand_i[base + e]; }
+  __syncthreads();
+  for (int pick = 0; pick < NP; ++pick) {
+    float best; int besti, slot;
+    block_argbest(sv, si, NC, rv, ri, rs, best, besti, slot);
+    if (threadIdx.x == 0) {
+      if (slot >= 0) si[slot] = 0x7fffffff;
       (bank ? nb2 : nb1)[(size_t)b * NP + pick] = besti;
       (bank ? sim2 : sim1)[(size_t)b * NP + pick] = best;
     }
+    __syncthreads();
   }
 }
 
 }  // namespace
 
+size_t ph_crd_bank_topk_workspace_bytes(int B) { return (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX * (sizeof(float) + sizeof(int)); }
+
 int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, const int64_t* idx, int PK,
                      const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
-                     int64_t* nb2, float* sim1, float* sim2, hipStream_t st) {
-  if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX) return PH_EINVAL;
-  hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2), dim3(256), 0, st, mem1, mem2, labels, idx, PK, batch_label,
-                     n_data, num_pos, nb1, nb2, sim1, sim2);
+                     int64_t* nb2, float* sim1, float* sim2, void* workspace, hipStream_t st) {
+  if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX || !workspace) return PH_EINVAL;
+  float* cv = reinterpret_cast<float*>(workspace);
+  int* ci = reinterpret_cast<int*>(cv + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
+  hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2, TOPK_SPLIT), dim3(256), 0, st, mem1, mem2, labels, idx, PK, batch_label,
+                     n_data, cv, ci);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(crd_bank_topk_merge_kernel, dim3(B, 2), dim3(256), 0, st, cv, ci, num_pos, nb1, nb2, sim1, sim2);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
