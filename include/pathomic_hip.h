@@ -170,7 +170,8 @@ int ph_crd_setz(float* params, const float* sums2, float count, float n_data, ph
 int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
                      const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
                      const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
-                     int feat_dim, float n_data, float inv_bnorm, ph_stream_t stream);
+                     int feat_dim, float n_data, float inv_bnorm, void* workspace /* may be NULL */, ph_stream_t stream);
+size_t ph_crd_loss_grad_workspace_bytes(int B);
 /* MIA-2023 v10 KNN positives (CRD_criterion_v10.py:72-79,110-116): class-masked full-bank cosine top-num_pos of each
  * query's own bank row, for both banks; labels = class of every bank row (int32 [n_data]) */
 size_t ph_crd_bank_topk_workspace_bytes(int B);

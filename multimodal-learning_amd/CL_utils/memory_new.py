@@ -60,10 +60,12 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None):
     dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
     dv2 = torch.empty_like(dv1)
     bnorm = float(mem.batch_norm_size or B)
+    # long column lists (nce_k = 4096 of the MIA trainers) are dealt to several workgroups per sample through a workspace
+    lg_ws = (torch.empty(L.ph_crd_loss_grad_workspace_bytes(B), device=dev, dtype=torch.uint8) if P2 + K2 >= 1024 else None)
     check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(posw_s), ptr(posw_t),
                              ptr(mem.memory_v1), ptr(mem.memory_v2),
                              ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, PK, P2, K2, D, float(mem.nLem),
-                             1.0 / bnorm, st), "ph_crd_loss_grad")
+                             1.0 / bnorm, ptr(lg_ws), st), "ph_crd_loss_grad")
     if per_sample:
         loss = lossp       # [B] per-sample losses (each already divided by the batch normaliser)
     else:

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(1024) void crd_loss_grad_kernel(const float* __rest
                                                             const float* __restrict__ params,
                                                             float* __restrict__ lossp, float* __restrict__ dv1,
                                                             float* __restrict__ dv2, int PK, int P2, int K2,
-                                                            float n_data, float inv_bnorm) {
+                                                            float n_data, float inv_bnorm, float* __restrict__ part) {
+  // gridDim.y > 1 (long column lists, e.g. nce_k = 4096): the columns of a sample are dealt to gridDim.y workgroups whose
+  // partial sums go to `part` and are added in a fixed order by crd_loss_grad_reduce_kernel
   const int b = blockIdx.x, S2 = P2 + K2;
   const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
   const float invT = 1.f / params[1], Z1 = params[2], Z2 = params[3];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(1024) void crd_loss_grad_kernel(const float* __rest
   // 32 half-waves per sample: the loop is a chain of dependent gathers (sel -> idx -> bank row), latency-bound; with 8
   // half-waves (256 threads) it took 54 us at B = 64, P2 + K2 = 532
   constexpr int NHW = 32;
-  for (int j = hw; j < S2; j += NHW) {
+  for (int j = blockIdx.y * NHW + hw; j < S2; j += NHW * gridDim.y) {
     const float x1 = xs[(size_t)b * S2 + j] / Z1, x2 = xt[(size_t)b * S2 + j] / Z2;
     float c1, c2;
     if (j < P2) {
@@ -214,12 +216,28 @@ __global__ __launch_bounds__(1024) void crd_loss_grad_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < NHW; ++q) t += sh[q][which][d];
-    (which ? dv2 : dv1)[(size_t)b * D + d] = t;
+    if (gridDim.y == 1) (which ? dv2 : dv1)[(size_t)b * D + d] = t;
+    else part[(((size_t)b * gridDim.y + blockIdx.y) * 2 + which) * D + d] = t;
   }
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int q = 0; q < NHW; ++q) t += shl[q];
-    lossp[b] = -t * inv_bnorm;
+    if (gridDim.y == 1) lossp[b] = -t * inv_bnorm;
+    else part[(size_t)gridDim.x * gridDim.y * 2 * D + (size_t)b * gridDim.y + blockIdx.y] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void crd_loss_grad_reduce_kernel(const float* __restrict__ part, float* __restrict__ lossp,
+                                                                   float* __restrict__ dv1, float* __restrict__ dv2, int NS,
+                                                                   float inv_bnorm) {
+  const int b = blockIdx.x, which = threadIdx.x >> 7, d = threadIdx.x & 127;
+  float t = 0.f;
+  for (int y = 0; y < NS; ++y) t += part[(((size_t)b * NS + y) * 2 + which) * D + d];
+  (which ? dv2 : dv1)[(size_t)b * D + d] = t;
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    for (int y = 0; y < NS; ++y) l += part[(size_t)gridDim.x * NS * 2 * D + (size_t)b * NS + y];
+    lossp[b] = -l * inv_bnorm;
   }
 }
 
@@ -415,14 +433,25 @@ int ph_crd_setz(float* params, const float* sums, float count, float n_data, hip
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
+constexpr int LG_SPLIT_MAX = 8;
+size_t ph_crd_loss_grad_workspace_bytes(int B) { return (size_t)B * LG_SPLIT_MAX * (2 * D + 1) * sizeof(float); }
+
 int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
                      const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
                      const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
-                     int feat_dim, float n_data, float inv_bnorm, hipStream_t st) {
+                     int feat_dim, float n_data, float inv_bnorm, void* workspace, hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
-  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B), dim3(1024), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
-                     posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, n_data, inv_bnorm);
+  int ns = workspace ? (P2 + K2) / 512 : 1;     // one workgroup per 512 columns of a sample, at most LG_SPLIT_MAX
+  ns = ns < 1 ? 1 : (ns > LG_SPLIT_MAX ? LG_SPLIT_MAX : ns);
+  hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B, ns), dim3(1024), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
+                     posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, n_data, inv_bnorm,
+                     reinterpret_cast<float*>(workspace));
   PH_LAUNCH_CHECK();
+  if (ns > 1) {
+    hipLaunchKernelGGL(crd_loss_grad_reduce_kernel, dim3(B), dim3(256), 0, st, reinterpret_cast<const float*>(workspace), lossp,
+                       dv1, dv2, ns, inv_bnorm);
+    PH_LAUNCH_CHECK();
+  }
   return PH_OK;
 }
 int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
