@@ -213,6 +213,12 @@ int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /*
 int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1,
                          double beta2, double eps, double weight_decay, const float* hyper, ph_stream_t stream);
 int ph_ema_update(float* ema, const float* p, size_t n, float alpha, ph_stream_t stream);
+/* define_reg (MICCAI-2022/networks_new.py:93-108 -> utils.py:60-198, the `lambda_reg * loss_reg` term of
+ * train_test_MT.py:209-217 and train_test_path_multi_distill.py:312-313): L1 norm of a contiguous run of fp32
+ * parameters.  ph_l1_sum: out[0] (+)= sum |w[i]|, `partials` = scratch of >= 1024 floats, fixed summation order.
+ * ph_l1_sign_axpy: g[i] += coef * coef_dev[0] * sgn(w[i]) (coef_dev may be NULL = 1), its backward. */
+int ph_l1_sum(const float* w, size_t n, float* partials, float* out, int accumulate, ph_stream_t stream);
+int ph_l1_sign_axpy(const float* w, float* g, size_t n, const float* coef_dev, float coef, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fine-grained convolution entry points (unit tests / other callers).  Activations NHWC in the precision

@@ -92,6 +92,8 @@ SIGNATURES = {
     "ph_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, f64, vp]),
     "ph_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, vp, vp]),
     "ph_ema_update": (i32, [vp, vp, sz, f32, vp]),
+    "ph_l1_sum": (i32, [vp, sz, vp, vp, i32, vp]),
+    "ph_l1_sign_axpy": (i32, [vp, vp, sz, vp, f32, vp]),
     "ph_prof_enable": (i32, [i32]),
     "ph_prof_reset": (i32, []),
     "ph_prof_summary": (i32, [vp, i32]),

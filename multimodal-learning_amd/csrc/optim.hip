@@ -220,6 +220,40 @@ __global__ __launch_bounds__(256) void gk_rows_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---- L1 weight regulariser of define_reg (reference networks_new.py:93-108 -> utils.py:60-198: sum of |W| over a list
+// of parameter tensors).  The parameters live in one flat fp32 buffer (train_step.FlatParams, zero padding between
+// tensors adds nothing), so a term is a handful of contiguous segments: pass 1 writes one partial per block, pass 2
+// adds them in a fixed order in double (bitwise reproducible); the backward adds coef * sign(W) into the flat gradient.
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ w, size_t n, float* __restrict__ parts) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += fabsf(w[i]);
+  s = wave_sum(s);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void l1_finish_kernel(const float* __restrict__ parts, int nparts, float* out, int accumulate) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += (double)parts[i];
+  s = wave_sum_d(s);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (float)((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+__global__ void l1_sign_axpy_kernel(const float* __restrict__ w, float* __restrict__ g, size_t n, const float* coef_dev, float coef) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float c = coef_dev ? coef * coef_dev[0] : coef;
+  const float x = w[i];
+  g[i] += x > 0.f ? c : (x < 0.f ? -c : 0.f);     // d|x|/dx = sgn(x), 0 at 0 (torch.abs backward)
+}
+
 }  // namespace
 
 int ph_gk_rows(const float* G, int ng, int B, int D, int use_thresh, float thresh, float* all_scale, hipStream_t st) {
@@ -292,6 +326,25 @@ int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* em
 
 int ph_ema_update(float* ema, const float* p, size_t n, float alpha, hipStream_t st) {
   hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ema, p, n, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_l1_sum(const float* w, size_t n, float* partials, float* out, int accumulate, hipStream_t st) {
+  if (!w || !partials || !out) return PH_EINVAL;
+  size_t nb = (n + 2047) / 2048;           // ~8 elements per thread; at most PH_L1_PARTIALS partial sums
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, w, n, partials);
+  hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(256), 0, st, partials, (int)nb, out, accumulate);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_l1_sign_axpy(const float* w, float* g, size_t n, const float* coef_dev, float coef, hipStream_t st) {
+  if (!w || !g) return PH_EINVAL;
+  if (n == 0) return PH_OK;
+  hipLaunchKernelGGL(l1_sign_axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, g, n, coef_dev, coef);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -48,10 +48,20 @@ def define_optimizer(opt, model):
 
 
 def define_reg(opt, model):
-    """networks_new.py:93-108; the stage-2 command uses --reg_type none."""
+    """networks_new.py:93-108: the L1 term the trainers scale with opt.lambda_reg (train_test_MT.py:209-217,
+    train_test_path_multi_distill.py:312-313).  A device scalar with a gradient (0 for 'none')."""
+    from . import utils as U
     if opt.reg_type == "none":
         return 0
-    raise NotImplementedError("reg_type [%s]: stage-2 hot path uses 'none' (README.md:30-33)" % opt.reg_type)
+    elif opt.reg_type == "path":
+        return U.regularize_path_weights(model=model)
+    elif opt.reg_type == "mm":
+        return U.regularize_MM_weights(model=model)
+    elif opt.reg_type == "all":
+        return U.regularize_weights(model=model)
+    elif opt.reg_type == "omic":
+        return U.regularize_MM_omic(model=model)
+    raise NotImplementedError("reg method [%s] is not implemented" % opt.reg_type)
 
 
 def define_scheduler(opt, optimizer):

@@ -392,3 +392,83 @@ def void_array(ptrs):
     for i, p in enumerate(ptrs):
         arr[i] = p
     return arr
+
+
+# ---------------------------------------------------------------- L1 weight regulariser (define_reg)
+_flat_registry = {}     # untyped-storage pointer of a FlatParams buffer -> weakref to it (train_step.FlatParams registers)
+
+
+def register_flat(fp):
+    import weakref
+    _flat_registry[fp.flat.untyped_storage().data_ptr()] = weakref.ref(fp)
+
+
+def _l1_segments(tensors):
+    """[(param pointer, element count, gradient pointer or None, tensors covered)]: runs of parameters that sit back
+    to back in one FlatParams buffer (16-byte aligned, zero padding in between: |0| = 0, sgn(0) = 0) become ONE
+    segment whose gradient goes straight into the flat gradient buffer; anything else is a segment of its own."""
+    segs = []
+    for t in tensors:
+        t = require_cuda(t, "parameter")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("define_reg expects contiguous float32 parameters")
+        ref = _flat_registry.get(t.untyped_storage().data_ptr())
+        fp = ref() if ref is not None else None
+        if fp is not None and fp.flat.untyped_storage().data_ptr() == t.untyped_storage().data_ptr():
+            off = (t.data_ptr() - fp.flat.data_ptr()) // 4
+            end = off + (t.numel() + 3) // 4 * 4
+            direct = (fp.grad is not None and t.requires_grad and t.grad is not None
+                      and t.grad.data_ptr() == fp.grad.data_ptr() + 4 * off)
+            last = segs[-1] if segs else None
+            if (last is not None and last["fp"] is fp and last["end"] == off and last["direct"] == direct):
+                last["end"] = end
+                last["tensors"].append(t)
+                continue
+            segs.append(dict(fp=fp, off=off, end=end, direct=direct, tensors=[t]))
+        else:
+            segs.append(dict(fp=None, off=0, end=t.numel(), direct=False, tensors=[t]))
+    return segs
+
+
+class L1RegFn(torch.autograd.Function):
+    """sum_i |W_i|.sum() of the reference's regularize_* helpers (utils.py:60-198) as a device scalar.  Backward:
+    sgn(W) * upstream, accumulated IN PLACE into the flat gradient buffer where the parameter's .grad is a view of it
+    (the optimiser's zero_grad() runs before backward() in every step class), returned to autograd otherwise."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        segs = _l1_segments(tensors)
+        dev = tensors[0].device
+        out = torch.zeros(1, device=dev, dtype=torch.float32)
+        scratch = torch.empty(1024, device=dev, dtype=torch.float32)
+        for sg in segs:
+            w = sg["fp"].flat[sg["off"]:sg["end"]] if sg["fp"] is not None else sg["tensors"][0].reshape(-1)
+            check(lib().ph_l1_sum(ptr(w), w.numel(), ptr(scratch), ptr(out), 1, stream()), "ph_l1_sum")
+        ctx.segs = segs
+        ctx.tensors = tensors
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.reshape(1).float().contiguous()
+        grads = {}
+        for sg in ctx.segs:
+            if sg["direct"]:
+                fp = sg["fp"]
+                check(lib().ph_l1_sign_axpy(ptr(fp.flat[sg["off"]:sg["end"]]), ptr(fp.grad[sg["off"]:sg["end"]]),
+                                            sg["end"] - sg["off"], ptr(g), 1.0, stream()), "ph_l1_sign_axpy")
+                continue
+            for t in sg["tensors"]:
+                if not t.requires_grad:
+                    continue
+                d = torch.zeros_like(t)
+                check(lib().ph_l1_sign_axpy(ptr(t), ptr(d), t.numel(), ptr(g), 1.0, stream()), "ph_l1_sign_axpy")
+                grads[id(t)] = d
+        return tuple(grads.get(id(t)) for t in ctx.tensors)
+
+
+def l1_norm_sum(tensors):
+    tensors = list(tensors)
+    if not tensors:
+        return None        # the reference's helpers return None when nothing matched (the caller's `lambda_reg * None` raises)
+    return L1RegFn.apply(*tensors)

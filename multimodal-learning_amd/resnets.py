@@ -245,11 +245,21 @@ class ResNet(nn.Module):
         dev = self.conv1.weight.device
         if persistent:
             return torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
+        # One workspace per plan key, never dropped behind the caller's back: a captured step graph holds the RAW
+        # pointer of the workspace it was captured with, so releasing it when a forward of another shape arrives (an
+        # evaluation batch between training epochs) would let later replays write into memory the allocator has handed
+        # to someone else.  release_workspaces() frees them explicitly.
         key = plan.key
         if key not in self._ws_cache:
-            self._ws_cache.clear()
             self._ws_cache[key] = torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
         return self._ws_cache[key]
+
+    def release_workspaces(self, keep=None):
+        """Free the cached trunk workspaces (all, or all but the plan key `keep` = (B, H, W, precision)).  Only legal
+        while no captured HIP graph replays this network: DistillStep.load_state_dict / a fresh enable_graph() rebuild
+        theirs."""
+        for k in [k for k in self._ws_cache if k != keep]:
+            del self._ws_cache[k]
 
     def _alloc_trunk_grads(self):
         """Gradient destinations of ph_resnet_backward.  With `_direct_grad` (set by DistillStep, whose optimiser

@@ -34,6 +34,7 @@ class FlatParams:
             t.data = self.flat[o:o + n].view(t.shape)
             if with_grad and t.requires_grad:
                 t.grad = self.grad[o:o + n].view(t.shape)
+        ops.register_flat(self)       # define_reg finds the flat layout of a parameter through its storage
 
     def segments(self, pred):
         """Maximal [start, end) runs of consecutive tensors for which pred(t) holds."""
@@ -158,19 +159,47 @@ class FusedAdam(torch.optim.Optimizer):
         ops.bump_weight_epoch()
 
     def state_dict(self):
+        """torch.optim.Adam's layout (state[i] = {step, exp_avg, exp_avg_sq} per parameter index, so the reference's
+        `optimizer.load_state_dict` - train_test_path_multi_distill.py:387-402 saves / restores exactly that - accepts
+        it) plus the flat buffers under "fused" for an exact, copy-only restore."""
         sd = super().state_dict()
+        if self._flat is not None and self._step > 0:
+            f = self._flat
+            sd["state"] = {i: dict(step=torch.tensor(float(self._step)),
+                                   exp_avg=self._m[o:o + t.numel()].view(t.shape).clone(),
+                                   exp_avg_sq=self._v[o:o + t.numel()].view(t.shape).clone())
+                           for i, (t, o) in enumerate(zip(f.tensors, f.offsets)) if t.requires_grad}
         sd["fused"] = dict(step=self._step, exp_avg=None if self._flat is None else self._m.clone(),
                            exp_avg_sq=None if self._flat is None else self._v.clone())
         return sd
 
     def load_state_dict(self, sd):
+        """Accepts this class's own state_dict or a plain torch.optim.Adam one (a checkpoint written by the reference)."""
+        sd = dict(sd)                      # the caller's checkpoint object stays intact (it may be loaded again)
         fused = sd.pop("fused", None)
+        per_param = sd.get("state") or {}
+        sd["state"] = {}                   # the moments live in the flat buffers, not in torch's per-parameter state
         super().load_state_dict(sd)
         if fused is not None and fused["exp_avg"] is not None:
             self._ensure_flat()
             self._step = fused["step"]
             self._m.copy_(fused["exp_avg"])
             self._v.copy_(fused["exp_avg_sq"])
+        elif per_param:
+            f = self._ensure_flat()
+            steps = set()
+            self._m.zero_(); self._v.zero_()
+            for i, st in per_param.items():
+                t, o = f.tensors[int(i)], f.offsets[int(i)]
+                if tuple(st["exp_avg"].shape) != tuple(t.shape):
+                    raise ValueError("optimizer state %d has shape %s, parameter %s" % (int(i), tuple(st["exp_avg"].shape),
+                                                                                       tuple(t.shape)))
+                self._m[o:o + t.numel()].copy_(st["exp_avg"].reshape(-1))
+                self._v[o:o + t.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+            if len(steps) != 1:
+                raise NotImplementedError("per-parameter step counts differ (%s): the fused kernel keeps one" % sorted(steps))
+            self._step = steps.pop()
 
 
 def update_ema_variables(model, ema_model, alpha, global_step):
@@ -231,6 +260,30 @@ def momentum_AEKD_loss(opt, optimizer, main_loss, feat_s, loss_t_list, mo_scale,
     return state, total_KD_loss
 
 
+def _validate_opt(opt, who):
+    """A drop-in must fail loudly where it diverges: option values the reference's batch body would honour and this
+    package does not implement raise here instead of silently training another objective."""
+    if getattr(opt, "task", "grad") != "grad":
+        raise NotImplementedError("%s: task %r - the survival (Cox) branch of the trainers is out of scope (SURVEY 2.1 #8); "
+                                  "only the grading task is built" % (who, opt.task))
+    if getattr(opt, "reg_type", "none") not in ("none", "path", "mm", "all", "omic"):
+        raise NotImplementedError("reg method [%s] is not implemented" % opt.reg_type)      # networks_new.py:106-107
+    if getattr(opt, "mode", "pathomic") != "pathomic":
+        raise NotImplementedError("%s: mode %r (the distillation trainers build the pathomic teacher and a path student)"
+                                  % (who, opt.mode))
+    if getattr(opt, "optimizer_type", "adam") != "adam":
+        raise NotImplementedError("%s: optimizer_type %r (the shipped commands use adam, options.py:126)"
+                                  % (who, opt.optimizer_type))
+    if getattr(opt, "act_type", "LSM") != "LSM":
+        raise NotImplementedError("%s: act_type %r (the grading task uses the log-softmax head)" % (who, opt.act_type))
+    if getattr(opt, "fusion_type", "pofusion") != "pofusion":
+        raise NotImplementedError("%s: fusion_type %r (pofusion is built)" % (who, opt.fusion_type))
+    if getattr(opt, "return_grad", "False") != "False":
+        raise NotImplementedError("%s: return_grad needs the reference's absent my_utils.compute_gradients" % who)
+    if getattr(opt, "use_vgg_features", 0):
+        raise NotImplementedError("%s: use_vgg_features (pre-extracted features bypass the ResNet trunk)" % who)
+
+
 # ----------------------------------------------------------------------------------------- the hot loop
 class DistillStep:
     """The batch body of train() (train_test_path_multi_distill.py:242-330) over the drop-in modules:
@@ -262,6 +315,7 @@ class DistillStep:
         else:
             raise ValueError("variant must be 'miccai2022', 'mia2022' or 'mia2023'")
         self.variant = variant
+        _validate_opt(opt, "DistillStep")
         self._mo_state = None     # momentum GK-Refine weights (mia2022), updated in place on the device
         self.sampler = None       # optional ContrastIndexSampler: draws sample_idx when the batch carries None
         self._mo_init = None
@@ -309,6 +363,15 @@ class DistillStep:
         n_student = len(list(self.model.parameters()))
         self.ema_flat = FlatParams(list(self.ema_model.parameters()))
         self.model._direct_grad = True     # trunk gradients are written straight into the flat .grad views
+        # `opt.lambda_reg * define_reg(opt, model)` (:312-313).  The stage-2 command passes --reg_type none; with `all`
+        # the L1 gradient is added into the same flat buffer, so the trunk's gradients must ACCUMULATE (autograd's
+        # AccumulateGrad) instead of overwriting.  `path` / `mm` / `omic` probe attributes the ResNet student does not
+        # have: the reference fails with AttributeError on its first batch, here already at construction.
+        self._reg_on = opt.reg_type != "none"
+        if self._reg_on:
+            from .networks_new import define_reg
+            define_reg(opt, self.model)
+            self.model._direct_grad = False
         for mod in self.ema_model.modules():
             if hasattr(mod, "_get_packed"):
                 mod._follow_epoch = True   # updated by the fused Adam+EMA kernel through raw pointers
@@ -352,6 +415,7 @@ class DistillStep:
             Hc = LossHeadCtx(self, grade, logits[-1].detach(), ema_logit_path.detach(), fuse_feat.detach(),
                              ema_path_feat.detach(), index, sample_idx, r1, r2, bnorm)
             loss = FusedDistillLossFn.apply(path_feat, Hc)
+            loss = self._add_reg(loss)                                                                      # :312-313
             self.optimizer.zero_grad()                                                                      # :326
             loss.backward()                                                                                 # :327
             if self.sync is not None:
@@ -392,7 +456,7 @@ class DistillStep:
         else:
             scale = None
             loss_KD = loss_div1 + loss_div2 + loss_kd1 + loss_kd2                                           # :309
-        loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :313
+        loss = self._add_reg(opt.lambda_nll * loss_cls + loss_KD)                                           # :312-313
         self.optimizer.zero_grad()                                                                          # :326
         loss.backward()                                                                                     # :327
         if self.sync is not None:
@@ -435,7 +499,7 @@ class DistillStep:
                 loss_KD = loss_KD * len(KD_loss_list)
         else:
             loss_KD = opt.alpha * loss_div + opt.beta * loss_kd                                             # :482
-        loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :486
+        loss = self._add_reg(opt.lambda_nll * loss_cls + loss_KD)                                           # :485-486
         self.optimizer.zero_grad()
         loss.backward()
         if self.sync is not None:
@@ -445,6 +509,13 @@ class DistillStep:
                     loss_kd1=(opt.beta * loss_kd).detach(), loss_kd2=z, scale=scale, logit_path=logit_path.detach(),
                     pred_path=pred_path.detach(), path_feat=path_feat.detach(), ema_logit=ema_logit_path,
                     fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+
+    def _add_reg(self, loss):
+        """+ opt.lambda_reg * define_reg(opt, model) (train_test_path_multi_distill.py:312-313)."""
+        if not self._reg_on:
+            return loss
+        from .networks_new import define_reg
+        return loss + self.opt.lambda_reg * define_reg(self.opt, self.model)
 
     def _fused_head_ok(self):
         """The closed-form loss head covers the shipped MICCAI stage-2 command: two teachers, CRD, GK-Refine with the CE
@@ -479,7 +550,7 @@ class DistillStep:
         else:
             scale = None
             loss_KD = opt.alpha * (loss_div1 + loss_div2) + opt.beta * (loss_kd1 + loss_kd2)                # :427
-        loss = opt.lambda_nll * loss_cls + loss_KD                                                          # :431
+        loss = self._add_reg(opt.lambda_nll * loss_cls + loss_KD)                                           # :430-431
         self.optimizer.zero_grad()
         loss.backward()
         if self.sync is not None:
@@ -536,6 +607,9 @@ class DistillStep:
         if self.zoo_kd is None and (opt.num_teachers != 2 or opt.distill != "crd"):
             raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd); "
                                       "variant 'mia2022' also runs the trainer's --distill baselines")
+        # :231-232 re-asserted per call: the reference sets train mode at every epoch because its test() leaves the
+        # networks in eval mode (evaluate.test does the same here); the EMA model is never put in eval mode there
+        self.module_list.train(); self.fix_model.train()
         self._capture_pre = None
         if batch is None:
             # on-device input pipeline (augment.ResidentTileLoader, `step.loader = loader`): the batch is produced from the
@@ -701,7 +775,35 @@ class DistillStep:
                     crd_kd_path_state_dict=self.criterion_kd_path.state_dict(),
                     scheduler_state_dict=self.scheduler.state_dict(), iter_num=self.iter_num,
                     teacher_rng_steps=rng,
-                    gk_momentum_scale=None if self._mo_state is None else self._mo_state.clone())
+                    gk_momentum_scale=None if self._mo_state is None else self._mo_state.clone(),
+                    # draw counters of the on-device input pipeline and the host RNG behind the CRD rank draws
+                    # (memory_new.py:311): without them a resumed run with step(None) / step.sampler draws other batches
+                    input_rng=self._input_rng_state())
+
+    def _input_rng_state(self, load=None):
+        """Device-side draw counters of step.sampler / step.loader (ContrastIndexSampler.step, DeviceAugment.step,
+        ResidentTileLoader.batch_no) and numpy's global RNG state; `load` restores a dict this method returned."""
+        loader = getattr(self, "loader", None)
+        cells = dict(sampler=getattr(getattr(self, "sampler", None), "step", None),
+                     loader_sampler=getattr(getattr(loader, "sampler", None), "step", None),
+                     loader_aug=getattr(getattr(loader, "aug", None), "step", None),
+                     loader_batch_no=getattr(loader, "batch_no", None))
+        if load is None:
+            out = {k: (None if t is None else t.clone()) for k, t in cells.items()}
+            out["numpy"] = np.random.get_state()
+            return out
+        for k, t in cells.items():
+            v = load.get(k)
+            if v is None:
+                continue
+            if t is None:
+                if k == "loader_batch_no" and loader is not None:
+                    loader.batch_no = v.to(self.device).clone()
+                    continue
+                raise RuntimeError("checkpoint carries the draw counter %r but this step has no such component" % k)
+            t.copy_(v)
+        if load.get("numpy") is not None:
+            np.random.set_state(load["numpy"])
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd["model_state_dict"])
@@ -722,6 +824,8 @@ class DistillStep:
         for name, mod in self.fix_model.named_modules():
             if hasattr(mod, "rng_step") and name in sd.get("teacher_rng_steps", {}):
                 mod.rng_step.copy_(sd["teacher_rng_steps"][name])
+        if sd.get("input_rng") is not None:
+            self._input_rng_state(load=sd["input_rng"])
         ops.bump_weight_epoch()      # packed MFMA weight images are rebuilt from the loaded parameters
         self._static = None          # a captured graph keeps pointing at valid buffers, but is rebuilt to be safe
         self._slots = None
@@ -765,8 +869,7 @@ class TeacherStage1Step:
         self.opt = opt
         self.device = torch.device(device)
         self.sync = sync
-        if opt.task != "grad":
-            raise NotImplementedError("stage-1 step implements the grading task (survival/Cox is out of scope)")
+        _validate_opt(opt, "TeacherStage1Step")
         if models is None:
             self.model = define_net(opt, k).to(self.device)
             self.ema_model = define_net(opt, k).to(self.device)
@@ -842,6 +945,7 @@ class TeacherStage1Step:
 
     def step(self, batch, epoch=0, batch_idx=None):
         opt = self.opt
+        self.model.train()              # train_test_MT.py:110 `module_list.train()` per epoch (its test() leaves eval mode)
         if epoch >= 15:
             opt.CRD_weight = 0.01                                                                # train_test_MT.py:118-119
         views, x_grph, x_omic, censor, survtime, grade, index, sample_idx = batch
@@ -903,7 +1007,12 @@ class TeacherStage1Step:
             loss_pred_KD = torch.zeros((), device=dev)
         nll = lambda p: ops.NLLFn.apply(p, grade, B)
         loss_nll = nll(pred_path) + nll(pred_omic) + nll(pred)                                  # :208-212
-        loss = opt.lambda_nll * loss_nll + loss_CRD + loss_pred_KD + loss_masking               # :214 (reg_type none); MIA-2023 :303-304
+        loss = opt.lambda_nll * loss_nll + loss_CRD + loss_pred_KD + loss_masking               # :217-218; MIA-2023 :303-304
+        loss_reg = torch.zeros((), device=dev)
+        if opt.reg_type != "none":      # :209 - the shipped stage-1 command keeps the default `omic` (options.py:132)
+            from .networks_new import define_reg
+            loss_reg = define_reg(opt, self.model)
+            loss = loss + opt.lambda_reg * loss_reg
         loss_orth = torch.zeros((), device=dev)
         if self.orth_on:
             loss_orth = self.Orth_loss(path_feat, omic_feat)                                    # :216-218
@@ -955,5 +1064,5 @@ class TeacherStage1Step:
         self.iter_num += 1
         return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),
                     loss_CRD=loss_CRD.detach(), loss_orth=loss_orth.detach(), loss_tsvd=loss_tsvd.detach(),
-                    loss_pred_KD_masking=loss_masking.detach(),
+                    loss_pred_KD_masking=loss_masking.detach(), loss_reg=loss_reg.detach(),
                     pred=pred.detach(), pred_path=pred_path.detach(), pred_omic=pred_omic.detach())

@@ -30,6 +30,44 @@ def init_net(net, init_type="normal", init_gain=0.02, gpu_ids=[]):
     return net
 
 
+# ---- regularisation (utils.py:57-198).  Same attribute walks as the reference, including what they do NOT find: the
+# helpers unwrap DataParallel with `model.module` and probe sub-modules with the `__hasattr__` method that only
+# PathomicNet defines (networks_new.py:356-369), so on a network without it (the ResNet student) `path` / `mm` / `omic`
+# raise AttributeError exactly as the reference does.
+def _l1(param_lists):
+    from . import ops
+    tensors = [W for ps in param_lists for W in ps]
+    return ops.l1_norm_sum(tensors)
+
+
+def regularize_weights(model, reg_type=None):
+    """utils.py:60-68 - every parameter of the model (output_range / output_shift included, as there)."""
+    return _l1([model.parameters()])
+
+
+def regularize_path_weights(model, reg_type=None):
+    """utils.py:71-86 - `classifier` then `linear` of the unwrapped model; a model without `.linear` (PathomicNet)
+    raises AttributeError in the reference and here."""
+    return _l1([model.module.classifier.parameters(), model.module.linear.parameters()])
+
+
+_MM_PARTS = ("omic_net", "linear_h_path", "linear_h_omic", "linear_h_grph", "linear_z_path", "linear_z_omic", "linear_z_grph",
+             "linear_o_path", "linear_o_omic", "linear_o_grph", "encoder1", "encoder2", "classifier")
+
+
+def regularize_MM_weights(model, reg_type=None):
+    """utils.py:88-183 - the listed direct sub-modules of the unwrapped model that exist (PathomicNet: omic_net and
+    classifier; the gating / encoder layers live inside `fusion` and are not direct children)."""
+    m = model.module
+    return _l1([getattr(m, name).parameters() for name in _MM_PARTS if m.__hasattr__(name)])
+
+
+def regularize_MM_omic(model, reg_type=None):
+    """utils.py:186-198 - the genomic SNN's parameters (default --reg_type of the stage-1 command)."""
+    m = model.module
+    return _l1([m.omic_net.parameters()] if m.__hasattr__("omic_net") else [])
+
+
 def count_parameters(model):
     return sum(p.numel() for p in model.parameters() if p.requires_grad)
 
