@@ -6,7 +6,7 @@ HBM - at the step rates of this package the PIL pipeline in four DataLoader work
     x_path, ema_x_path = aug(src_u8)                    # src_u8 [B, SH, SW, 3] uint8 (device) -> two f32 [B, 3, S, S] views
 
 The draws come from a counter RNG keyed by (seed, step, image, view) - reproducible, not numpy's stream.  The colour
-arithmetic restates PIL / torchvision, which are absent here: parity unpinned (csrc/augment.hip, oracle/augment.py)."""
+arithmetic is Pillow's as torchvision drives it, pinned bit for bit against Pillow (tests/golden/colorjitter_pil.npz)."""
 import torch
 
 from ._lib import lib, check, ptr, stream, require_cuda

@@ -5,11 +5,11 @@
 // grey mean the contrast step needs, one writes both fp32 NCHW views.  Byte work, HBM-bound: 0.8 MB read + 3 MB written
 // per 512 x 512 view.
 //
-// torchvision / PIL are not in this image, so the colour arithmetic is RESTATED from their documented algorithms and is
-// "parity unpinned" (see oracle/augment.py, which states the same arithmetic in numpy and is what the tests compare
-// against): PIL ImageEnhance = Image.blend(degenerate, image, factor) on uint8 with truncation; brightness blends with
-// black, contrast with the rounded mean of the ITU-R 601-2 luma, saturation with the per-pixel luma; the four steps run
-// in a random order; hue shifts H in a float HSV round trip.
+// The colour arithmetic is Pillow's, as torchvision's PIL backend drives it, and is PINNED against Pillow itself
+// (tests/golden/colorjitter_pil.npz, produced by the real ImageEnhance / convert("HSV") calls; oracle/augment.py states
+// the same arithmetic in numpy): ImageEnhance = Image.blend(degenerate, image, factor) on uint8 with truncation;
+// brightness blends with black, contrast with the rounded mean of the ITU-R 601-2 luma, saturation with the per-pixel
+// luma; the four steps run in a drawn order; hue is a wrapping add on the uint8 H channel of Pillow's HSV image.
 #include "ph_common.h"
 #include "ph_kernels.h"
 
@@ -61,36 +61,43 @@ __device__ __forceinline__ int blend8(int d, int v, float f) {
   return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
 }
 
+// torchvision functional_pil.adjust_hue: img.convert("HSV"), wrapping uint8 add of uint8(hue_factor * 255) on H,
+// convert("RGB") - Pillow's Convert.c (rgb2hsv_row / hsv2rgb) restated with its float / double mix; no contraction to
+// FMA (the C library evaluates every product and sum separately).  Pinned bit for bit against Pillow itself
+// (tests/golden/make_golden_colorjitter.py; oracle/augment.py is checked against Pillow over all 2^24 colours).
+__device__ __forceinline__ int clip8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 __device__ __forceinline__ void hue_shift(int& r, int& g, int& b, float hf) {
-  const float R = r / 255.f, G = g / 255.f, B = b / 255.f;
-  const float mx = fmaxf(R, fmaxf(G, B)), mn = fminf(R, fminf(G, B)), d = mx - mn;
-  float h = 0.f;
-  if (d > 0.f) {
-    if (mx == R) h = (G - B) / d;
-    else if (mx == G) h = 2.f + (B - R) / d;
-    else h = 4.f + (R - G) / d;
-    h /= 6.f;
-    h -= floorf(h);
+#pragma clang fp contract(off)
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  int uh = 0, us = 0;
+  const int uv = maxc;
+  if (minc != maxc) {
+    const float cr = (float)(maxc - minc);
+    const float s = __fdiv_rn(cr, (float)maxc);
+    const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+    float h;
+    if (r == maxc) h = __fsub_rn(bc, gc);
+    else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+    else h = (float)(4.0 + (double)gc - (double)rc);
+    h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+    uh = clip8((int)((double)h * 255.0));
+    us = clip8((int)((double)s * 255.0));
   }
-  const float s = mx > 0.f ? d / mx : 0.f, v = mx;
-  h += hf;
-  h -= floorf(h);
-  const float h6 = h * 6.f;
-  const int i = (int)floorf(h6) % 6;
-  const float fr = h6 - floorf(h6);
-  const float p = v * (1.f - s), q = v * (1.f - s * fr), t = v * (1.f - s * (1.f - fr));
-  float rr, gg, bb;
-  switch (i) {
-    case 0: rr = v; gg = t; bb = p; break;
-    case 1: rr = q; gg = v; bb = p; break;
-    case 2: rr = p; gg = v; bb = t; break;
-    case 3: rr = p; gg = q; bb = v; break;
-    case 4: rr = t; gg = p; bb = v; break;
-    default: rr = v; gg = p; bb = q; break;
+  uh = (uh + ((int)((double)hf * 255.0) & 255)) & 255;      // np.uint8(hue_factor * 255), wrapping add
+  if (us == 0) { r = g = b = uv; return; }
+  const double h6 = (double)(float)uh * 6.0 / 255.0;
+  const double fi = floor(h6), f = h6 - fi, fs = (double)(float)us / 255.0, v = (double)(float)uv;
+  const double om = 1.0 - f, a1 = fs * f, a2 = fs * om;
+  const int p = clip8((int)floor(v * (1.0 - fs) + 0.5)), q = clip8((int)floor(v * (1.0 - a1) + 0.5)),
+            t = clip8((int)floor(v * (1.0 - a2) + 0.5));      // C round() of non-negative values
+  switch ((int)fi % 6) {
+    case 0: r = uv; g = t; b = p; break;
+    case 1: r = q; g = uv; b = p; break;
+    case 2: r = p; g = uv; b = t; break;
+    case 3: r = p; g = q; b = uv; break;
+    case 4: r = t; g = p; b = uv; break;
+    default: r = uv; g = p; b = q; break;
   }
-  r = min(255, max(0, (int)rintf(rr * 255.f)));
-  g = min(255, max(0, (int)rintf(gg * 255.f)));
-  b = min(255, max(0, (int)rintf(bb * 255.f)));
 }
 
 // the colour steps in their drawn order; stops in front of the contrast step when `until_contrast`

@@ -2,14 +2,19 @@
 (MICCAI-2022/data_loaders_MT.py:168-175: RandomHorizontalFlip, RandomVerticalFlip, RandomCrop, ColorJitter(0.1, 0.1,
 0.05, 0.01), ToTensor, Normalize(0.5, 0.5), applied twice by TransformTwice :51-53) for GIVEN random draws.
 
-PARITY UNPINNED: torchvision and PIL are absent from this image, so the colour arithmetic cannot be checked against the
-reference's dependency.  It follows their published algorithms: PIL `ImageEnhance` = `Image.blend(degenerate, image,
-factor)` on uint8 with truncation (ImagingBlend: `(UINT8)(in1 + alpha * (in2 - in1))`, clipped when alpha is outside
-[0, 1]); Brightness blends with black, Contrast with the solid grey `int(mean(L) + 0.5)`, Color (saturation) with the
-per-pixel L; L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16; ColorJitter applies the four steps in a random order;
-hue is a float HSV round trip with H shifted by the factor (the PIL version works on uint8 HSV - the largest
-deviation one should expect from the real dependency, at most a few grey levels at hue 0.01).  Geometry and
-normalisation are unambiguous.  Only tests/ may import this module."""
+PINNED against the reference's own dependency: the algorithm lives in torchvision's PIL backend (absent from this
+image) over Pillow (present, 12.2.0).  torchvision's `adjust_brightness / contrast / saturation` are
+`PIL.ImageEnhance.Brightness / Contrast / Color(img).enhance(factor)` and `adjust_hue` is `img.convert("HSV")`, a
+wrapping uint8 add of `uint8(hue_factor * 255)` on H, `convert("RGB")`; ColorJitter applies the four in a drawn order.
+tests/golden/make_golden_colorjitter.py runs exactly those Pillow calls and writes tests/golden/colorjitter_pil.npz;
+tests/test_oracle_augment.py holds this file to it bit for bit (and, where Pillow imports, to Pillow itself over all
+2^24 colours for both colour-space conversions).
+
+Pillow's arithmetic as restated here: `ImageEnhance` = `Image.blend(degenerate, image, factor)` on uint8 with
+truncation (`(UINT8)(in1 + alpha * (in2 - in1))` in float, clipped when alpha is outside [0, 1]); Brightness blends
+with black, Contrast with the solid grey `int(mean(L) + 0.5)`, Color with the per-pixel L; L = (19595 R + 38470 G +
+7471 B + 0x8000) >> 16; RGB -> HSV and back follow Pillow's Convert.c (float / double mix reproduced below).
+Only tests/ may import this module."""
 import numpy as np
 
 
@@ -27,27 +32,52 @@ def blend8(deg, img, f):
     return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int64)))
 
 
+def rgb_to_hsv_u8(rgb):
+    """Pillow `convert("HSV")` (Convert.c rgb2hsv_row): uint8 H, S, V.  The C code keeps rc / gc / bc / s / h in
+    float variables and evaluates the expressions that contain a double literal in double."""
+    r, g, b = rgb[..., 0].astype(np.int64), rgb[..., 1].astype(np.int64), rgb[..., 2].astype(np.int64)
+    maxc = np.maximum(r, np.maximum(g, b)); minc = np.minimum(r, np.minimum(g, b))
+    cr = (maxc - minc).astype(np.float32)
+    crs = np.where(cr > 0, cr, np.float32(1))
+    s = (cr / np.where(maxc > 0, maxc, 1).astype(np.float32)).astype(np.float32)
+    rc = ((maxc - r).astype(np.float32) / crs).astype(np.float32)
+    gc = ((maxc - g).astype(np.float32) / crs).astype(np.float32)
+    bc = ((maxc - b).astype(np.float32) / crs).astype(np.float32)
+    h = np.where(r == maxc, (bc - gc).astype(np.float32).astype(np.float64),
+                 np.where(g == maxc, 2.0 + rc.astype(np.float64) - bc.astype(np.float64),
+                          4.0 + gc.astype(np.float64) - rc.astype(np.float64))).astype(np.float32)
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    us = np.clip((s.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    grey = maxc == minc
+    return np.where(grey, 0, uh), np.where(grey, 0, us), maxc
+
+
+def hsv_to_rgb_u8(h, s, v):
+    """Pillow `convert("RGB")` from HSV (Convert.c hsv2rgb): double arithmetic, C round() (half away from zero)."""
+    h6 = h.astype(np.float32).astype(np.float64) * 6.0 / 255.0
+    i = np.floor(h6)
+    f = h6 - i
+    fs = s.astype(np.float32).astype(np.float64) / 255.0
+    vf = v.astype(np.float32).astype(np.float64)
+    rnd = lambda x: np.clip(np.floor(x + 0.5), 0, 255).astype(np.int64)       # noqa: E731  (arguments are >= 0)
+    p, q, t = rnd(vf * (1.0 - fs)), rnd(vf * (1.0 - fs * f)), rnd(vf * (1.0 - fs * (1.0 - f)))
+    ii = i.astype(np.int64) % 6
+    V = v.astype(np.int64)
+    r = np.choose(ii, [V, q, p, p, t, V]); g = np.choose(ii, [t, V, V, q, p, p]); b = np.choose(ii, [p, p, t, V, V, q])
+    grey = s == 0
+    return np.stack([np.where(grey, V, r), np.where(grey, V, g), np.where(grey, V, b)], -1)
+
+
+def hue_delta(hf):
+    """torchvision `np.uint8(hue_factor * 255)`: truncation toward zero, then the uint8 wrap."""
+    return int(np.float64(hf) * 255.0) & 255
+
+
 def hue_shift(rgb, hf):
-    x = rgb.astype(np.float32) / np.float32(255)
-    R, G, B = x[..., 0], x[..., 1], x[..., 2]
-    mx, mn = x.max(-1), x.min(-1)
-    d = mx - mn
-    safe = np.where(d > 0, d, np.float32(1))
-    h = np.where(mx == R, (G - B) / safe, np.where(mx == G, np.float32(2) + (B - R) / safe, np.float32(4) + (R - G) / safe))
-    h = (h / np.float32(6)).astype(np.float32)
-    h = np.where(d > 0, h - np.floor(h), np.float32(0)).astype(np.float32)
-    s = np.where(mx > 0, d / np.where(mx > 0, mx, np.float32(1)), np.float32(0)).astype(np.float32)
-    v = mx
-    h = (h + np.float32(hf)).astype(np.float32)
-    h = (h - np.floor(h)).astype(np.float32)
-    h6 = (h * np.float32(6)).astype(np.float32)
-    i = np.floor(h6).astype(np.int64) % 6
-    fr = (h6 - np.floor(h6)).astype(np.float32)
-    one = np.float32(1)
-    p = (v * (one - s)).astype(np.float32); q = (v * (one - s * fr)).astype(np.float32); t = (v * (one - s * (one - fr))).astype(np.float32)
-    rr = np.choose(i, [v, q, p, p, t, v]); gg = np.choose(i, [t, v, v, q, p, p]); bb = np.choose(i, [p, p, t, v, v, q])
-    out = np.stack([rr, gg, bb], -1).astype(np.float32) * np.float32(255)
-    return np.clip(np.rint(out), 0, 255).astype(np.int64)
+    """torchvision functional_pil.adjust_hue: wrap-add on the uint8 H channel of the HSV image."""
+    h, s, v = rgb_to_hsv_u8(rgb)
+    return hsv_to_rgb_u8((h + hue_delta(hf)) & 255, s, v)
 
 
 def one_view(src, prm):
