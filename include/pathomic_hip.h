@@ -180,6 +180,12 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
                      int64_t* nb2, float* sim1, float* sim2, void* workspace, ph_stream_t stream);
 int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
                   int B, int feat_dim, ph_stream_t stream);
+/* MIA-2023 v10 class-centre positives (`--pos_extra centers --nce_p 2`, CRD_criterion_v10.py:84-89,121-126: the mean
+ * bank row of every class, recomputed per call).  mem_ext = a bank allocated with n_data + num_classes rows; row
+ * n_data + c receives the mean of rows members[offsets[c] .. offsets[c+1]).  max_class_rows = the largest class. */
+size_t ph_crd_class_centers_workspace_bytes(int num_classes, int max_class_rows);
+int ph_crd_class_centers(float* mem_ext, const int* members, const int* offsets, int num_classes, int max_class_rows,
+                         int n_data, int feat_dim, void* workspace, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GK-Refine (AEKD_loss, train_test_path_multi_distill.py:41-70) and optimiser

@@ -4,7 +4,10 @@ nearest neighbours (cosine) of the query's own bank row, weighted by their simil
 
 The reference copies both banks to the host and calls sklearn's cosine_similarity + two torch.sort over n_data per
 query every step (:72-79,110-116); here `ph_crd_bank_topk` scans the bank on the GPU.
-`pos_extra == "centers"` (k-means class centres, sklearn KMeans) is parity-unpinned in SURVEY section 8-c and not built."""
+`pos_extra == "centers"` with nce_p == 2 (:81-101: the positives are the MEAN bank row of the query's class and the query's
+own row, the other classes' means join the negatives) is built: `ph_crd_class_centers` writes the class means behind the
+bank and the same fused kernels run over the extended column lists.  nce_p > 2 clusters every class with sklearn KMeans
+from a random initialisation at every call - not reproducible, parity-unpinned - and raises."""
 import math
 
 import numpy as np
@@ -46,6 +49,33 @@ class ContrastMemory(nn.Module):
         super()._load_from_state_dict(*a, **k)
         self._z_set = bool((self.params[2:4] > 0).all().item())
 
+    def ensure_center_rows(self, dev):
+        """`pos_extra == "centers"`: re-home both banks into allocations with len(class_idx) extra rows behind the
+        n_data bank rows (the buffers stay [n_data, D] views, so state_dict / load_state_dict are unchanged) and build
+        the flat class-member lists once.  Module.to() / .cuda() replace the buffers by compact copies; the next call
+        re-homes them."""
+        C = len(self.class_idx)
+        n, D = self.nLem, self.memory_v1.shape[1]
+        for name in ("memory_v1", "memory_v2"):
+            ext = getattr(self, "_ext_" + name, None)
+            cur = getattr(self, name)
+            if ext is None or ext.device != cur.device or cur.data_ptr() != ext.data_ptr():
+                ext = torch.zeros(n + C, D, device=cur.device, dtype=torch.float32)
+                ext[:n].copy_(cur)
+                setattr(self, "_ext_" + name, ext)
+                self._buffers[name] = ext[:n]
+        if getattr(self, "_members", None) is None or self._members.device != dev:
+            lists = [np.asarray(m).astype(np.int32).reshape(-1) for m in self.class_idx]
+            off = np.zeros(C + 1, dtype=np.int32)
+            off[1:] = np.cumsum([len(x) for x in lists])
+            cat = np.concatenate(lists) if off[-1] else np.zeros(1, dtype=np.int32)
+            self._members = torch.as_tensor(cat, device=dev)
+            self._member_off = torch.as_tensor(off, device=dev)
+            self._max_class = int(max(len(x) for x in lists))
+            self._center_ws = torch.empty(lib().ph_crd_class_centers_workspace_bytes(C, self._max_class), device=dev,
+                                          dtype=torch.uint8)
+            self._others = torch.as_tensor([[j for j in range(C) if j != c] for c in range(C)], device=dev, dtype=torch.int64)
+
 
 class CRDLoss(nn.Module):
     """CRD_criterion_v10.py:180-239: forward(sample_weights, f_s, f_t, batch_label, idx, contrast_idx)
@@ -58,9 +88,12 @@ class CRDLoss(nn.Module):
         self.contrast = ContrastMemory(opt.feat_dim, n_data, train_class_idx, opt.nce_k, opt.nce_t, opt.nce_m)
         self.num_pos = opt.nce_p
         self.pos_extra = opt.pos_extra
-        if self.pos_extra != "neighbors":
-            raise NotImplementedError("pos_extra '%s': only 'neighbors' (train_20230805.sh) is built; 'centers' needs "
-                                      "sklearn KMeans and is parity-unpinned (SURVEY section 8-c)" % self.pos_extra)
+        if self.pos_extra not in ("neighbors", "centers"):
+            raise NotImplementedError("pos_extra '%s' (CRD_criterion_v10.py knows 'neighbors' and 'centers')" % self.pos_extra)
+        if self.pos_extra == "centers" and self.num_pos != 2:
+            raise NotImplementedError("pos_extra 'centers' with nce_p %d: nce_p > 2 runs sklearn KMeans from a random "
+                                      "initialisation per class and call (:90-93) - not reproducible, parity-unpinned; "
+                                      "nce_p == 2 (class means) is built" % self.num_pos)
         self.criterion_t = ContrastLoss_v2(n_data)
         self.criterion_s = ContrastLoss_v2(n_data)
 
@@ -75,6 +108,8 @@ class CRDLoss(nn.Module):
         dev = v1.device
         contrast_idx = contrast_idx.contiguous()
         batch_label = batch_label.to(dev).long().contiguous()
+        if self.pos_extra == "centers":
+            return self._forward_centers(sample_weights, v1, v2, batch_label, idx, contrast_idx)
         nb1 = torch.empty(B, NP, device=dev, dtype=torch.int64); nb2 = torch.empty_like(nb1)
         sim1 = torch.empty(B, NP, device=dev, dtype=torch.float32); sim2 = torch.empty_like(sim1)
         ws = torch.empty(lib().ph_crd_bank_topk_workspace_bytes(B), device=dev, dtype=torch.uint8)
@@ -94,6 +129,36 @@ class CRDLoss(nn.Module):
         w = sample_weights.to(dev).reshape(-1) if torch.is_tensor(sample_weights) else float(sample_weights)
         bn = float(mem.batch_norm_size or B)                                 # global batch under data parallelism
         sample_loss = w * rows * bn                                          # the reference's per-sample values
+        return sample_loss.sum(0) / bn, sample_loss
+
+
+    def _forward_centers(self, sample_weights, v1, v2, batch_label, idx, contrast_idx):
+        """:81-101 / :118-139 with num_pos == 2 and ContrastLoss (:241-277): columns = [class centre, the K + 1 sampled
+        rows (the first is the query's own), the other classes' centres]; the first two are the equally weighted
+        positives."""
+        mem = self.contrast
+        K, n, dev = mem.K, mem.nLem, v1.device
+        B = v1.shape[0]
+        C = len(mem.class_idx)
+        mem.ensure_center_rows(dev)
+        for bank in (mem.memory_v1, mem.memory_v2):
+            check(lib().ph_crd_class_centers(ptr(bank), ptr(mem._members), ptr(mem._member_off), C, mem._max_class, n,
+                                             v1.shape[1], ptr(mem._center_ws), stream()), "ph_crd_class_centers")
+        # the other classes in ascending order (np.argwhere(onehot == 0)[:, 1], :63-64)
+        others = mem._others[batch_label]                                          # [B, C - 1]
+        cols = torch.cat(((n + batch_label).view(B, 1), contrast_idx, n + others), 1).contiguous()
+        mem.P, mem.P2, mem.K2 = 2, 2, K + C - 1
+        mem._idx_bank2 = None
+        mem._posw_s = mem._posw_t = None                                           # ContrastLoss: 1 / P each
+        K_saved = mem.K
+        mem.K = K + C - 1                                                          # crd_core reads P + K as the list width
+        try:
+            rows = _CRDCoreFn.apply(v1, v2, mem, idx, cols, None, True)
+        finally:
+            mem.K = K_saved
+        w = sample_weights.to(dev).reshape(-1) if torch.is_tensor(sample_weights) else float(sample_weights)
+        bn = float(mem.batch_norm_size or B)
+        sample_loss = w * rows * bn
         return sample_loss.sum(0) / bn, sample_loss
 
 

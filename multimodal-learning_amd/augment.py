@@ -42,7 +42,8 @@ class DeviceAugment:
             self.step += 1
         else:
             params = params.to(src.device).float().contiguous().clone()
-            params[..., 12:] = 0          # the grey-sum accumulator slot
+            params[..., 12] = 0
+            params[..., 14:] = 0          # the grey-sum accumulator slot (column 13 = mask of disabled steps, kept)
         if out is not None:          # caller-owned buffers (the resident input sets a captured step graph reads from)
             out0, out1 = out
             for t in (out0, out1):

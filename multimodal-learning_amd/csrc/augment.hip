@@ -17,6 +17,8 @@ namespace {
 
 constexpr int AP = 16;   // floats per (image, view) parameter row:
 // 0 flipH 1 flipV 2 top 3 left 4 brightness 5 contrast 6 saturation 7 hue 8..11 order (0 b, 1 c, 2 s, 3 h) 12 grey mean
+// 13 bit mask of DISABLED steps (bit k = step k is skipped: torchvision's ColorJitter drops a step whose range is zero -
+//    note that an enabled hue step with factor 0 still runs Pillow's lossy uint8 HSV round trip)
 // 14..15: the 64-bit integer grey sum (must be zero on entry to ph_augment_apply)
 
 __device__ __forceinline__ uint64_t amix(uint64_t z) {
@@ -49,7 +51,8 @@ __global__ void augment_params_kernel(float* __restrict__ params, int n, uint64_
     for (int t = q; t < 3 - k; ++t) pool[t] = pool[t + 1];
     if (k < 3) f /= (3 - k);
   }
-  p[12] = 0.f; p[13] = p[14] = p[15] = 0.f;
+  p[12] = 0.f; p[14] = p[15] = 0.f;
+  p[13] = (float)((jb == 0.f ? 1 : 0) | (jc == 0.f ? 2 : 0) | (js == 0.f ? 4 : 0) | (jh == 0.f ? 8 : 0));
 }
 
 __device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
@@ -102,9 +105,11 @@ __device__ __forceinline__ void hue_shift(int& r, int& g, int& b, float hf) {
 
 // the colour steps in their drawn order; stops in front of the contrast step when `until_contrast`
 __device__ __forceinline__ void jitter(int& r, int& g, int& b, const float* p, int mean, bool until_contrast) {
+  const int off = (int)p[13];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int op = (int)p[8 + k];
+    if ((off >> op) & 1) continue;
     if (op == 0) { r = blend8(0, r, p[4]); g = blend8(0, g, p[4]); b = blend8(0, b, p[4]); }
     else if (op == 1) {
       if (until_contrast) return;

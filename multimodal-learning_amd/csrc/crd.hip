@@ -383,6 +383,36 @@ __global__ __launch_bounds__(256) void crd_bank_topk_merge_kernel(const float* _
   }
 }
 
+
+// ---- class-mean bank rows (MIA-2023 `pos_extra == "centers"`, nce_p == 2; reference
+// "MIA 2023/stage2_unimodal_student/CL_utils/CRD_criterion_v10.py":84-89,121-126: torch.mean over the bank rows of
+// every class, recomputed at every call).  The centres are written behind the bank, rows n_data .. n_data + C - 1 of an
+// allocation of n_data + C rows, so that the score / loss / gradient kernels address them through the ordinary column
+// index lists.  Coalesced 512-B row reads; partial sums per (class, 256-row chunk), combined in a fixed order in
+// double: bitwise reproducible.
+constexpr int CC_ROWS = 256;
+__global__ __launch_bounds__(256) void class_center_partial_kernel(const float* __restrict__ mem, const int* __restrict__ members,
+                                                                   const int* __restrict__ offsets, float* __restrict__ parts,
+                                                                   int nchunks) {
+  const int c = blockIdx.y, chunk = blockIdx.x;
+  const int lo = offsets[c] + chunk * CC_ROWS, hi = min(offsets[c + 1], lo + CC_ROWS);
+  const int f = threadIdx.x & (D - 1), rl = threadIdx.x >> 7;     // 2 row lanes x 128 features
+  float s = 0.f;
+  for (int r = lo + rl; r < hi; r += 2) s += mem[(size_t)members[r] * D + f];
+  __shared__ float sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < D) parts[((size_t)c * nchunks + chunk) * D + f] = sh[threadIdx.x] + sh[threadIdx.x + D];
+}
+__global__ void class_center_finish_kernel(const float* __restrict__ parts, const int* __restrict__ offsets, float* __restrict__ mem,
+                                           int nchunks, int n_data) {
+  const int c = blockIdx.x, f = threadIdx.x;
+  const int cnt = offsets[c + 1] - offsets[c], used = (cnt + CC_ROWS - 1) / CC_ROWS;
+  double s = 0.0;
+  for (int k = 0; k < used; ++k) s += (double)parts[((size_t)c * nchunks + k) * D + f];
+  mem[((size_t)n_data + c) * D + f] = cnt > 0 ? (float)(s / (double)cnt) : 0.f;
+}
+
 }  // namespace
 
 size_t ph_crd_bank_topk_workspace_bytes(int B) { return (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX * (sizeof(float) + sizeof(int)); }
@@ -458,6 +488,23 @@ int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, co
                   int B, int feat_dim, hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
   hipLaunchKernelGGL(crd_update_kernel, dim3(cdiv(2 * B, 4)), dim3(256), 0, st, mem1, mem2, v1, v2, y, params, B);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+size_t ph_crd_class_centers_workspace_bytes(int num_classes, int max_class_rows) {
+  return (size_t)num_classes * (size_t)cdiv(max_class_rows > 0 ? max_class_rows : 1, CC_ROWS) * D * sizeof(float);
+}
+
+int ph_crd_class_centers(float* mem_ext, const int* members, const int* offsets, int num_classes, int max_class_rows,
+                         int n_data, int feat_dim, void* workspace, hipStream_t st) {
+  if (feat_dim != D || !mem_ext || !members || !offsets || !workspace || num_classes < 1) return PH_EINVAL;
+  const int nchunks = cdiv(max_class_rows > 0 ? max_class_rows : 1, CC_ROWS);
+  hipLaunchKernelGGL(class_center_partial_kernel, dim3(nchunks, num_classes), dim3(256), 0, st, mem_ext, members, offsets,
+                     reinterpret_cast<float*>(workspace), nchunks);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(class_center_finish_kernel, dim3(num_classes), dim3(D), 0, st, reinterpret_cast<const float*>(workspace),
+                     offsets, mem_ext, nchunks, n_data);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -81,7 +81,9 @@ def hue_shift(rgb, hf):
 
 
 def one_view(src, prm):
-    """src uint8 [SH, SW, 3]; prm = dict(flipH, flipV, top, left, S, b, c, s, h, order) -> (f32 [3, S, S], grey mean)."""
+    """src uint8 [SH, SW, 3]; prm = dict(flipH, flipV, top, left, S, b, c, s, h, order[, skip]) -> (f32 [3, S, S], grey
+    mean).  `skip`: steps torchvision's ColorJitter drops because their range is zero (an enabled hue step with factor 0
+    still runs Pillow's lossy uint8 HSV round trip)."""
     img = src
     if prm["flipH"]:
         img = img[:, ::-1]
@@ -91,6 +93,8 @@ def one_view(src, prm):
     img = img[prm["top"]:prm["top"] + S, prm["left"]:prm["left"] + S].astype(np.int64)
     mean = None
     for op in prm["order"]:
+        if op in prm.get("skip", ()):
+            continue
         if op == 0:
             img = blend8(0, img, prm["b"])
         elif op == 1:

@@ -223,6 +223,57 @@ def crd_v10_loss(st, sample_weights, f_s, f_t, batch_label, y, idx, num_pos):
     return ls + lt, sls + slt, dict(nb1=nb1, nb2=nb2, sim1=s1, sim2=s2)
 
 
+def crd_v10_centers_loss(st, sample_weights, f_s, f_t, batch_label, y, idx, class_idx, num_pos=2):
+    """CRDLoss.forward with pos_extra == "centers" and num_pos == 2 (CRD_criterion_v10.py:81-101, :118-139, :228-231,
+    ContrastLoss :241-277): the positives of a query are the MEAN bank row of its class (:88-89) and its own bank row,
+    the negatives its K sampled rows plus the centres of the other classes.  num_pos > 2 replaces the mean by sklearn
+    KMeans centres (random initialisation: not reproducible, not restated).  Returns (loss, sample_loss[B])."""
+    if num_pos != 2:
+        raise NotImplementedError("num_pos > 2 uses sklearn KMeans (random init): parity unpinned")
+    v1 = embed_forward(f_s, st.embed_s["linear.weight"], st.embed_s["linear.bias"])
+    v2 = embed_forward(f_t, st.embed_t["linear.weight"], st.embed_t["linear.bias"])
+    K = int(st.params[0].item()); T = st.params[1].item()
+    B, D = v1.shape
+    n_out = st.memory_v1.size(0)
+    C = len(class_idx)
+    onehot = F.one_hot(batch_label, num_classes=C).numpy()
+    import numpy as np
+    neg_labels = torch.as_tensor(np.argwhere(onehot == 0)[:, 1])                 # :63-64, ascending other classes
+
+    def side(mem):
+        centers = torch.stack([mem[torch.as_tensor(np.asarray(class_idx[c])).long()].mean(0) for c in range(C)]).view(C, 1, D)
+        w = torch.index_select(mem, 0, idx.view(-1)).detach().view(B, K + 1, D)
+        pos_c = torch.index_select(centers, 0, batch_label).view(B, num_pos - 1, D)
+        neg_c = torch.index_select(centers, 0, neg_labels).view(B, (C - 1) * (num_pos - 1), D)
+        return torch.cat((pos_c, w, neg_c), 1)
+
+    out_v2 = torch.exp(torch.bmm(side(st.memory_v1), v2.view(B, D, 1)) / T)
+    out_v1 = torch.exp(torch.bmm(side(st.memory_v2), v1.view(B, D, 1)) / T)
+    if st.params[2].item() < 0:
+        st.params[2] = out_v1.mean().detach() * n_out
+    if st.params[3].item() < 0:
+        st.params[3] = out_v2.mean().detach() * n_out
+    out_v1 = out_v1 / st.params[2].item()
+    out_v2 = out_v2 / st.params[3].item()
+    _bank_update(st, v1, v2, y)
+
+    def closs(x):                                                                # ContrastLoss :246-277
+        P = num_pos
+        m = x.size(1) - P
+        Pn = 1 / float(st.n_data)
+        P_pos = x.narrow(1, 0, P)
+        log_D1 = torch.div(P_pos, P_pos.add(m * Pn + EPS)).log()
+        P_neg = x.narrow(1, P, m)
+        log_D0 = torch.div(torch.full_like(P_neg, m * Pn), P_neg.add(m * Pn + EPS)).log()
+        sl = -(log_D1.squeeze(-1) + log_D0.sum(1).view(B, 1).repeat(1, P)).sum(1) / P
+        sl = sample_weights.view(-1) * sl
+        return sl.sum(0) / B, sl
+
+    ls, sls = closs(out_v1)
+    lt, slt = closs(out_v2)
+    return ls + lt, sls + slt
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Row a16: t-SVD low-rank constraint of the MIA-2022 stage-1 trainer ("MIA 2022/train_test_tSVD.py").
 # update_adj_tensor (:57-70) and the penalty (:413-431) are pinned by tests/golden/mia2022_tsvd.npz (produced by running

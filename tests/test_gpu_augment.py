@@ -113,6 +113,7 @@ def test_neutral_jitter_is_crop_flip_normalise_exactly():
     src = _src(B, SH, SW, 2)
     prm = torch.zeros(B, 2, 16)
     prm[:, :, 4:7] = 1.0
+    prm[:, :, 13] = 8.0          # hue step dropped (ColorJitter(hue=0)): enabled, it would run Pillow's lossy HSV round trip
     prm[:, :, 8:12] = torch.tensor([2.0, 0.0, 3.0, 1.0])
     prm[:, 0, 0] = 1; prm[:, 1, 1] = 1
     prm[:, :, 2] = 5; prm[:, :, 3] = 11

@@ -229,6 +229,58 @@ def test_mia2023_crd_v10_golden(golden_dir):
     R.finish()
 
 
+def test_mia2023_crd_v10_centers_golden(golden_dir):
+    """`--pos_extra centers --nce_p 2` (CRD_criterion_v10.py:81-101): class-mean positives / negatives vs the reference's
+    CRDLoss, two calls (Z set on the first, the centres recomputed from the updated bank on the second); state_dict keeps
+    the reference's [n_data, 128] bank shape although the centres live behind the bank rows; nce_p > 2 raises."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.CL_utils import CRD_criterion_v10 as V10
+    from oracle import weights as W
+    from oracle.variants import CRDv10State
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "mia2023_crd_v10_centers.npz"))
+    labels = torch.as_tensor(g["labels"])
+    n_data = int(g["n_data"])
+    class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+    opt = m.stage2_opt(nce_k=int(g["K"]), nce_p=int(g["num_pos"]), pos_extra="centers")
+    crd = V10.CRDLoss(opt, n_data, class_idx)
+    crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 52))
+    crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 53))
+    st = CRDv10State(n_data, labels, K=int(g["K"]), seed=int(g["bank_seed"]))
+    crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+    crd = crd.cuda(); crd.contrast.verbose = False
+    R = Report("MIA-2023 CRD_criterion_v10 (centers, nce_p 2) vs reference golden")
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).cuda().requires_grad_(True)
+        bank_before = crd.contrast.memory_v1.detach().clone()
+        loss, sl = crd(torch.as_tensor(g[f"w{it}"]).cuda(), f_s, torch.as_tensor(g[f"f_t{it}"]).cuda(),
+                       torch.as_tensor(g[f"grade{it}"]).cuda(), torch.as_tensor(g[f"index{it}"]).cuda(),
+                       torch.as_tensor(g[f"sidx{it}"]).cuda())
+        gs = torch.autograd.grad(loss, [f_s, crd.embed_s.linear.weight, crd.embed_t.linear.weight])
+        R.close(g[f"loss{it}"], loss, 1e-4, 1e-5, f"loss call {it}")
+        R.close(g[f"sample_loss{it}"], sl, 1e-3, 1e-5, f"sample_loss call {it}")
+        R.close(g[f"g_fs{it}"], gs[0], 1e-6, 1e-3, f"d f_s call {it}"); R.close(g[f"g_ws{it}"], gs[1], 1e-6, 1e-3, f"d W_s call {it}")
+        R.close(g[f"g_wt{it}"], gs[2], 1e-6, 1e-3, f"d W_t call {it}")
+        R.close(g[f"params{it}"], crd.contrast.params, 1e-2, 1e-4, f"params/Z call {it}")
+        ix = torch.as_tensor(g[f"index{it}"]).cuda()
+        R.close(g[f"bank_v1_rows{it}"], crd.contrast.memory_v1[ix], 1e-6, 0, f"bank-1 rows call {it}")
+        R.close(g[f"bank_v2_rows{it}"], crd.contrast.memory_v2[ix], 1e-6, 0, f"bank-2 rows call {it}")
+        # the centre rows behind the bank are the class means of the PRE-update bank
+        ext = crd.contrast._ext_memory_v1
+        for c in range(3):
+            R.close(bank_before[torch.as_tensor(class_idx[c]).cuda()].double().mean(0), ext[n_data + c], 2e-7, 1e-6, f"centre {c} call {it}")
+    R.finish()
+    sd = crd.state_dict()
+    assert tuple(sd["contrast.memory_v1"].shape) == (n_data, 128) and tuple(sd["contrast.memory_v2"].shape) == (n_data, 128)
+    crd2 = V10.CRDLoss(opt, n_data, class_idx).cuda()
+    crd2.load_state_dict(sd)
+    assert torch.equal(crd2.contrast.memory_v1, crd.contrast.memory_v1)
+    with pytest.raises(NotImplementedError):
+        V10.CRDLoss(m.stage2_opt(nce_k=16, nce_p=3, pos_extra="centers"), n_data, class_idx)
+    with pytest.raises(NotImplementedError):
+        V10.CRDLoss(m.stage2_opt(nce_k=16, nce_p=3, pos_extra="prototypes"), n_data, class_idx)
+
+
 def test_mia2023_bank_topk_bit_exact():
     """The KNN indices are integer work: identical to torch.sort of the class-masked cosine on the same bank."""
     from multimodal_learning_amd._lib import lib, ptr, stream, check

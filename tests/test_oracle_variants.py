@@ -63,6 +63,30 @@ def test_mia2023_crd_v10(golden_dir):
         _close(g[f"bank_v1_rows{it}"], st.memory_v1[torch.as_tensor(g[f"index{it}"])], 1e-6)
 
 
+def test_mia2023_crd_v10_centers(golden_dir):
+    """pos_extra == "centers", nce_p == 2 (class-mean centres) against the reference's CRDLoss, two calls."""
+    from oracle.variants import CRDv10State, crd_v10_centers_loss
+    g = np.load(os.path.join(golden_dir, "mia2023_crd_v10_centers.npz"))
+    labels = g["labels"]
+    class_idx = [np.nonzero(labels == c)[0] for c in range(3)]
+    st = CRDv10State(int(g["n_data"]), labels, K=int(g["K"]), seed=int(g["bank_seed"]),
+                     embed_s=W.make_state_dict(W.embed_shapes(), 52), embed_t=W.make_state_dict(W.embed_shapes(), 53))
+    for d in (st.embed_s, st.embed_t):
+        for v in d.values():
+            v.requires_grad_(True)
+    for it in range(2):
+        f_s = torch.as_tensor(g[f"f_s{it}"]).requires_grad_(True)
+        loss, sl = crd_v10_centers_loss(st, torch.as_tensor(g[f"w{it}"]), f_s, torch.as_tensor(g[f"f_t{it}"]),
+                                        torch.as_tensor(g[f"grade{it}"]), torch.as_tensor(g[f"index{it}"]),
+                                        torch.as_tensor(g[f"sidx{it}"]), class_idx, int(g["num_pos"]))
+        gs = torch.autograd.grad(loss, [f_s, st.embed_s["linear.weight"], st.embed_t["linear.weight"]])
+        _close(g[f"loss{it}"], loss, 1e-5, 1e-5); _close(g[f"sample_loss{it}"], sl, 1e-4, 1e-5)
+        _close(g[f"g_fs{it}"], gs[0], 1e-6, 1e-3); _close(g[f"g_ws{it}"], gs[1], 1e-6, 1e-3)
+        _close(g[f"g_wt{it}"], gs[2], 1e-6, 1e-3); _close(g[f"params{it}"], st.params, 1e-2, 1e-5)
+        _close(g[f"bank_v1_rows{it}"], st.memory_v1[torch.as_tensor(g[f"index{it}"])], 1e-6)
+        _close(g[f"bank_v2_rows{it}"], st.memory_v2[torch.as_tensor(g[f"index{it}"])], 1e-6)
+
+
 def test_mia2023_rows(golden_dir):
     from oracle.variants import distill_kl_per_sample, assign_sample_weights, gk_refine_thresh
     g = np.load(os.path.join(golden_dir, "mia2023_rows.npz"))
@@ -182,18 +206,21 @@ def test_sampler_rule_restatement_properties():
 
 
 def test_augment_oracle_structure():
-    """oracle/augment.py (numpy restatement of the loader transform, parity unpinned for the colour arithmetic): neutral
-    factors reduce it to flip + crop + normalise exactly; a brightness factor scales with truncation; the contrast mean is
-    the rounded luma mean of the image as it enters that step."""
+    """oracle/augment.py (numpy restatement of the loader transform; the colour arithmetic is pinned against Pillow in
+    tests/test_oracle_augment.py): neutral factors with the hue step dropped reduce it to flip + crop + normalise
+    exactly, an enabled hue step with factor 0 costs Pillow's uint8 HSV round trip; a brightness factor scales with
+    truncation; the contrast mean is the rounded luma mean of the image as it enters that step."""
     from oracle import augment as OA
     rng = np.random.default_rng(3)
     src = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
     base = dict(flipH=1, flipV=1, top=4, left=9, S=32, b=1.0, c=1.0, s=1.0, h=0.0, order=(0, 1, 2, 3))
-    out, mean = OA.one_view(src, base)
+    out, mean = OA.one_view(src, dict(base, skip=(3,)))
     ref = src[::-1, ::-1][4:36, 9:41].astype(np.float32).transpose(2, 0, 1) / 255
-    assert np.abs(out - (ref - 0.5) / 0.5).max() <= 2.0 / 255 * 2     # (neutral hue: float HSV round trip, <= 1 level)
+    assert np.array_equal(out, (ref - np.float32(0.5)) / np.float32(0.5))
+    out_h, _ = OA.one_view(src, base)     # hue enabled with factor 0: the uint8 HSV round trip moves a few grey levels
+    assert 0 < np.abs(out_h - out).max() <= 2.0 / 255 * 8
     assert mean == int(OA.luma(src[::-1, ::-1][4:36, 9:41]).mean() + 0.5)
-    out_b, _ = OA.one_view(src, dict(base, b=0.5, order=(0, 2, 1, 3), h=0.0, flipH=0, flipV=0))
+    out_b, _ = OA.one_view(src, dict(base, b=0.5, order=(0, 2, 1, 3), h=0.0, flipH=0, flipV=0, skip=(3,)))
     crop = src[4:36, 9:41].astype(np.int64)
     half = (crop * 0.5).astype(np.int64)
     got = np.rint((out_b * 0.5 + 0.5) * 255).astype(np.int64).transpose(1, 2, 0)
