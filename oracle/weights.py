@@ -139,3 +139,17 @@ def make_state_dict(shapes, seed):
             t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
         sd[key] = t
     return sd
+
+
+def adam_moments(named_shapes, scales, seed):
+    """Deterministic, PLAUSIBLE Adam moments for a "mid-training" optimiser state (tests/golden/make_golden_midstate.py):
+    exp_avg ~ 0.3 c N(0, 1) and exp_avg_sq = c^2 U(0.5, 1.5) per tensor, c = that tensor's gradient scale (stored in the
+    fixture).  With sqrt(v) ~ c the update lr * m_hat / (sqrt(v_hat) + eps) is a SMOOTH function of the fresh gradient -
+    unlike the first steps from zero moments, where it is sign(g) and amplifies rounding into 1e-2 logit differences."""
+    out = OrderedDict()
+    for name, shape in named_shapes:
+        c = float(scales[name])
+        m = torch.randn(shape, generator=_gen(seed, "m:" + name)) * (0.3 * c)
+        v = (torch.rand(shape, generator=_gen(seed, "v:" + name)) + 0.5) * (c * c)
+        out[name] = (m, v)
+    return out

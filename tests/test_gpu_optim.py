@@ -1,0 +1,62 @@
+"""The fused Adam + EMA kernel (ph_adam_ema_step_dev; reference networks_new.py:85 torch.optim.Adam and
+train_test_path_multi_distill.py:34-38 update_ema_variables) in isolation against torch.optim.Adam on the CPU, fed the
+SAME gradients: the update itself, decoupled from whatever produced the gradient."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_adam_and_ema_equal_torch_adam_given_the_same_gradients():
+    import multimodal_learning_amd as m
+    torch.manual_seed(3)
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (3, 128), (3,), (5,)]      # sizes that are not multiples of 4 included
+    ref_p = [torch.nn.Parameter(torch.randn(s) * 0.1) for s in shapes]
+    ref_ema = [p.detach().clone() * 0.9 + 0.01 for p in ref_p]
+    dev_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    ema_p = [torch.nn.Parameter(e.clone().cuda(), requires_grad=False) for e in ref_ema]
+    kw = dict(lr=5e-4, betas=(0.9, 0.999), weight_decay=4e-4)
+    ref_opt = torch.optim.Adam(ref_p, **kw)
+    opt = m.FusedAdam(dev_p, **kw)
+    flat = opt.flat
+    opt.ema_flat = m.FlatParams(ema_p)
+    opt.ema_range = (0, flat.numel)
+    # a mid-training optimiser state in torch's own layout, imported by both
+    state = {i: dict(step=torch.tensor(11.0), exp_avg=torch.randn(s) * 1e-3, exp_avg_sq=torch.rand(s) * 1e-5 + 1e-9)
+             for i, s in enumerate(shapes)}
+    sd = ref_opt.state_dict()
+    sd["state"] = {i: {k: v.clone() for k, v in st.items()} for i, st in state.items()}
+    ref_opt.load_state_dict(sd)
+    sd2 = opt.state_dict(); sd2.pop("fused"); sd2["state"] = state
+    opt.load_state_dict(sd2)
+    for it in range(3):
+        grads = [torch.randn(s) * (10.0 ** -(it + i % 3)) for i, s in enumerate(shapes)]
+        grads[1][:] = 0.0                                    # an all-zero gradient: weight decay and momentum only
+        for p, q, g in zip(ref_p, dev_p, grads):
+            p.grad = g.clone()
+        opt.zero_grad()
+        for q, g in zip(dev_p, grads):
+            q.grad.copy_(g)
+        alpha = min(1 - 1 / (it + 12), 0.99)
+        opt.ema_alpha = alpha
+        ref_opt.step()
+        opt.step()
+        for e, p in zip(ref_ema, ref_p):
+            e.mul_(alpha).add_(p.detach(), alpha=1 - alpha)
+        for i, (p, q, e, f) in enumerate(zip(ref_p, dev_p, ref_ema, ema_p)):
+            dp = (p.detach() - q.detach().cpu()).abs().max().item()
+            de = (e - f.detach().cpu()).abs().max().item()
+            assert dp <= 2e-8 + 2e-7 * p.detach().abs().max().item(), (it, i, dp)
+            assert de <= 2e-8 + 2e-7 * e.abs().max().item(), (it, i, de)
+    # exported state (torch layout) equals torch's
+    out = opt.state_dict()["state"]
+    for i, p in enumerate(ref_p):
+        st = ref_opt.state[p]
+        assert int(out[i]["step"]) == int(st["step"]) == 14
+        assert np.allclose(out[i]["exp_avg"].cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-12)
+        assert np.allclose(out[i]["exp_avg_sq"].cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-16)
+    # and a reload of the same checkpoint object works twice (load_state_dict must not consume its argument)
+    ck = opt.state_dict()
+    opt.load_state_dict(ck); opt.load_state_dict(ck)
+    assert "fused" in ck and opt._step == 14

@@ -717,3 +717,95 @@ def test_mia2022_distill_baselines(distill):
             assert torch.isfinite(g).all() and float(g.abs().max()) > 0
     finally:
         m.set_precision("bf16")
+
+
+def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
+    """Post-update parity as a REAL check.  tests/golden/make_golden_midstate.py runs the reference
+    for two steps from a mid-training state: Adam step count 7 with non-zero moments (per-tensor recipe scaled by the
+    reference's own gradient scale), an EMA model of its own, iter_num 7, CRD constants Z already set.  There the Adam
+    update is a smooth function of the gradient (not sign(g) as in the first steps from zero moments), so everything is
+    asserted at the north-star tolerance: step 0's pre-update quantities AND its update (parameters, EMA, Adam moments,
+    bank rows at ~1e-6), and - the point - step 1's logits / losses / GK-Refine weights, which depend on every piece of
+    the update path.  The optimiser state enters through FusedAdam.load_state_dict in torch.optim.Adam's own layout
+    (what a checkpoint written by the reference holds)."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    from tests.gpu_util import Report
+    g = np.load(os.path.join(golden_dir, "midstate_b8_h96.npz"))
+    seed, n_data, t0 = int(g["seed"]), int(g["n_data"]), int(g["t0"])
+    m.set_precision("bf16x6")
+    try:
+        step = _mk_step(default_opt(), n_data, seed=seed)
+        # ---- the mid-training state
+        names = ["student." + k for k, _ in step.model.named_parameters()]
+        for i in range(2):
+            names += [f"crd{i}.embed_s.linear.weight", f"crd{i}.embed_s.linear.bias", f"crd{i}.embed_t.linear.weight",
+                      f"crd{i}.embed_t.linear.bias"]
+        params = list(step.module_list.parameters())
+        assert len(names) == len(params)
+        scales = dict(zip([str(s) for s in g["scale_names"]], g["scale_values"]))
+        trainable = [(n, tuple(p.shape)) for n, p in zip(names, params) if p.requires_grad]
+        mom = W.adam_moments(trainable, scales, seed + 30)
+        sd = step.optimizer.state_dict()
+        sd.pop("fused")
+        sd["state"] = {i: dict(step=torch.tensor(float(t0)), exp_avg=mom[n][0], exp_avg_sq=mom[n][1])
+                       for i, (n, p) in enumerate(zip(names, params)) if p.requires_grad}
+        step.optimizer.load_state_dict(sd)
+        assert step.optimizer._step == t0
+        step.iter_num = t0
+        for crd, key in ((step.criterion_kd, "Z0"), (step.criterion_kd_path, "Z1")):
+            crd.contrast.params[2:4] = torch.as_tensor(g[key]).cuda()
+            crd.contrast._z_set = True
+        R = Report("2 distill steps from a mid-training state, parity mode vs REFERENCE golden (B=8, 96x96)")
+        cut = lambda t: t.detach().reshape(-1)[:4096]      # noqa: E731
+        watch = ("conv1.weight", "layer2.0.conv1.weight", "layer4.1.bn2.weight", "fc_new1.0.weight", "fc_new2.weight",
+                 "fc_new2.bias")
+        named = dict(step.model.named_parameters())
+        enamed = dict(step.ema_model.named_parameters())
+        flat = step.optimizer.flat
+        off = {id(t): o for t, o in zip(flat.tensors, flat.offsets)}
+        grads0 = {}
+        orig = step.optimizer.step
+
+        def spy(*a, **k):
+            if not grads0:
+                for kk in watch:
+                    grads0[kk] = named[kk].grad.detach().clone()
+                grads0["embed_s0"] = step.criterion_kd.embed_s.linear.weight.grad.detach().clone()
+            return orig(*a, **k)
+        step.optimizer.step = spy
+        for it in range(2):
+            bt = synthetic_batch(int(g["B"]), int(g["H"]), n_data=n_data, seed=310 + it)
+            out = step.step(_tuple(bt), epoch=int(g["epoch"]), ranks=[g["ranks"][2 * it], g["ranks"][2 * it + 1]])
+            for k, key in (("logit_path", "logit_path"), ("ema_logit", "ema_logit"), ("fuse_logit", "fuse_logit")):
+                R.close(g[f"{key}{it}"], out[k], 1e-3, 0, f"{k} step {it}")
+            for k in ("loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2", "loss"):
+                ref = g[f"{k}{it}"] * (1.0 if k in ("loss_cls", "loss") else (step.opt.alpha if "div" in k else step.opt.beta))
+                R.close(ref, out[k], 1e-3, 1e-4, f"{k} step {it}")
+            R.close(g[f"scale{it}"], out["scale"], 2e-3, 1e-3, f"GK-Refine scale step {it}")
+            for k in watch:
+                if it == 0:
+                    R.close(g["g0_" + k], cut(grads0[k]), 1e-6, 2e-3, f"grad {k}")
+                R.close(g[f"p{it}_{k}"], cut(named[k]), 5e-6, 0, f"param {k} after step {it}")
+                R.close(g[f"e{it}_{k}"], cut(enamed[k]), 5e-6, 0, f"EMA {k} after step {it}")
+                o = off[id(named[k])]
+                n = named[k].numel()
+                R.close(g[f"m{it}_{k}"], cut(step.optimizer._m[o:o + n]), 1e-7, 2e-3, f"exp_avg {k} after step {it}")
+                R.close(g[f"v{it}_{k}"], cut(step.optimizer._v[o:o + n]), 1e-10, 2e-3, f"exp_avg_sq {k} after step {it}")
+            if it == 0:
+                R.close(g["g0_embed_s0"], cut(grads0["embed_s0"]), 1e-6, 2e-3, "grad embed_s0")
+            sdm, sde = step.model.state_dict(), step.ema_model.state_dict()
+            R.close(g[f"p_abs_sum{it}"], sum(v.double().abs().sum() for v in sdm.values() if v.dtype.is_floating_point), 0, 2e-6,
+                    f"sum|student| after step {it}")
+            R.close(g[f"ema_abs_sum{it}"], sum(v.double().abs().sum() for v in sde.values() if v.dtype.is_floating_point), 0, 2e-6,
+                    f"sum|EMA| after step {it}")
+            R.close(g[f"rm_bn1_{it}"], sdm["bn1.running_mean"], 1e-5, 1e-4, f"bn1 running_mean after step {it}")
+            R.close(g[f"rv_l4_{it}"], sdm["layer4.1.bn2.running_var"], 1e-5, 1e-3, f"layer4.1.bn2 running_var after step {it}")
+            ix = bt["index"].cuda()
+            R.close(g[f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[ix], 1e-5, 0, f"bank0 v1 rows step {it}")
+            R.close(g[f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[ix], 1e-5, 0, f"bank1 v2 rows step {it}")
+            R.close(g[f"params0_{it}"], step.criterion_kd.contrast.params, 1e-3, 1e-6, f"CRD params / Z step {it}")
+        R.finish()
+    finally:
+        m.set_precision("bf16")

@@ -200,3 +200,49 @@ def test_teacher_backward_vs_reference_golden(golden_dir):
         grads = torch.autograd.grad(loss, [sd[k] for k in names] + [x_omic], allow_unused=True)
         named = {k: (gr.numpy() if gr is not None else np.zeros(tuple(sd[k].shape), np.float32)) for k, gr in zip(names, grads[:-1])}
         _teacher_bwd_check(named, grads[-1].numpy(), loss.item(), g, tag, 2e-4)
+
+
+def load_midstate(g, orc):
+    """Put a DistillOracle into the mid-training state of tests/golden/make_golden_midstate.py (also used by the GPU test
+    for the names / recipe)."""
+    scales = dict(zip([str(s) for s in g["scale_names"]], g["scale_values"]))
+    trainable = [(n, tuple(p.shape)) for n, p in orc.trainable()]
+    mom = W.adam_moments(trainable, scales, int(g["seed"]) + 30)
+    orc.adam_t = int(g["t0"])
+    orc.iter_num = int(g["t0"])
+    for n, (m, v) in mom.items():
+        orc._m[n], orc._v[n] = m.clone(), v.clone()
+    for i, key in enumerate(("Z0", "Z1")):
+        orc.crd[i].params[2:4] = torch.as_tensor(g[key])
+    return mom
+
+
+def test_two_steps_from_mid_training_state(golden_dir):
+    """The update path at the north-star tolerance: from a state with non-zero Adam moments (step count 7), an EMA
+    model of its own, Z already set, the reference's SECOND step (logits, losses, GK-Refine weights after one Adam +
+    EMA + bank update) is reproduced within 1e-3 - which the zero-moment start of the three-step fixture cannot show,
+    because Adam's first updates are sign(g)."""
+    g = _ld(golden_dir, "midstate_b8_h96.npz")
+    torch.set_num_threads(8)
+    orc = DistillOracle(default_opt(), seed=int(g["seed"]), n_data=int(g["n_data"]))
+    load_midstate(g, orc)
+    cut = lambda t: t.reshape(-1)[:4096]      # noqa: E731
+    for it in range(2):
+        bt = synthetic_batch(int(g["B"]), int(g["H"]), n_data=int(g["n_data"]), seed=310 + it)
+        out = orc.step(bt, mid_ranks=[g["ranks"][2 * it], g["ranks"][2 * it + 1]])
+        for k in ("logit_path", "ema_logit", "fuse_logit"):
+            _close(g[f"{k}{it}"], out[k], 1e-3, 0)
+        for k in ("loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2", "loss"):
+            _close(g[f"{k}{it}"], out[k], 1e-3, 1e-4)
+        _close(g[f"scale{it}"], out["scale"], 2e-3, 1e-3)
+        for k in ("conv1.weight", "layer2.0.conv1.weight", "layer4.1.bn2.weight", "fc_new1.0.weight", "fc_new2.weight",
+                  "fc_new2.bias"):
+            if it == 0:
+                _close(g["g0_" + k], cut(out["grads"]["student." + k]), 1e-6, 2e-3)
+            _close(g[f"p{it}_{k}"], cut(orc.student[k]), 2e-6, 0)          # lr = 5e-4: a wrong update is ~1e-4
+            _close(g[f"e{it}_{k}"], cut(orc.ema[k]), 2e-6, 0)
+            _close(g[f"m{it}_{k}"], cut(orc._m["student." + k]), 1e-7, 2e-3)
+            _close(g[f"v{it}_{k}"], cut(orc._v["student." + k]), 1e-10, 2e-3)
+        _close(g[f"params0_{it}"], orc.crd[0].params, 1e-3, 1e-6)             # Z stays what it was
+        _close(g[f"bank0_v1_rows{it}"], orc.crd[0].memory_v1[bt["index"]], 1e-5)
+        _close(g[f"bank1_v2_rows{it}"], orc.crd[1].memory_v2[bt["index"]], 1e-5)
