@@ -215,7 +215,7 @@ int ph_gk_rows(const float* G, int ng, int B, int D, int use_thresh, float thres
 int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, size_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int step, double ema_alpha,
                      ph_stream_t stream);
-/* HIP-graph-replayable form: hyper = device float[4] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha} */
+/* HIP-graph-replayable form: hyper = device float[5] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha} */
 int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1,
                          double beta2, double eps, double weight_decay, const float* hyper, ph_stream_t stream);
 int ph_ema_update(float* ema, const float* p, size_t n, float alpha, ph_stream_t stream);

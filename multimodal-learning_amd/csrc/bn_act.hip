@@ -202,7 +202,11 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ g, T* __restrict__ 
 template <typename T>
 struct DzPlain {
   const T* g; const T* a; const T* y;
-  __device__ __forceinline__ void get(size_t i8, float (&dz)[8], float (&yy)[8]) const {
+  // optional: the ReLU mask of a BatchNorm whose OWN output went through the ReLU (bn1 of a BasicBlock: a1 =
+  // relu(y * scale + shift)) is a function of y, which the kernels read anyway - the activation tensor `a` is then not
+  // read at all (2 of the 6 / 8 bytes per element of the reduce / apply pass)
+  const float* mscale; const float* mshift;
+  __device__ __forceinline__ void get(size_t i8, int c, float (&dz)[8], float (&yy)[8]) const {
     load8(g + i8 * 8, dz);
     load8(y + i8 * 8, yy);
     if (a) {
@@ -210,6 +214,9 @@ struct DzPlain {
       load8(a + i8 * 8, m);
 #pragma unroll
       for (int k = 0; k < 8; ++k) dz[k] = m[k] > 0.f ? dz[k] : 0.f;
+    } else if (mscale) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = (yy[k] * mscale[c + k] + mshift[c + k]) > 0.f ? dz[k] : 0.f;
     }
   }
 };
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float
   const size_t p0 = (size_t)blockIdx.x * per, p1 = min(npix, p0 + per);
   for (size_t p = p0 + pl; p < p1; p += npl) {
     float dz[8], yy[8];
-    src.get(p * C8 + cg, dz, yy);
+    src.get(p * C8 + cg, c, dz, yy);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       s1[k] += dz[k];
@@ -280,7 +287,7 @@ __global__ void bn_bwd_apply_kernel(Src src, const float* __restrict__ mean, con
   if (i >= n8) return;
   const int c = (int)(i % C8) * 8;
   float dz[8], yy[8];
-  src.get(i, dz, yy);
+  src.get(i, c, dz, yy);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const float is = invstd[c + k];
@@ -513,13 +520,14 @@ int ph_bn_bwd_parts(size_t npix, int C) {
 }
 
 int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
-                            float* parts, size_t npix, int C, int prec, hipStream_t st) {
+                            float* parts, size_t npix, int C, int prec, const float* mscale, const float* mshift,
+                            hipStream_t st) {
   const int nb = ph_bn_bwd_parts(npix, C);
   if (prec == PH_PREC_BF16) {
-    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y};
+    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y, mscale, mshift};
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, DzPlain<bf16>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
   } else {
-    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y};
+    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y, mscale, mshift};
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, DzPlain<float>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
   }
   PH_LAUNCH_CHECK();
@@ -535,13 +543,13 @@ int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double coun
 
 int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
-                           int prec, hipStream_t st) {
+                           int prec, const float* mscale, const float* mshift, hipStream_t st) {
   const size_t n8 = npix * (C / 8);
   if (prec == PH_PREC_BF16) {
-    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y};
+    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y, mscale, mshift};
     hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, DzPlain<bf16>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (bf16*)dy, n8, C / 8);
   } else {
-    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y};
+    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y, mscale, mshift};
     hipLaunchKernelGGL((bn_bwd_apply_kernel<float, DzPlain<float>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (float*)dy, n8, C / 8);
   }
   PH_LAUNCH_CHECK();

@@ -86,9 +86,12 @@ __global__ void gk_finish_kernel(const float* __restrict__ gram, const float* __
 // Adam (torch.optim.Adam semantics) + optional EMA of the parameters, 4 elements per thread.
 //   g' = g + wd*p ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 //   ema = alpha*ema + (1-alpha)*p_new
+// (1 - beta1), (1 - beta2), (1 - alpha) arrive as the host's double-precision differences rounded to float once, which
+// is what torch's `addcmul_(g, g, value=1 - beta2)` / `add_(p, alpha=1 - alpha)` pass: 1.f - 0.999f is 1.3e-5 off.
 __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, size_t n, float lr, float b1, float b2,
-                                float eps, float wd, float bc1, float bc2_sqrt, float ema_alpha) {
+                                float omb1, float omb2, float eps, float wd, float bc1, float bc2_sqrt, float ema_alpha,
+                                float om_alpha) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   const float step = lr / bc1;
@@ -98,8 +101,8 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gg = Gr[k] + wd * P[k];
-      M[k] = b1 * M[k] + (1.f - b1) * gg;
-      V[k] = b2 * V[k] + (1.f - b2) * gg * gg;
+      M[k] = b1 * M[k] + omb1 * gg;
+      V[k] = b2 * V[k] + omb2 * gg * gg;
       P[k] -= step * M[k] / (sqrtf(V[k]) / bc2_sqrt + eps);
     }
     *reinterpret_cast<f32x4*>(p + i) = P;
@@ -108,16 +111,16 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
     if (ema) {
       f32x4 E = *reinterpret_cast<f32x4*>(ema + i);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) E[k] = ema_alpha * E[k] + (1.f - ema_alpha) * P[k];
+      for (int k = 0; k < 4; ++k) E[k] = ema_alpha * E[k] + om_alpha * P[k];
       *reinterpret_cast<f32x4*>(ema + i) = E;
     }
   } else {
     for (size_t e = i; e < n; ++e) {
       const float gg = g[e] + wd * p[e];
-      m[e] = b1 * m[e] + (1.f - b1) * gg;
-      v[e] = b2 * v[e] + (1.f - b2) * gg * gg;
+      m[e] = b1 * m[e] + omb1 * gg;
+      v[e] = b2 * v[e] + omb2 * gg * gg;
       p[e] -= step * m[e] / (sqrtf(v[e]) / bc2_sqrt + eps);
-      if (ema) ema[e] = ema_alpha * ema[e] + (1.f - ema_alpha) * p[e];
+      if (ema) ema[e] = ema_alpha * ema[e] + om_alpha * p[e];
     }
   }
 }
@@ -126,18 +129,18 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
 // launch can live inside a captured HIP graph and be replayed with new values
 __global__ void adam_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                     float* __restrict__ v, float* __restrict__ ema, size_t n, float b1, float b2,
-                                    float eps, float wd, const float* __restrict__ hyper) {
+                                    float omb1, float omb2, float eps, float wd, const float* __restrict__ hyper) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
-  const float step = hyper[0] / hyper[1], bc2_sqrt = hyper[2], ema_alpha = hyper[3];
+  const float step = hyper[0] / hyper[1], bc2_sqrt = hyper[2], ema_alpha = hyper[3], om_alpha = hyper[4];
   if (i + 4 <= n) {
     f32x4 P = *reinterpret_cast<f32x4*>(p + i), Gr = *reinterpret_cast<const f32x4*>(g + i);
     f32x4 M = *reinterpret_cast<f32x4*>(m + i), V = *reinterpret_cast<f32x4*>(v + i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gg = Gr[k] + wd * P[k];
-      M[k] = b1 * M[k] + (1.f - b1) * gg;
-      V[k] = b2 * V[k] + (1.f - b2) * gg * gg;
+      M[k] = b1 * M[k] + omb1 * gg;
+      V[k] = b2 * V[k] + omb2 * gg * gg;
       P[k] -= step * M[k] / (sqrtf(V[k]) / bc2_sqrt + eps);
     }
     *reinterpret_cast<f32x4*>(p + i) = P;
@@ -146,16 +149,16 @@ __global__ void adam_ema_dev_kernel(float* __restrict__ p, const float* __restri
     if (ema) {
       f32x4 E = *reinterpret_cast<f32x4*>(ema + i);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) E[k] = ema_alpha * E[k] + (1.f - ema_alpha) * P[k];
+      for (int k = 0; k < 4; ++k) E[k] = ema_alpha * E[k] + om_alpha * P[k];
       *reinterpret_cast<f32x4*>(ema + i) = E;
     }
   } else {
     for (size_t e = i; e < n; ++e) {
       const float gg = g[e] + wd * p[e];
-      m[e] = b1 * m[e] + (1.f - b1) * gg;
-      v[e] = b2 * v[e] + (1.f - b2) * gg * gg;
+      m[e] = b1 * m[e] + omb1 * gg;
+      v[e] = b2 * v[e] + omb2 * gg * gg;
       p[e] -= step * m[e] / (sqrtf(v[e]) / bc2_sqrt + eps);
-      if (ema) ema[e] = ema_alpha * ema[e] + (1.f - ema_alpha) * p[e];
+      if (ema) ema[e] = ema_alpha * ema[e] + om_alpha * p[e];
     }
   }
 }
@@ -310,7 +313,8 @@ int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, s
   const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
   const size_t nt = (n + 3) / 4;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, m, v, ema, n, (float)lr,
-                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, bc1, bc2s, (float)ema_alpha);
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, bc1,
+                     bc2s, (float)ema_alpha, (float)(1.0 - ema_alpha));
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -319,7 +323,8 @@ int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* em
                          double eps, double weight_decay, const float* hyper, hipStream_t st) {
   const size_t nt = (n + 3) / 4;
   hipLaunchKernelGGL(adam_ema_dev_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, m, v, ema, n,
-                     (float)beta1, (float)beta2, (float)eps, (float)weight_decay, hyper);
+                     (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                     hyper);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -125,14 +125,16 @@ int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int ac
 // BN backward: dz = g * (a > 0 ? 1 : 0) (a may be null).  reduce -> parts [nparts][2][C] (sum dz, sum dz*xhat)
 int ph_bn_bwd_parts(size_t npix, int C);   // <= 1024
 int ph_stem_bwd_parts(int B, int H);         // partial rows written by ph_stem_bwd_reduce_launch
+// mscale / mshift (optional, with a == null): mask = (y * mscale + mshift > 0), the ReLU of this BN's own output
 int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
-                            float* parts, size_t npix, int C, int prec, hipStream_t st);
+                            float* parts, size_t npix, int C, int prec, const float* mscale, const float* mshift,
+                            hipStream_t st);
 // parts -> dgamma, dbeta, c1 = mean(dz), c2 = mean(dz*xhat)
 int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
                               float* c1, float* c2, hipStream_t st);
 int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
-                           int prec, hipStream_t st);
+                           int prec, const float* mscale, const float* mshift, hipStream_t st);
 // stem: da0 = scatter of d_pool through the saved argmax, dz = da0 * (bn(y0) > 0)
 int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,

@@ -216,8 +216,7 @@ int conv_fwd(const Ctx& c, int ui, const void* in) {
     t.IH = u.OH; t.IW = u.OW; S = 1;
   }
   int rc = ph_tapconv_launch(&t, S, P->prec, c.st);
-  if (rc) return rc;
-  if (c.eval) return PH_OK;    // scale/shift were preset from the running statistics
+  if (rc || c.eval) return rc;      // (eval: scale/shift were preset from the running statistics)
   const int nparts = ph_tapconv_stat_parts(&t, S, P->prec);
   float* rm = c.update_running ? (float*)c.params[ui * 6 + 3] : nullptr;
   return ph_bn_finalize_launch(t.stats, nparts, u.Cout, (double)P->B * u.OH * u.OW, 1e-5f, 0.1f,
@@ -291,8 +290,9 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
   return ph_wgrad_reduce_launch(w.slab, dw, w.nchunks, u.KS, u.Cout, u.Cin, c.st);
 }
 
-// BN backward of unit ui: dz = g * (a > 0) -> dgamma/dbeta, dy (into ws dy buffer)
-int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta) {
+// BN backward of unit ui: dz = g * (a > 0) -> dgamma/dbeta, dy (into ws dy buffer).  self_mask: `a` is this unit's own
+// relu(bn(y)) (bn1 of a block) - the mask is recomputed from y and `a` is not read.
+int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta, bool self_mask = false) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   const size_t npix = (size_t)P->B * u.OH * u.OW;
@@ -300,12 +300,15 @@ int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* 
   float* c1 = reinterpret_cast<float*>(c.ws + P->cc_off);
   float* c2 = c1 + 512;
   const void* y = c.ws + u.y_off;
-  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, c.st);
+  const float* ms = self_mask ? c.stat(u, 2) : nullptr;
+  const float* mh = self_mask ? c.stat(u, 3) : nullptr;
+  if (self_mask) a = nullptr;
+  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, ms, mh, c.st);
   if (rc) return rc;
   rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix, u.Cout), u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
   if (rc) return rc;
   return ph_bn_bwd_apply_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), (const float*)c.params[ui * 6 + 1], c1, c2, dy, npix,
-                                u.Cout, P->prec, c.st);
+                                u.Cout, P->prec, ms, mh, c.st);
 }
 
 }  // namespace
@@ -415,7 +418,7 @@ int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, co
     if ((rc = conv_wgrad(c, b.u2, a1, dyb, (float*)grads[b.u2 * 3 + 0]))) return rc;
     if ((rc = conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr))) return rc;
     // bn1 <- d_a1 * (a1 > 0)
-    if ((rc = bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2]))) return rc;
+    if ((rc = bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true))) return rc;
     if ((rc = conv_wgrad(c, b.u1, xin, dyb, (float*)grads[b.u1 * 3 + 0]))) return rc;
     if (b.uds < 0) {
       // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
@@ -475,7 +478,7 @@ int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, c
   auto bn_eval_bwd = [&](int ui, const void* g, const void* a, void* dy) -> int {
     const Unit& u = P->units[ui];
     return ph_bn_bwd_apply_launch(g, a, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), (const float*)params[ui * 6 + 1], c1, c2,
-                                  dy, (size_t)P->B * u.OH * u.OW, u.Cout, P->prec, st);
+                                  dy, (size_t)P->B * u.OH * u.OW, u.Cout, P->prec, nullptr, nullptr, st);
   };
   {
     const Block& b = P->blocks[7];

@@ -89,7 +89,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_flat = None      # optional FlatParams of the EMA model to update in the same kernel
         self.ema_alpha = None
         self.ema_range = None
-        self._hyper = None        # device float[4] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha}: graph-replayable
+        self._hyper = None        # device float[8] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha, 0, 0, 0}: graph-replayable
         self._hyper_host = None
         self._prepared = False
 
@@ -102,8 +102,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._m = torch.zeros_like(self._flat.flat)
             self._v = torch.zeros_like(self._flat.flat)
             self._segs = self._flat.segments(lambda t: t.requires_grad)
-            self._hyper = torch.zeros(4, device=ps[0].device, dtype=torch.float32)
-            self._hyper_host = PinnedRing((4,), torch.float32)
+            self._hyper = torch.zeros(8, device=ps[0].device, dtype=torch.float32)
+            self._hyper_host = PinnedRing((8,), torch.float32)
             ops.bump_weight_epoch()
         return self._flat
 
@@ -115,8 +115,9 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1
         b1, b2 = g["betas"]
-        self._hyper_host.upload(self._hyper, [g["lr"], 1.0 - b1 ** self._step, math.sqrt(1.0 - b2 ** self._step),
-                                              self.ema_alpha if self.ema_alpha is not None else 0.0])
+        a = self.ema_alpha if self.ema_alpha is not None else 0.0
+        self._hyper_host.upload(self._hyper, [g["lr"], 1.0 - b1 ** self._step, math.sqrt(1.0 - b2 ** self._step), a, 1.0 - a,
+                                              0.0, 0.0, 0.0])
         self._prepared = True
 
     @property

@@ -46,13 +46,21 @@ def cls_of(name):
     return None
 
 
+dur = {}     # kernel name -> summed duration (ns) of its profiled dispatches (last load_pmc call)
+
+
 def load_pmc(path):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(set)
+    seen = set()
+    dur.clear()
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            dur[k] = dur.get(k, 0) + int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return agg, {k: len(v) for k, v in cnt.items()}
 
 
@@ -77,13 +85,24 @@ def main():
         with open(os.path.join(out, f"{tag}_pmc_sq.txt"), "w") as o:
             o.write("# rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
                     "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 (eager bench, 6 steps)\n")
-            o.write(f"{'kernel':<80s} {'n':>5s} {'lds_conflict/lds_active':>24s} {'wait_any/wave_cycles':>22s} {'mfma_busy/busy/4':>18s}\n")
+            # MFMA utilisation at the ACTUAL shader clock: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs
+            # (32 per v_mfma_f32_32x32x16_bf16: the tapconv2 launch of 2 359 296 MFMAs reads 75 497 472), SQ_BUSY_CYCLES sums
+            # the kernel's duration in shader cycles over the 32 shader engines (81.7 us x 1.87 GHz x 32 = 4.89e6), so the
+            # fraction of matrix-pipe cycles in use is mfma_busy / (busy / 32 * 1024).  (r01 divided by 4 instead of 32:
+            # its column was 8x too large.)
+            o.write(f"{'kernel':<80s} {'n':>5s} {'lds_conflict/lds_active':>24s} {'wait_any/wave_cycles':>22s} {'mfma_util':>10s} {'clock_GHz':>10s}\n")
+            tot_m = tot_b = 0.0
             for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0))[:14]:
                 d = agg[k]
                 o.write(f"{short(k)[:80]:<80s} {cnt[k]:5d} "
                         f"{d.get('SQ_LDS_BANK_CONFLICT',0)/max(d.get('SQ_LDS_IDX_ACTIVE',0),1):24.3f} "
                         f"{d.get('SQ_WAIT_ANY',0)/max(d.get('SQ_WAVE_CYCLES',0),1):22.3f} "
-                        f"{d.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/max(d.get('SQ_BUSY_CYCLES',0),1)/4:18.3f}\n")
+                        f"{d.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/max(d.get('SQ_BUSY_CYCLES',0),1)/32:10.3f} "
+                        f"{d.get('SQ_BUSY_CYCLES',0)/32/max(dur.get(k,0),1):10.2f}\n")
+            for k, d in agg.items():
+                tot_m += d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0); tot_b += d.get("SQ_BUSY_CYCLES", 0)
+            o.write(f"# all kernels of the profiled steps: MFMA busy {tot_m:.4g} SIMD-cycles / ({tot_b:.4g} / 32 x 1024) = "
+                    f"{tot_m / max(tot_b, 1) / 32:.3f} of the matrix-pipe cycles while a kernel runs\n")
     # ---- HBM traffic per launch of the MFMA kernel classes
     ff = glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))
     fw = glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))

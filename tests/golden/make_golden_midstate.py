@@ -69,6 +69,7 @@ def main():
         crds.append(c)
     ml = torch.nn.ModuleList([student, crds[0].embed_s, crds[0].embed_t, crds[1].embed_s, crds[1].embed_t])
     optimizer = NN.define_optimizer(opt, ml)
+    scheduler = NN.define_scheduler(opt, optimizer)      # :212 - LambdaLR applies its epoch-0 factor (1 - 1/31) on creation
     kl = DistillKL(opt.kd_T)
     names = ["student." + k for k, _ in student.named_parameters()]
     for i in range(2):
@@ -128,7 +129,7 @@ def main():
         optimizer.state[p] = dict(step=torch.tensor(float(T0)), exp_avg=m.clone(), exp_avg_sq=v.clone())
     iter_num = T0
 
-    rec = dict(B=B, H=H, n_data=N_DATA, seed=SEED, t0=T0, epoch=EPOCH, Z0=Z[0], Z1=Z[1],
+    rec = dict(B=B, H=H, n_data=N_DATA, seed=SEED, t0=T0, epoch=EPOCH, Z0=Z[0], Z1=Z[1], lr=optimizer.param_groups[0]["lr"],
                scale_names=np.array(list(scales.keys())), scale_values=np.array(list(scales.values()), dtype=np.float64))
     watch = ("conv1.weight", "layer2.0.conv1.weight", "layer4.1.bn2.weight", "fc_new1.0.weight", "fc_new2.weight", "fc_new2.bias")
     cut = lambda t: t.detach().reshape(-1)[:4096].clone()       # noqa: E731  (leading 4096 elements of the larger tensors)

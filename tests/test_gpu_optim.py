@@ -54,8 +54,9 @@ def test_fused_adam_and_ema_equal_torch_adam_given_the_same_gradients():
     for i, p in enumerate(ref_p):
         st = ref_opt.state[p]
         assert int(out[i]["step"]) == int(st["step"]) == 14
-        assert np.allclose(out[i]["exp_avg"].cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-12)
-        assert np.allclose(out[i]["exp_avg_sq"].cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-16)
+        for key in ("exp_avg", "exp_avg_sq"):       # (fused multiply-add vs two roundings: a few ulp of the larger term)
+            a, b = out[i][key].cpu().numpy(), st[key].numpy()
+            assert np.abs(a - b).max() <= 4e-7 * np.abs(b).max() + 1e-20, (i, key, np.abs(a - b).max(), np.abs(b).max())
     # and a reload of the same checkpoint object works twice (load_state_dict must not consume its argument)
     ck = opt.state_dict()
     opt.load_state_dict(ck); opt.load_state_dict(ck)

@@ -210,6 +210,7 @@ def load_midstate(g, orc):
     mom = W.adam_moments(trainable, scales, int(g["seed"]) + 30)
     orc.adam_t = int(g["t0"])
     orc.iter_num = int(g["t0"])
+    orc.lr = float(g["lr"])            # the trainer's LambdaLR has applied its epoch-0 factor (define_scheduler, :212)
     for n, (m, v) in mom.items():
         orc._m[n], orc._v[n] = m.clone(), v.clone()
     for i, key in enumerate(("Z0", "Z1")):
