@@ -8,8 +8,18 @@
 
 Workload (BASELINE.json configs[1]): per-GPU batch 64 synthetic 512x512 ROI tiles + 320-d genomic vectors,
 bf16 perf mode, README stage-2 flags, dropout 0.1 (the reference default: teacher Dropout/AlphaDropout live),
-n_data = 1024 CRD bank rows.  Weak scaling: 64 tiles per GPU at every N.  Inputs are resident in HBM
-before the timed region.  Prints ONE JSON line on rank 0.
+n_data = 1024 CRD bank rows.  Weak scaling: 64 tiles per GPU at every N (the top-level `value`).  Inputs are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Beside the headline value the line carries (round 2):
+  roofline.step_frac    algorithmic FLOPs of the whole step / time / dense bf16 MFMA peak (the north-star's 70 % is a
+                        whole-path number; `frac` is the dominant kernel's)
+  roofline.hbm          achieved GB/s of the HBM-bound CRD / optimiser / BatchNorm-apply kernels against 8 TB/s
+  parity_mode           the same step in the `bf16x6` arithmetic that meets the 1e-3 logit tolerance (N = 1)
+  cpu_baseline.faithful the reference-faithful 3 forward + 6 backward CPU figure next to the 3 + 1 one
+  north_star_global_256 N > 1: BASELINE configs[2] / the north-star's strong-scaling point - global batch 256 split over
+                        the N GPUs (32 tiles per GPU at N = 8), measured after the weak-scaling run
+  --north-star          N = 1: batch 256 on one GPU (the north-star's single-GPU roofline point) as the headline
 """
 import argparse
 import ctypes
@@ -29,6 +39,13 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
              "tapconv2_kernel<2,2,4,false> (3x3 stride-1 fwd+dgrad, Cout>=128)",
              "tapconv2_l1_kernel (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1, two wave groups)"]
 NCLS = len(CLS_NAMES)
+HBM_NAMES = ["crd_score_kernel (2 banks x B x 1000 rows of 512 B)", "crd_loss_grad_kernel (2 banks x B x 532 rows of 512 B)",
+             "adam_ema_dev_kernel (28 B / parameter + 8 B / EMA parameter)", "bn_apply_kernel (2-3 activation tensors)"]
+NALL = NCLS + len(HBM_NAMES)
+HBM_PEAK_GBS = 8000.0            # HBM3E peak (6290 GB/s measured with a float4 copy), same guide
+# algorithmic FLOPs of the step per 512x512 tile: 3 ResNet-18 forwards + 1 backward without the image gradient
+# (SURVEY 8-d layer table: 93.52 GFLOP); convolutions scale with the tile area
+STEP_GFLOP_PER_TILE_512 = 93.52
 
 
 def make_batch(B, H, n_data, opt, device, seed):
@@ -47,7 +64,7 @@ def make_batch(B, H, n_data, opt, device, seed):
     return ((d(x_path), d(ema_x_path)), d(z), d(x_omic), d(z), d(z), d(grade), d(index), d(sample_idx))
 
 
-def cpu_baseline(nsteps=10):
+def cpu_baseline(nsteps=10, faithful_steps=3):
     """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/test_oracle_golden.py) timed on
     this host for BASELINE config 1 (B=16, 224x224), 3 fwd + 1 bwd ("minimal") mode.  Threads are capped at 16:
     at B=16 torch's CPU kernels stop scaling there (with all 256 host threads of the GPU box the same step takes
@@ -63,9 +80,55 @@ def cpu_baseline(nsteps=10):
     for i in range(nsteps):
         orc.step(synthetic_batch(16, 224, seed=1 + i))
     dt = (time.time() - t0) / nsteps
-    return {"value": round(16.0 / dt, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": f"{nsteps} distill steps of BASELINE config 1 (B=16, 224x224, 320-d omic, fp32, 3 fwd + 1 bwd), "
-                      f"{dt:.2f} s/step after 1 warm-up"}
+    res = {"value": round(16.0 / dt, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+           "sample": f"{nsteps} distill steps of BASELINE config 1 (B=16, 224x224, 320-d omic, fp32, 3 fwd + 1 bwd), "
+                     f"{dt:.2f} s/step after 1 warm-up; NOT comparable per tile with the GPU figure (224x224 fp32 tiles "
+                     f"against 512x512 bf16 tiles: 5.2x the FLOPs each)"}
+    if faithful_steps > 0:
+        # what the reference executes: AEKD_loss runs one FULL backward per loss (train_test_path_multi_distill.py:49-56),
+        # 3 forwards + 6 backwards per step for the same numbers
+        t0 = time.time()
+        for i in range(faithful_steps):
+            orc.step(synthetic_batch(16, 224, seed=50 + i), faithful=True)
+        dtf = (time.time() - t0) / faithful_steps
+        res["faithful"] = {"value": round(16.0 / dtf, 3), "unit": "tiles/s",
+                           "sample": f"{faithful_steps} steps in the reference's own execution order (3 fwd + 6 bwd), {dtf:.2f} s/step"}
+    return res
+
+
+def measure(step, batches, steps, warmup, sync, device, graph=True, loader=False):
+    """W untimed steps (>= 3 when the step is replayed from a HIP graph: two eager ones, one that captures), then
+    exactly K timed steps between barrier + synchronize pairs; max over ranks.  Returns (seconds, last outputs)."""
+    import torch
+    if graph:
+        step.enable_graph()          # steps 0-1 run eagerly, step 2 captures, later steps replay one HIP graph
+    for i in range(max(warmup, 3 if graph else 0)):
+        step.step(batches[i % 2], epoch=1)
+    if graph and not loader:
+        # the two resident batches are adopted in place as the graph's input sets (no staging copy); the second set's
+        # graph is captured here - capture executes nothing - so that the timed region only replays
+        step.precapture(batches[1], epoch=1)
+    return step, batches
+
+
+def timed(step, batches, steps, sync, device):
+    import torch
+    if sync is not None:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = step.step(batches[i % 2], epoch=1)
+    torch.cuda.synchronize()
+    if sync is not None:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if sync is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    return dt, out
 
 
 def main():
@@ -80,6 +143,12 @@ def main():
                          "captured in the same HIP graph as the step - NOT the default metric, whose inputs are resident "
                          "when the timed region starts")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--north-star", action="store_true",
+                    help="N = 1: batch 256 on one GPU - the single-GPU roofline point of the north-star (BASELINE.json)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x6 (parity arithmetic) measurement")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the extra global-batch-256 (configs[2]) measurement")
+    ap.add_argument("--strong-batch", type=int, default=0,
+                    help="testing aid: run the extra strong-scaling measurement with this many tiles per GPU whatever N is")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not replay the step from a captured HIP graph")
@@ -88,6 +157,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
                     "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
     args = ap.parse_args()
+    if args.north_star:
+        args.batch = 256
 
     import numpy as np
     import torch
@@ -130,27 +201,10 @@ def main():
         step.loader = loader
         batches = [None, None]
     L = m.lib()
-    if not args.eager:
-        step.enable_graph()          # steps 0-1 run eagerly, step 2 captures, later steps replay one HIP graph
-    for i in range(max(args.warmup, 0 if args.eager else 3)):
-        step.step(batches[i % 2], epoch=1)
-    if not args.eager:
-        # the two resident batches are adopted in place as the graph's input sets (no staging copy); the second set's
-        # graph is captured here - capture executes nothing - so that the timed region only replays
-        if not args.device_loader:
-            step.precapture(batches[1], epoch=1)
+    measure(step, batches, args.steps, args.warmup, sync, device, graph=not args.eager, loader=args.device_loader)
     if args.eager and not args.no_kernel_timer:
         L.ph_prof_reset(); L.ph_prof_enable(1)
-    if sync is not None:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step.step(batches[i % 2], epoch=1)
-    torch.cuda.synchronize()
-    if sync is not None:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+    dt, out = timed(step, batches, args.steps, sync, device)
     L.ph_prof_enable(0)
     timer_region = "the timed region (eager)"
     if not args.eager and not args.no_kernel_timer:
@@ -168,13 +222,53 @@ def main():
         prof_steps = 3
     else:
         prof_steps = args.steps
-    if sync is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
     loss = out["loss"].item()
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in benchmark: %r" % loss)
+
+    def extra_run(batch, prec, steps):
+        """One more measurement on a fresh step object (another per-GPU batch or another arithmetic), same protocol."""
+        m.set_precision(prec)
+        try:
+            o2 = m.stage2_opt(dropout_rate=0.1, batch_size=batch)
+            np.random.seed(2019 if sync is not None else 2019 + rank)
+            st2 = m.DistillStep(o2, n_data, device=device, sync=sync)
+            for crd in (st2.criterion_kd, st2.criterion_kd_path):
+                crd.contrast.verbose = False
+            b2 = [make_batch(batch, args.size, n_data, o2, device, seed=rank * 100 + 7 + i) for i in range(2)]
+            measure(st2, b2, steps, 3, sync, device, graph=not args.eager)
+            d2, o = timed(st2, b2, steps, sync, device)
+            l2 = o["loss"].item()
+            if not np.isfinite(l2):
+                raise SystemExit("non-finite loss in the extra benchmark run: %r" % l2)
+            for mod in (st2.model, st2.ema_model, st2.fix_model.path_net):
+                mod.release_workspaces()
+            del st2, b2
+            torch.cuda.empty_cache()
+            return d2, l2
+        finally:
+            m.set_precision("bf16")
+
+    strong = None
+    if args.strong_batch > 0 or (world > 1 and not args.no_strong and 256 % world == 0 and (256 // world) != args.batch):
+        # BASELINE configs[2] ("Batch 256 DDP across 8 x MI355X") and the north-star's ">= 6x at 8 GPUs": the GLOBAL batch
+        # of the single-GPU north-star point split over the N GPUs - strong scaling against `bench.py --north-star`
+        per = args.strong_batch if args.strong_batch > 0 else 256 // world
+        d2, l2 = extra_run(per, "bf16", args.steps)
+        strong = {"workload": "BASELINE configs[2] / north-star strong scaling: global batch 256 = %d tiles per GPU x %d GPUs, "
+                              "512x512, bf16, RCCL gradient / bank / Gram exchanges" % (per, world),
+                  "value": round(per * world * args.steps / d2, 2), "unit": "tiles/s",
+                  "ms_per_step": round(1000.0 * d2 / args.steps, 3), "tiles_per_gpu": per, "global_batch": per * world,
+                  "scaling": "strong", "final_loss": round(l2, 4)}
+    parity = None
+    if world == 1 and not args.no_parity_mode and not args.device_loader:
+        # the arithmetic that meets the north-star's 1e-3 logit tolerance (fp32 activations, 3-plane split bf16 operands,
+        # six MFMA products per k-step); same step, same sizes
+        psteps = max(2, min(args.steps, 5))
+        d2, l2 = extra_run(args.batch, "bf16x6", psteps)
+        parity = {"arithmetic": "bf16x6 (fp32 activations, 6 bf16 MFMA products per k-step: fp32-equivalent, logits within 1e-3 "
+                                "of the reference)", "value": round(args.batch * psteps / d2, 2), "unit": "tiles/s",
+                  "ms_per_step": round(1000.0 * d2 / psteps, 3), "steps": psteps, "final_loss": round(l2, 4)}
 
     if rank == 0:
         tiles = args.batch * world * args.steps
@@ -185,7 +279,10 @@ def main():
                "config": {"workload": "%s: teacher+student distill step, bf16, batch %d per GPU, "
                                       "%dx%d tiles, 320-d omic, CRD P=300/K=700->P2=20/K2=512, n_data=1024, "
                                       "GK-Refine on, Adam+EMA, dropout 0.1"
-                                      % ("BASELINE configs[1]" if (args.batch, args.size) == (64, 512) else
+                                      % (("BASELINE configs[1]" + (" per GPU, weak scaling (global batch %d)" % (64 * world)
+                                                                  if world > 1 else ""))
+                                         if (args.batch, args.size) == (64, 512) else
+                                         "north-star single-GPU point (batch 256)" if (args.batch, args.size, world) == (256, 512, 1) else
                                          "BASELINE configs[0] shape" if (args.batch, args.size) == (16, 224) else "custom",
                                          args.batch, args.size, args.size),
                           "tiles_per_gpu": args.batch, "tile": args.size, "global_batch": args.batch * world,
@@ -195,30 +292,58 @@ def main():
                                              if args.device_loader else "inputs resident in HBM when the timed region starts")}}
         # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region)
         if not args.no_kernel_timer:
-            buf = (ctypes.c_double * (3 * NCLS))()
-            L.ph_prof_summary(buf, NCLS)
+            buf = (ctypes.c_double * (3 * NALL))()
+            L.ph_prof_summary(buf, NALL)
             rows = [(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c in range(NCLS)]
             dom = max(range(NCLS), key=lambda c: buf[3 * c + 1])
             n, ms, fl = buf[3 * dom], buf[3 * dom + 1], buf[3 * dom + 2]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = None
-            tf = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get(str(dom), {}).get("bytes_per_launch")
-                except Exception:
-                    traffic = None
+            tname = None
+            for tname in ("r02_traffic.json", "r01_traffic.json"):
+                tf = os.path.join(ROOT, "profiles", tname)
+                if os.path.exists(tf):
+                    try:
+                        traffic = json.load(open(tf)).get(str(dom), {}).get("bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                    break
+            step_gflop = STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2 * args.batch * world
+            step_tflops = step_gflop / (1000.0 * dt / args.steps)          # GFLOP / ms = TFLOP/s, whole job
+            hbm = []
+            for j, name in enumerate(HBM_NAMES):
+                a, b, c = buf[3 * (NCLS + j)], buf[3 * (NCLS + j) + 1], buf[3 * (NCLS + j) + 2]
+                gbs = c / (b * 1e-3) / 1e9 if b > 0 else 0.0
+                hbm.append({"kernel": name, "launches": int(a), "total_ms": round(b, 3), "avg_launch_us": round(1000.0 * b / max(a, 1), 2),
+                            "algorithmic_mb_per_launch": round(c / max(a, 1) / 1e6, 2), "achieved_gbs": round(gbs, 1),
+                            "peak_gbs": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4)})
             res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                               "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction)",
+                               "traffic_note": "HBM bytes per launch from profiles/%s (rocprofv3 --pmc FETCH_SIZE / "
+                                               "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction)" % tname,
                                "kernel": CLS_NAMES[dom], "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                               "step_frac": round(step_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "step_tflops_per_gpu": round(step_tflops / world, 1),
+                               "step_note": "whole step: %.2f GFLOP per tile (3 ResNet-18 forwards + 1 backward, SURVEY 8-d) x tiles / "
+                                            "ms_per_step / 2500 TFLOP/s; the reference executes 276.8 GFLOP per tile for the same "
+                                            "numbers (6 backward passes)" % (STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2),
                                "all_kernels": [{"kernel": k, "launches": int(a), "total_ms": round(b, 3),
-                                                "tflops": round(c / (b * 1e-3) / 1e12, 2) if b > 0 else 0.0}
+                                                "tflops": round(c / (b * 1e-3) / 1e12, 2) if b > 0 else 0.0,
+                                                "frac": round(c / (b * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if b > 0 else 0.0}
                                                for (k, a, b, c) in rows],
+                               "hbm": hbm,
                                "mfma_kernel_ms_per_step": round(sum(r[2] for r in rows) / prof_steps, 3),
-                               "timer_region": timer_region}
+                               "timer_region": timer_region + " (HIP events around single launches: includes ~4 us of launch "
+                                                              "gap per launch over the rocprofv3 durations in profiles/)"}
+        else:
+            step_gflop = STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2 * args.batch * world
+            res["roofline"] = {"bound": "mfma", "step_frac": round(step_gflop / (1000.0 * dt / args.steps) / world / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        if strong is not None:
+            res["north_star_global_256"] = strong
+        if parity is not None:
+            res["parity_mode"] = parity
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -327,7 +327,8 @@ int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn /* may be NULL *
  * launch stream.  Classes: 0 first-generation tap-conv Cout=64 (dgrad parity classes), 1 first-generation tap-conv
  * Cout>=128 stride 1 (1x1, dgrad parity classes), 2 tap-conv stride 2, 3 wgrad, 4 stem forward, 5 stem wgrad,
  * 6 tapconv2 3x3 stride-1 Cout>=128 (fwd + dgrad), 7 tapconv2 3x3 stride-1 Cin=Cout=64 (layer 1).
- * out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic FLOPs}; 8 classes.
+ * out[cls*3 + {0,1,2}] = {launches, total ms, total algorithmic work}; 12 classes: 0-7 the MFMA kernels (work = FLOPs),
+ * 8-11 the HBM-bound crd_score / crd_loss_grad / adam_ema / bn_apply kernels (work = algorithmic bytes).
  * ---------------------------------------------------------------------------------------------- */
 int ph_prof_enable(int on);
 int ph_prof_reset(void);

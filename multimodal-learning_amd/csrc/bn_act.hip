@@ -470,12 +470,16 @@ int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, co
                        const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,
                        hipStream_t st) {
   const size_t n8 = npix * (C / 8);
+  void* tok = nullptr;
+  if (ph_prof_on())
+    ph_prof_begin(PH_CLS_BN_APPLY, (double)npix * C * (prec == PH_PREC_BF16 ? 2.0 : 4.0) * ((res || y_r) ? 3.0 : 2.0), st, &tok);
   if (prec == PH_PREC_BF16)
     hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nblk(n8)), dim3(256), 0, st, (const bf16*)y, scale, shift,
                        (const bf16*)res, (const bf16*)y_r, scale_r, shift_r, (bf16*)out, n8, C / 8, relu);
   else
     hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblk(n8)), dim3(256), 0, st, (const float*)y, scale, shift,
                        (const float*)res, (const float*)y_r, scale_r, shift_r, (float*)out, n8, C / 8, relu);
+  ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

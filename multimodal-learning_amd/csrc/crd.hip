@@ -14,6 +14,7 @@
 // resident for the reference's dataset sizes.
 #include "ph_common.h"
 #include "ph_dense.h"
+#include "ph_kernels.h"
 
 namespace {
 
@@ -435,8 +436,12 @@ int ph_crd_score(const float* v1, const float* v2, const int64_t* idx, const int
                  const float* mem2, float* out1, float* out2, float* diff, int B, int PK, int feat_dim, float T,
                  hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
+  void* tok = nullptr;
+  if (ph_prof_on())   // algorithmic bytes: one 512-B row of each bank per (sample, column) + the three [B][P+K] outputs
+    ph_prof_begin(PH_CLS_CRD_SCORE, 2.0 * B * PK * D * 4 + 3.0 * B * PK * 4 + 2.0 * B * D * 4, st, &tok);
   hipLaunchKernelGGL(crd_score_kernel, dim3(cdiv(PK, 64), B), dim3(256), 0, st, v1, v2, idx,
                      idx_bank2 ? idx_bank2 : idx, mem1, mem2, out1, out2, diff, PK, 1.f / T);
+  ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -473,6 +478,9 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
   if (feat_dim != D) return PH_EINVAL;
   int ns = workspace ? (P2 + K2) / 512 : 1;     // one workgroup per 512 columns of a sample, at most LG_SPLIT_MAX
   ns = ns < 1 ? 1 : (ns > LG_SPLIT_MAX ? LG_SPLIT_MAX : ns);
+  void* tok = nullptr;
+  if (ph_prof_on())   // algorithmic bytes: the selected rows of both banks + the two gradient rows per sample
+    ph_prof_begin(PH_CLS_CRD_LOSSGRAD, 2.0 * B * (P2 + K2) * D * 4 + 2.0 * B * D * 4 + 2.0 * B * (P2 + K2) * 4, st, &tok);
   hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B, ns), dim3(1024), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
                      posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, n_data, inv_bnorm,
                      reinterpret_cast<float*>(workspace));
@@ -482,6 +490,7 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
                        dv1, dv2, ns, inv_bnorm);
     PH_LAUNCH_CHECK();
   }
+  ph_prof_end(tok, st);
   return PH_OK;
 }
 int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,

@@ -3,6 +3,7 @@
 // train_test_path_multi_distill.py:34-38 update_ema_variables).  HBM-bound streaming kernels.
 #include "ph_common.h"
 #include "ph_dense.h"
+#include "ph_kernels.h"
 
 namespace {
 
@@ -322,9 +323,12 @@ int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, s
 int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1, double beta2,
                          double eps, double weight_decay, const float* hyper, hipStream_t st) {
   const size_t nt = (n + 3) / 4;
+  void* tok = nullptr;
+  if (ph_prof_on()) ph_prof_begin(PH_CLS_ADAM_EMA, (double)n * (ema ? 36.0 : 28.0), st, &tok);   // p, m, v r/w + g (+ ema r/w)
   hipLaunchKernelGGL(adam_ema_dev_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, m, v, ema, n,
                      (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay,
                      hyper);
+  ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

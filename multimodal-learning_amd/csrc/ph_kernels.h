@@ -13,7 +13,12 @@
 #define PH_CLS_STEM_WGRAD 5
 #define PH_CLS_TAPCONV2 6       // tapconv2_kernel<2,2,4,false>: 3x3 stride-1 fwd + dgrad, Cout >= 128  (the dominant kernel)
 #define PH_CLS_TAPCONV2_RES 7   // tapconv2_kernel<4,1,2,true>: 3x3 stride-1 fwd + dgrad, Cin = Cout = 64 (layer 1)
-#define PH_NCLS 8
+// HBM-bound classes: the `work` of these is algorithmic BYTES, not FLOPs
+#define PH_CLS_CRD_SCORE 8      // crd_score_kernel: 2 banks x B x (P+K) rows of 512 B
+#define PH_CLS_CRD_LOSSGRAD 9   // crd_loss_grad_kernel (+ its reduce): 2 banks x B x (P2+K2) rows of 512 B
+#define PH_CLS_ADAM_EMA 10      // adam_ema(_dev)_kernel: 28 B per parameter + 8 B per EMA parameter
+#define PH_CLS_BN_APPLY 11      // bn_apply_kernel: y (+ residual | + downsample y) read, activation written
+#define PH_NCLS 12
 #define PH_NUM_CLS 6
 bool ph_prof_on();
 int ph_num_cus();   // compute units of the current device (cached)
