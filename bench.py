@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not replay the step from a captured HIP graph")
     ap.add_argument("--generic-loss-head", action="store_true",
                     help="A/B: per-loss autograd graphs + GK-Refine by five small backward passes instead of loss_head.py")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
                     "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
     args = ap.parse_args()
@@ -185,6 +187,9 @@ def main():
     step = m.DistillStep(opt, n_data, device=device, sync=sync)
     for crd in (step.criterion_kd, step.criterion_kd_path):
         crd.contrast.verbose = False
+    if args.no_fuse:
+        step.ema_model._no_fuse = True
+        step.fix_model.path_net._no_fuse = True
     batches = [make_batch(args.batch, args.size, n_data, opt, device, seed=rank * 100 + i) for i in range(2)]
     if sync is not None:
         np.random.seed(2019)   # the 'mid' rank draw is host RNG state shared by all replicas

@@ -59,7 +59,10 @@ int ph_resnet_unit_shape(const PhResnetPlan* plan, int unit, int* out4 /* Cout, 
  * every optimiser step */
 int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, void* packed, ph_stream_t stream);
 /* x_nchw [B,3,H,W] f32 -> f3 [B,256], f4 [B,512] f32 (either may be NULL).  flags bit0: train mode, update the running
- * statistics; bit1: eval mode (normalise with the running statistics; no backward) */
+ * statistics; bit1: eval mode (normalise with the running statistics; no backward); bit2: forward only - no
+ * ph_resnet_backward will read this workspace (the no_grad EMA / teacher forwards of train_test_path_multi_distill.py:
+ * 253-256): bn1 + ReLU of every BasicBlock (resnets.py:61-63) is then applied by conv2 while it stages its input and the
+ * a1 tensor is not materialised (perf mode); bit3: keep the separate passes nevertheless (A/B and test switch) */
 int ph_resnet_forward(const PhResnetPlan* plan, const void* const* params, const void* packed, const float* x_nchw,
                       void* workspace, float* f3, float* f4, int flags, ph_stream_t stream);
 int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,

@@ -482,6 +482,7 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->ntaps < 1 || p->ntaps > 9 || (S != 1 && S != 2)) return PH_EINVAL;
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
+  if (p->in_scale) return PH_EINVAL;      // the in-LDS BatchNorm + ReLU of the input exists in the second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
   if (prec == PH_PREC_BF16X6) return launch_T<float>(*p, S, st);
   return PH_EINVAL;

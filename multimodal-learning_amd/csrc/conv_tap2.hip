@@ -33,6 +33,28 @@ __device__ unsigned long long ph_tap_trace[PH_TRACE_WGS * 12];
 #endif
 
 __device__ const u32x4 ph_zero16[4] = {};   // source of out-of-image halo pixels
+// ... when the input's BatchNorm + ReLU is applied in LDS (PhTapConv::in_scale): padding must be zero AFTER that map, for
+// any scale / shift.  Quiet NaNs do it: fma(NaN, s, b) = NaN and the ReLU's v_max_f32(NaN, 0) returns the number, 0.
+__device__ const u32x4 ph_nan16[4] = {{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u}, {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u},
+                                      {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u}, {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u}};
+
+// relu(x * s + h) on the 8 bf16 values of one 16-byte chunk (channel 2q in the low half of dword q), result rounded to
+// bf16 like the stand-alone bn_apply pass stores it
+__device__ __forceinline__ u32x4 bn_relu_chunk(u32x4 v, const f32x4& sA, const f32x4& sB, const f32x4& hA, const f32x4& hB) {
+  u32x4 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = __builtin_bit_cast(float, v[q] << 16), x1 = __builtin_bit_cast(float, v[q] & 0xffff0000u);
+    const float s0 = q < 2 ? sA[2 * q] : sB[2 * q - 4], s1 = q < 2 ? sA[2 * q + 1] : sB[2 * q - 3];
+    const float h0 = q < 2 ? hA[2 * q] : hB[2 * q - 4], h1 = q < 2 ? hA[2 * q + 1] : hB[2 * q - 3];
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 r;
+    r[0] = (bf16)fmaxf(x0 * s0 + h0, 0.f);
+    r[1] = (bf16)fmaxf(x1 * s1 + h1, 0.f);
+    o[q] = __builtin_bit_cast(unsigned, r);
+  }
+  return o;
+}
 
 typedef __attribute__((address_space(3))) unsigned char lds_uchar;
 
@@ -72,7 +94,8 @@ struct Tap2Cfg {
   static constexpr int HALO_TAPS = 6;              // taps 0..5 of a slice issue the next slice's halo ...
   static constexpr int HPT = (NHE + HALO_TAPS - 1) / HALO_TAPS;   // ... HPT pieces per wave each
   static constexpr int LDS_MAIN = 2 * A_BYTES + (RES ? NTAPS : RING) * TAPB;
-  static constexpr int LDS_BYTES = LDS_MAIN + 4096;   // + the workgroup's BatchNorm partial row (Cout <= 512)
+  static constexpr int SS_OFF = LDS_MAIN + 4096;       // [2][512] floats: scale / shift of the input's BatchNorm (in_scale)
+  static constexpr int LDS_BYTES = LDS_MAIN + 4096 + 4096;   // + the workgroup's BatchNorm partial row (Cout <= 512) + SS
   static constexpr int NTH = WM * WN * 64;
   static constexpr int NHALF = FM / 2;                       // the C tile is staged in NHALF passes of 2 fragments
   static constexpr int C_BYTES = WM * 4 * TW * BNT * 2;      // one pass of the C tile (bf16)
@@ -192,7 +215,23 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     }
     return m;
   };
-  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(ph_zero16);
+  const bool fuse_in = p.in_scale != nullptr;
+  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(fuse_in ? ph_nan16 : ph_zero16);
+  // BatchNorm + ReLU of the INPUT applied in LDS (PhTapConv::in_scale): every wave transforms the halo pieces it issued
+  // itself (its own counted vmcnt wait covers them; the next barrier publishes the result).  The chunk of lane l in
+  // piece wave + 4e holds channel group cgrp of the slice for every e (the swizzle term (4 * piece) & 15 drops out).
+  float* ss = reinterpret_cast<float*>(smem + C::SS_OFF);
+  const int cgrp = (((lane & 15) ^ ((wave * 4 + (lane >> 4)) & 15)) & 7) * 8;
+  auto xform_halo = [&](int abuf, int k0) {
+    const f32x4 sA = *reinterpret_cast<const f32x4*>(ss + k0 + cgrp), sB = *reinterpret_cast<const f32x4*>(ss + k0 + cgrp + 4);
+    const f32x4 hA = *reinterpret_cast<const f32x4*>(ss + 512 + k0 + cgrp), hB = *reinterpret_cast<const f32x4*>(ss + 512 + k0 + cgrp + 4);
+#pragma unroll
+    for (int e = 0; e < C::NHE; ++e)
+      if (wave + 4 * e < C::NHD) {
+        u32x4* a = reinterpret_cast<u32x4*>(smem + abuf * C::A_BYTES + (wave + 4 * e) * 1024 + lane * 16);
+        *a = bn_relu_chunk(*a, sA, sB, hA, hB);
+      }
+  };
 
   // ---- per-lane fragment addressing
   int prow[FM];   // halo pixel index of this lane's row in M fragment i (fragment f covers tile rows 2f, 2f+1)
@@ -234,6 +273,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   // and no per-tile reduction / barriers in the epilogue.  Fixed order of additions: bitwise reproducible.
   float* stat_acc = reinterpret_cast<float*>(smem + C::LDS_MAIN);
   for (int i = tid; i < 2 * p.Cout; i += NTH) stat_acc[i] = 0.f;   // (published by the prologue barrier)
+  if (p.in_scale) {   // (read before any LDS-DMA is in flight; published by the barrier below)
+    float* ss_ = reinterpret_cast<float*>(smem + C::SS_OFF);
+    for (int i = tid; i < p.Cin; i += NTH) { ss_[i] = p.in_scale[i]; ss_[512 + i] = p.in_shift[i]; }
+    __syncthreads();
+  }
   f32x2 s1[FN], s2[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
@@ -386,6 +430,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   }
   zero_acc();
   PH_WAIT_VMCNT(0);
+  if (fuse_in) xform_halo(0, 0);
   PH_BARRIER();
   PH_TRACE(1);
 
@@ -495,6 +540,10 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
           // ---- tap end: the weight pieces of stream tap gt+2 (and a halo that is due) have landed once at most the
           // pieces issued during this tap are still in flight; the barrier publishes them and releases ring slot gt & 3
           if (t < C::HALO_TAPS) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(4);
+          // all halo pieces of the next slice (issued in taps 0..5) have landed once tap 6 has passed its wait: apply
+          // the input's BatchNorm + ReLU to this wave's pieces; the barriers of taps 6 and 7 publish them before the last
+          // k-step of tap 8 reads the next slice's first fragments
+          if (t == C::HALO_TAPS) { if (fuse_in) xform_halo(acur ^ 1, wk0); }
           PH_BARRIER();
         }
         ++gt;
@@ -560,7 +609,8 @@ struct L1Cfg {
   static constexpr int TAPB = BNT * 128;
   static constexpr int B_BASE = 2 * A_BYTES;
   static constexpr int LDS_MAIN = B_BASE + NTAPS * TAPB;
-  static constexpr int LDS_BYTES = LDS_MAIN + 8 * 2 * BNT * 4;   // + the final BatchNorm reduce [8 waves][2][64]
+  static constexpr int SS_OFF = LDS_MAIN + 8 * 2 * BNT * 4;      // [2][64] floats: scale / shift of the input's BatchNorm
+  static constexpr int LDS_BYTES = SS_OFF + 2 * BNT * 4;         // + the final BatchNorm reduce [8 waves][2][64] + SS
   static constexpr int NTH = 512;
   static constexpr int NWP = NTAPS * TAPB / 1024 / 8;            // weight DMA pieces per wave in the prologue
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -637,8 +687,23 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
   int hr_base = pix0 / HPW, hc_base = pix0 - hr_base * HPW;
   int hoff_base = (int)(((long)hr_base * row_st + (long)hc_base * pix_st + (u0 & 7) * 8) * 2);
   const int hd_row = (int)((row_st + 14 * pix_st) * 2), hd_wrap = (int)((row_st - 18 * pix_st) * 2);
-  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(ph_zero16);
+  const bool fuse_in = p.in_scale != nullptr;
+  const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(fuse_in ? ph_nan16 : ph_zero16);
   const unsigned a_lds = lds0 + grp * C::A_BYTES;
+  // BatchNorm + ReLU of the input applied in LDS (PhTapConv::in_scale), see tapconv2_kernel: each wave transforms the
+  // pieces it issued, after its vmcnt(0) at the end of the store phase and before the barrier that opens the matrix phase
+  auto xform_halo = [&]() {
+    const float* ss = reinterpret_cast<const float*>(smem + C::SS_OFF);
+    const int cg8 = (u0 & 7) * 8;
+    const f32x4 sA = *reinterpret_cast<const f32x4*>(ss + cg8), sB = *reinterpret_cast<const f32x4*>(ss + cg8 + 4);
+    const f32x4 hA = *reinterpret_cast<const f32x4*>(ss + BNT + cg8), hB = *reinterpret_cast<const f32x4*>(ss + BNT + cg8 + 4);
+#pragma unroll
+    for (int e = 0; e < C::NHE; ++e)
+      if (wm + 4 * e < C::NHD) {
+        u32x4* a = reinterpret_cast<u32x4*>(smem + grp * C::A_BYTES + (wm + 4 * e) * 1024 + lane * 16);
+        *a = bn_relu_chunk(*a, sA, sB, hA, hB);
+      }
+  };
   // The next halo is issued piece by piece BETWEEN the blocks of the epilogue (halo_piece): issued back to back, the
   // 11 wave-instructions of 1 KiB each wait ~2400 cycles for the address/data path to accept them.
   unsigned h_rowok = 0, h_colok = 0;
@@ -829,6 +894,11 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
     else with_full(std::false_type{});
   };
 
+  if (fuse_in) {   // (before any LDS-DMA is in flight)
+    float* ss = reinterpret_cast<float*>(smem + C::SS_OFF);
+    if (tid < 2 * BNT) ss[tid] = tid < BNT ? p.in_scale[tid] : p.in_shift[tid - BNT];
+    __syncthreads();
+  }
   // ---- prologue: all 9 taps of weights (8 waves x NWP pieces) and each group's first halo
   {
 #pragma unroll
@@ -848,6 +918,7 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
   }
   if (n_mine > 1) tc_next = decode(tile_id(2 + grp));
   PH_WAIT_VMCNT(0);
+  if (fuse_in && n_mine > 0) xform_halo();
   PH_BARRIER();
   PH_TRACE(1);
 
@@ -934,6 +1005,7 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
       if (i + 2 < n_mine) tc_next = decode(tile_id(2 * (i + 2) + grp));
       const unsigned long long e2_ = PH_CLKF();
       PH_WAIT_VMCNT(0);
+      if (fuse_in && halo) xform_halo();
       const unsigned long long e3_ = PH_CLK();
       cyc_e += e3_ - q2_;
       cyc_e1 += e1_ - q2_; cyc_e2 += e2_ - e1_; cyc_e3 += e3_ - e2_;
@@ -1053,6 +1125,7 @@ int ph_tapconv2_stat_parts(const PhTapConv* p) {
 }
 
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
+  if (p->in_scale && (!p->in_shift || p->Cin > 512)) return PH_EINVAL;
   if (p->Cout % 128 == 0) return launch2<2, 2, 4, false>(*p, st);
 #ifdef PH_L1_ONE_GROUP   // A/B build: the one-wave-per-SIMD resident-weights configuration
   return launch2<4, 1, 2, true>(*p, st);

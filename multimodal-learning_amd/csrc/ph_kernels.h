@@ -33,6 +33,10 @@ struct PhTapConv {
   float* stats;          // [B*tiles][2][Cout] per-workgroup sum / sum-of-squares partials, or null
   const void* res_g;     // optional: out += res_g * (res_a > 0 | 1)   (dgrad residual fusion)
   const void* res_a;
+  // optional (second-generation stride-1 kernels only): `in` is the RAW output of a convolution whose BatchNorm + ReLU
+  // has not been applied - relu(in * in_scale[c] + in_shift[c]) is applied to every halo tile in LDS right after its
+  // LDS-DMA has landed (no separate bn_apply pass, no second activation tensor in HBM).  Forward-only networks.
+  const float* in_scale; const float* in_shift;
   int B, IH, IW, Cin, Cout;
   int OHt, OWt;          // extent of the (r,c) output-position space this launch covers
   int OH, OW;            // full output tensor dims; output pixel = (r*os+oa_h, c*os+oa_w)

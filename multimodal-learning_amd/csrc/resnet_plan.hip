@@ -200,11 +200,12 @@ struct Ctx {
   }
 };
 
-int conv_fwd(const Ctx& c, int ui, const void* in) {
+int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullptr, const float* in_shift = nullptr) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhTapConv t{};
   t.in = in; t.w = c.pk + u.wf_off; t.wplane = u.wplane;
+  t.in_scale = in_scale; t.in_shift = in_shift;
   t.out = c.ws + u.y_off; t.stats = c.eval ? nullptr : reinterpret_cast<float*>(c.ws + P->parts_off);
   t.B = P->B; t.IH = u.IH; t.IW = u.IW; t.Cin = u.Cin; t.Cout = u.Cout;
   t.OHt = u.OH; t.OWt = u.OW; t.OH = u.OH; t.OW = u.OW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
@@ -315,7 +316,11 @@ int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* 
 
 extern "C" {
 
-// flags: bit0 = update BN running statistics (train mode); bit1 = eval mode (normalise with the running statistics)
+// flags: bit0 = update BN running statistics (train mode); bit1 = eval mode (normalise with the running statistics);
+// bit2 = forward only: no backward will read this workspace (the EMA and teacher networks of the distillation step) - in
+// perf mode bn1 + ReLU of every block is then applied by conv2 itself while it stages its input (conv_tap2.hip,
+// PhTapConv::in_scale): the a1 tensor is neither written nor read, 8 bn_apply launches per forward disappear;
+// bit3 = A/B and test switch: keep the separate bn_apply passes although bit2 is set
 int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const void* packed, const float* x_nchw,
                       void* ws_, float* f3, float* f4, int flags, hipStream_t st) {
   if (!P || !params || !packed || !x_nchw || !ws_) return PH_EINVAL;
@@ -353,16 +358,24 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
                                         P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
   }
+  // conv2 of every block is 3x3 / stride 1 with Cin = Cout in {64, 128, 256, 512}: always a second-generation kernel in perf mode
+  const bool fuse_a1 = (flags & 4) && !(flags & 8) && P->prec == PH_PREC_BF16;
   for (size_t bi = 0; bi < P->blocks.size(); ++bi) {
     const Block& b = P->blocks[bi];
     const Unit& u1 = P->units[b.u1];
     const Unit& u2 = P->units[b.u2];
     const size_t npix = (size_t)P->B * b.OH * b.OW;
     if ((rc = conv_fwd(c, b.u1, ws + b.in_off))) return rc;
-    if ((rc = ph_bn_apply_launch(ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3), nullptr, nullptr, nullptr, nullptr,
-                                 ws + b.a1_off, npix, b.Cout, 1, P->prec, st)))
-      return rc;
-    if ((rc = conv_fwd(c, b.u2, ws + b.a1_off))) return rc;
+    // (measured per launch, B = 64, 512^2: the in-LDS pass costs the conv +10 us in layer 1 and +13 us in layers 2-4 - it
+    // runs with the matrix pipe idle - against bn_apply launches of 49 / 25 / 13 / 8 us: fused where it pays)
+    if (fuse_a1 && b.Cout <= 128) {
+      if ((rc = conv_fwd(c, b.u2, ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3)))) return rc;
+    } else {
+      if ((rc = ph_bn_apply_launch(ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3), nullptr, nullptr, nullptr, nullptr,
+                                   ws + b.a1_off, npix, b.Cout, 1, P->prec, st)))
+        return rc;
+      if ((rc = conv_fwd(c, b.u2, ws + b.a1_off))) return rc;
+    }
     if (b.uds >= 0) {
       const Unit& ud = P->units[b.uds];
       if ((rc = conv_fwd(c, b.uds, ws + b.in_off))) return rc;

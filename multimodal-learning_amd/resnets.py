@@ -90,8 +90,12 @@ class _TrunkFn(torch.autograd.Function):
         ws = net._get_workspace(plan, persistent=need_grad)
         f3 = torch.empty(B, 256, device=x.device, dtype=torch.float32)
         f4 = torch.empty(B, 512, device=x.device, dtype=torch.float32)
-        check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4),
-                                      1 if net.training else 2, stream()), "ph_resnet_forward")
+        # flags of ph_resnet_forward: train / eval; +4 when no backward will follow (no gradient is recorded: the EMA and
+        # teacher networks of the distillation step) - the trunk then fuses bn1 + ReLU into conv2's operand staging;
+        # +8 (`net._no_fuse`, an A/B and test switch) keeps the separate passes
+        flags = (1 if net.training else 2) | (0 if any(ctx.needs_input_grad) else 4) | (8 if getattr(net, "_no_fuse", False) else 0)
+        check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4), flags, stream()),
+              "ph_resnet_forward")
         ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table
         ctx.input_only = not net.training      # eval mode: the backward produces the image gradient only
         ctx.set_materialize_grads(False)

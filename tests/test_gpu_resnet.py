@@ -449,3 +449,32 @@ def test_image_gradient_perf_mode_tracks_parity_mode():
     cos = float((a @ b) / (a.norm() * b.norm()))
     assert cos > 0.9, cos
     assert 0.8 < float(b.norm() / a.norm()) < 1.25
+
+
+@pytest.mark.parametrize("B,H", [(6, 160), (3, 96), (20, 224)])
+def test_fused_input_batchnorm_equals_separate_pass(B, H):
+    """Forward-only networks (the EMA student and the teacher) run conv2 of every block on the RAW conv1 output and apply
+    bn1 + ReLU to each halo tile in LDS (conv_tap2.hip, PhTapConv::in_scale; padding enters as NaN and leaves the ReLU
+    as 0).  The separate bn_apply pass rounds the same values to bf16 before conv2 reads them, so both paths feed the
+    MFMAs identical operands in identical order: outputs must be BITWISE equal - train and eval mode, ragged tile
+    edges (160 -> 40 / 20 / 10 / 5 pixel maps), repeated launches."""
+    import multimodal_learning_amd as m
+    from oracle.step import synthetic_batch
+    m.set_precision("bf16")
+    x = synthetic_batch(B, H, seed=31)["x_path"].cuda()
+    for training in (True, False):
+        outs = {}
+        for no_fuse in (True, False, False):
+            net = _student()
+            net.train(training)
+            net._no_fuse = no_fuse
+            with torch.no_grad():
+                f3, feat, hazard, pred, _ = net(x_path=x)
+            key = "separate" if no_fuse else ("fused" if "fused" not in outs else "fused again")
+            outs[key] = (f3.clone(), feat.clone(), hazard.clone(), {k: v.clone() for k, v in net.state_dict().items() if "running" in k})
+        for other in ("fused", "fused again"):
+            for a, b in zip(outs["separate"][:3], outs[other][:3]):
+                assert torch.equal(a, b), (training, other, (a - b).abs().max().item())
+            for k, v in outs["separate"][3].items():
+                assert torch.equal(v, outs[other][3][k]), (training, k)
+        assert torch.isfinite(outs["fused"][2]).all()
