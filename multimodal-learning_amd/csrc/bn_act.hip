@@ -106,7 +106,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
 }
 
 // stem: relu(bn(y0)) -> maxpool 3x3/2 pad 1; argmax position code (kh*3+kw, first max wins) saved as u8
-template <typename T>
+template <typename T, bool IDX>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                        const float* __restrict__ shift, T* __restrict__ out,
                                        uint8_t* __restrict__ idx, int B, int H, int W, int C8) {
@@ -140,15 +140,18 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __r
         // the pooled value equals pooling the stored bf16 activation; only an exact-vs-rounded tie can pick another
         // - equally large after rounding - tap.  Rounding every tap cost a third of this VALU-bound kernel.)
         const float a = fmaxf(v[k] * sc[k] + sh[k], 0.f);
-        if (a > best[k]) { best[k] = a; bi[k] = kh * 3 + kw; }
+        if constexpr (IDX) { if (a > best[k]) { best[k] = a; bi[k] = kh * 3 + kw; } }
+        else best[k] = fmaxf(best[k], a);
       }
     }
   }
   store8(out + i * 8, best);
-  uint64_t packed = 0;
+  if constexpr (IDX) {
+    uint64_t packed = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) packed |= (uint64_t)(bi[k] & 0xff) << (8 * k);
-  *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;
+    for (int k = 0; k < 8; ++k) packed |= (uint64_t)(bi[k] & 0xff) << (8 * k);
+    *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;
+  }
 }
 
 // global average pool [B][HW][C] -> [B][C] fp32; block = (b, 64-channel chunk)
@@ -488,12 +491,11 @@ int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* sh
                               int H, int W, int C, int prec, hipStream_t st) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const size_t n = (size_t)B * OH * OW * (C / 8);
-  if (prec == PH_PREC_BF16)
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, (const bf16*)y, scale, shift,
-                       (bf16*)out, idx, B, H, W, C / 8);
-  else
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, (const float*)y, scale, shift,
-                       (float*)out, idx, B, H, W, C / 8);
+#define PH_POOL_LAUNCH(T, IDX) \
+  hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, IDX>), dim3(nblk(n)), dim3(256), 0, st, (const T*)y, scale, shift, (T*)out, idx, B, H, W, C / 8)
+  if (prec == PH_PREC_BF16) { if (idx) PH_POOL_LAUNCH(bf16, true); else PH_POOL_LAUNCH(bf16, false); }
+  else { if (idx) PH_POOL_LAUNCH(float, true); else PH_POOL_LAUNCH(float, false); }
+#undef PH_POOL_LAUNCH
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

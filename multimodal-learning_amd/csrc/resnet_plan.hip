@@ -50,7 +50,7 @@ int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
   const int th = ph_wgrad_tile_h((u.KS == 1) ? 1 : u.S);
   const int ntiles = B * cdiv(u.OH, th) * cdiv(u.OW, 16);
   const int blocks = (u.Cout / 64) * (u.Cin / 64);
-  int want = cdiv(512, blocks);            // ~2 workgroups per CU; few partial slabs to reduce (HBM-bound)
+  int want = cdiv(512, blocks);            // ~2 workgroups per CU (A/B on one box: 256 -> +0.2 ms / step, 384 and 768 -> +0.33)
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   int tpc = cdiv(ntiles, want);
@@ -354,8 +354,9 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
                                     c.stat(u, 1), c.stat(u, 2), c.stat(u, 3), rm, (float*)params[4],
                                     (int64_t*)params[5], st)))
       return rc;
-    if ((rc = ph_bn_relu_maxpool_launch(ws + u.y_off, c.stat(u, 2), c.stat(u, 3), ws + P->p0_off, ws + P->idx_off,
-                                        P->B, u.OH, u.OW, 64, P->prec, st)))
+    // (forward only: nobody scatters a gradient through the pooling windows - the argmax codes are not produced)
+    if ((rc = ph_bn_relu_maxpool_launch(ws + u.y_off, c.stat(u, 2), c.stat(u, 3), ws + P->p0_off,
+                                        (flags & 4) ? nullptr : ws + P->idx_off, P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
   }
   // conv2 of every block is 3x3 / stride 1 with Cin = Cout in {64, 128, 256, 512}: always a second-generation kernel in perf mode
