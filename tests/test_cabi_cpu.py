@@ -86,3 +86,73 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+_ASAN_CHILD = r'''
+import ctypes as C, sys
+L = C.CDLL(sys.argv[1])
+vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+L.ph_resnet_plan_create.restype = vp; L.ph_resnet_plan_create.argtypes = [i32] * 4
+L.ph_resnet_plan_destroy.argtypes = [vp]
+for f in ("ph_resnet_workspace_bytes", "ph_resnet_packed_bytes"):
+    getattr(L, f).restype = sz; getattr(L, f).argtypes = [vp]
+L.ph_resnet_num_units.argtypes = [vp]
+L.ph_resnet_unit_shape.argtypes = [vp, i32, vp]
+L.ph_resnet_tensor_info.argtypes = [vp, i32, i32, vp, vp]
+L.ph_conv2d_workspace_bytes.restype = sz; L.ph_conv2d_workspace_bytes.argtypes = [i32] * 8
+L.ph_tsvd_workspace_bytes.restype = sz; L.ph_tsvd_workspace_bytes.argtypes = [i32, i32]
+L.ph_crd_class_centers_workspace_bytes.restype = sz; L.ph_crd_class_centers_workspace_bytes.argtypes = [i32, i32]
+n = 0
+for (B, H, W) in ((1, 32, 32), (3, 96, 160), (16, 224, 224), (64, 512, 512), (256, 512, 512), (2, 33, 47)):
+    for prec in (0, 1):
+        p = L.ph_resnet_plan_create(B, H, W, prec)
+        assert p, (B, H, W, prec)
+        assert L.ph_resnet_num_units(p) == 20 and L.ph_resnet_workspace_bytes(p) > 0 and L.ph_resnet_packed_bytes(p) > 0
+        out4 = (C.c_int * 4)()
+        for u in range(-1, 22):
+            rc = L.ph_resnet_unit_shape(p, u, out4)
+            assert (rc == 0) == (0 <= u < 20), (u, rc)
+        off = C.c_size_t(0)
+        for what in range(0, 5):
+            for idx in range(-1, 22):
+                rc = L.ph_resnet_tensor_info(p, what, idx, C.byref(off), out4)
+                if rc == 0:
+                    assert off.value < L.ph_resnet_workspace_bytes(p)
+        L.ph_resnet_plan_destroy(p)
+        n += 1
+for bad in ((0, 64, 64, 0), (1, 8, 8, 0), (1, 64, 64, 5), (-3, 64, 64, 1)):
+    assert not L.ph_resnet_plan_create(*bad)
+assert L.ph_resnet_workspace_bytes(None) == 0 and L.ph_resnet_num_units(None) == 0
+L.ph_resnet_plan_destroy(None)
+assert L.ph_conv2d_workspace_bytes(64, 64, 128, 128, 64, 3, 1, 1) > 0 and L.ph_tsvd_workspace_bytes(128, 8) > 0
+assert L.ph_crd_class_centers_workspace_bytes(3, 70000) > 0
+# argument checks that must return before anything touches a device
+L.ph_resnet_forward.argtypes = [vp] * 7 + [i32, vp]
+assert L.ph_resnet_forward(None, None, None, None, None, None, None, 1, None) == -22
+L.ph_crd_class_centers.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+assert L.ph_crd_class_centers(None, None, None, 3, 10, 100, 128, None, None) == -22
+print("ASAN-CHILD-OK", n)
+'''
+
+
+def test_host_logic_under_asan(tmp_path):
+    """SURVEY section 5: the host side of the C-ABI (plan construction, workspace layout, argument validation) under
+    AddressSanitizer.  `make -C csrc asan` compiles every translation unit --offload-host-only with -fsanitize=address
+    (CPU only: GPU ASAN / XNACK are not available); a child interpreter preloads the ASAN runtime, loads that library
+    and walks the host entry points - any heap / stack / global overflow or use-after-free aborts the child."""
+    import glob
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "multimodal-learning_amd", "csrc")
+    rt = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+    if not rt:
+        pytest.skip("no ASAN runtime in this image")
+    r = subprocess.run(["make", "-C", csrc, "asan", "-j8"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lib = os.path.join(ROOT, "multimodal-learning_amd", "libpathomic_hip_asan.so")
+    script = tmp_path / "child.py"
+    script.write_text(_ASAN_CHILD)
+    env = dict(os.environ, LD_PRELOAD=rt[0], ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1")
+    r = subprocess.run([sys.executable, str(script), lib], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ASAN-CHILD-OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
