@@ -52,7 +52,7 @@ def main():
     from oracle.variants import CRDv3State
     B, H, n_data, K = 8, 64, 1024, opt.nce_k
 
-    def run(dt, rec):
+    def run(dt, rec, warm=None, collect=False):
         with contextlib.redirect_stdout(io.StringIO()):
             student = NN.define_net(opt, 1, path_only=True)
             ema = NN.define_net(opt, 1, path_only=True)
@@ -76,11 +76,17 @@ def main():
             crds.append(c)
         ml = torch.nn.ModuleList([student, crds[0].embed_s, crds[0].embed_t, crds[1].embed_s, crds[1].embed_t])
         optimizer = NN.define_optimizer(opt, ml)
+        import _warm
+        wnames, wparams = _warm.param_names(student), list(ml.parameters())
+        if warm is not None:
+            _warm.set_torch_adam(optimizer, wnames, wparams, warm)
+            NN.define_scheduler(opt, optimizer)     # the trainer's LambdaLR applies its epoch-0 factor on creation
+            rec["lr"] = optimizer.param_groups[0]["lr"]
         kl = DistillKL(opt.kd_T)
         for mod in (student, ema, teacher, crds[0], crds[1]):
             mod.to(dt)
         ml.train(); teacher.train()
-        scale, iter_num = None, 0
+        scale, iter_num = None, (_warm.T0 if warm is not None else 0)
         epochs = [3, 3, 7]               # the epoch weight changes between steps (the CRD loss is multiplied by it)
         for it in range(3):
             bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=300 + it)
@@ -105,6 +111,8 @@ def main():
             loss = opt.lambda_nll * loss_cls + loss_KD        # reg_type none: define_reg contributes 0
             optimizer.zero_grad()
             loss.backward()
+            if collect:
+                return _warm.grad_scales(wnames, wparams, opt.weight_decay)
             if it == 0:
                 rec.update(g0_conv1=student.conv1.weight.grad.clone(), g0_fc2_w=student.fc_new2.weight.grad.clone(),
                            g0_embed_s0=crds[0].embed_s.linear.weight.grad.clone(),
@@ -126,8 +134,17 @@ def main():
 
     rec = dict(B=B, H=H, n_data=n_data, K=K, grads_m=opt.grads_m, niter_decay=opt.niter_decay, alpha=opt.alpha,
                beta=opt.beta)
+    rec_meta = dict(rec)
     run(torch.float32, rec)
     np.savez_compressed(os.path.join(HERE, "mia2022_step_b8_h64.npz"), **npz(rec))
+    # the same three steps from a mid-training optimiser state (tests/golden/_warm.py): every step comparable at 1e-3
+    import _warm
+    scales = run(torch.float32, {}, collect=True)
+    recw = dict(rec_meta)
+    recw.update(_warm.pack_scales(scales)); recw["t0"] = _warm.T0
+    run(torch.float32, recw, warm=scales)
+    recw = {k: v for k, v in recw.items() if not k.startswith(("path_feat", "g0_conv1"))}
+    np.savez_compressed(os.path.join(HERE, "mia2022_step_warm_b8_h64.npz"), **npz(recw))
     # the same calls in double precision: the noise floor that steps >= 1 are judged against (Adam's first updates
     # are sign-like and amplify fp32 rounding; see tests/golden/make_fp64_truth.py)
     rec64 = {}

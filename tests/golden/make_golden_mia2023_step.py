@@ -60,7 +60,7 @@ def main():
     labels = torch.randint(0, 3, (n_data,), generator=torch.Generator().manual_seed(11))
     class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
 
-    def run(dt, rec):
+    def run(dt, rec, warm=None, collect=False):
         with contextlib.redirect_stdout(io.StringIO()):
             student = NN.define_net(opt, 1, path_only=True)
             ema = NN.define_net(opt, 1, path_only=True)
@@ -84,11 +84,17 @@ def main():
             crds.append(c)
         ml = torch.nn.ModuleList([student, crds[0].embed_s, crds[0].embed_t, crds[1].embed_s, crds[1].embed_t])
         optimizer = NN.define_optimizer(opt, ml)
+        import _warm
+        wnames, wparams = _warm.param_names(student), list(ml.parameters())
+        if warm is not None:
+            _warm.set_torch_adam(optimizer, wnames, wparams, warm)
+            NN.define_scheduler(opt, optimizer)     # the trainer's LambdaLR applies its epoch-0 factor on creation
+            rec["lr"] = optimizer.param_groups[0]["lr"]
         kl = DistillKL(opt.kd_T)
         for mod in (student, ema, teacher, crds[0], crds[1]):
             mod.to(dt)
         ml.train(); teacher.train()
-        iter_num = 0
+        iter_num = _warm.T0 if warm is not None else 0
         epochs = [0, 1, 2]               # start_reweight = 1: step 0 runs with unit query weights, steps 1-2 re-weighted
         for it in range(3):
             bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=400 + it)
@@ -121,6 +127,8 @@ def main():
             loss = opt.lambda_nll * loss_cls + loss_KD        # reg_type none: define_reg contributes 0
             optimizer.zero_grad()
             loss.backward()
+            if collect:
+                return _warm.grad_scales(wnames, wparams, opt.weight_decay)
             if it == 0:
                 rec.update(g0_conv1=student.conv1.weight.grad.clone(), g0_fc2_w=student.fc_new2.weight.grad.clone(),
                            g0_embed_s0=crds[0].embed_s.linear.weight.grad.clone(),
@@ -142,8 +150,17 @@ def main():
 
     rec = dict(B=B, H=H, n_data=n_data, K=K, num_pos=opt.nce_p, labels=labels, alpha=opt.alpha, beta=opt.beta,
                start_reweight=opt.start_reweight, max_discrep=opt.max_discrep, grads_thresh=opt.grads_thresh)
+    rec_meta = dict(rec)
     run(torch.float32, rec)
     np.savez_compressed(os.path.join(HERE, "mia2023_step_b8_h64.npz"), **npz(rec))
+    # the same three steps from a mid-training optimiser state (tests/golden/_warm.py): every step comparable at 1e-3
+    import _warm
+    scales = run(torch.float32, {}, collect=True)
+    recw = dict(rec_meta)
+    recw.update(_warm.pack_scales(scales)); recw["t0"] = _warm.T0
+    run(torch.float32, recw, warm=scales)
+    recw = {k: v for k, v in recw.items() if not k.startswith(("path_feat", "g0_conv1"))}
+    np.savez_compressed(os.path.join(HERE, "mia2023_step_warm_b8_h64.npz"), **npz(recw))
     # the same calls in double precision: the noise floor that steps >= 1 are judged against (Adam's first updates
     # are sign-like and amplify fp32 rounding; see tests/golden/make_fp64_truth.py)
     rec64 = {}

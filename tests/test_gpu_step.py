@@ -813,3 +813,77 @@ def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
         R.finish()
     finally:
         m.set_precision("bf16")
+
+
+@pytest.mark.parametrize("variant", ["mia2022", "mia2023"])
+def test_variant_steps_from_mid_training_state_vs_reference_golden(golden_dir, variant):
+    """The MIA-2022 / MIA-2023 batch bodies (rows a17 / a18) for THREE steps at the north-star tolerance: same fixtures as
+    the cold-start tests above but with Adam started from a mid-training state (tests/golden/_warm.py: step count 7,
+    moments of the size of the reference's own gradients) - so steps 1 and 2, which carry the momentum GK-Refine weights
+    (mia2022), the re-weighting switch and the KNN bank (mia2023), the bank updates, Adam and the EMA across iterations,
+    are asserted at 1e-3 instead of against a noise floor."""
+    import sys
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    from oracle.variants import CRDv3State, CRDv10State
+    from tests.gpu_util import Report
+    sys.path.insert(0, golden_dir)
+    import _warm
+    g = np.load(os.path.join(golden_dir, f"{variant}_step_warm_b8_h64.npz"))
+    B, H, n_data, K = int(g["B"]), int(g["H"]), int(g["n_data"]), int(g["K"])
+    kw = {}
+    if variant == "mia2022":
+        opt = default_opt(nce_k=K, grads_m=float(g["grads_m"]), grads_thresh="False", thresh=0.1, niter_decay=int(g["niter_decay"]))
+        epochs, seed0 = [3, 3, 7], 300
+    else:
+        labels = torch.as_tensor(g["labels"])
+        kw["train_class_idx"] = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+        opt = default_opt(nce_k=K, nce_p=int(g["num_pos"]), pos_extra="neighbors", neg_mode="all_others",
+                          start_reweight=int(g["start_reweight"]), discrep_scale=1, max_discrep=float(g["max_discrep"]),
+                          use_grads_thresh="True", grads_thresh=float(g["grads_thresh"]), loss_weighting="GK_refine", batch_size=B)
+        epochs, seed0 = [0, 1, 2], 400
+    m.set_precision("bf16x6")
+    try:
+        step = m.DistillStep(opt, n_data, device="cuda", variant=variant, **kw)
+        step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+        step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+        step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+        for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+            crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 10 + 2 * i))
+            crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 11 + 2 * i))
+            st = CRDv3State(n_data, K=K, seed=20 + i) if variant == "mia2022" else CRDv10State(n_data, labels, K=K, seed=20 + i)
+            crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+            crd.contrast.verbose = False
+        names = _warm.param_names(step.model)
+        params = list(step.module_list.parameters())
+        assert len(names) == len(params)
+        _warm.load_fused_adam(step.optimizer, names, params, _warm.unpack_scales(g))
+        step.iter_num = int(g["t0"])
+        assert abs(step.optimizer.param_groups[0]["lr"] - float(g["lr"])) < 1e-12
+        R = Report(f"3 {variant} distill steps from a mid-training optimiser state, parity mode vs REFERENCE golden (B=8, 64x64)")
+        keys = [("logit_path", "logit_path"), ("ema_logit", "ema_logit"), ("fuse_logit", "fuse_logit"), ("loss_cls", "loss_cls"),
+                ("loss_div1_", "loss_div1"), ("loss_div2_", "loss_div2"), ("loss_kd1_", "loss_kd1"), ("loss_kd2_", "loss_kd2"),
+                ("loss", "loss")]
+        if variant == "mia2023":
+            keys += [("w1_", "w1"), ("w2_", "w2"), ("rows_div1_", "rows_div1"), ("rows_kd1_", "rows_kd1")]
+        for it in range(3):
+            bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=seed0 + it)
+            if variant == "mia2023":
+                bt["grade"] = labels[bt["index"]]
+            out = step.step(_tuple(bt), epoch=epochs[it])
+            sd, esd = step.model.state_dict(), step.ema_model.state_dict()
+            idx = bt["index"].cuda()
+            for key, name in keys:
+                R.close(g[f"{key}{it}"], out[name], 1e-3, 1e-4, f"{name} step {it}")
+            # mia2023: the per-sample GK weights are 0/1 decisions on cosines (thresholded): compared as decisions
+            R.close(g[f"scale{it}"], out["scale"], 2e-3 if variant == "mia2022" else 1e-6, 1e-3 if variant == "mia2022" else 0,
+                    f"GK-Refine weights step {it}")
+            R.close(g[f"p_fc2_{it}"], sd["fc_new2.weight"], 5e-6, 0, f"Adam-updated fc2 step {it}")
+            R.close(g[f"ema_fc2_{it}"], esd["fc_new2.weight"], 5e-6, 0, f"EMA fc2 step {it}")
+            R.close(g[f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[idx], 2e-5, 0, f"bank0 rows step {it}")
+            R.close(g[f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[idx], 2e-5, 0, f"bank1 rows step {it}")
+            R.close(g[f"params0_{it}"], step.criterion_kd.contrast.params, 1e-2, 1e-5, f"CRD params / Z step {it}")
+        R.finish()
+    finally:
+        m.set_precision("bf16")
