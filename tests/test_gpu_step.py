@@ -881,8 +881,8 @@ def test_variant_steps_from_mid_training_state_vs_reference_golden(golden_dir, v
                     f"GK-Refine weights step {it}")
             R.close(g[f"p_fc2_{it}"], sd["fc_new2.weight"], 5e-6, 0, f"Adam-updated fc2 step {it}")
             R.close(g[f"ema_fc2_{it}"], esd["fc_new2.weight"], 5e-6, 0, f"EMA fc2 step {it}")
-            R.close(g[f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[idx], 2e-5, 0, f"bank0 rows step {it}")
-            R.close(g[f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[idx], 2e-5, 0, f"bank1 rows step {it}")
+            R.close(g[f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[idx], 1e-4, 0, f"bank0 rows step {it}")
+            R.close(g[f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[idx], 1e-4, 0, f"bank1 rows step {it}")
             R.close(g[f"params0_{it}"], step.criterion_kd.contrast.params, 1e-2, 1e-5, f"CRD params / Z step {it}")
         R.finish()
     finally:
