@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not replay the step from a captured HIP graph")
     ap.add_argument("--generic-loss-head", action="store_true",
                     help="A/B: per-loss autograd graphs + GK-Refine by five small backward passes instead of loss_head.py")
+    ap.add_argument("--no-masked", action="store_true",
+                    help="A/B switch: first-generation kernel for the 3x3 stride-2 convolutions (not the masked tap grid)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
@@ -190,6 +192,9 @@ def main():
     if args.no_fuse:
         step.ema_model._no_fuse = True
         step.fix_model.path_net._no_fuse = True
+    if args.no_masked:
+        for net in (step.model, step.ema_model, step.fix_model.path_net):
+            net._no_masked = True
     batches = [make_batch(args.batch, args.size, n_data, opt, device, seed=rank * 100 + i) for i in range(2)]
     if sync is not None:
         np.random.seed(2019)   # the 'mid' rank draw is host RNG state shared by all replicas
@@ -297,8 +302,12 @@ def main():
                                              if args.device_loader else "inputs resident in HBM when the timed region starts")}}
         # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region)
         if not args.no_kernel_timer:
-            buf = (ctypes.c_double * (3 * NALL))()
-            L.ph_prof_summary(buf, NALL)
+            buf4 = (ctypes.c_double * (4 * NALL))()
+            L.ph_prof_summary4(buf4, NALL)
+            buf = [0.0] * (3 * NALL)
+            byt = [0.0] * NALL
+            for c in range(NALL):
+                buf[3 * c], buf[3 * c + 1], buf[3 * c + 2], byt[c] = buf4[4 * c], buf4[4 * c + 1], buf4[4 * c + 2], buf4[4 * c + 3]
             rows = [(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c in range(NCLS)]
             dom = max(range(NCLS), key=lambda c: buf[3 * c + 1])
             n, ms, fl = buf[3 * dom], buf[3 * dom + 1], buf[3 * dom + 2]
@@ -315,6 +324,19 @@ def main():
                     break
             step_gflop = STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2 * args.batch * world
             step_tflops = step_gflop / (1000.0 * dt / args.steps)          # GFLOP / ms = TFLOP/s, whole job
+
+            def per_kernel(name, launches, ms_, flops, nbytes):
+                """One MFMA kernel class against BOTH rooflines; `bound` = the one its algorithmic intensity puts it under
+                (machine balance 2500 TFLOP/s / 8 TB/s = 312 FLOP/B), `frac` = achieved / peak of that roofline."""
+                tf = flops / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+                gb = nbytes / (ms_ * 1e-3) / 1e9 if ms_ > 0 else 0.0
+                inten = flops / nbytes if nbytes > 0 else float("inf")
+                bound = "mfma" if inten >= MFMA_BF16_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
+                fm, fh = tf / MFMA_BF16_PEAK_TFLOPS, gb / HBM_PEAK_GBS
+                return {"kernel": name, "launches": int(launches), "total_ms": round(ms_, 3), "tflops": round(tf, 2),
+                        "frac_mfma": round(fm, 4), "algorithmic_gbs": round(gb, 1), "frac_hbm": round(fh, 4),
+                        "flop_per_byte": round(inten, 1) if nbytes > 0 else None, "bound": bound,
+                        "frac": round(fm if bound == "mfma" else fh, 4)}
             hbm = []
             for j, name in enumerate(HBM_NAMES):
                 a, b, c = buf[3 * (NCLS + j)], buf[3 * (NCLS + j) + 1], buf[3 * (NCLS + j) + 2]
@@ -333,10 +355,8 @@ def main():
                                "step_note": "whole step: %.2f GFLOP per tile (3 ResNet-18 forwards + 1 backward, SURVEY 8-d) x tiles / "
                                             "ms_per_step / 2500 TFLOP/s; the reference executes 276.8 GFLOP per tile for the same "
                                             "numbers (6 backward passes)" % (STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2),
-                               "all_kernels": [{"kernel": k, "launches": int(a), "total_ms": round(b, 3),
-                                                "tflops": round(c / (b * 1e-3) / 1e12, 2) if b > 0 else 0.0,
-                                                "frac": round(c / (b * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if b > 0 else 0.0}
-                                               for (k, a, b, c) in rows],
+                               "all_kernels": [per_kernel(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2], byt[c])
+                                               for c in range(NCLS)],
                                "hbm": hbm,
                                "mfma_kernel_ms_per_step": round(sum(r[2] for r in rows) / prof_steps, 3),
                                "timer_region": timer_region + " (HIP events around single launches: includes ~4 us of launch "

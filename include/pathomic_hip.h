@@ -336,6 +336,8 @@ int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn /* may be NULL *
 int ph_prof_enable(int on);
 int ph_prof_reset(void);
 int ph_prof_summary(double* out, int nclasses);
+/* out[cls*4 + {0,1,2,3}] = {launches, total ms, total algorithmic work, total algorithmic HBM bytes} */
+int ph_prof_summary4(double* out, int nclasses);
 
 #ifdef __cplusplus
 }

@@ -397,7 +397,9 @@ int ph_stem_stat_parts(int B, int OH, int OW) { return cdiv(B * cdiv(OH, TH) * c
 int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
   dim3 grid(ph_stem_stat_parts(p->B, p->OH, p->OW));
   void* tok = nullptr;
-  if (ph_prof_on()) ph_prof_begin(PH_CLS_STEM_FWD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0, st, &tok);
+  if (ph_prof_on())   // bytes: the packed image (4 channels) once + the 64-channel output
+    ph_prof_begin2(PH_CLS_STEM_FWD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0,
+                   ((double)p->B * p->IH * p->IW * 4 + (double)p->B * p->OH * p->OW * 64) * (prec == PH_PREC_BF16 ? 2.0 : 4.0), st, &tok);
   struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
   if (prec == PH_PREC_BF16) {
     static bool done = false;
@@ -419,7 +421,9 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
   dim3 grid(p->nchunks);
   void* tok = nullptr;
-  if (ph_prof_on()) ph_prof_begin(PH_CLS_STEM_WGRAD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0, st, &tok);
+  if (ph_prof_on())
+    ph_prof_begin2(PH_CLS_STEM_WGRAD, 2.0 * p->B * p->OH * p->OW * 64.0 * 147.0,
+                   ((double)p->B * p->IH * p->IW * 4 + (double)p->B * p->OH * p->OW * 64) * (prec == PH_PREC_BF16 ? 2.0 : 4.0), st, &tok);
   struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
   const int base = TH * TW * 128 + XB;
   if (prec == PH_PREC_BF16) {

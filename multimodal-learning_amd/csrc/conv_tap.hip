@@ -443,13 +443,26 @@ int launch_cfg(const PhTapConv& p, hipStream_t st) {
   dim3 grid(cdiv(p.OHt, TH) * cdiv(p.OWt, 16), p.Cout / BNT, p.B);
   void* tok = nullptr;
   if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
-    ph_prof_begin(S == 2 ? PH_CLS_TAPCONV_S2 : (BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128),
-                  2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
+    ph_prof_begin2(S == 2 ? PH_CLS_TAPCONV_S2 : (BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128),
+                   2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, ph_tapconv_bytes(p, S, sizeof(T)), st, &tok);
   hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
+
+}  // namespace
+// algorithmic HBM bytes of a tap-conv launch: the input pixels its taps touch (at most the whole input view; all planes
+// of a masked stride-2 forward), the output positions it writes (+ the residual it reads; all classes of a masked
+// stride-2 dgrad), the weight slabs of its taps - each counted once
+double ph_tapconv_bytes(const PhTapConv& p, int S, int es) {
+  const double in_pix = (double)p.B * ((double)p.OHt * S + 2) * ((double)p.OWt * S + 2);
+  const double in_full = (double)p.B * p.IH * p.IW;
+  const double in = (in_pix < in_full ? in_pix : in_full) * p.Cin * es * (p.m_groups ? p.m_groups : 1);
+  const double out = (double)p.B * p.OHt * p.OWt * p.Cout * es * (p.res_g ? (p.res_a ? 3.0 : 2.0) : 1.0);
+  return in + out + (double)p.ntaps * p.Cin * p.Cout * 2.0;
+}
+namespace {
 
 template <typename T>
 int launch_T(const PhTapConv& p, int S, hipStream_t st) {
@@ -482,7 +495,7 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->ntaps < 1 || p->ntaps > 9 || (S != 1 && S != 2)) return PH_EINVAL;
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
-  if (p->in_scale) return PH_EINVAL;      // the in-LDS BatchNorm + ReLU of the input exists in the second-generation kernels only
+  if (p->in_scale || p->m_groups) return PH_EINVAL;   // in-LDS BatchNorm + ReLU / masked tap grids: second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
   if (prec == PH_PREC_BF16X6) return launch_T<float>(*p, S, st);
   return PH_EINVAL;

@@ -108,9 +108,10 @@ struct Tap2Cfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int WM, int WN, int FM_, bool RES>
+template <int WM, int WN, int FM_, bool RES, bool MASKED = false>
 __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   using C = Tap2Cfg<WM, WN, FM_, RES>;
+  static_assert(!MASKED || !RES, "masked taps: streamed-weights configuration only");
   constexpr int FM = C::FM, FN = C::FN, TH = C::TH, TW = C::TW, BNT = C::BNT;
   constexpr int HPW = C::HPW, HP = C::HP, NTH = C::NTH, NTAPS = C::NTAPS;
   typedef __bf16 T;
@@ -174,11 +175,22 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     return (local < per_xcd && t < total) ? t : -1;
   };
 
-  const int nslices = p.Cin >> 6;
-  // tap table in a VGPR (lane t holds tap t), read with v_readlane: no memory access on the tap path
+  const int nsl_c = p.Cin >> 6;      // 64-channel slices of the real channel count
+  const int nsl_sh = nsl_c == 1 ? 0 : (nsl_c == 2 ? 1 : (nsl_c == 4 ? 2 : 3));
+  const int nslices = MASKED ? nsl_c * 4 : nsl_c;      // masked: the four pixel-parity planes of a stride-2 forward
+  // tap table in a VGPR (lane t holds tap t; masked: lane 9 g + t holds grid tap t of plane g), read with v_readlane: no
+  // memory access on the tap path
   int tap_tab = 0;
-  if (lane < NTAPS) tap_tab = p.wtap[lane] << 16;
-  auto tap_slab = [&](int t) { return __builtin_amdgcn_readlane(tap_tab, t) >> 16; };
+  if constexpr (MASKED) {
+    if (lane < 36) tap_tab = p.m_slab[lane / 9][lane % 9] << 16;
+  } else {
+    if (lane < NTAPS) tap_tab = p.wtap[lane] << 16;
+  }
+  auto tap_slab = [&](int g, int t) { return __builtin_amdgcn_readlane(tap_tab, MASKED ? g * 9 + t : t) >> 16; };
+  // slice index -> (plane, channel offset, element offset of the plane's input view)
+  auto slice_grp = [&](int sl) { return MASKED ? (sl >> nsl_sh) : 0; };
+  auto slice_k0 = [&](int sl) { return MASKED ? ((sl & (nsl_c - 1)) << 6) : (sl << 6); };
+  auto slice_in_off = [&](int sl) -> long { return MASKED ? p.m_in_off[sl >> nsl_sh] + slice_k0(sl) : (long)(sl << 6); };
 
   // ---- per-lane DMA sources.  Piece d of an LDS image covers row pairs 4d..4d+3; lane l writes slot l & 15 of row
   // pair rp = 4d + (l >> 4), which the swizzle assigns to (row 2*rp + (u >> 3), chunk u & 7), u = (l & 15) ^ (rp & 15)
@@ -311,6 +323,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     constexpr bool FULL = decltype(fullc)::value;   // the tile lies completely inside the output: no masking
     constexpr int RM = decltype(rmc)::value;
     const int r0 = tc.r0, c0 = tc.c0, n0 = tc.n0;
+    const int oa_h = p.oa_h, oa_w = p.oa_w;
     T* out = reinterpret_cast<T*>(p.out) + (size_t)tc.b * p.OH * p.OW * p.Cout;
     const T* resg = reinterpret_cast<const T*>(p.res_g) + (size_t)tc.b * p.OH * p.OW * p.Cout;
     const T* resa = reinterpret_cast<const T*>(p.res_a) + (size_t)tc.b * p.OH * p.OW * p.Cout;
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
           const int fr = (__popc(m >> 1) + khalf) & 1;     // columns 2m, 2m+1 share q >> 2 = m >> 1
           const int r = r0 + (wm * FM + i) * 2 + fr, c = c0 + 2 * m + (lane & 1);
           mine[m] = FULL || (r < p.OHt && c < p.OWt);
-          o[m] = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + (nrow[0] & ~1);
+          o[m] = ((size_t)(r * p.os + oa_h) * p.OW + (c * p.os + oa_w)) * p.Cout + n0 + (nrow[0] & ~1);
         }
         bf16x2 rg[8][FN], ra[8][FN];
         if constexpr (RM > 0) {
@@ -406,23 +419,24 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   if (nvalid) tnext = decode(tn);
   int hm_cur = halo_mask(tcur.iy_base, tcur.ix_base);
   int hm_next = nvalid ? halo_mask(tnext.iy_base, tnext.ix_base) : hm_cur;
-  auto halo_base = [&](const TileCtx& tc, int k0) {   // address of channel k0 of the halo origin pixel (may lie outside)
-    return reinterpret_cast<const unsigned char*>(tc.in) + ((long)tc.iy_base * row_st + (long)tc.ix_base * pix_st + k0) * 2;
+  auto halo_base = [&](const TileCtx& tc, long off) {   // address of element `off` (channel offset of the slice, + the
+    // group's view offset when masked) of the halo origin pixel (may lie outside the image)
+    return reinterpret_cast<const unsigned char*>(tc.in) + ((long)tc.iy_base * row_st + (long)tc.ix_base * pix_st + off) * 2;
   };
-  auto w_base = [&](int n0, int k0, int tap) {
-    return reinterpret_cast<const unsigned char*>(wbase + ((size_t)tap_slab(tap) * p.Cout + n0) * p.Cin + k0);
+  auto w_base = [&](int n0, int k0, int g, int tap) {
+    return reinterpret_cast<const unsigned char*>(wbase + ((size_t)tap_slab(g, tap) * p.Cout + n0) * p.Cin + k0);
   };
 
   // prologue: first halo and the first RING-1 taps of weights
   {
-    const unsigned char* hb = halo_base(tcur, 0);
+    const unsigned char* hb = halo_base(tcur, slice_in_off(0));
 #pragma unroll
     for (int e = 0; e < C::NHE; ++e)
       if (wave + 4 * e < C::NHD)
         lds_dma16(((hm_cur >> e) & 1) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
 #pragma unroll
     for (int j = 0; j < (RES ? NTAPS : C::RING - 1); ++j) {
-      const unsigned char* wb = w_base(tcur.n0, 0, j);
+      const unsigned char* wb = w_base(tcur.n0, 0, 0, j);
 #pragma unroll
       for (int e = 0; e < C::NBE; ++e)
         lds_dma16(wb + wb_off[e], lds0 + B_BASE + j * C::TAPB + (wave * C::NBE + e) * 1024);
@@ -490,22 +504,36 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   (void)ql0_;
   int acur = 0, gt = 0;
   for (int k = 0;; ++k) {   // tiles of this workgroup
-    for (int sl = 0; sl < nslices; ++sl) {
+    // One 64-channel slice = 9 grid taps.  `mk` / `mkn`: the taps that are LIVE in this slice / in the slice that
+    // follows it in the stream (all nine, except in the masked grid of a stride-2 forward).  Literals at every call
+    // site: after inlining and unrolling every liveness test folds - no run-time branch, no second arm merging the 128
+    // accumulators.  A dead tap keeps its place in the stream (ring slot, halo pieces) but issues no MFMAs, no weight
+    // DMAs (nor does anyone fetch weights FOR it), and waits / joins a barrier only where a later live tap needs it:
+    //   wait    at the end of tap t  <=  tap t+2 is live (its weights, issued in tap t-1, must be published before tap
+    //           t+1 pre-reads... tap t+2's first fragments are read at the end of tap t+1), or t = HALO_TAPS (the halo);
+    //   barrier at the end of tap t  <=  a wait, or taps t and t+4 are live (ring slot t & 3 is refilled from tap t+1 on),
+    //           or t = 8 (the other halo buffer is refilled from the next slice's tap 0 on).
+    // (Not a generic lambda: clang rejects asm operands that name captured variables inside one.)
+    auto slice_body = [&](const int sl, const unsigned mk, const unsigned mkn) __attribute__((always_inline)) {
       const unsigned long long q0_ = PH_CLK();   // (per-slice stamps only: a stamp costs ~50 cycles with its s_waitcnt)
       const bool last_sl = sl + 1 == nslices;
       // source of the next slice's halo (next slice of this tile / slice 0 of the next tile / past the end: this tile)
       const bool h_next_tile = last_sl && nvalid;
-      const unsigned char* hb = h_next_tile ? halo_base(tnext, 0) : halo_base(tcur, last_sl ? 0 : (sl + 1) << 6);
+      const int nsl = last_sl ? 0 : sl + 1;                       // index of the next slice inside its tile
+      const unsigned char* hb = h_next_tile ? halo_base(tnext, slice_in_off(0)) : halo_base(tcur, slice_in_off(nsl));
       const int hm = h_next_tile ? hm_next : hm_cur;
       // weights of the taps that wrap into the next slice / tile
       const int wn0 = (last_sl && nvalid) ? tnext.n0 : tcur.n0;
-      const int wk0 = last_sl ? 0 : (sl + 1) << 6;
+      const int wk0 = slice_k0(nsl);
+      const int gc = slice_grp(sl), wg = slice_grp(nsl);
       const unsigned long long q0b_ = PH_CLK();
       cyc_s += q0b_ - q0_;
+      auto live = [&](int u) { return u < NTAPS ? ((mk >> u) & 1u) != 0 : ((mkn >> (u - NTAPS)) & 1u) != 0; };
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
+        const bool lv = live(t), lv1 = live(t + 1), lv2 = live(t + 2), lv3 = live(t + 3), lv4 = live(t + 4);
         // weight pieces of stream tap gt+3 -> ring slot (gt+3) & 3 (released by the barrier that ended tap gt-1)
-        const unsigned char* wb = (t + 3 < NTAPS) ? w_base(tcur.n0, sl << 6, t + 3) : w_base(wn0, wk0, t + 3 - NTAPS);
+        const unsigned char* wb = (t + 3 < NTAPS) ? w_base(tcur.n0, slice_k0(sl), gc, t + 3) : w_base(wn0, wk0, wg, t + 3 - NTAPS);
         const unsigned wdst = lds0 + B_BASE + ((gt + 3) & 3) * C::TAPB + wave * C::NBE * 1024;
         const unsigned hdst = lds0 + (acur ^ 1) * C::A_BYTES + wave * 1024;
 #define PH_DMA_B(E) lds_dma16(wb + wb_off[E], wdst + (E) * 1024)
@@ -516,10 +544,24 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   } while (0)
         const int toff_n = ((t + 1) % NTAPS) / 3 * HPW + ((t + 1) % NTAPS) % 3;
         const int abuf_n = t + 1 == NTAPS ? (acur ^ 1) : acur;
-        if constexpr (FM == 4) {
+        if (!lv) {
+          // ---- dead tap of a masked grid
+          if constexpr (FM == 4) {
+            if (lv3) { PH_DMA_B(0); PH_DMA_B(1); PH_DMA_B(2); PH_DMA_B(3); }
+            if (t < C::HALO_TAPS) { PH_DMA_H(2 * t); PH_DMA_H(2 * t + 1); }
+            if (lv1) {   // the first fragments of the next tap, read where a live tap reads them
+              tap_addr(toff_n, abuf_n, (gt + 1) & 3);
+#pragma unroll
+              for (int i = 0; i < FM; ++i) fa[0][i] = PH_LDA(aaddr, i, 0);
+#pragma unroll
+              for (int j = 0; j < FN; ++j) fb[0][j] = PH_LDA(bxs, j, 0);
+            }
+            PH_SB();
+          }
+        } else if constexpr (FM == 4) {
           // ---- 32 MFMAs; the tap's DMA pieces ride between them
-          PH_KSTEP(0, 1, 1, PH_NOP_, PH_DMA_B(0), PH_NOP_, PH_NOP_, PH_DMA_B(1), PH_NOP_, PH_NOP_, PH_DMA_B(2));
-          PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, PH_DMA_B(3), PH_NOP_, PH_NOP_,
+          PH_KSTEP(0, 1, 1, PH_NOP_, if (lv3) PH_DMA_B(0), PH_NOP_, PH_NOP_, if (lv3) PH_DMA_B(1), PH_NOP_, PH_NOP_, if (lv3) PH_DMA_B(2));
+          PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, if (lv3) PH_DMA_B(3), PH_NOP_, PH_NOP_,
                    if (t < C::HALO_TAPS) PH_DMA_H(2 * t), PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t + 1));
           PH_KSTEP(0, 1, 3, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
           tap_addr(toff_n, abuf_n, (gt + 1) & 3);
@@ -539,17 +581,39 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
         if constexpr (!RES) {
           // ---- tap end: the weight pieces of stream tap gt+2 (and a halo that is due) have landed once at most the
           // pieces issued during this tap are still in flight; the barrier publishes them and releases ring slot gt & 3
-          if (t < C::HALO_TAPS) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(4);
+          const bool need_wait = lv2 || t == C::HALO_TAPS;
+          const bool need_bar = need_wait || (lv && lv4) || t == NTAPS - 1;
+          if (need_wait) {   // at most this tap's own pieces may still be in flight
+            if (t < C::HALO_TAPS) { if (lv3) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(2); }
+            else { if (lv3) PH_WAIT_VMCNT(4); else PH_WAIT_VMCNT(0); }
+          }
           // all halo pieces of the next slice (issued in taps 0..5) have landed once tap 6 has passed its wait: apply
           // the input's BatchNorm + ReLU to this wave's pieces; the barriers of taps 6 and 7 publish them before the last
           // k-step of tap 8 reads the next slice's first fragments
           if (t == C::HALO_TAPS) { if (fuse_in) xform_halo(acur ^ 1, wk0); }
-          PH_BARRIER();
+          if (need_bar) PH_BARRIER();
         }
         ++gt;
       }
       acur ^= 1;
       cyc_c += PH_CLK() - q0b_;
+    };
+    if constexpr (!MASKED) {
+      for (int sl = 0; sl < nslices; ++sl) slice_body(sl, 511u, 511u);
+    } else {
+      // stride-2 forward: the four pixel-parity planes in a fixed order, plane (a, b) with its (1 + a)(1 + b) live grid
+      // taps (ph_tapconv2_setup_s2_fwd): rows gy = 1 (a = 0) or 0, 1 (a = 1), columns likewise.  The last slice of a
+      // plane is followed by the next plane's mask (the last plane's by plane 0 of the next tile).
+      constexpr unsigned M0 = 0x010u, M1 = 0x018u, M2 = 0x012u, M3 = 0x01Bu;
+      const int nl = nsl_c - 1;
+      for (int s = 0; s < nl; ++s) slice_body(s, M0, M0);
+      slice_body(nl, M0, M1);
+      for (int s = 0; s < nl; ++s) slice_body(nsl_c + s, M1, M1);
+      slice_body(nsl_c + nl, M1, M2);
+      for (int s = 0; s < nl; ++s) slice_body(2 * nsl_c + s, M2, M2);
+      slice_body(2 * nsl_c + nl, M2, M3);
+      for (int s = 0; s < nl; ++s) slice_body(3 * nsl_c + s, M3, M3);
+      slice_body(3 * nsl_c + nl, M3, M0);
     }
     const unsigned long long q2b_ = PH_CLK();
     if constexpr (RES) PH_BARRIER();   // no per-tap barrier in this configuration: all waves are done with the A buffer
@@ -1074,17 +1138,17 @@ int launch_l1(const PhTapConv& p, hipStream_t st) {
   dim3 grid(total < resident ? total : resident);
   void* tok = nullptr;
   if (ph_prof_on())
-    ph_prof_begin(PH_CLS_TAPCONV2_RES, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
+    ph_prof_begin2(PH_CLS_TAPCONV2_RES, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, ph_tapconv_bytes(p, 1, 2), st, &tok);
   hipLaunchKernelGGL(tapconv2_l1_kernel, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 
-template <int WM, int WN, int FM, bool RES>
+template <int WM, int WN, int FM, bool RES, bool MASKED = false>
 int launch2(const PhTapConv& p, hipStream_t st) {
   using C = Tap2Cfg<WM, WN, FM, RES>;
-  auto kern = tapconv2_kernel<WM, WN, FM, RES>;
+  auto kern = tapconv2_kernel<WM, WN, FM, RES, MASKED>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1096,9 +1160,14 @@ int launch2(const PhTapConv& p, hipStream_t st) {
   const int resident = ph_num_cus();   // one workgroup per CU (LDS)
   dim3 grid(total < resident ? total : resident);
   void* tok = nullptr;
-  if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
-    ph_prof_begin(RES ? PH_CLS_TAPCONV2_RES : PH_CLS_TAPCONV2,
-                  2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, st, &tok);
+  if (ph_prof_on()) {   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin (masked: the LIVE taps of all groups)
+    double taps = p.ntaps;
+    if (MASKED) {
+      taps = 9;      // 1 + 2 + 2 + 4 live taps over the four planes, each on Cin channels
+    }
+    ph_prof_begin2(MASKED ? PH_CLS_TAPCONV2_MASKED : (RES ? PH_CLS_TAPCONV2_RES : PH_CLS_TAPCONV2),
+                   2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * taps * p.Cin, ph_tapconv_bytes(p, 1, 2), st, &tok);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
@@ -1107,9 +1176,48 @@ int launch2(const PhTapConv& p, hipStream_t st) {
 
 }  // namespace
 
+// ---- stride-2 3x3 convolutions as MASKED stride-1 tap grids (PhTapConv::m_*).  Both fill the tap-grid part of a
+// descriptor whose tensors / batch / channel fields the caller has set (forward: in = x [B][IH][IW][Cin], Cin / Cout of
+// the convolution; dgrad: in = dy [B][OH][OW][Cout_fwd], t->Cin = Cout_fwd, t->Cout = Cin_fwd, OH / OW of dx) and
+// return false when the shape is not eligible (odd sizes, channel counts the <2,2,4> configuration does not tile,
+// parity mode): the caller then runs the first-generation kernels.
+//
+// Forward: output (r, c) reads input (2r + kh - 1, 2c + kw - 1).  On the pixel-parity plane (a, b) = pixels (2i + a,
+// 2j + b) - a strided view of x - that is plane pixel (r + gy - 1, c + gx - 1) with grid tap gy = 1 for kh = 1 (a = 0)
+// and gy = 0 / 1 for kh = 0 / 2 (a = 1): plane (a, b) has (1 + a)(1 + b) live taps, 9 in all, every input pixel is
+// staged once, and the K loop walks 4 * Cin / 64 slices.
+bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec) {
+  if (prec != PH_PREC_BF16 || Cout % 128 || Cout > 512 || Cin % 64 || Cin > 512 || ((Cin >> 6) & ((Cin >> 6) - 1)) ||
+      (IH & 1) || (IW & 1))
+    return false;
+  t->in_pix_stride = 2L * Cin; t->in_row_stride = 2L * IW * Cin; t->in_img_stride = (long)IH * IW * Cin;
+  t->IH = IH / 2; t->IW = IW / 2;
+  t->iy0 = -1; t->ix0 = -1; t->ntaps = 9;
+  for (int k = 0; k < 9; ++k) { t->dy[k] = k / 3; t->dx[k] = k % 3; t->wtap[k] = 0; }
+  t->m_groups = 4;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int g = a * 2 + b;
+      t->m_in_off[g] = ((long)a * IW + b) * Cin;
+      t->m_mask[g] = 0;
+      for (int gy = 0; gy < 3; ++gy)
+        for (int gx = 0; gx < 3; ++gx) {
+          const int kh = a ? (gy == 0 ? 0 : (gy == 1 ? 2 : -1)) : (gy == 1 ? 1 : -1);
+          const int kw = b ? (gx == 0 ? 0 : (gx == 1 ? 2 : -1)) : (gx == 1 ? 1 : -1);
+          const bool live = kh >= 0 && kw >= 0;
+          t->m_slab[g][gy * 3 + gx] = live ? kh * 3 + kw : 0;
+          if (live) t->m_mask[g] |= 1 << (gy * 3 + gx);
+        }
+    }
+  // the kernel hard-codes these live-tap sets (its four slice loops): keep them in step
+  if (t->m_mask[0] != 0x010 || t->m_mask[1] != 0x018 || t->m_mask[2] != 0x012 || t->m_mask[3] != 0x01B) return false;
+  return true;
+}
+
 // 0: not eligible (the first-generation kernel runs); otherwise the tile height of the configuration chosen
 int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec) {
   if (S != 1 || prec != PH_PREC_BF16 || p->ntaps != 9 || p->Cout > 512) return 0;
+  if (p->m_groups && (p->Cout % 128 || p->m_groups != 4 || ((p->Cin >> 6) & ((p->Cin >> 6) - 1)) || p->Cin > 512)) return 0;
   if (p->Cout % 128 && !(p->Cout == 64 && p->Cin == 64)) return 0;
   for (int k = 0; k < 9; ++k)   // the kernel hard-codes the 3x3 tap geometry (only the weight slab order is a table)
     if (p->dy[k] != k / 3 || p->dx[k] != k % 3) return 0;
@@ -1126,6 +1234,7 @@ int ph_tapconv2_stat_parts(const PhTapConv* p) {
 
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
   if (p->in_scale && (!p->in_shift || p->Cin > 512)) return PH_EINVAL;
+  if (p->m_groups) return (p->Cout % 128 == 0 && !p->in_scale) ? launch2<2, 2, 4, false, true>(*p, st) : PH_EINVAL;
   if (p->Cout % 128 == 0) return launch2<2, 2, 4, false>(*p, st);
 #ifdef PH_L1_ONE_GROUP   // A/B build: the one-wave-per-SIMD resident-weights configuration
   return launch2<4, 1, 2, true>(*p, st);

@@ -234,7 +234,9 @@ int launch_wg(const PhWgrad& p, hipStream_t st) {
   dim3 grid((p.Cout / 64) * (p.Cin / 64), p.nchunks);
   void* tok = nullptr;
   if (ph_prof_on())
-    ph_prof_begin(PH_CLS_WGRAD, 2.0 * p.B * p.OH * p.OW * (double)p.Cout * p.KS * p.KS * p.Cin, st, &tok);
+    ph_prof_begin2(PH_CLS_WGRAD, 2.0 * p.B * p.OH * p.OW * (double)p.Cout * p.KS * p.KS * p.Cin,
+                   ((double)p.B * p.IH * p.IW * p.Cin + (double)p.B * p.OH * p.OW * p.Cout) * sizeof(T) +
+                       (double)p.nchunks * p.KS * p.KS * p.Cout * p.Cin * 4.0, st, &tok);   // x + dy once, the fp32 slab
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();

@@ -18,11 +18,14 @@
 #define PH_CLS_CRD_LOSSGRAD 9   // crd_loss_grad_kernel (+ its reduce): 2 banks x B x (P2+K2) rows of 512 B
 #define PH_CLS_ADAM_EMA 10      // adam_ema(_dev)_kernel: 28 B per parameter + 8 B per EMA parameter
 #define PH_CLS_BN_APPLY 11      // bn_apply_kernel: y (+ residual | + downsample y) read, activation written
-#define PH_NCLS 12
+#define PH_CLS_TAPCONV2_MASKED 12   // tapconv2_kernel<2,2,4,false,MASKED>: stride-2 fwd / merged-class dgrad as masked stride-1 grids
+#define PH_NCLS 13
 #define PH_NUM_CLS 6
 bool ph_prof_on();
 int ph_num_cus();   // compute units of the current device (cached)
 void ph_prof_begin(int cls, double work, hipStream_t st, void** token);
+// + the launch's ALGORITHMIC HBM bytes (input + output activations + packed weights, each counted once)
+void ph_prof_begin2(int cls, double work, double bytes, hipStream_t st, void** token);
 void ph_prof_end(void* token, hipStream_t st);
 
 struct PhTapConv {
@@ -48,13 +51,25 @@ struct PhTapConv {
   // element strides of the input view (0 = dense NHWC: Cin, IW*Cin, IH*IW*Cin).  A 1x1 stride-2 convolution is run
   // as a 1x1 stride-1 tap-conv over the view {pixel stride 2*Cin, row stride 2*IW*Cin} (no wasted halo pixels).
   long in_pix_stride, in_row_stride, in_img_stride;
+  // optional MASKED 3x3 tap grid (second-generation kernel <2,2,4,false> only; m_groups = 4, 0 = off): a stride-2 3x3
+  // FORWARD convolution as a stride-1 tap-conv over the four pixel-parity planes of its input - strided views
+  // (in_pix/row_stride = 2 pixels / 2 rows) starting m_in_off[g] elements into `in`; the K loop walks 4 * Cin/64
+  // slices; in plane g only the grid taps of m_mask[g] are live (dead taps issue their operand DMAs - the pipeline's
+  // bookkeeping stays - but no MFMAs).  Filled by ph_tapconv2_setup_s2_fwd.
+  int m_groups;
+  int m_mask[4];         // bit t: grid tap t (row-major, dy = t / 3, dx = t % 3) is live (fixed sets, see the kernel)
+  int m_slab[4][9];      // weight slab of every grid tap (any valid slab for dead taps)
+  long m_in_off[4];
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
+double ph_tapconv_bytes(const PhTapConv& p, int S, int es);
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec);
 // second-generation stride-1 perf-mode kernel (conv_tap2.hip): tile height of the configuration it would run, 0 = not eligible
 int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec);
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st);
 int ph_tapconv2_stat_parts(const PhTapConv* p);   // one BatchNorm partial row per persistent workgroup
+// stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
+bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 
 struct PhWgrad {
   const void* x;         // [B][IH][IW][Cin]

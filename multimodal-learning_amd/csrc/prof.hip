@@ -8,7 +8,7 @@
 #include "ph_dense.h"
 
 namespace {
-struct Rec { hipEvent_t a, b; int cls; double work; };
+struct Rec { hipEvent_t a, b; int cls; double work, bytes; };
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -29,13 +29,15 @@ hipEvent_t take_event() {
 
 bool ph_prof_on() { return g_on; }
 
-void ph_prof_begin(int cls, double work, hipStream_t st, void** token) {
+void ph_prof_begin(int cls, double work, hipStream_t st, void** token) { ph_prof_begin2(cls, work, 0.0, st, token); }
+
+void ph_prof_begin2(int cls, double work, double bytes, hipStream_t st, void** token) {
   *token = nullptr;
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);
   hipEvent_t a = take_event(), b = take_event();
   if (!a || !b) return;
-  g_recs.push_back(Rec{a, b, cls, work});
+  g_recs.push_back(Rec{a, b, cls, work, bytes});
   (void)hipEventRecord(a, st);
   *token = reinterpret_cast<void*>(g_recs.size());   // index + 1
 }
@@ -58,6 +60,23 @@ int ph_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_recs.clear();
   g_pool_next = 0;
+  return PH_OK;
+}
+
+// out[cls*4 + {0,1,2,3}] = {launches, total milliseconds, total algorithmic work, total algorithmic bytes}
+int ph_prof_summary4(double* out, int nclasses) {
+  if (hipDeviceSynchronize() != hipSuccess) return PH_ELAUNCH;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int i = 0; i < nclasses * 4; ++i) out[i] = 0.0;
+  for (const Rec& r : g_recs) {
+    if (r.cls < 0 || r.cls >= nclasses) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    out[r.cls * 4 + 0] += 1.0;
+    out[r.cls * 4 + 1] += ms;
+    out[r.cls * 4 + 2] += r.work;
+    out[r.cls * 4 + 3] += r.bytes;
+  }
   return PH_OK;
 }
 

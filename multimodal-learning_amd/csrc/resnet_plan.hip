@@ -42,6 +42,7 @@ struct PhResnetPlan {
   size_t ws_bytes, packed_bytes;
   int PH0, PW0;   // pooled dims
   size_t act_max;   // max block-level activation bytes
+  mutable int no_masked = 0;   // A/B and test switch, set by the last forward's flag bit3 and followed by its backward
 };
 
 namespace {
@@ -195,6 +196,7 @@ struct Ctx {
   hipStream_t st;
   int update_running;
   int eval;
+  int no_masked = 0;      // A/B and test switch (forward flag bit3): first-generation kernels for the stride-2 convolutions
   float* stat(const Unit& u, int which) const {
     return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
   }
@@ -212,6 +214,8 @@ int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullp
   t.iy0 = -u.pad; t.ix0 = -u.pad; t.ntaps = u.KS * u.KS;
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / u.KS; t.dx[k] = k % u.KS; t.wtap[k] = k; }
   int S = u.S;
+  // 3x3 / stride 2 in perf mode: a stride-1 MASKED tap grid over the four pixel-parity planes of the input (conv_tap2.hip)
+  if (u.KS == 3 && u.S == 2 && u.pad == 1 && !c.no_masked && ph_tapconv2_setup_s2_fwd(&t, u.Cin, u.Cout, u.IH, u.IW, P->prec)) S = 1;
   if (u.KS == 1 && u.S == 2) {   // 1x1 / stride 2 == 1x1 / stride 1 over the even-pixel view of the input
     t.in_pix_stride = 2L * u.Cin; t.in_row_stride = 2L * u.IW * u.Cin; t.in_img_stride = (long)u.IH * u.IW * u.Cin;
     t.IH = u.OH; t.IW = u.OW; S = 1;
@@ -320,12 +324,15 @@ extern "C" {
 // bit2 = forward only: no backward will read this workspace (the EMA and teacher networks of the distillation step) - in
 // perf mode bn1 + ReLU of every block is then applied by conv2 itself while it stages its input (conv_tap2.hip,
 // PhTapConv::in_scale): the a1 tensor is neither written nor read, 8 bn_apply launches per forward disappear;
-// bit3 = A/B and test switch: keep the separate bn_apply passes although bit2 is set
+// bit3 = A/B and test switch: separate bn_apply passes although bit2 is set;
+// bit4 = A/B and test switch: the first-generation kernel for the 3x3 stride-2 convolutions (not the masked grid)
 int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const void* packed, const float* x_nchw,
                       void* ws_, float* f3, float* f4, int flags, hipStream_t st) {
   if (!P || !params || !packed || !x_nchw || !ws_) return PH_EINVAL;
   Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st,
         (flags & 2) ? 0 : (flags & 1), (flags & 2) ? 1 : 0};
+  P->no_masked = (flags & 16) ? 1 : 0;
+  c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
   int rc = ph_pack_input_launch(x_nchw, ws + P->x4_off, P->B, P->H, P->W, P->prec, st);
   if (rc) return rc;
@@ -409,6 +416,7 @@ int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, co
   if (!P || !params || !packed || !ws_ || !g_f4 || !grads || part < -1 || part > 1) return PH_EINVAL;
   const int bi_hi = part == 1 ? 3 : 7, bi_lo = part == 0 ? 4 : 0;
   Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0};
+  c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
   unsigned char* gcur = ws + P->g0_off;
   unsigned char* gnext = ws + P->g1_off;
@@ -479,6 +487,7 @@ int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, c
                              const float* g_f3, const float* g_f4, float* dx_nchw, hipStream_t st) {
   if (!P || !params || !packed || !ws_ || !g_f4 || !dx_nchw) return PH_EINVAL;
   Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0, 1};
+  c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
   unsigned char* gcur = ws + P->g0_off;
   unsigned char* gnext = ws + P->g1_off;

@@ -92,8 +92,10 @@ class _TrunkFn(torch.autograd.Function):
         f4 = torch.empty(B, 512, device=x.device, dtype=torch.float32)
         # flags of ph_resnet_forward: train / eval; +4 when no backward will follow (no gradient is recorded: the EMA and
         # teacher networks of the distillation step) - the trunk then fuses bn1 + ReLU into conv2's operand staging;
-        # +8 (`net._no_fuse`, an A/B and test switch) keeps the separate passes
-        flags = (1 if net.training else 2) | (0 if any(ctx.needs_input_grad) else 4) | (8 if getattr(net, "_no_fuse", False) else 0)
+        # +8 (`net._no_fuse`, an A/B and test switch) keeps the separate passes; +16 (`net._no_masked`, likewise) keeps the
+        # first-generation kernel for the 3x3 stride-2 convolutions
+        flags = (1 if net.training else 2) | (0 if any(ctx.needs_input_grad) else 4) | (8 if getattr(net, "_no_fuse", False) else 0) | \
+            (16 if getattr(net, "_no_masked", False) else 0)
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4), flags, stream()),
               "ph_resnet_forward")
         ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table

@@ -478,3 +478,27 @@ def test_fused_input_batchnorm_equals_separate_pass(B, H):
             for k, v in outs["separate"][3].items():
                 assert torch.equal(v, outs[other][3][k]), (training, k)
         assert torch.isfinite(outs["fused"][2]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H", [(4, 128), (3, 160)])
+def test_masked_stride2_grid_vs_first_generation_kernel(B, H):
+    """The 3x3 stride-2 convolutions (conv1 of layers 2-4) run in perf mode as a MASKED stride-1 grid over the four
+    pixel-parity planes of their input (conv_tap2.hip, ph_tapconv2_setup_s2_fwd).  Same products, another summation
+    order than the first-generation stride-2 kernel: features, loss-side outputs and parameter gradients of a train-mode
+    forward + backward agree to bf16 rounding of the activations (ragged maps at 160)."""
+    import multimodal_learning_amd as m
+    from oracle.step import synthetic_batch
+    m.set_precision("bf16")
+    x = synthetic_batch(B, H, seed=33)["x_path"].cuda()
+    res = {}
+    for no_masked in (True, False):
+        net = _student()
+        net.train()
+        net._no_masked = no_masked
+        f3, feat, hazard, pred, _ = net(x_path=x)
+        (feat.square().mean() + hazard.sum()).backward()
+        res[no_masked] = (f3.detach(), feat.detach(), torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]))
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(b).all()
+        assert (a - b).norm() <= 2e-2 * a.norm(), ((a - b).norm() / a.norm()).item()
