@@ -427,6 +427,24 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     return reinterpret_cast<const unsigned char*>(wbase + ((size_t)tap_slab(g, tap) * p.Cout + n0) * p.Cin + k0);
   };
 
+  // masked grid: the weight stream runs over the LIVE taps only - live tap l of a tile is (plane, slice, i-th live tap
+  // of the plane), planes in order, L = 1, 2, 2, 4 live taps per slice.  The iterator below is three live taps ahead
+  // of the MFMAs (scalar state; it enters the next tile while the MFMAs still finish this one).
+  int wq_p = 0, wq_s = 0, wq_i = 0, wq_n0 = tcur.n0;
+  auto wq_addr = [&]() {
+    const int tapid = (int)((0x4310004100430004ull >> (16 * wq_p + 4 * wq_i)) & 15);   // grid taps 4 | 3 4 | 1 4 | 0 1 3 4
+    return w_base(wq_n0, wq_s << 6, wq_p, tapid);
+  };
+  auto wq_next = [&]() {
+    if (++wq_i == ((0x4221 >> (4 * wq_p)) & 15)) {
+      wq_i = 0;
+      if (++wq_s == nsl_c) {
+        wq_s = 0;
+        if (++wq_p == 4) { wq_p = 0; wq_n0 = nvalid ? tnext.n0 : tcur.n0; }
+      }
+    }
+  };
+
   // prologue: first halo and the first RING-1 taps of weights
   {
     const unsigned char* hb = halo_base(tcur, slice_in_off(0));
@@ -436,7 +454,8 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
         lds_dma16(((hm_cur >> e) & 1) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
 #pragma unroll
     for (int j = 0; j < (RES ? NTAPS : C::RING - 1); ++j) {
-      const unsigned char* wb = w_base(tcur.n0, 0, 0, j);
+      const unsigned char* wb = MASKED ? wq_addr() : w_base(tcur.n0, 0, 0, j);
+      if constexpr (MASKED) wq_next();
 #pragma unroll
       for (int e = 0; e < C::NBE; ++e)
         lds_dma16(wb + wb_off[e], lds0 + B_BASE + j * C::TAPB + (wave * C::NBE + e) * 1024);
@@ -507,12 +526,12 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
     // One 64-channel slice = 9 grid taps.  `mk` / `mkn`: the taps that are LIVE in this slice / in the slice that
     // follows it in the stream (all nine, except in the masked grid of a stride-2 forward).  Literals at every call
     // site: after inlining and unrolling every liveness test folds - no run-time branch, no second arm merging the 128
-    // accumulators.  A dead tap keeps its place in the stream (ring slot, halo pieces) but issues no MFMAs, no weight
-    // DMAs (nor does anyone fetch weights FOR it), and waits / joins a barrier only where a later live tap needs it:
-    //   wait    at the end of tap t  <=  tap t+2 is live (its weights, issued in tap t-1, must be published before tap
-    //           t+1 pre-reads... tap t+2's first fragments are read at the end of tap t+1), or t = HALO_TAPS (the halo);
-    //   barrier at the end of tap t  <=  a wait, or taps t and t+4 are live (ring slot t & 3 is refilled from tap t+1 on),
-    //           or t = 8 (the other halo buffer is refilled from the next slice's tap 0 on).
+    // accumulators.  In the masked grid a dead tap issues nothing but its share of the next slice's halo (and, in
+    // front of a live tap, that tap's first fragment reads): no MFMAs, no weight DMAs, no wait, no barrier, no ring
+    // slot.  `gt` counts LIVE taps there: the weight ring, its three-taps-ahead prefetch (wq_*) and the end-of-tap
+    // wait + barrier are those of the dense stream over the live taps alone, so a dead tap costs a few issue cycles.
+    // The halo pieces go out in grid taps 0..2 (four per wave each) and are complete at the end-of-tap wait of grid
+    // tap 4, which is live in every plane and is the last live tap of its slice.
     // (Not a generic lambda: clang rejects asm operands that name captured variables inside one.)
     auto slice_body = [&](const int sl, const unsigned mk, const unsigned mkn) __attribute__((always_inline)) {
       const unsigned long long q0_ = PH_CLK();   // (per-slice stamps only: a stamp costs ~50 cycles with its s_waitcnt)
@@ -531,9 +550,16 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       auto live = [&](int u) { return u < NTAPS ? ((mk >> u) & 1u) != 0 : ((mkn >> (u - NTAPS)) & 1u) != 0; };
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {
-        const bool lv = live(t), lv1 = live(t + 1), lv2 = live(t + 2), lv3 = live(t + 3), lv4 = live(t + 4);
+        const bool lv = live(t), lv1 = live(t + 1);
         // weight pieces of stream tap gt+3 -> ring slot (gt+3) & 3 (released by the barrier that ended tap gt-1)
-        const unsigned char* wb = (t + 3 < NTAPS) ? w_base(tcur.n0, slice_k0(sl), gc, t + 3) : w_base(wn0, wk0, wg, t + 3 - NTAPS);
+        const unsigned char* wb;
+        if constexpr (MASKED) {
+          wb = nullptr;
+          if (lv) { wb = wq_addr(); wq_next(); }
+        } else {
+          wb = (t + 3 < NTAPS) ? w_base(tcur.n0, slice_k0(sl), gc, t + 3) : w_base(wn0, wk0, wg, t + 3 - NTAPS);
+        }
+        constexpr int HT = MASKED ? 3 : C::HALO_TAPS, HPP = MASKED ? 4 : 2;   // halo: grid taps 0..HT-1, HPP pieces each
         const unsigned wdst = lds0 + B_BASE + ((gt + 3) & 3) * C::TAPB + wave * C::NBE * 1024;
         const unsigned hdst = lds0 + (acur ^ 1) * C::A_BYTES + wave * 1024;
 #define PH_DMA_B(E) lds_dma16(wb + wb_off[E], wdst + (E) * 1024)
@@ -547,10 +573,9 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
         if (!lv) {
           // ---- dead tap of a masked grid
           if constexpr (FM == 4) {
-            if (lv3) { PH_DMA_B(0); PH_DMA_B(1); PH_DMA_B(2); PH_DMA_B(3); }
-            if (t < C::HALO_TAPS) { PH_DMA_H(2 * t); PH_DMA_H(2 * t + 1); }
+            if (t < HT) { PH_DMA_H(HPP * t); PH_DMA_H(HPP * t + 1); PH_DMA_H(HPP * t + 2); PH_DMA_H(HPP * t + 3); }
             if (lv1) {   // the first fragments of the next tap, read where a live tap reads them
-              tap_addr(toff_n, abuf_n, (gt + 1) & 3);
+              tap_addr(toff_n, abuf_n, gt & 3);
 #pragma unroll
               for (int i = 0; i < FM; ++i) fa[0][i] = PH_LDA(aaddr, i, 0);
 #pragma unroll
@@ -560,10 +585,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
           }
         } else if constexpr (FM == 4) {
           // ---- 32 MFMAs; the tap's DMA pieces ride between them
-          PH_KSTEP(0, 1, 1, PH_NOP_, if (lv3) PH_DMA_B(0), PH_NOP_, PH_NOP_, if (lv3) PH_DMA_B(1), PH_NOP_, PH_NOP_, if (lv3) PH_DMA_B(2));
-          PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, if (lv3) PH_DMA_B(3), PH_NOP_, PH_NOP_,
-                   if (t < C::HALO_TAPS) PH_DMA_H(2 * t), PH_NOP_, if (t < C::HALO_TAPS) PH_DMA_H(2 * t + 1));
-          PH_KSTEP(0, 1, 3, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
+          PH_KSTEP(0, 1, 1, PH_NOP_, PH_DMA_B(0), PH_NOP_, PH_NOP_, PH_DMA_B(1), PH_NOP_, PH_NOP_, PH_DMA_B(2));
+          PH_KSTEP(1, 0, 2, PH_NOP_, PH_NOP_, PH_DMA_B(3), PH_NOP_, PH_NOP_,
+                   if (t < HT) PH_DMA_H(HPP * t), PH_NOP_, if (t < HT) PH_DMA_H(HPP * t + 1));
+          PH_KSTEP(0, 1, 3, PH_NOP_, if (MASKED && t < HT) PH_DMA_H(HPP * t + 2), PH_NOP_, PH_NOP_,
+                   if (MASKED && t < HT) PH_DMA_H(HPP * t + 3), PH_NOP_, PH_NOP_, PH_NOP_);
           tap_addr(toff_n, abuf_n, (gt + 1) & 3);
           PH_KSTEP(1, 0, 0, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_, PH_NOP_);
         } else {
@@ -581,19 +607,21 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
         if constexpr (!RES) {
           // ---- tap end: the weight pieces of stream tap gt+2 (and a halo that is due) have landed once at most the
           // pieces issued during this tap are still in flight; the barrier publishes them and releases ring slot gt & 3
-          const bool need_wait = lv2 || t == C::HALO_TAPS;
-          const bool need_bar = need_wait || (lv && lv4) || t == NTAPS - 1;
-          if (need_wait) {   // at most this tap's own pieces may still be in flight
-            if (t < C::HALO_TAPS) { if (lv3) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(2); }
-            else { if (lv3) PH_WAIT_VMCNT(4); else PH_WAIT_VMCNT(0); }
+          if constexpr (MASKED) {
+            static_assert(!MASKED || (HT * HPP >= C::NHE), "halo piece schedule of the masked grid");
+            if (lv) { if (t < HT) PH_WAIT_VMCNT(8); else PH_WAIT_VMCNT(4); }
+            if (t == 4) { if (fuse_in) xform_halo(acur ^ 1, wk0); }   // every halo piece (taps 0..2) is older than tap 4
+            if (lv) PH_BARRIER();
+          } else {
+            if (t < C::HALO_TAPS) PH_WAIT_VMCNT(6); else PH_WAIT_VMCNT(4);
+            // all halo pieces of the next slice (issued in taps 0..5) have landed once tap 6 has passed its wait: apply
+            // the input's BatchNorm + ReLU to this wave's pieces; the barriers of taps 6 and 7 publish them before the
+            // last k-step of tap 8 reads the next slice's first fragments
+            if (t == C::HALO_TAPS) { if (fuse_in) xform_halo(acur ^ 1, wk0); }
+            PH_BARRIER();
           }
-          // all halo pieces of the next slice (issued in taps 0..5) have landed once tap 6 has passed its wait: apply
-          // the input's BatchNorm + ReLU to this wave's pieces; the barriers of taps 6 and 7 publish them before the last
-          // k-step of tap 8 reads the next slice's first fragments
-          if (t == C::HALO_TAPS) { if (fuse_in) xform_halo(acur ^ 1, wk0); }
-          if (need_bar) PH_BARRIER();
         }
-        ++gt;
+        if (!MASKED || lv) ++gt;
       }
       acur ^= 1;
       cyc_c += PH_CLK() - q0b_;
@@ -605,6 +633,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
       // taps (ph_tapconv2_setup_s2_fwd): rows gy = 1 (a = 0) or 0, 1 (a = 1), columns likewise.  The last slice of a
       // plane is followed by the next plane's mask (the last plane's by plane 0 of the next tile).
       constexpr unsigned M0 = 0x010u, M1 = 0x018u, M2 = 0x012u, M3 = 0x01Bu;
+      static_assert(((M0 & M1 & M2 & M3) & 0x10u) && !((M0 | M1 | M2 | M3) & ~0x1Bu), "tap 4 live and last, tap 2 dead");
       const int nl = nsl_c - 1;
       for (int s = 0; s < nl; ++s) slice_body(s, M0, M0);
       slice_body(nl, M0, M1);

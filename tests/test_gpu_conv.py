@@ -111,6 +111,49 @@ def test_tapconv2_multitile_stream(case):
     assert_close(dx_ref, nchw_cpu(dx), 1e-6, 1.0 / 128, "multi-tile conv dgrad")
 
 
+MASKED_S2 = [  # Cin, Cout, H (input), B
+    (64, 128, 64, 40),      # 1 slice per plane, 32 x 32 maps: 160 tiles ... x 1 Cout block
+    (64, 128, 128, 12),     # 64 x 64 maps: 192 tiles (the 512^2 layer-2 shape)
+    (128, 256, 48, 48),     # 2 slices per plane, ragged 24 x 24 maps, 2 Cout blocks: 384 tiles
+    (256, 512, 30, 40),     # 4 slices per plane, 15 x 15 maps (odd: the last input row / column is never read), 160 x 4 tiles
+    (128, 256, 9, 3),       # one partial tile per image
+]
+
+
+@pytest.mark.parametrize("case", MASKED_S2)
+def test_tapconv2_masked_stride2_stream(case):
+    """3x3 / stride 2 / pad 1 forward in perf mode = the persistent tap-conv kernel over a MASKED 3x3 grid on the four
+    pixel-parity planes of the input (conv_tap2.hip: tapconv2_kernel<2,2,4,false,true>, ph_tapconv2_setup_s2_fwd): the
+    weight ring runs over the 9 live (plane, tap) pairs per 64 channels only, dead taps carry the halo DMAs.  Sized
+    so that workgroups walk several tiles and Cout blocks (cross-tile weight prefetch, plane and slice boundaries for
+    1 / 2 / 4 slices per plane), ragged and odd maps; against F.conv2d with the same operand rounding; statistics;
+    repeated launches must be bitwise equal (a read of a buffer still being filled would not be)."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, B = case
+    g = torch.Generator().manual_seed(3 * Cin + Cout + H + B)
+    x = (torch.randn(B, Cin, H, H, generator=g)).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5)
+    torch.set_num_threads(8)
+    y_ref = F.conv2d(x, w.bfloat16().float(), None, 2, 1)
+    OH = y_ref.shape[-1]
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 2, 1), device="cuda", dtype=torch.uint8)
+    xd = nhwc(x, torch.bfloat16); wd = w.cuda()
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    outs = []
+    for rep in range(4):
+        y = torch.full((B, OH, OH, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 2, 1, 0, ptr(ws),
+                              stream()), "fwd")
+        outs.append((y.clone(), s1.clone(), s2.clone()))
+    assert_close(y_ref, nchw_cpu(outs[0][0]), 1e-6, 1.0 / 128, "masked stride-2 conv fwd")
+    assert_close(y_ref.sum(dim=(0, 2, 3)), outs[0][1].cpu(), 1e-2, 1e-3, "channel sum")
+    assert_close((y_ref ** 2).sum(dim=(0, 2, 3)), outs[0][2].cpu(), 1e-2, 1e-3, "channel sumsq")
+    for rep in range(1, 4):
+        assert torch.equal(outs[0][0].view(torch.int16), outs[rep][0].view(torch.int16)), "fwd differs between launches"
+        assert torch.equal(outs[0][1], outs[rep][1]) and torch.equal(outs[0][2], outs[rep][2])
+
+
 RES_CASES = [  # Cin (= dgrad output channels), Cout, H, B
     (64, 64, 32, 8),        # layer-1 kernel (two wave groups), full tiles
     (64, 64, 40, 12),       # layer-1 kernel, partial tiles, several tiles per group
