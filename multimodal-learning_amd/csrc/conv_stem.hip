@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
             own[0] = (bf16)v0;
             own[1] = (bf16)v1;
             const unsigned x = __builtin_bit_cast(unsigned, own);
-            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
             if (FULL || mine) *reinterpret_cast<unsigned*>(dst + j * 32) = __builtin_amdgcn_perm(y, x, psel);
           }
         }

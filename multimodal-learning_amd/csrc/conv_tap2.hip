@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
             own[0] = (bf16)v[0];
             own[1] = (bf16)v[1];
             const unsigned x = __builtin_bit_cast(unsigned, own);
-            const unsigned y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);   // lane ^ 1
+            const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
             bf16x2 w = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(y, x, psel));
             if constexpr (RM > 0) {
               w[0] = (bf16)((float)w[0] + ((RM < 2 || (float)ra[m][j][0] > 0.f) ? (float)rg[m][j][0] : 0.f));

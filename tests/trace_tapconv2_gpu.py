@@ -22,18 +22,21 @@ L.ph_debug_tap2_trace.argtypes = [vp, i32]
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 H0 = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-shapes = [("layer1 3x3", 64, 64, H0 // 4), ("layer2 3x3", 128, 128, H0 // 8), ("layer3 3x3", 256, 256, H0 // 16),
-          ("layer4 3x3", 512, 512, H0 // 32)]
+shapes = [("layer1 3x3", 64, 64, H0 // 4, 1), ("layer2 3x3", 128, 128, H0 // 8, 1), ("layer3 3x3", 256, 256, H0 // 16, 1),
+          ("layer4 3x3", 512, 512, H0 // 32, 1),
+          # stride-2 forward convs (masked grid: `stages` = live taps)
+          ("layer2.0.conv1 3x3/2", 64, 128, H0 // 4, 2), ("layer3.0.conv1 3x3/2", 128, 256, H0 // 8, 2),
+          ("layer4.0.conv1 3x3/2", 256, 512, H0 // 16, 2)]
 ptr = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for name, Cin, Cout, H in shapes:
+for name, Cin, Cout, H, S in shapes:
     x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
-    y = torch.empty(B, H, H, Cout, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(B, H // S, H // S, Cout, device="cuda", dtype=torch.bfloat16)
     s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
-    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 1, 1), device="cuda", dtype=torch.uint8)
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, S, 1), device="cuda", dtype=torch.uint8)
     for _ in range(3):
-        assert L.ph_conv2d_fwd(ptr(x), ptr(w), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 1, 1, 0, ptr(ws), st) == 0
+        assert L.ph_conv2d_fwd(ptr(x), ptr(w), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, S, 1, 0, ptr(ws), st) == 0
     torch.cuda.synchronize()
     nwg = 256
     buf = np.zeros((nwg, 12), dtype=np.uint64)
@@ -42,7 +45,7 @@ for name, Cin, Cout, H in shapes:
     span = (buf[:, 5].astype(np.int64).max() - t0) * 0.01
     life = (buf[:, 5].astype(np.int64) - buf[:, 0].astype(np.int64)) * 0.01
     prol = (buf[:, 1].astype(np.int64) - buf[:, 0].astype(np.int64)) * 0.01
-    fl = 2.0 * B * H * H * Cout * 9 * Cin
+    fl = 2.0 * B * (H // S) * (H // S) * Cout * 9 * Cin
     ns = np.median(buf[:, 11].astype(np.float64))
     loop = np.median(buf[:, 10].astype(np.float64))
     med = lambda k: np.median(buf[:, k].astype(np.float64))
