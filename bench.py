@@ -39,9 +39,11 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
              "tapconv2_kernel<2,2,4,false> (3x3 stride-1 fwd+dgrad, Cout>=128)",
              "tapconv2_l1_kernel (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1, two wave groups)"]
 NCLS = len(CLS_NAMES)
+# ... + class 12 of ph_kernels.h (behind the four HBM-bound classes 8-11)
+MASKED_CLS, MASKED_NAME = 12, "tapconv2_kernel<2,2,4,false,masked> (3x3 stride-2 fwd as a masked grid over the 4 pixel-parity planes)"
 HBM_NAMES = ["crd_score_kernel (2 banks x B x 1000 rows of 512 B)", "crd_loss_grad_kernel (2 banks x B x 532 rows of 512 B)",
              "adam_ema_dev_kernel (28 B / parameter + 8 B / EMA parameter)", "bn_apply_kernel (2-3 activation tensors)"]
-NALL = NCLS + len(HBM_NAMES)
+NALL = NCLS + len(HBM_NAMES) + 1
 HBM_PEAK_GBS = 8000.0            # HBM3E peak (6290 GB/s measured with a float4 copy), same guide
 # algorithmic FLOPs of the step per 512x512 tile: 3 ResNet-18 forwards + 1 backward without the image gradient
 # (SURVEY 8-d layer table: 93.52 GFLOP); convolutions scale with the tile area
@@ -308,8 +310,9 @@ def main():
             byt = [0.0] * NALL
             for c in range(NALL):
                 buf[3 * c], buf[3 * c + 1], buf[3 * c + 2], byt[c] = buf4[4 * c], buf4[4 * c + 1], buf4[4 * c + 2], buf4[4 * c + 3]
-            rows = [(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c in range(NCLS)]
-            dom = max(range(NCLS), key=lambda c: buf[3 * c + 1])
+            mfma_cls = [(c, CLS_NAMES[c]) for c in range(NCLS)] + [(MASKED_CLS, MASKED_NAME)]
+            rows = [(nm, buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c, nm in mfma_cls]
+            dom, dom_name = max(mfma_cls, key=lambda cn: buf[3 * cn[0] + 1])
             n, ms, fl = buf[3 * dom], buf[3 * dom + 1], buf[3 * dom + 2]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = None
@@ -348,15 +351,15 @@ def main():
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_note": "HBM bytes per launch from profiles/%s (rocprofv3 --pmc FETCH_SIZE / "
                                                "WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction)" % tname,
-                               "kernel": CLS_NAMES[dom], "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
+                               "kernel": dom_name, "launches": int(n), "avg_launch_ms": round(ms / max(n, 1), 4),
                                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                                "step_frac": round(step_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                "step_tflops_per_gpu": round(step_tflops / world, 1),
                                "step_note": "whole step: %.2f GFLOP per tile (3 ResNet-18 forwards + 1 backward, SURVEY 8-d) x tiles / "
                                             "ms_per_step / 2500 TFLOP/s; the reference executes 276.8 GFLOP per tile for the same "
                                             "numbers (6 backward passes)" % (STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2),
-                               "all_kernels": [per_kernel(CLS_NAMES[c], buf[3 * c], buf[3 * c + 1], buf[3 * c + 2], byt[c])
-                                               for c in range(NCLS)],
+                               "all_kernels": [per_kernel(nm, buf[3 * c], buf[3 * c + 1], buf[3 * c + 2], byt[c])
+                                               for c, nm in mfma_cls if buf[3 * c] > 0],
                                "hbm": hbm,
                                "mfma_kernel_ms_per_step": round(sum(r[2] for r in rows) / prof_steps, 3),
                                "timer_region": timer_region + " (HIP events around single launches: includes ~4 us of launch "

@@ -27,7 +27,9 @@ def cls_of(name):
     n = name
     if "tapconv2_l1_kernel" in n:   # layer 1 (Cin = Cout = 64): two wave groups, resident weights
         return 7
-    if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel, Cout >= 128
+    if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel, Cout >= 128; <..., true>: masked stride-2 grid
+        if "false, true" in n or "Lb0ELb1E" in n:
+            return 12
         return 7 if ("4, 1, 2" in n or "Li4ELi1ELi2E" in n) else 6
     if "tapconv_kernel" in n:
         if "Li2ELi8ELi128" in n or ", 2, 8, 128" in n:
@@ -73,7 +75,7 @@ def main():
         rows = list(csv.DictReader(open(f[0])))
         tot = sum(int(r["TotalDurationNs"]) for r in rows)
         with open(os.path.join(out, f"{tag}_kernel_stats.txt"), "w") as o:
-            o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3   (total kernel time {tot/1e6:.1f} ms)\n")
+            o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode   (total kernel time {tot/1e6:.1f} ms)\n")
             o.write(f"{'kernel':<100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}\n")
             for r in rows[:45]:
                 o.write(f"{short(r['Name'])[:100]:<100s} {r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} "
