@@ -41,7 +41,9 @@ def test_three_steps_vs_reference_golden(golden_dir):
     Steps 1-2 (after Adam updates): the reference's own fp32 run sits 1e-2..6e-2 from the fp64 truth on
     logits/loss (tests/golden/make_fp64_truth.py) because Adam's sign-like first steps amplify rounding, so the
     assertion is made against that noise floor: |HIP - truth| <= 6 x |reference_fp32 - truth| (+ the step's
-    trajectory noise scale) + 1e-3."""
+    trajectory noise scale) + 1e-3.  That bound cannot see a 1e-2 bug after step 0: the REAL post-update check (every
+    quantity at 1e-3, steps 0 and 1) is test_two_steps_from_mid_training_state_vs_reference_golden below, which starts
+    both sides from a state where Adam is not sign-like; this test keeps steps 1-2 only as a cold-start regime check."""
     import multimodal_learning_amd as m
     from oracle.step import default_opt, synthetic_batch
     from tests.gpu_util import assert_close, maxerr, Report
