@@ -41,9 +41,11 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
 NCLS = len(CLS_NAMES)
 # ... + class 12 of ph_kernels.h (behind the four HBM-bound classes 8-11)
 MASKED_CLS, MASKED_NAME = 12, "tapconv2_kernel<2,2,4,false,masked> (3x3 stride-2 fwd as a masked grid over the 4 pixel-parity planes)"
+FUSED_CLS = [(13, "tapconv2_kernel<2,2,4,false> + input BatchNorm/ReLU applied in LDS (conv2 of layer 2, forward-only networks)"),
+             (14, "tapconv2_l1_kernel + input BatchNorm/ReLU applied in LDS (conv2 of layer 1, forward-only networks)")]
 HBM_NAMES = ["crd_score_kernel (2 banks x B x 1000 rows of 512 B)", "crd_loss_grad_kernel (2 banks x B x 532 rows of 512 B)",
              "adam_ema_dev_kernel (28 B / parameter + 8 B / EMA parameter)", "bn_apply_kernel (2-3 activation tensors)"]
-NALL = NCLS + len(HBM_NAMES) + 1
+NALL = NCLS + len(HBM_NAMES) + 1 + len(FUSED_CLS)
 HBM_PEAK_GBS = 8000.0            # HBM3E peak (6290 GB/s measured with a float4 copy), same guide
 # algorithmic FLOPs of the step per 512x512 tile: 3 ResNet-18 forwards + 1 backward without the image gradient
 # (SURVEY 8-d layer table: 93.52 GFLOP); convolutions scale with the tile area
@@ -310,7 +312,7 @@ def main():
             byt = [0.0] * NALL
             for c in range(NALL):
                 buf[3 * c], buf[3 * c + 1], buf[3 * c + 2], byt[c] = buf4[4 * c], buf4[4 * c + 1], buf4[4 * c + 2], buf4[4 * c + 3]
-            mfma_cls = [(c, CLS_NAMES[c]) for c in range(NCLS)] + [(MASKED_CLS, MASKED_NAME)]
+            mfma_cls = [(c, CLS_NAMES[c]) for c in range(NCLS)] + [(MASKED_CLS, MASKED_NAME)] + FUSED_CLS
             rows = [(nm, buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]) for c, nm in mfma_cls]
             dom, dom_name = max(mfma_cls, key=lambda cn: buf[3 * cn[0] + 1])
             n, ms, fl = buf[3 * dom], buf[3 * dom + 1], buf[3 * dom + 2]

@@ -1167,7 +1167,7 @@ int launch_l1(const PhTapConv& p, hipStream_t st) {
   dim3 grid(total < resident ? total : resident);
   void* tok = nullptr;
   if (ph_prof_on())
-    ph_prof_begin2(PH_CLS_TAPCONV2_RES, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, ph_tapconv_bytes(p, 1, 2), st, &tok);
+    ph_prof_begin2(p.in_scale ? PH_CLS_TAPCONV2_RES_FUSEDIN : PH_CLS_TAPCONV2_RES, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, ph_tapconv_bytes(p, 1, 2), st, &tok);
   hipLaunchKernelGGL(tapconv2_l1_kernel, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
@@ -1194,7 +1194,7 @@ int launch2(const PhTapConv& p, hipStream_t st) {
     if (MASKED) {
       taps = 9;      // 1 + 2 + 2 + 4 live taps over the four planes, each on Cin channels
     }
-    ph_prof_begin2(MASKED ? PH_CLS_TAPCONV2_MASKED : (RES ? PH_CLS_TAPCONV2_RES : PH_CLS_TAPCONV2),
+    ph_prof_begin2(MASKED ? PH_CLS_TAPCONV2_MASKED : (RES ? PH_CLS_TAPCONV2_RES : (p.in_scale ? PH_CLS_TAPCONV2_FUSEDIN : PH_CLS_TAPCONV2)),
                    2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * taps * p.Cin, ph_tapconv_bytes(p, 1, 2), st, &tok);
   }
   hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);

@@ -19,7 +19,9 @@
 #define PH_CLS_ADAM_EMA 10      // adam_ema(_dev)_kernel: 28 B per parameter + 8 B per EMA parameter
 #define PH_CLS_BN_APPLY 11      // bn_apply_kernel: y (+ residual | + downsample y) read, activation written
 #define PH_CLS_TAPCONV2_MASKED 12   // tapconv2_kernel<2,2,4,false,MASKED>: stride-2 fwd / merged-class dgrad as masked stride-1 grids
-#define PH_NCLS 13
+#define PH_CLS_TAPCONV2_FUSEDIN 13   // class 6 launches that also apply their input's BatchNorm + ReLU in LDS (PhTapConv::in_scale)
+#define PH_CLS_TAPCONV2_RES_FUSEDIN 14   // class 7 (layer-1 kernel) launches that do
+#define PH_NCLS 15
 #define PH_NUM_CLS 6
 bool ph_prof_on();
 int ph_num_cus();   // compute units of the current device (cached)
