@@ -227,3 +227,136 @@ def test_student_backward_perf_vs_parity_at_benchmark_size():
           f"{worst}; {len(small)} BN tensors worst {small[worst_s]:.4f} at {worst_s}")
     assert big[worst] >= 0.70 and big[worst] >= med - 0.12, (worst, big[worst], med)
     assert small[worst_s] >= 0.50, (worst_s, small[worst_s])
+
+
+# ---- the whole distillation step at the benchmarked size (BASELINE configs[1]; configs[3] / [4]-like variants: nce_k 4096,
+# MIA-2023 with its 65 536-row bank).  No CPU oracle finishes this in test time, so the checks are properties:
+#   * finite outputs over two steps;
+#   * determinism: a second step object built from the same seeds reproduces losses, logits and the updated student
+#     BITWISE (fixed-order reductions everywhere, no float atomics);
+#   * batch-duplication invariance: in a batch whose rows 32..63 repeat rows 0..31 (both views, omic vector, label) the
+#     train-mode BatchNorm statistics are those of the first half, every tile of the second half is computed by OTHER
+#     workgroups at OTHER positions of their persistent tile lists, and the per-row outputs of the three networks must
+#     be bitwise equal between the halves - a tile-stream bug that depends on where a tile sits (the class the small
+#     parity tests cannot see) breaks exactly this.
+def _variant_step(variant, B, seed):
+    import numpy as np
+    import multimodal_learning_amd as m
+    torch.manual_seed(seed)
+    np.random.seed(2019)
+    opt = m.stage2_opt(dropout_rate=0.0, batch_size=B)
+    kw = {}
+    if variant == "miccai2022":
+        n_data, K = 1024, opt.nce_p + opt.nce_k - 1
+    elif variant == "mia2022":
+        opt.nce_k, opt.grads_m, opt.grads_thresh, opt.thresh = 4096, 0.9, "False", 0.1
+        n_data, K = 16384, 4096
+        kw["variant"] = "mia2022"
+    else:
+        n_data, K = 65536, 4096
+        for k, v in dict(nce_k=4096, nce_p=4, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
+                         max_discrep=2.0, use_grads_thresh="True", grads_thresh=0.0, loss_weighting="GK_refine").items():
+            setattr(opt, k, v)
+        labels = torch.arange(n_data) % 3
+        kw["variant"] = "mia2023"
+        kw["train_class_idx"] = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+    step = m.DistillStep(opt, n_data, device="cuda", **kw)
+    for c in (step.criterion_kd, step.criterion_kd_path):
+        c.contrast.verbose = False
+    return step, n_data, K
+
+
+def _dup_batch(B, H, n_data, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    h = B // 2
+    x = _images(h, H, seed)
+    x2 = (x + 0.01 * torch.randn(h, 3, H, H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed + 1))).clamp_(-1, 1)
+    om = torch.randn(h, 320, generator=g)
+    index = torch.randperm(n_data, generator=g)[:B]
+    grade = (index % 3)
+    grade[h:] = grade[:h]
+    sidx = torch.randint(0, n_data, (B, K + 1), generator=g)
+    sidx[:, 0] = index
+    z = torch.zeros(B)
+    d = lambda t: t.cuda()
+    return ((torch.cat([x, x]), torch.cat([x2, x2])), d(z), d(torch.cat([om, om])), d(z), d(z), d(grade), d(index), d(sidx))
+
+
+@pytest.mark.parametrize("variant", ["miccai2022", "mia2022", "mia2023"])
+def test_distill_step_at_benchmark_size(variant):
+    import multimodal_learning_amd as m
+    B, H = 64, 512
+    m.set_precision("bf16")
+    runs = []
+    for rep in range(2):
+        step, n_data, K = _variant_step(variant, B, seed=5)
+        outs = []
+        for it in range(2):
+            out = step.step(_dup_batch(B, H, n_data, K, seed=40 + it), epoch=1)
+            outs.append({k: out[k].detach().float().clone() for k in ("loss", "logit_path", "ema_logit", "fuse_logit", "path_feat")})
+        torch.cuda.synchronize()
+        psum = torch.cat([p.detach().flatten() for p in step.model.parameters()]).double().sum()
+        runs.append((outs, psum))
+        for crd in (step.criterion_kd, step.criterion_kd_path):
+            assert torch.isfinite(crd.contrast.memory_v1).all() and torch.isfinite(crd.contrast.memory_v2).all()
+        for net in (step.model, step.ema_model, step.fix_model.path_net):
+            net.release_workspaces()
+        del step
+        torch.cuda.empty_cache()
+    h = B // 2
+    for it in range(2):
+        o = runs[0][0][it]
+        for k, v in o.items():
+            assert torch.isfinite(v).all(), (variant, it, k)
+        # batch-duplication invariance of the per-row outputs (step 0: all three networks; step 1: again, after an update)
+        for k in ("logit_path", "ema_logit", "fuse_logit", "path_feat"):
+            assert torch.equal(o[k][:h], o[k][h:]), (variant, it, k, (o[k][:h] - o[k][h:]).abs().max().item())
+        # determinism across step objects
+        for k, v in o.items():
+            assert torch.equal(v, runs[1][0][it][k]), (variant, it, k)
+    assert runs[0][1].item() == runs[1][1].item(), "updated student differs between two runs from the same seeds"
+
+
+def test_tsvd_stage1_step_at_config3_size():
+    """BASELINE configs[3] (MIA-2022 train_test_tSVD, batch 128) at the benchmark tile size: the stage-1 step (student +
+    mean-teacher PathomicNet, t-SVD constraint with 4 views, one-sided Jacobi prox at B = 128) on 128 tiles of 512 x 512
+    in perf mode - finite, bitwise reproducible from the same seeds, and the auxiliary tensors it leaves behind are the
+    float64 oracle's proximal operator of the adjacency tensors it computed."""
+    import numpy as np
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle import variants as OV
+    B, H = 128, 512
+    m.set_precision("bf16")
+    res = []
+    for rep in range(2):
+        torch.manual_seed(3)
+        opt = m.stage2_opt(dropout_rate=0.0, batch_size=B, cut_fuse_grad=True, num_teachers=2)
+        opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, 1.0, 0, 0, "False"
+        opt.tSVD_loss, opt.tSVD_mode, opt.n_views, opt.aux_iter = "True", "pathomic", 4, 1
+        opt.mu, opt.pho, opt.max_mu, opt.Lambda_global = 0.01, 1.5, 1.0, 0.05
+        model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+        model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3)); ema.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 4))
+        st = m.TeacherStage1Step(opt, device="cuda", models=(model.cuda(), ema.cuda()))
+        g = torch.Generator().manual_seed(9)
+        x = _images(B, H, 61)
+        x2 = (x + 0.01 * torch.randn(B, 3, H, H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(62))).clamp_(-1, 1)
+        z = torch.zeros(B)
+        batch = ((x, x2), z, torch.randn(B, 320, generator=g).cuda(), z, z, torch.randint(0, 3, (B,), generator=g).cuda(),
+                 torch.arange(B).cuda(), torch.zeros(B, 2, dtype=torch.long).cuda())
+        out = st.step(batch)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out["loss"]).all() and torch.isfinite(out["loss_tsvd"]).all()
+        if rep == 0:
+            for adj, aux, tnn in ((st.adj_tensor1, st.aux_tensor1, st.path_TNN), (st.adj_tensor2, st.aux_tensor2, st.omic_TNN)):
+                stack = torch.stack([a.detach().cpu() for a in adj], dim=2)
+                ref, tnn_ref = OV.update_aux(stack, opt.Lambda_global / opt.mu)
+                got = torch.stack([a.cpu() for a in aux], dim=2).numpy()
+                assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1.0)
+                assert abs(float(tnn) - tnn_ref) <= 1e-4 * max(abs(tnn_ref), 1.0)
+        res.append((out["loss"].detach().clone(), out["loss_tsvd"].detach().clone(),
+                    torch.cat([p.detach().flatten() for p in model.parameters()]).double().sum()))
+        del st, model, ema, x, x2, batch
+        torch.cuda.empty_cache()
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b), "stage-1 t-SVD step is not reproducible at B = 128 / 512 x 512"
