@@ -193,11 +193,11 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   auto slice_in_off = [&](int sl) -> long { return MASKED ? p.m_in_off[sl >> nsl_sh] + slice_k0(sl) : (long)(sl << 6); };
 
   // ---- per-lane DMA sources.  Piece d of an LDS image covers row pairs 4d..4d+3; lane l writes slot l & 15 of row
-  // pair rp = 4d + (l >> 4), which the swizzle assigns to (row 2*rp + (u >> 3), chunk u & 7), u = (l & 15) ^ (rp & 15)
+  // pair rp = 4d + (l >> 4), which the swizzle assigns to (row 2*rp + (u >> 3), chunk u & 7), u = (l & 15) ^ (rp & PH_SWZ_MASK)
   int wb_off[C::NBE];   // weights: byte offset of this lane's chunk inside a [BNT][Cin] tap block
 #pragma unroll
   for (int e = 0; e < C::NBE; ++e) {
-    const int rp = (wave * C::NBE + e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & 15);
+    const int rp = (wave * C::NBE + e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & PH_SWZ_MASK);
     wb_off[e] = ((2 * rp + (u >> 3)) * p.Cin + (u & 7) * 8) * 2;
   }
   // halo piece h = wave + 4e: byte offset of this lane's chunk relative to the tile's halo origin pixel, and the halo
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   int h_off[C::NHE], h_rc[C::NHE];
 #pragma unroll
   for (int e = 0; e < C::NHE; ++e) {
-    const int rp = (wave + 4 * e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & 15);
+    const int rp = (wave + 4 * e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & PH_SWZ_MASK);
     const int pix = 2 * rp + (u >> 3), hr = pix / HPW, hc = pix - hr * HPW;
     h_rc[e] = pix < HP ? ((hr << 8) | hc) : -1;
     h_off[e] = (int)(((long)hr * row_st + (long)hc * pix_st + (u & 7) * 8) * 2);
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
   // pair rp = 4h + (lane >> 4) advances by 16 per e, so the swizzled slot u is the same for all e and the pixel index
   // advances by 32 = one halo row + 14 columns: (row, column, byte offset) are carried incrementally instead of kept
   // in 22 registers per lane (two waves per SIMD: the register file is the scarce resource here).
-  const int rp0 = wm * 4 + (lane >> 4), u0 = (lane & 15) ^ (rp0 & 15);
+  const int rp0 = wm * 4 + (lane >> 4), u0 = (lane & 15) ^ (rp0 & PH_SWZ_MASK);
   const int pix0 = 2 * rp0 + (u0 >> 3);
   int hr_base = pix0 / HPW, hc_base = pix0 - hr_base * HPW;
   int hoff_base = (int)(((long)hr_base * row_st + (long)hc_base * pix_st + (u0 & 7) * 8) * 2);
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
 #pragma unroll
     for (int j = 0; j < C::NWP; ++j) {
       const int q = wave * C::NWP + j, tap = q >> 3;          // 8 pieces of 1 KiB per tap
-      const int rp = (q & 7) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & 15);
+      const int rp = (q & 7) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & PH_SWZ_MASK);
       const int slab = __builtin_amdgcn_readlane(tap_tab, tap) >> 16;
       const unsigned char* wb = reinterpret_cast<const unsigned char*>(wbase + (size_t)slab * p.Cout * p.Cin);
       lds_dma16(wb + ((2 * rp + (u >> 3)) * p.Cin + (u & 7) * 8) * 2, lds0 + B_BASE + q * 1024);
