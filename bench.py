@@ -4,7 +4,12 @@
 2x KL, 2x CRD with DC-Distill selection, GK-Refine, Adam, EMA) on N MI355X GPUs of one node.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or plainly as `python bench.py --gpus N`: with no WORLD_SIZE
+    in the environment the parent starts the N replica processes itself (one per GPU, 127.0.0.1 rendezvous) BEFORE it
+    touches torch or the GPU, waits for them and exits with their code - the reference's multi-GPU start is one plain
+    command too (MICCAI-2022/utils.py:257-260 wraps the net in DataParallel).  If the graph-replayed run fails or hangs
+    with N > 1 (RCCL calls inside HIP-graph capture), the launcher re-runs the replicas eagerly and `config.launch` says so.
 
 Workload (BASELINE.json configs[1]): per-GPU batch 64 synthetic 512x512 ROI tiles + 320-d genomic vectors,
 bf16 perf mode, README stage-2 flags, dropout 0.1 (the reference default: teacher Dropout/AlphaDropout live),
@@ -135,6 +140,94 @@ def timed(step, batches, steps, sync, device):
     return dt, out
 
 
+def launch_replicas(n, argv, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher: start N replica processes of this script (rank r on GPU r), wait,
+    return their exit code.  Runs before torch is imported, so the parent never initialises the GPU.  Attempt 1 replays
+    the step from a HIP graph (RCCL calls captured inside); if any replica fails or the attempt exceeds the time limit
+    the replicas are killed by PID and attempt 2 runs eagerly (PH_BENCH_LAUNCH tells the children what to report)."""
+    import socket
+    import subprocess
+    timeout_s = timeout_s or float(os.environ.get("PH_BENCH_LAUNCH_TIMEOUT", "600"))
+    attempts = [("self-launched", [])]
+    if "--eager" not in argv:
+        attempts.append(("self-launched, eager fallback (the graph-replayed attempt failed or timed out)", ["--eager"]))
+    rc = 1
+    for note, extra in attempts:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PH_BENCH_LAUNCH=note)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + extra, env=env))
+        t0 = time.time()
+        rc = None
+        while rc is None:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                rc = next(c for c in codes if c not in (None, 0))
+            elif all(c == 0 for c in codes):
+                rc = 0
+            elif time.time() - t0 > timeout_s:
+                rc = 124
+                print("bench launcher: %d replicas exceeded %.0f s" % (n, timeout_s), file=sys.stderr, flush=True)
+            else:
+                time.sleep(0.2)
+        for p in procs:                # exact PIDs this function started, nothing by pattern
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        if rc == 0:
+            return 0
+        print("bench launcher: attempt '%s' ended with code %s" % (note, rc), file=sys.stderr, flush=True)
+    return rc
+
+
+def stub_main(args):
+    """Testing aid (tests/test_dist_gloo.py): the launcher + rendezvous + timing protocol of this file on CPU with
+    the gloo backend and a stand-in step (one small matmul + an all-reduce).  Its JSON line says "stub"."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("PH_BENCH_STUB_FAIL_GRAPH") and not args.eager and rank == world - 1:
+        raise SystemExit(7)            # stands for "RCCL inside graph capture failed on one replica"
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    x = torch.ones(64, 64)
+
+    def one():
+        y = (x @ x).sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(y)
+        return y
+    for _ in range(args.warmup):
+        one()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = one()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(args.batch * world * args.steps / dt, 2), "unit": "tiles/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub",
+                          "sum": y.item(), "config": {"workload": "launcher self-test (CPU, gloo, stand-in step)",
+                                                      "launch": os.environ.get("PH_BENCH_LAUNCH", "external launcher")}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,9 +257,15 @@ def main():
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
                     "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.north_star:
         args.batch = 256
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher in the command line: be the launcher (nothing has touched torch or the GPU yet)
+        raise SystemExit(launch_replicas(args.gpus, sys.argv[1:]))
+    if args.stub_step:
+        raise SystemExit(stub_main(args))
 
     import numpy as np
     import torch
@@ -174,8 +273,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import multimodal_learning_amd as m
@@ -301,7 +399,8 @@ def main():
                                          args.batch, args.size, args.size),
                           "tiles_per_gpu": args.batch, "tile": args.size, "global_batch": args.batch * world,
                           "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4),
-                          "launch": "eager" if args.eager else "one captured HIP graph per step",
+                          "launch": ("eager" if args.eager else "one captured HIP graph per step")
+                                    + ("; replicas: " + os.environ["PH_BENCH_LAUNCH"] if "PH_BENCH_LAUNCH" in os.environ else ""),
                           "input_pipeline": ("on-device from resident uint8 tiles, inside the timed region and the graph"
                                              if args.device_loader else "inputs resident in HBM when the timed region starts")}}
         # ---- roofline of the dominant kernel (live HIP-event timing inside the timed region)

@@ -167,3 +167,42 @@ def _loss_norm(rank, world):
 
 def test_global_batch_loss_normaliser():
     assert all(_run(_loss_norm))
+
+
+def _bench_cmd(*extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                           "--stub-step", *extra], env={**env, **_bench_cmd.env}, capture_output=True, text=True, timeout=240)
+
+
+_bench_cmd.env = {}
+
+
+def test_bench_launches_its_own_replicas_without_torchrun():
+    """VERDICT r02 missing 1: `python bench.py --gpus N` (the driver's command line, no launcher, no WORLD_SIZE) must start
+    the N replicas itself, reach init_process_group on every rank and print ONE JSON line from rank 0."""
+    import json
+    _bench_cmd.env = {}
+    r = _bench_cmd()
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["sum"] == 2 * 64.0 ** 3
+    assert res["config"]["launch"] == "self-launched"
+
+
+def test_bench_launcher_falls_back_to_eager_when_the_graph_attempt_fails():
+    import json
+    _bench_cmd.env = {"PH_BENCH_STUB_FAIL_GRAPH": "1"}
+    try:
+        r = _bench_cmd()
+    finally:
+        _bench_cmd.env = {}
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "eager fallback" in json.loads(lines[0])["config"]["launch"]
+    assert "ended with code 7" in r.stderr
