@@ -381,7 +381,11 @@ class DistillStep:
         self.optimizer.ema_range = (0, end)
         if sync is not None:
             sync.attach(self)
-            if hasattr(sync, "begin_grad_slice") and getattr(opt, "overlap_grad_allreduce", True):
+            # with a regulariser the trunk gradients reach the flat buffer later, through AccumulateGrad (_direct_grad is
+            # False): the layer-3/4 slice is NOT final when the trunk backward passes layer 3, so its all-reduce must not
+            # start there (it would reduce a buffer that is still being accumulated into: ADVICE r02)
+            if (hasattr(sync, "begin_grad_slice") and getattr(opt, "overlap_grad_allreduce", True)
+                    and self.model._direct_grad):
                 # everything from layer3.0.conv1.weight to the end of the flat buffer (layers 3-4, heads, CRD embeddings)
                 # is final once the trunk backward has passed layer 3: its all-reduce starts there (dist.begin_grad_slice)
                 first = self.model.layer3[0].conv1.weight
@@ -516,12 +520,19 @@ class DistillStep:
         if not self._reg_on:
             return loss
         from .networks_new import define_reg
-        return loss + self.opt.lambda_reg * define_reg(self.opt, self.model)
+        # replicas SUM their losses / gradients (global-batch normalisers): the batch-independent L1 term is split evenly
+        # so that the sum carries it once, as the reference's one DataParallel process does
+        w = self.sync.world_size if self.sync is not None else 1
+        return loss + (self.opt.lambda_reg / w) * define_reg(self.opt, self.model)
 
     def _fused_head_ok(self):
         """The closed-form loss head covers the shipped MICCAI stage-2 command: two teachers, CRD, GK-Refine with the CE
         gradient, a log-softmax grading head.  `opt.fused_loss_head = False` selects the generic autograd path."""
         opt = self.opt
+        if self._reg_on:
+            # the fused head WRITES fc_new2's gradients (accumulate=False) after L1RegFn.backward has added
+            # lambda_reg * sgn(W) into the same flat buffer: the L1 term on fc_new2 would be lost (ADVICE r02)
+            return False
         return (self.variant == "miccai2022" and getattr(opt, "fused_loss_head", True) and opt.assign_weights == "True"
                 and bool(opt.CE_grads) and opt.num_teachers == 2 and opt.distill == "crd"
                 and isinstance(getattr(self.model, "fc_new2", None), nn.Linear)
@@ -1013,7 +1024,8 @@ class TeacherStage1Step:
         if opt.reg_type != "none":      # :209 - the shipped stage-1 command keeps the default `omic` (options.py:132)
             from .networks_new import define_reg
             loss_reg = define_reg(opt, self.model)
-            loss = loss + opt.lambda_reg * loss_reg
+            # split over the replicas, whose losses / gradients are summed (see DistillStep._add_reg)
+            loss = loss + (opt.lambda_reg / (self.sync.world_size if self.sync is not None else 1)) * loss_reg
         loss_orth = torch.zeros((), device=dev)
         if self.orth_on:
             loss_orth = self.Orth_loss(path_feat, omic_feat)                                    # :216-218

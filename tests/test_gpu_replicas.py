@@ -90,11 +90,11 @@ class LocalSync:
             crd.contrast.sync = self
 
 
-def _build(variant, sync, B, n_data, labels):
+def _build(variant, sync, B, n_data, labels, **over):
     import multimodal_learning_amd as m
     from oracle import weights as W
     from oracle.step import default_opt
-    kw = dict(batch_size=B)
+    kw = dict(batch_size=B, **over)
     if variant == "miccai2022":
         opt = default_opt(**kw)
         step = m.DistillStep(opt, n_data, device="cuda", sync=sync)
@@ -207,6 +207,58 @@ def test_two_replicas_equal_one_process_on_the_global_batch(variant):
         for c0, c1 in zip((reps[0].criterion_kd, reps[0].criterion_kd_path), (reps[1].criterion_kd, reps[1].criterion_kd_path)):
             assert torch.equal(c0.contrast.memory_v1, c1.contrast.memory_v1)
             assert torch.equal(c0.contrast.params, c1.contrast.params)
+    finally:
+        m.set_precision("bf16")
+
+
+def test_two_replicas_with_the_l1_regulariser_stay_identical_and_average_their_gradients():
+    """with --reg_type all the trunk gradients reach the flat buffer through AccumulateGrad AFTER the point
+    where the overlapped all-reduce of the layer-3/4 slice used to start, so that slice must not be announced early
+    (LocalSync(expect_slice=False) asserts no announcement arrives), the replicas must end bitwise equal, and the head
+    gradients must equal the single process on the global batch plus lambda_reg * sgn(W) once (not once per replica)."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.dist import shard_batch
+    B, H, n_data = 8, 64, 1024
+    labels = torch.randint(0, 3, (n_data,), generator=torch.Generator().manual_seed(5))
+    m.set_precision("bf16x6")
+    try:
+        batch = _batch("miccai2022", B, H, n_data, labels)
+        ranks = [np.arange(30, 50), np.arange(45, 65)]
+        single, opt = _build("miccai2022", None, B, n_data, labels, reg_type="all")
+        single.step(batch, epoch=3, ranks=ranks)
+        torch.cuda.synchronize()
+        g1 = _head_grads(single)
+        group = LocalGroup(2)
+        reps = [_build("miccai2022", LocalSync(group, r, expect_slice=False), B // 2, n_data, labels, reg_type="all")[0]
+                for r in range(2)]
+        assert all(getattr(r.model, "_grad_ready_hook", None) is None for r in reps)
+        errs = []
+
+        def run(r):
+            try:
+                torch.cuda.set_device(0)
+                reps[r].step(shard_batch(batch, r, 2), epoch=3, ranks=ranks)
+                torch.cuda.synchronize()
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                group.barrier.abort()
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(300)
+        if errs:
+            raise errs[0]
+        f0, f1 = reps[0].optimizer.flat, reps[1].optimizer.flat
+        assert torch.equal(f0.grad, f1.grad) and torch.equal(f0.flat, f1.flat)
+        g2 = _head_grads(reps[0])
+        # the replicas SUM their gradients; the data terms add up to the single process' through the global-batch
+        # normalisers and the L1 term (lambda_reg / world_size per replica) to lambda_reg * sgn(W) once - g1 holds it too
+        for k in ("fc_new2.weight", "fc_new2.bias"):
+            err = float((g2[k] - g1[k]).abs().max())
+            assert err <= 1e-3 * float(g1[k].abs().max()) + 2e-5, (k, err)
+        w = dict(single.model.named_parameters())["fc_new2.weight"].detach()
+        assert float(g1["fc_new2.weight"].abs().max()) > 0 and opt.lambda_reg > 0 and float(w.abs().max()) > 0
     finally:
         m.set_precision("bf16")
 
