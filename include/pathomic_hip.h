@@ -183,6 +183,20 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
                      int64_t* nb2, float* sim1, float* sim2, void* workspace, ph_stream_t stream);
 int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
                   int B, int feat_dim, ph_stream_t stream);
+/* ContrastMemory_v3.forward as a STANDALONE call returning (out_v1, out_v2) [B][P2+K2] (memory_new.py:362-379: selected
+ * scores / Z); also gathers the selected PRE-update bank rows (rows1 from memory_v1, rows2 from memory_v2, each
+ * [B][P2+K2][128]) that its backward needs after the in-call momentum update (:382-395) has overwritten the bank. */
+int ph_crd_outputs(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                   const float* mem1, const float* mem2, const float* params, float* out1, float* out2, float* rows1,
+                   float* rows2, int B, int PK, int S2, int feat_dim, ph_stream_t stream);
+/* backward of the above: dv1 = sum_j g1 out1 / T rows2, dv2 = sum_j g2 out2 / T rows1 (g1 / g2 may be NULL = zero) */
+int ph_crd_outputs_bwd(const float* g1, const float* g2, const float* out1, const float* out2, const float* rows1,
+                       const float* rows2, float T, float* dv1, float* dv2, int B, int S2, int feat_dim,
+                       ph_stream_t stream);
+/* ContrastLoss_v2.forward (CL_utils/CRD_loss.py:221-252) on x [B][S] with P positives first: rows[b] = the per-sample
+ * loss of the sample_KD == "True" branch (:246-250); the "False" branch's scalar (:240-244) is sum(rows) / B.
+ * dx[b][j] = d rows[b] / d x[b][j]. */
+int ph_contrast_loss_v2(const float* x, float* rows, float* dx, int B, int S, int P, float n_data, ph_stream_t stream);
 /* MIA-2023 v10 class-centre positives (`--pos_extra centers --nce_p 2`, CRD_criterion_v10.py:84-89,121-126: the mean
  * bank row of every class, recomputed per call).  mem_ext = a bank allocated with n_data + num_classes rows; row
  * n_data + c receives the mean of rows members[offsets[c] .. offsets[c+1]).  max_class_rows = the largest class. */

@@ -36,8 +36,36 @@ class CRDLoss(nn.Module):
         return self.contrast.loss(epoch, f_s, f_t, idx, contrast_idx, self.select_pos_mode, ranks)
 
 
+class _ContrastLossV2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, P, n_data, per_sample):
+        from .._lib import lib, check, ptr, stream
+        B, S = x.shape[0], x.shape[1]
+        xf = ops._f32(x).reshape(B, S).contiguous()
+        rows = torch.empty(B, device=x.device, dtype=torch.float32)
+        dx = torch.empty(B, S, device=x.device, dtype=torch.float32)
+        check(lib().ph_contrast_loss_v2(ptr(xf), ptr(rows), ptr(dx), B, S, int(P), float(n_data), stream()),
+              "ph_contrast_loss_v2")
+        ctx.save_for_backward(dx)
+        ctx.shape, ctx.per_sample = tuple(x.shape), per_sample
+        if per_sample:
+            return rows
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        check(lib().ph_sum(ptr(rows), ptr(out), B, 1.0 / B, stream()), "ph_sum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        B = dx.shape[0]
+        g = g.reshape(-1, 1) if ctx.per_sample else g / B
+        return (dx * g).reshape(ctx.shape), None, None, None
+
+
 class ContrastLoss_v2(nn.Module):
-    """Kept for API compatibility (attribute of CRDLoss); its arithmetic is fused into ph_crd_loss_grad."""
+    """CRD_loss.py:212-252.  Inside CRDLoss its arithmetic is fused into ph_crd_loss_grad; called directly it evaluates
+    the same formulas on x [B, P+N, 1] (positives first): a 0-d loss for sample_KD == "False" (:240-244), the per-sample
+    losses [B] for sample_KD == "True" (:246-250)."""
 
     def __init__(self, n_data, sample_KD):
         super().__init__()
@@ -45,7 +73,9 @@ class ContrastLoss_v2(nn.Module):
         self.sample_KD = sample_KD
 
     def forward(self, x, P):
-        raise NotImplementedError("ContrastLoss_v2 is fused into the CRD loss kernel; call CRDLoss.forward")
+        if self.sample_KD not in ("False", "True"):
+            raise UnboundLocalError("local variable 'loss' referenced before assignment")   # what :252 raises there
+        return _ContrastLossV2Fn.apply(x, P, self.n_data, self.sample_KD == "True")
 
 
 class Embed(nn.Module):

@@ -13,11 +13,13 @@ from .. import ops
 from .._lib import lib, check, ptr, stream, require_cuda
 
 
-def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None):
+def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None, outputs_only=False):
     """The fused CRD step on normalised embeddings: scores against the PRE-update banks, pair selection, first-call Z,
     NCE loss, analytic gradients, bank momentum update.  Returns (loss, dv1, dv2) with dv = d loss / d v for a unit
     upstream gradient (per_sample: row b of dv belongs to loss[b]).  `loss_out`: optional 0-d destination of the summed
-    loss.  No autograd here: _CRDCoreFn wraps it, the fused loss head of DistillStep calls it directly."""
+    loss.  No autograd here: _CRDCoreFn wraps it, the fused loss head of DistillStep calls it directly.
+    `outputs_only`: the standalone ContrastMemory_v3.forward - instead of the loss, return (out_v1, out_v2, rows1, rows2):
+    the selected scores / Z [B, P2+K2] and the gathered pre-update bank rows its backward needs."""
     v1, v2 = ops._f32(v1), ops._f32(v2)
     B, D = v1.shape
     P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
@@ -56,6 +58,16 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None):
             z = mem.params[2:4].tolist()
             print("normalization constant Z_v1 is set to {:.1f}".format(z[0]))
             print("normalization constant Z_v2 is set to {:.1f}".format(z[1]))
+    if outputs_only:
+        o1 = torch.empty(B, S2, device=dev, dtype=torch.float32)
+        o2 = torch.empty_like(o1)
+        rows1 = torch.empty(B, S2, D, device=dev, dtype=torch.float32)
+        rows2 = torch.empty_like(rows1)
+        check(L.ph_crd_outputs(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(mem.memory_v1), ptr(mem.memory_v2),
+                               ptr(mem.params), ptr(o1), ptr(o2), ptr(rows1), ptr(rows2), B, PK, S2, D, st), "ph_crd_outputs")
+        _crd_update(mem, y, v1, v2, D)
+        mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
+        return o1, o2, rows1, rows2
     lossp = torch.empty(B, device=dev, dtype=torch.float32)
     dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
     dv2 = torch.empty_like(dv1)
@@ -71,16 +83,20 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None):
     else:
         loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
         check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
-    # momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica
-    # applies the update of the whole global batch
+    _crd_update(mem, y, v1, v2, D)
+    mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
+    return loss, dv1, dv2
+
+
+def _crd_update(mem, y, v1, v2, D):
+    """Momentum update AFTER scoring (memory_new.py:382-395); under data parallelism every replica applies the update of
+    the whole global batch."""
     if mem.sync is not None:
         yy, vv1, vv2 = mem.sync.all_gather_rows(y, v1.detach(), v2.detach())
     else:
         yy, vv1, vv2 = y, v1.detach(), v2.detach()
-    check(L.ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
-                          yy.shape[0], D, st), "ph_crd_update")
-    mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
-    return loss, dv1, dv2
+    check(lib().ph_crd_update(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(vv1), ptr(vv2), ptr(yy), ptr(mem.params),
+                              yy.shape[0], D, stream()), "ph_crd_update")
 
 
 class _CRDCoreFn(torch.autograd.Function):
@@ -99,6 +115,31 @@ class _CRDCoreFn(torch.autograd.Function):
         if ctx.per_sample:
             g = g.reshape(-1, 1)      # d loss_b / d v_b is row b of dv
         return dv1 * g, dv2 * g, None, None, None, None, None
+
+
+class _CRDOutputsFn(torch.autograd.Function):
+    """(v1, v2) -> (out_v1, out_v2) of ContrastMemory_v3.forward (memory_new.py:249-397), each [B, P2+K2, 1]:
+    out_v1 = exp(memory_v2[sel] . v1 / T) / Z_v1 depends on v1 only, out_v2 on v2 only (Z are constants, :368-379)."""
+
+    @staticmethod
+    def forward(ctx, v1, v2, mem, y, idx, ranks):
+        o1, o2, rows1, rows2 = crd_core(v1, v2, mem, y, idx, ranks, outputs_only=True)
+        ctx.save_for_backward(o1, o2, rows1, rows2)
+        ctx.T = float(mem.T)
+        return o1.unsqueeze(-1), o2.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        o1, o2, rows1, rows2 = ctx.saved_tensors
+        B, S2 = o1.shape
+        D = rows1.shape[2]
+        g1 = None if g1 is None else ops._f32(g1).reshape(B, S2).contiguous()
+        g2 = None if g2 is None else ops._f32(g2).reshape(B, S2).contiguous()
+        dv1 = torch.empty(B, D, device=o1.device, dtype=torch.float32)
+        dv2 = torch.empty_like(dv1)
+        check(lib().ph_crd_outputs_bwd(ptr(g1), ptr(g2), ptr(o1), ptr(o2), ptr(rows1), ptr(rows2), ctx.T, ptr(dv1), ptr(dv2),
+                                       B, S2, D, stream()), "ph_crd_outputs_bwd")
+        return dv1, dv2, None, None, None, None
 
 
 class ContrastMemory_v3(nn.Module):
@@ -147,9 +188,23 @@ class ContrastMemory_v3(nn.Module):
             raise RuntimeError("select_pos_mode '%s' needs nce_p > %d" % (select_pos_mode, int(r.max())))
         return torch.as_tensor(np.asarray(r), dtype=torch.int32)
 
-    def loss(self, epoch, v1, v2, y, idx, select_pos_mode="mid", ranks=None):
+    def _ranks(self, epoch, select_pos_mode, ranks, dev):
         if ranks is None:
             ranks = self.draw_ranks(epoch, select_pos_mode)
         if ranks is not None and not (torch.is_tensor(ranks) and ranks.is_cuda and ranks.dtype == torch.int32):
-            ranks = torch.as_tensor(np.asarray(ranks), dtype=torch.int32).to(v1.device, non_blocking=True)
-        return _CRDCoreFn.apply(v1, v2, self, y, idx, ranks)
+            ranks = torch.as_tensor(np.asarray(ranks), dtype=torch.int32).to(dev, non_blocking=True)
+        return ranks
+
+    def loss(self, epoch, v1, v2, y, idx, select_pos_mode="mid", ranks=None):
+        """s_loss + t_loss of CRDLoss.forward (CRD_loss.py:167-174) in one fused pass (what CRDLoss calls)."""
+        return _CRDCoreFn.apply(v1, v2, self, y, idx, self._ranks(epoch, select_pos_mode, ranks, v1.device))
+
+    def forward(self, epoch, v1, v2, y, idx=None, select_pos_mode="mid", ranks=None):
+        """memory_new.py:249-397 as written: returns (out_v1, out_v2), each [B, P2+K2, 1] (selected positives first),
+        differentiable w.r.t. v1 / v2; sets Z on the first call, momentum-updates the rows `y` of both banks.  The rank
+        list of the `mid` / `random` / `curriculum` modes comes from numpy's global RNG exactly as in the reference
+        (:311-322) unless `ranks` is given."""
+        if idx is None:
+            raise NotImplementedError("idx=None (AliasMethod.draw, memory_new.py:265-267): the loaders always pass "
+                                      "contrast_idx")
+        return _CRDOutputsFn.apply(v1, v2, self, y, idx, self._ranks(epoch, select_pos_mode, ranks, v1.device))

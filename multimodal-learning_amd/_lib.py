@@ -84,6 +84,9 @@ SIGNATURES = {
     "ph_crd_loss_grad_workspace_bytes": (sz, [i32]),
     "ph_crd_loss_grad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
     "ph_crd_update": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "ph_crd_outputs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "ph_crd_outputs_bwd": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),
+    "ph_contrast_loss_v2": (i32, [vp, vp, vp, i32, i32, i32, f32, vp]),
     "ph_crd_class_centers_workspace_bytes": (sz, [i32, i32]),
     "ph_crd_class_centers": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "ph_gram": (i32, [vp, vp, i32, i32, vp]),

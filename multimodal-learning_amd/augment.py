@@ -41,7 +41,15 @@ class DeviceAugment:
                   "ph_augment_params")
             self.step += 1
         else:
+            # Caller-supplied parameters (tests, replaying a recorded draw; not the hot path, so a host check is fine).
+            # Layout [B, 2, NPARAM]: 0-11 flips / crop / jitter factors / step order (oracle/augment.py::draw_params),
+            # 12 and 14-15 scratch (zeroed here), 13 = BIT MASK of disabled colour steps (bit k set: ColorJitter dropped
+            # step k because its range is zero) - the kernel casts it to int, so it must be an integer in 0..15.
             params = params.to(src.device).float().contiguous().clone()
+            c13 = params[..., 13]
+            if not bool(((c13 >= 0) & (c13 <= 15) & (c13 == c13.round())).all().item()):
+                raise ValueError("augmentation params column 13 is the mask of disabled colour steps: integers 0..15 "
+                                 "(got values outside that set - a parameter block from before the layout change?)")
             params[..., 12] = 0
             params[..., 14:] = 0          # the grey-sum accumulator slot (column 13 = mask of disabled steps, kept)
         if out is not None:          # caller-owned buffers (the resident input sets a captured step graph reads from)

@@ -414,6 +414,91 @@ __global__ void class_center_finish_kernel(const float* __restrict__ parts, cons
   mem[((size_t)n_data + c) * D + f] = cnt > 0 ? (float)(s / (double)cnt) : 0.f;
 }
 
+// ---- the memory module / the NCE criterion as STANDALONE calls (ContrastMemory_v3.forward returns (out_v1, out_v2),
+// memory_new.py:249-397; ContrastLoss_v2.forward, CRD_loss.py:221-252).  CRDLoss itself runs the fused kernels above.
+// out1[b][j] = xs[b][j] / Z_v1, out2 = xt / Z_v2 (:378-379) and the selected PRE-update bank rows are gathered for the
+// backward (the momentum update of :382-395 happens inside the same forward call, so a later backward cannot read them
+// from the bank any more): rows2[b][j] = mem2[idx_b2[b][sel]] feeds d out_v1 / d v1, rows1 = mem1[idx[b][sel]] d out_v2 / d v2.
+// grid (ceil(S2/8), B), block 256 = 8 half-waves, one (sample, column) per half-wave.
+__global__ __launch_bounds__(256) void crd_outputs_kernel(const float* __restrict__ xs, const float* __restrict__ xt,
+                                                          const int* __restrict__ sel, const int64_t* __restrict__ idx,
+                                                          const int64_t* __restrict__ idx_b2,
+                                                          const float* __restrict__ mem1, const float* __restrict__ mem2,
+                                                          const float* __restrict__ params, float* __restrict__ out1,
+                                                          float* __restrict__ out2, float* __restrict__ rows1,
+                                                          float* __restrict__ rows2, int PK, int S2) {
+  const int b = blockIdx.y, hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int j = blockIdx.x * 8 + hw;
+  if (j >= S2) return;
+  const size_t o = (size_t)b * S2 + j;
+  const int col = sel[o];
+  const int64_t row = idx[(size_t)b * PK + col], row2 = idx_b2[(size_t)b * PK + col];
+  *reinterpret_cast<f32x4*>(rows1 + o * D + l * 4) = *reinterpret_cast<const f32x4*>(mem1 + row * D + l * 4);
+  *reinterpret_cast<f32x4*>(rows2 + o * D + l * 4) = *reinterpret_cast<const f32x4*>(mem2 + row2 * D + l * 4);
+  if (l == 0) {
+    out1[o] = xs[o] / params[2];
+    out2[o] = xt[o] / params[3];
+  }
+}
+
+// dv1[b] = sum_j g1[b][j] out1[b][j] / T * rows2[b][j][:], dv2[b] = sum_j g2[b][j] out2[b][j] / T * rows1[b][j][:]
+// (out = exp(row . v / T) / Z with Z a constant: memory_new.py:270-278,378-379).  One block per (sample, side), fixed
+// summation order (8 half-waves stride the columns, then a fixed-order LDS combine).
+__global__ __launch_bounds__(256) void crd_outputs_bwd_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                              const float* __restrict__ out1, const float* __restrict__ out2,
+                                                              const float* __restrict__ rows1, const float* __restrict__ rows2,
+                                                              float invT, float* __restrict__ dv1, float* __restrict__ dv2,
+                                                              int S2) {
+  const int b = blockIdx.x, side = blockIdx.y, hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const float* g = side ? g2 : g1;
+  const float* out = side ? out2 : out1;
+  const float* rows = side ? rows1 : rows2;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int j = hw; j < S2; j += 8) {
+    const size_t o = (size_t)b * S2 + j;
+    const float c = (g ? g[o] : 0.f) * out[o] * invT;
+    const f32x4 r = *reinterpret_cast<const f32x4*>(rows + o * D + l * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += c * r[k];
+  }
+  __shared__ float sh[8][D];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sh[hw][l * 4 + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sh[q][threadIdx.x];
+    (side ? dv2 : dv1)[(size_t)b * D + threadIdx.x] = t;
+  }
+}
+
+// ContrastLoss_v2.forward(x [B][P+N], P) (CRD_loss.py:221-252): m = N, Pn = 1 / n_data, c = m Pn + eps;
+//   rows[b] = -( sum_p log(x/(x+c)) / P + sum_n log(m Pn / (x+c)) )      (the sample_KD == "True" branch's per-sample loss)
+//   the sample_KD == "False" branch's scalar is sum_b rows[b] / B (host: ph_sum with scale 1/B)
+//   dx[b][j] = d rows[b] / d x[b][j] = -c / (x (x+c)) / P (positives), +1 / (x+c) (negatives)
+__global__ __launch_bounds__(256) void contrast_loss_v2_kernel(const float* __restrict__ x, float* __restrict__ rows,
+                                                               float* __restrict__ dx, int S, int P, float n_data) {
+  const int b = blockIdx.x;
+  const float mPn = (float)(S - P) / n_data, c = mPn + 1e-7f;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < S; j += blockDim.x) {
+    const float v = x[(size_t)b * S + j];
+    if (j < P) {
+      acc += (double)logf(v / (v + c)) / (double)P;
+      dx[(size_t)b * S + j] = -(c / (v * (v + c))) / (float)P;
+    } else {
+      acc += (double)logf(mPn / (v + c));
+      dx[(size_t)b * S + j] = 1.f / (v + c);
+    }
+  }
+  __shared__ double sh[4];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) rows[b] = -(float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
 }  // namespace
 
 size_t ph_crd_bank_topk_workspace_bytes(int B) { return (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX * (sizeof(float) + sizeof(int)); }
@@ -514,6 +599,32 @@ int ph_crd_class_centers(float* mem_ext, const int* members, const int* offsets,
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(class_center_finish_kernel, dim3(num_classes), dim3(D), 0, st, reinterpret_cast<const float*>(workspace),
                      offsets, mem_ext, nchunks, n_data);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_crd_outputs(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                   const float* mem1, const float* mem2, const float* params, float* out1, float* out2, float* rows1,
+                   float* rows2, int B, int PK, int S2, int feat_dim, hipStream_t st) {
+  if (feat_dim != D || B < 1 || S2 < 1) return PH_EINVAL;
+  hipLaunchKernelGGL(crd_outputs_kernel, dim3(cdiv(S2, 8), B), dim3(256), 0, st, xs, xt, sel, idx,
+                     idx_bank2 ? idx_bank2 : idx, mem1, mem2, params, out1, out2, rows1, rows2, PK, S2);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_crd_outputs_bwd(const float* g1, const float* g2, const float* out1, const float* out2, const float* rows1,
+                       const float* rows2, float T, float* dv1, float* dv2, int B, int S2, int feat_dim, hipStream_t st) {
+  if (feat_dim != D || B < 1 || S2 < 1) return PH_EINVAL;
+  hipLaunchKernelGGL(crd_outputs_bwd_kernel, dim3(B, 2), dim3(256), 0, st, g1, g2, out1, out2, rows1, rows2, 1.f / T, dv1,
+                     dv2, S2);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_contrast_loss_v2(const float* x, float* rows, float* dx, int B, int S, int P, float n_data, hipStream_t st) {
+  if (B < 1 || P < 1 || P >= S) return PH_EINVAL;
+  hipLaunchKernelGGL(contrast_loss_v2_kernel, dim3(B), dim3(256), 0, st, x, rows, dx, S, P, n_data);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -251,21 +251,34 @@ class ResNet(nn.Module):
         dev = self.conv1.weight.device
         if persistent:
             return torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
-        # One workspace per plan key, never dropped behind the caller's back: a captured step graph holds the RAW
-        # pointer of the workspace it was captured with, so releasing it when a forward of another shape arrives (an
-        # evaluation batch between training epochs) would let later replays write into memory the allocator has handed
-        # to someone else.  release_workspaces() frees them explicitly.
+        # A captured step graph holds the RAW pointer of the workspace it was captured with, so a workspace that is
+        # requested WHILE a stream capture is running is pinned for good (releasing it when a forward of another shape
+        # arrives - an evaluation batch between training epochs - would let later replays write into memory the
+        # allocator has handed to someone else).  Everything else (ragged last batches, evaluation batches, the bench's
+        # extra runs) lives in a small LRU: at B = 64 / 512 x 512 one workspace is 2.6 GB, and a long run with varying
+        # batch sizes must not keep one per shape.  release_workspaces() frees explicitly.
         key = plan.key
-        if key not in self._ws_cache:
-            self._ws_cache[key] = torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
-        return self._ws_cache[key]
+        pinned = self.__dict__.setdefault("_ws_pinned", set())
+        if torch.cuda.is_current_stream_capturing():
+            pinned.add(key)
+        ws = self._ws_cache.pop(key, None)
+        if ws is None:
+            loose = [k for k in self._ws_cache if k not in pinned]
+            for k in loose[:max(0, len(loose) - (self._WS_LRU - 1))]:      # dict order = least recently used first
+                del self._ws_cache[k]
+            ws = torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
+        self._ws_cache[key] = ws                                          # (re-)inserted last = most recently used
+        return ws
+
+    _WS_LRU = 2      # un-pinned workspaces kept per network
 
     def release_workspaces(self, keep=None):
-        """Free the cached trunk workspaces (all, or all but the plan key `keep` = (B, H, W, precision)).  Only legal
-        while no captured HIP graph replays this network: DistillStep.load_state_dict / a fresh enable_graph() rebuild
-        theirs."""
+        """Free the cached trunk workspaces (all, or all but the plan key `keep` = (B, H, W, precision)), pinned ones
+        included.  Only legal while no captured HIP graph replays this network: DistillStep.load_state_dict / a fresh
+        enable_graph() rebuild theirs."""
         for k in [k for k in self._ws_cache if k != keep]:
             del self._ws_cache[k]
+        self.__dict__.setdefault("_ws_pinned", set()).intersection_update({keep})
 
     def _alloc_trunk_grads(self):
         """Gradient destinations of ph_resnet_backward.  With `_direct_grad` (set by DistillStep, whose optimiser

@@ -802,7 +802,11 @@ class DistillStep:
                      loader_batch_no=getattr(loader, "batch_no", None))
         if load is None:
             out = {k: (None if t is None else t.clone()) for k, t in cells.items()}
-            out["numpy"] = np.random.get_state()
+            # numpy's MT19937 state as tensors / plain scalars: `torch.load(weights_only=True)` (the default since
+            # torch 2.6) rejects numpy globals, so the raw get_state() tuple would make the checkpoint unloadable
+            name, key, pos, has_gauss, cached = np.random.get_state()
+            out["numpy"] = dict(name=str(name), key=torch.from_numpy(key.astype(np.int64)), pos=int(pos),
+                                has_gauss=int(has_gauss), cached_gaussian=float(cached))
             return out
         for k, t in cells.items():
             v = load.get(k)
@@ -814,8 +818,13 @@ class DistillStep:
                     continue
                 raise RuntimeError("checkpoint carries the draw counter %r but this step has no such component" % k)
             t.copy_(v)
-        if load.get("numpy") is not None:
-            np.random.set_state(load["numpy"])
+        st = load.get("numpy")
+        if st is not None:
+            # NOTE: restores the PROCESS-GLOBAL numpy RNG (the reference draws its CRD ranks from it, memory_new.py:311)
+            if isinstance(st, dict):
+                st = (st["name"], np.asarray(st["key"].cpu().numpy(), dtype=np.uint32), int(st["pos"]), int(st["has_gauss"]),
+                      float(st["cached_gaussian"]))
+            np.random.set_state(st)
 
     def load_state_dict(self, sd):
         self.model.load_state_dict(sd["model_state_dict"])

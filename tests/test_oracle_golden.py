@@ -247,3 +247,37 @@ def test_two_steps_from_mid_training_state(golden_dir):
         _close(g[f"params0_{it}"], orc.crd[0].params, 1e-3, 1e-6)             # Z stays what it was
         _close(g[f"bank0_v1_rows{it}"], orc.crd[0].memory_v1[bt["index"]], 1e-5)
         _close(g[f"bank1_v2_rows{it}"], orc.crd[1].memory_v2[bt["index"]], 1e-5)
+
+
+@pytest.mark.parametrize("mode", ["mid", "hard"])
+def test_contrast_memory_v3_forward_outputs(golden_dir, mode):
+    """The oracle's ContrastMemory_v3.forward against the reference class run STANDALONE (tests/golden/
+    make_golden_crd_forward.py): (out_v1, out_v2), their gradients, Z and the updated rows over two calls."""
+    from oracle.losses import contrast_memory_v3
+    g = np.load(os.path.join(golden_dir, "crd_forward.npz"))
+    st = CRDState(int(g["n_data"]), seed=int(g["bank_seed"]), P=int(g["P"]), K=int(g["K"]))
+    for it in range(2):
+        t = f"{mode}{it}"
+        v1 = torch.as_tensor(g[f"v1_{t}"]).requires_grad_(True); v2 = torch.as_tensor(g[f"v2_{t}"]).requires_grad_(True)
+        ranks = g[f"ranks_{mode}"][it] if mode == "mid" else None
+        o1, o2, _ = contrast_memory_v3(st, v1, v2, torch.as_tensor(g[f"y_{t}"]), torch.as_tensor(g[f"idx_{t}"]),
+                                       int(g["P2"]), int(g["K2"]), mode, ranks)
+        gv1, gv2 = torch.autograd.grad((o1 * torch.as_tensor(g[f"w1_{t}"])).sum() + (o2 * torch.as_tensor(g[f"w2_{t}"])).sum(),
+                                       [v1, v2])
+        np.testing.assert_allclose(o1.detach().numpy(), g[f"out1_{t}"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(o2.detach().numpy(), g[f"out2_{t}"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(gv1.numpy(), g[f"gv1_{t}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(gv2.numpy(), g[f"gv2_{t}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(st.params.numpy(), g[f"params_{t}"], rtol=1e-6)
+        y = torch.as_tensor(g[f"y_{t}"])
+        np.testing.assert_allclose(st.memory_v1[y].numpy(), g[f"rows1_{t}"], atol=1e-6)
+
+
+def test_contrast_loss_v2_standalone(golden_dir):
+    from oracle.losses import contrast_loss_v2
+    g = np.load(os.path.join(golden_dir, "crd_forward.npz"))
+    x = torch.as_tensor(g["cl_x"]).requires_grad_(True)
+    loss = contrast_loss_v2(x, int(g["P2"]), int(g["n_data"]))
+    (gx,) = torch.autograd.grad(loss, [x])
+    np.testing.assert_allclose(loss.item(), float(g["cl_loss_False"]), rtol=1e-6)
+    np.testing.assert_allclose(gx.numpy(), g["cl_gx_False"], rtol=1e-5, atol=1e-7)
