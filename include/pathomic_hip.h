@@ -74,6 +74,14 @@ int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, cons
  * backward (utils.py:257-260). */
 int ph_resnet_backward_part(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
                             const float* g_f3, const float* g_f4, void* const* grads, int part, ph_stream_t stream);
+/* Test access: the same backward cut off after `stop_after` >= 1 launch groups ("stages": the avgpool backward, then per
+ * BasicBlock bn2 / wgrad(conv2) / dgrad(conv2) / bn1 / wgrad(conv1) / dgrad(conv1) [+ bn / wgrad / dgrad of the
+ * downsample branch], then the stem's BatchNorm reduction, its apply pass, its weight gradient) - autograd of
+ * resnets.py:58-74,219-222 one node at a time.  Only scratch buffers are written, so it can be re-run; with
+ * ph_resnet_tensor_info (what 4-9: the scratch buffers, the BatchNorm statistics, the pool arg codes) a harness compares
+ * every stage with a reference computed from that stage's own inputs (tests/test_gpu_fullsize.py). */
+int ph_resnet_backward_debug(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
+                             const float* g_f3, const float* g_f4, void* const* grads, int stop_after, ph_stream_t stream);
 /* Gradient with respect to the image [B,3,H,W] f32 of an EVAL-mode forward (flags bit1; BatchNorm backward is then
  * gamma * invstd * dz, no parameter gradients).  The reference needs it for the MIA-2023 stage-1 superpixel attention
  * masks ("MIA 2023/stage1_multi_modal_teacher/train_test_MT_SP_Masking.py":62-75: model.eval(); cost.backward();

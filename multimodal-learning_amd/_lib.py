@@ -29,6 +29,7 @@ SIGNATURES = {
     "ph_resnet_backward_input": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "ph_stem_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_resnet_backward_part": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "ph_resnet_backward_debug": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ph_resnet_tensor_info": (i32, [vp, i32, i32, vp, vp]),
     "ph_sgemm": (i32, [vp, vp, vp, vp, i32, i32, i32, lng, lng, lng, lng, lng, i32, i32, vp]),
     "ph_sgemm_splitk": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, lng, lng, lng, lng, lng, i32, vp]),

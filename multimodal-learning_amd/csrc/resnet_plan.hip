@@ -400,19 +400,21 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   return PH_OK;
 }
 
-// grads: per unit 3 pointers [dw (OIHW f32), dgamma, dbeta]; g_f3 may be null.  Needs the activations the
-// matching ph_resnet_forward left in `ws`.
-int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
-                       const float* g_f3, const float* g_f4, void* const* grads, hipStream_t st) {
-  return ph_resnet_backward_part(P, params, packed, ws_, g_f3, g_f4, grads, -1, st);
-}
+}  // extern "C"
 
-// part -1: everything; part 0: layers 4 and 3 (blocks 7..4); part 1: layers 2 and 1 (blocks 3..0) and the stem.  After
-// part 0 every gradient of layers 3-4 (93 % of the trunk's parameter bytes) is final: a data-parallel caller starts
-// their all-reduce there and overlaps it with part 1.  An even number of blocks per part keeps the ping-pong buffers
-// of the block gradient where the next part expects them.
-int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
-                            const float* g_f3, const float* g_f4, void* const* grads, int part, hipStream_t st) {
+namespace {
+
+// Every launch group of the backward is one numbered STAGE (1, 2, ...).  `stop` > 0 ends the call after that many stages:
+// a test harness steps through the backward and compares each stage's output with a reference computed from that
+// stage's own inputs (tests/test_gpu_fullsize.py); the product entry points pass 0.
+#define PH_STAGE(call)                                   \
+  do {                                                   \
+    if ((rc = (call))) return rc;                        \
+    if (stop > 0 && ++nst == stop) return PH_OK;         \
+  } while (0)
+
+int backward_impl(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_, const float* g_f3,
+                  const float* g_f4, void* const* grads, int part, int stop, hipStream_t st) {
   if (!P || !params || !packed || !ws_ || !g_f4 || !grads || part < -1 || part > 1) return PH_EINVAL;
   const int bi_hi = part == 1 ? 3 : 7, bi_lo = part == 0 ? 4 : 0;
   Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0};
@@ -422,34 +424,33 @@ int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, co
   unsigned char* gnext = ws + P->g1_off;
   unsigned char* dyb = ws + P->dy_off;
   unsigned char* dab = ws + P->da_off;
-  int rc;
+  int rc, nst = 0;
   if (part != 1) {
     if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
     const Block& b = P->blocks[7];
-    if ((rc = ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st))) return rc;
+    PH_STAGE(ph_avgpool_bwd_launch(g_f4, gcur, P->B, b.OH * b.OW, b.Cout, 0, P->prec, st));
   }
   for (int bi = bi_hi; bi >= bi_lo; --bi) {
     const Block& b = P->blocks[bi];
-    if (bi == 5 && g_f3)
-      if ((rc = ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st))) return rc;
+    if (bi == 5 && g_f3) PH_STAGE(ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st));
     const void* out = ws + b.out_off;
     const void* a1 = ws + b.a1_off;
     const void* xin = ws + b.in_off;
     // bn2 <- d_out * (out > 0)
-    if ((rc = bn_bwd(c, b.u2, gcur, out, dyb, (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]))) return rc;
-    if ((rc = conv_wgrad(c, b.u2, a1, dyb, (float*)grads[b.u2 * 3 + 0]))) return rc;
-    if ((rc = conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr))) return rc;
+    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dyb, (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]));
+    PH_STAGE(conv_wgrad(c, b.u2, a1, dyb, (float*)grads[b.u2 * 3 + 0]));
+    PH_STAGE(conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr));
     // bn1 <- d_a1 * (a1 > 0)
-    if ((rc = bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true))) return rc;
-    if ((rc = conv_wgrad(c, b.u1, xin, dyb, (float*)grads[b.u1 * 3 + 0]))) return rc;
+    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true));
+    PH_STAGE(conv_wgrad(c, b.u1, xin, dyb, (float*)grads[b.u1 * 3 + 0]));
     if (b.uds < 0) {
       // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
-      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, gcur, out))) return rc;
+      PH_STAGE(conv_dgrad(c, b.u1, dyb, gnext, gcur, out));
     } else {
-      if ((rc = conv_dgrad(c, b.u1, dyb, gnext, nullptr, nullptr))) return rc;
-      if ((rc = bn_bwd(c, b.uds, gcur, out, dyb, (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]))) return rc;
-      if ((rc = conv_wgrad(c, b.uds, xin, dyb, (float*)grads[b.uds * 3 + 0]))) return rc;
-      if ((rc = conv_dgrad(c, b.uds, dyb, gnext, gnext, nullptr))) return rc;   // in-place accumulate
+      PH_STAGE(conv_dgrad(c, b.u1, dyb, gnext, nullptr, nullptr));
+      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dyb, (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]));
+      PH_STAGE(conv_wgrad(c, b.uds, xin, dyb, (float*)grads[b.uds * 3 + 0]));
+      PH_STAGE(conv_dgrad(c, b.uds, dyb, gnext, gnext, nullptr));   // in-place accumulate
     }
     unsigned char* t = gcur; gcur = gnext; gnext = t;
   }
@@ -462,21 +463,49 @@ int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, co
     if ((rc = ph_stem_bwd_reduce_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
                                         c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
-    if ((rc = ph_bn_bwd_finalize_launch(parts, ph_stem_bwd_parts(P->B, u.OH), 64, (double)npix, (float*)grads[1],
-                                        (float*)grads[2], c1, c2, st)))
-      return rc;
-    if ((rc = ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
-                                       c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64,
-                                       P->prec, st)))
-      return rc;
+    PH_STAGE(ph_bn_bwd_finalize_launch(parts, ph_stem_bwd_parts(P->B, u.OH), 64, (double)npix, (float*)grads[1],
+                                       (float*)grads[2], c1, c2, st));
+    PH_STAGE(ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
+                                      c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64,
+                                      P->prec, st));
     PhStemWgrad w{};
     w.x4 = ws + P->x4_off; w.dy = dyb; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
     w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
     if ((rc = ph_stem_wgrad_launch(&w, P->prec, st))) return rc;
-    if ((rc = ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, st))) return rc;
+    PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, st));
   }
   return PH_OK;
+}
+#undef PH_STAGE
+
+}  // namespace
+
+extern "C" {
+
+// grads: per unit 3 pointers [dw (OIHW f32), dgamma, dbeta]; g_f3 may be null.  Needs the activations the
+// matching ph_resnet_forward left in `ws`.
+int ph_resnet_backward(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
+                       const float* g_f3, const float* g_f4, void* const* grads, hipStream_t st) {
+  return backward_impl(P, params, packed, ws_, g_f3, g_f4, grads, -1, 0, st);
+}
+
+// part -1: everything; part 0: layers 4 and 3 (blocks 7..4); part 1: layers 2 and 1 (blocks 3..0) and the stem.  After
+// part 0 every gradient of layers 3-4 (93 % of the trunk's parameter bytes) is final: a data-parallel caller starts
+// their all-reduce there and overlaps it with part 1.  An even number of blocks per part keeps the ping-pong buffers
+// of the block gradient where the next part expects them.
+int ph_resnet_backward_part(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
+                            const float* g_f3, const float* g_f4, void* const* grads, int part, hipStream_t st) {
+  return backward_impl(P, params, packed, ws_, g_f3, g_f4, grads, part, 0, st);
+}
+
+// test access: the whole backward, cut off after `stop_after` stages (>= 1; see PH_STAGE above for the numbering: the
+// avgpool backward, then per block bn2 / wgrad2 / dgrad2 / bn1 / wgrad1 / dgrad1 (+ bn_ds / wgrad_ds / dgrad_ds), then the
+// stem's BatchNorm reduction, its apply pass and its weight gradient).  Re-runnable: it only writes scratch buffers.
+int ph_resnet_backward_debug(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
+                             const float* g_f3, const float* g_f4, void* const* grads, int stop_after, hipStream_t st) {
+  if (stop_after < 1) return PH_EINVAL;
+  return backward_impl(P, params, packed, ws_, g_f3, g_f4, grads, -1, stop_after, st);
 }
 
 // Gradient with respect to the IMAGE of an eval-mode forward (flags bit1): BatchNorm is a fixed per-channel scale, so
@@ -533,7 +562,7 @@ int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, c
 }
 
 // debug / test access: byte offset + dims of an intermediate activation in the workspace
-//   what: 0 = unit raw output y (id = unit), 1 = block output (id = block), 2 = block a1, 3 = pooled stem
+//   what: 0 = unit raw output y (id = unit), 1 = block output (id = block), 2 = block a1, 3 = pooled stem, 4-9 below
 int ph_resnet_tensor_info(const PhResnetPlan* P, int what, int id, size_t* byte_off, int* dims4) {
   if (!P) return PH_EINVAL;
   if (what == 0 && id >= 0 && id < (int)P->units.size()) {
@@ -549,6 +578,21 @@ int ph_resnet_tensor_info(const PhResnetPlan* P, int what, int id, size_t* byte_
   }
   if (what == 3) {
     *byte_off = P->p0_off; dims4[0] = P->B; dims4[1] = P->PH0; dims4[2] = P->PW0; dims4[3] = 64;
+    return PH_OK;
+  }
+  // backward scratch (dims are the caller's: the buffers are reused at every size): 4 / 5 = the two ping-pong block
+  // gradient buffers, 6 = dy (BatchNorm-backward output), 7 = d_a1, 9 = the stem's max-pool arg codes (1 byte each)
+  if (what >= 4 && what <= 7) {
+    *byte_off = what == 4 ? P->g0_off : what == 5 ? P->g1_off : what == 6 ? P->dy_off : P->da_off;
+    dims4[0] = dims4[1] = dims4[2] = dims4[3] = 0;
+    return PH_OK;
+  }
+  if (what == 8 && id >= 0 && id < (int)P->units.size()) {   // fp32 [4][Cout]: mean, invstd, scale, shift of the unit's BatchNorm
+    *byte_off = P->units[id].st_off; dims4[0] = 4; dims4[1] = P->units[id].Cout; dims4[2] = dims4[3] = 1;
+    return PH_OK;
+  }
+  if (what == 9) {
+    *byte_off = P->idx_off; dims4[0] = P->B; dims4[1] = P->PH0; dims4[2] = P->PW0; dims4[3] = 64;
     return PH_OK;
   }
   return PH_EINVAL;

@@ -229,6 +229,207 @@ def test_student_backward_perf_vs_parity_at_benchmark_size():
     assert small[worst_s] >= 0.50, (worst_s, small[worst_s])
 
 
+def test_every_backward_stage_at_benchmark_size():
+    """VERDICT r02 missing 3: the perf-mode (bf16) BACKWARD like for like at BASELINE configs[1] (64 x 512 x 512) - autograd
+    of resnets.py:58-74,219-222 one node at a time.  ph_resnet_backward_debug cuts the backward off after k launch
+    groups; after each cut the newest output (BatchNorm-backward dy + dgamma / dbeta of all 20 BatchNorm units incl. the
+    stem, the weight gradient of all 20 convolutions incl. `wgrad_reduce`, every dgrad incl. the residual-masked and the
+    in-place downsample ones, the avgpool scatters, the stem's pooled-gradient scatter) is compared with plain fp32
+    PyTorch fed the GPU's OWN inputs of that stage (read out of the workspace), so nothing is carried from stage to stage:
+    bf16-stored tensors are held to bf16 rounding (2^-7 of the tensor's maximum), fp32 parameter gradients to 2e-3.
+    ReLU masks are re-derived from bf16 data exactly as the kernels do; an element whose pre-activation is within
+    rounding of zero may still fall on the other side (fused multiply-add vs two roundings), so mask-dependent tensors
+    may hold a handful (<= 1e-6 of the elements) of outliers, which are counted and printed."""
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd import ops
+    from multimodal_learning_amd._lib import lib, check, ptr, stream
+    B, H = 64, 512
+    m.set_precision("bf16")
+    net = _student()
+    net.train()
+    x = _images(B, H, 29)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    f3, feat, hazard, pred, _ = net(x_path=x)
+    ctx = f3.grad_fn
+    plan, ws, packed, table = ctx.plan, ctx.ws, ctx.packed, ctx.table
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g4 = torch.randn(B, 512, device="cuda", generator=gen)
+    g3 = 0.5 * torch.randn(B, 256, device="cuda", generator=gen)
+    params = net._trunk_params()
+    grads = [torch.full_like(p, float("nan")) for p in params]
+    ga = ops.void_array([g.data_ptr() for g in grads])
+    L = lib()
+    rb = lambda t: t.bfloat16().float()      # noqa: E731
+    bf = torch.bfloat16
+
+    def run(stop):
+        check(L.ph_resnet_backward_debug(plan.h, table, ptr(packed), ptr(ws), ptr(g3), ptr(g4), ga, stop, stream()), "backward_debug")
+
+    def info(what, idx):
+        off = C.c_size_t(0)
+        dims = (C.c_int * 4)()
+        check(L.ph_resnet_tensor_info(plan.h, what, idx, C.byref(off), dims), "tensor_info")
+        return off.value, tuple(dims)
+
+    def act(what, idx, dims=None):           # bf16 NHWC tensor of the workspace -> NCHW fp32 copy
+        off, d = info(what, idx)
+        d = dims or d
+        n = d[0] * d[1] * d[2] * d[3]
+        return ws[off: off + 2 * n].view(bf).view(*d).float().permute(0, 3, 1, 2).contiguous()
+
+    def stats(unit):                         # mean, invstd, scale, shift of the unit's BatchNorm, each [1,C,1,1]
+        off, d = info(8, unit)
+        t = ws[off: off + 16 * d[1]].view(torch.float32).view(4, d[1]).clone()
+        return [t[i].view(1, -1, 1, 1) for i in range(4)]
+
+    worst, outliers = {}, {}
+
+    def rel(ref, got, what, tol, allow=0.0):
+        scale_ = ref.abs().max().clamp_min(1e-30)
+        err = (ref - got).abs()
+        nbad = int((err > tol * scale_).sum().item())
+        ok = nbad <= allow * ref.numel() + (4 if allow > 0 else 0)
+        e = (err.max() / scale_).item()
+        if allow > 0 and nbad:
+            outliers[what] = nbad
+            e = (torch.where(err > tol * scale_, torch.zeros_like(err), err).max() / scale_).item()
+        worst[what] = e
+        assert ok and torch.isfinite(got).all(), (what, e, nbad, ref.numel())
+
+    def unit_names():
+        names = ["conv1|bn1"]
+        for li in range(1, 5):
+            for bi in range(2):
+                p = f"layer{li}.{bi}"
+                names += [f"{p}.conv1|{p}.bn1", f"{p}.conv2|{p}.bn2"]
+                if (p + ".downsample.0.weight") in sd:
+                    names.append(f"{p}.downsample.0|{p}.downsample.1")
+        return names
+    names = unit_names()
+
+    def bn_stage(u, g, mask, y, dims, what, stage, dy_stage=None):
+        """One BatchNorm-backward launch group: reference from (g, mask, y, the unit's statistics).  (The stem's sums and
+        its apply pass are two launch groups: `dy_stage`.)"""
+        mean, invstd, _, _ = stats(u)
+        gamma = sd[names[u].split("|")[1] + ".weight"].view(1, -1, 1, 1)
+        dz = torch.where(mask, g, torch.zeros_like(g))
+        xh = (y - mean) * invstd
+        n = float(g.shape[0] * g.shape[2] * g.shape[3])
+        dbeta = dz.double().sum(dim=(0, 2, 3))
+        dgamma = (dz.double() * xh.double()).sum(dim=(0, 2, 3))
+        ref = gamma * invstd * (dz - (dbeta / n).float().view(1, -1, 1, 1) - xh * (dgamma / n).float().view(1, -1, 1, 1))
+        run(stage)
+        asum = dz.abs().double().sum(dim=(0, 2, 3)).float().max()      # a channel sum may cancel: judged against sum |dz|
+        e1 = ((grads[3 * u + 2] - dbeta.float()).abs().max() / asum).item()
+        e2 = ((grads[3 * u + 1] - dgamma.float()).abs().max() / (dz.abs() * xh.abs()).double().sum(dim=(0, 2, 3)).float().max()).item()
+        worst[what + " dbeta"], worst[what + " dgamma"] = e1, e2
+        assert e1 <= 3e-4 and e2 <= 3e-4, (what, e1, e2)
+        if dy_stage is not None:
+            run(dy_stage)
+        dy = act(6, 0, dims)
+        rel(ref, dy, what + " dy", 1.0 / 128, allow=1e-6)
+        return dy
+
+    def conv_grads(u, xin, dy, stride, pad, what, stage_w, stage_d, dx_dims, dx_what, extra=None):
+        """wgrad launch group, then the dgrad launch group; reference = PyTorch's own convolution autograd."""
+        wname = names[u].split("|")[0] + ".weight"
+        xr = xin.clone().requires_grad_(stage_d is not None)
+        wr = rb(sd[wname]).requires_grad_(True)
+        F.conv2d(xr, wr, None, stride, pad).backward(dy)
+        run(stage_w)
+        rel(wr.grad, grads[3 * u], what + " wgrad", 2e-3)
+        if stage_d is None:
+            return None
+        run(stage_d)
+        ref = xr.grad if extra is None else xr.grad + extra
+        dx = act(dx_what, 0, dx_dims)
+        rel(ref, dx, what + " dgrad", 1.0 / 128, allow=1e-6 if extra is not None else 0.0)
+        return dx
+
+    try:
+        stage = 1
+        run(stage)                                                        # avgpool backward of f4 into the first buffer
+        off, d7 = info(1, 7)
+        gcur = act(4, 0, d7)
+        rel((g4 / (d7[1] * d7[2])).view(B, 512, 1, 1).expand(-1, -1, d7[1], d7[2]), gcur, "avgpool bwd f4", 1.0 / 128)
+        unit_of = {}
+        u = 1
+        for li in range(1, 5):
+            for bi in range(2):
+                has_ds = (f"layer{li}.{bi}.downsample.0.weight") in sd
+                unit_of[(li - 1) * 2 + bi] = (u, u + 1, u + 2 if has_ds else -1)
+                u += 3 if has_ds else 2
+        nbn = 0
+        for blk in range(7, -1, -1):
+            li, bi = blk // 2 + 1, blk % 2
+            p = f"layer{li}.{bi}"
+            u1, u2, uds = unit_of[blk]
+            stride = 2 if (li > 1 and bi == 0) else 1
+            cur_what, nxt_what = (4, 5) if (7 - blk) % 2 == 0 else (5, 4)
+            _, dout = info(1, blk)
+            din = info(1, blk - 1)[1] if blk > 0 else info(3, 0)[1]
+            if blk == 5:
+                stage += 1
+                run(stage)
+                ref = gcur + (g3 / (dout[1] * dout[2])).view(B, 256, 1, 1)
+                gcur = act(cur_what, 0, dout)
+                rel(ref, gcur, "avgpool bwd f3 (accumulate)", 1.0 / 128)
+            out = act(1, blk)
+            omask = out > 0
+            # bn2
+            stage += 1
+            dy2 = bn_stage(u2, gcur, omask, act(0, u2), dout, p + ".bn2", stage); nbn += 1
+            a1 = act(2, blk)
+            dab = conv_grads(u2, a1, dy2, 1, 1, p + ".conv2", stage + 1, stage + 2, dout, 7)
+            stage += 2
+            del a1, dy2
+            # bn1: the ReLU mask is re-derived from y1 with the forward's scale / shift (bn_act.hip DzPlain::mscale)
+            y1 = act(0, u1)
+            _, _, sc1, sh1 = stats(u1)
+            stage += 1
+            dy1 = bn_stage(u1, dab, (y1 * sc1 + sh1) > 0, y1, dout, p + ".bn1", stage); nbn += 1
+            del y1, dab
+            xin = act(1, blk - 1) if blk > 0 else act(3, 0)
+            if uds < 0:
+                gnext = conv_grads(u1, xin, dy1, stride, 1, p + ".conv1 (+ residual)", stage + 1, stage + 2, din, nxt_what,
+                                   extra=torch.where(omask, gcur, torch.zeros_like(gcur)))
+                stage += 2
+            else:
+                gnext = conv_grads(u1, xin, dy1, stride, 1, p + ".conv1", stage + 1, stage + 2, din, nxt_what)
+                stage += 3
+                dyd = bn_stage(uds, gcur, omask, act(0, uds), dout, p + ".downsample.1", stage); nbn += 1
+                gnext = conv_grads(uds, xin, dyd, stride, 0, p + ".downsample.0 (in place)", stage + 1, stage + 2, din, nxt_what,
+                                   extra=gnext)
+                stage += 2
+                del dyd
+            del dy1, xin, out, omask
+            gcur = gnext
+        # ---- stem: pooled gradient -> arg-max scatter -> ReLU mask -> BatchNorm backward -> weight gradient
+        y0 = act(0, 0)
+        mean, invstd, sc0, sh0 = stats(0)
+        offi, di = info(9, 0)
+        code = ws[offi: offi + di[0] * di[1] * di[2] * di[3]].view(di).permute(0, 3, 1, 2).long()     # [B,64,PH,PW], kh*3+kw
+        PH, PW = di[1], di[2]
+        OH, OW = y0.shape[2], y0.shape[3]
+        hh = (2 * torch.arange(PH, device="cuda") - 1).view(1, 1, PH, 1) + code // 3
+        wwp = (2 * torch.arange(PW, device="cuda") - 1).view(1, 1, 1, PW) + code % 3
+        flat = (hh * OW + wwp).view(B, 64, -1)
+        dz = torch.zeros(B, 64, OH * OW, device="cuda").scatter_add_(2, flat, gcur.reshape(B, 64, -1)).view(B, 64, OH, OW)
+        del hh, wwp, flat, code
+        stage += 2      # the BatchNorm sums over pooled pixels, then the apply pass
+        dy0 = bn_stage(0, dz, (y0 * sc0 + sh0) > 0, y0, (B, OH, OW, 64), "stem bn1 (pool scatter + relu)", stage - 1, stage); nbn += 1
+        del dz, y0
+        conv_grads(0, rb(x), dy0, 2, 3, "stem conv1", stage + 1, None, None, None)
+        stage += 1
+        assert nbn == 20 and len([k for k in worst if k.endswith("wgrad")]) == 20 and stage == 62
+        assert all(torch.isfinite(g).all() for g in grads)
+        w = max(worst, key=worst.get)
+        print(f"\nbf16 B={B} 512x512 backward: {len(worst)} stage outputs like for like ({stage} launch groups), worst "
+              f"{worst[w]:.2e} at {w}; mask outliers {outliers}")
+    finally:
+        m.set_precision("bf16")
+
+
 # ---- the whole distillation step at the benchmarked size (BASELINE configs[1]; configs[3] / [4]-like variants: nce_k 4096,
 # MIA-2023 with its 65 536-row bank).  No CPU oracle finishes this in test time, so the checks are properties:
 #   * finite outputs over two steps;
