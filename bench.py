@@ -50,7 +50,8 @@ FUSED_CLS = [(13, "tapconv2_kernel<2,2,4,false> + input BatchNorm/ReLU applied i
              (14, "tapconv2_l1_kernel + input BatchNorm/ReLU applied in LDS (conv2 of layer 1, forward-only networks)")]
 HBM_NAMES = ["crd_score_kernel (2 banks x B x 1000 rows of 512 B)", "crd_loss_grad_kernel (2 banks x B x 532 rows of 512 B)",
              "adam_ema_dev_kernel (28 B / parameter + 8 B / EMA parameter)", "bn_apply_kernel (2-3 activation tensors)"]
-NALL = NCLS + len(HBM_NAMES) + 1 + len(FUSED_CLS)
+TOPK_CLS = 15                    # ph_kernels.h PH_CLS_CRD_TOPK
+NALL = 16                        # = PH_NCLS
 HBM_PEAK_GBS = 8000.0            # HBM3E peak (6290 GB/s measured with a float4 copy), same guide
 # algorithmic FLOPs of the step per 512x512 tile: 3 ResNet-18 forwards + 1 backward without the image gradient
 # (SURVEY 8-d layer table: 93.52 GFLOP); convolutions scale with the tile area
@@ -102,6 +103,131 @@ def cpu_baseline(nsteps=10, faithful_steps=3):
         dtf = (time.time() - t0) / faithful_steps
         res["faithful"] = {"value": round(16.0 / dtf, 3), "unit": "tiles/s",
                            "sample": f"{faithful_steps} steps in the reference's own execution order (3 fwd + 6 bwd), {dtf:.2f} s/step"}
+    return res
+
+
+def variant_setup(name, B, H, device, rank=0, sync=None):
+    """The other stage-2 bodies / the stage-1 t-SVD trainer at BASELINE sizes (configs[3] / configs[4], single-GPU legs):
+    "mia2022": MIA-2022 stage 2, vanilla K+1 CRD bank with nce_k 4096 (bank 16 384 rows), momentum GK-Refine;
+    "mia2023": MIA-2023 stage 2 = configs[4]: n_data 65 536 bank rows, nce_k 4096, nce_p 6 class-aware KNN positives
+               (the full-bank cosine scan of CRD_criterion_v10.py:45-176), per-sample GK-Refine;
+    "tsvd":    MIA-2022 stage-1 trainer with the t-SVD low-rank term (train_test_tSVD.py:299-431) = configs[3].
+    Returns (step object, [batch, batch], description)."""
+    import numpy as np
+    import torch
+    import multimodal_learning_amd as m
+    g = torch.Generator().manual_seed(4321 + rank)
+    d = lambda t: t.to(device)      # noqa: E731
+
+    def batch(n_data, K, labels=None):
+        x = torch.rand(B, 3, H, H, generator=g) * 2 - 1
+        index = torch.randperm(n_data, generator=g)[:B]
+        sidx = torch.randint(0, n_data, (B, K + 1), generator=g); sidx[:, 0] = index
+        grade = labels[index] if labels is not None else torch.randint(0, 3, (B,), generator=g)
+        z = torch.zeros(B)
+        return ((d(x), d(x + 0.01 * torch.randn(B, 3, H, H, generator=g))), d(z), d(torch.randn(B, 320, generator=g)), d(z), d(z),
+                d(grade), d(index), d(sidx))
+    if name == "mia2022":
+        opt = m.stage2_opt(dropout_rate=0.1, batch_size=B)
+        opt.nce_k, opt.grads_m, opt.grads_thresh, opt.thresh = 4096, 0.9, "False", 0.1
+        n_data = 16384
+        step = m.DistillStep(opt, n_data, device=device, variant="mia2022", sync=sync)
+        desc = "MIA-2022 stage 2 (train_test_path_multi_distill_v2.py): CRD bank %d rows, nce_k 4096, momentum GK-Refine" % n_data
+        bts = [batch(n_data, 4096) for _ in range(2)]
+    elif name == "mia2023":
+        n_data = 65536
+        labels = torch.arange(n_data) % 3
+        opt = m.stage2_opt(dropout_rate=0.1, batch_size=B)
+        for k, v in dict(nce_k=4096, nce_p=6, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
+                         max_discrep=2.0, use_grads_thresh="True", grads_thresh=0.0, loss_weighting="GK_refine").items():
+            setattr(opt, k, v)
+        cls = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+        step = m.DistillStep(opt, n_data, device=device, variant="mia2023", train_class_idx=cls, sync=sync)
+        desc = ("BASELINE configs[4] single-GPU leg: MIA-2023 stage 2, CRD bank %d rows (full-bank class-masked cosine KNN, "
+                "nce_p 6), nce_k 4096, per-sample GK-Refine" % n_data)
+        bts = [batch(n_data, 4096, labels) for _ in range(2)]
+    elif name == "tsvd":
+        opt = m.stage2_opt(dropout_rate=0.1, batch_size=B, cut_fuse_grad=True, num_teachers=2)
+        opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, 1.0, 0, 0, "False"
+        # "MIA 2022/options.py":13-21 defaults (n_views 4, Lambda_global 0.05, pho 1.1, max_mu 1) with mu started at 1e-2 so that
+        # the soft threshold Lambda / mu does not zero every singular value (a warm run's regime)
+        opt.tSVD_loss, opt.n_views, opt.tSVD_mode, opt.mu, opt.pho, opt.max_mu = "True", 4, "pathomic", 1e-2, 1.1, 1.0
+        opt.Lambda_global, opt.aux_iter = 0.05, 1
+        step = m.TeacherStage1Step(opt, device=device, sync=sync)
+        desc = ("BASELINE configs[3] single-GPU leg: MIA-2022 stage-1 trainer with the t-SVD term (train_test_tSVD.py), %d tiles, "
+                "4 views, auxiliary update every batch; eager launches" % B)
+        bts = [make_batch(B, H, 1024, opt, device, seed=rank * 100 + 31 + i) for i in range(2)]
+    else:
+        raise SystemExit("unknown variant %r" % name)
+    for c in (getattr(step, "criterion_kd", None), getattr(step, "criterion_kd_path", None)):
+        if c is not None:
+            c.contrast.verbose = False
+    return step, bts, desc
+
+
+def run_variant(name, B, H, device, L, steps=5):
+    """5 steps of one variant with resident inputs (graph replay for the stage-2 bodies), then 2 eager steps under the
+    in-library event timer for the CRD kernels' achieved GB/s.  Returns the `variants[name]` object of the JSON line."""
+    import torch
+    import multimodal_learning_amd as m
+    step, bts, desc = variant_setup(name, B, H, device)
+    graph = hasattr(step, "enable_graph")
+    if graph:
+        step.enable_graph()
+    for i in range(4):
+        step.step(bts[i % 2], epoch=5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step.step(bts[i % 2], epoch=5)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": desc, "tiles_per_gpu": B, "steps": steps, "ms_per_step": round(1000.0 * dt / steps, 3),
+           "value": round(B * steps / dt, 2), "unit": "tiles/s", "final_loss": round(float(out["loss"]), 4),
+           "launch": "one captured HIP graph per step" if graph else "eager"}
+    if graph:
+        step._want_graph = False
+        step._side_stream = None
+        step.step(bts[0], epoch=5)
+        L.ph_prof_reset(); L.ph_prof_enable(1)
+        for i in range(2):
+            step.step(bts[i % 2], epoch=5)
+        torch.cuda.synchronize()
+        L.ph_prof_enable(0)
+        buf = (ctypes.c_double * (4 * NALL))()
+        L.ph_prof_summary4(buf, NALL)
+        traffic = {}
+        tf = os.path.join(ROOT, "profiles", "r03_crd_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(name, {})
+        rows = []
+        for cls, key, nm in ((8, "crd_score", "crd_score_kernel: 2 banks x B x (P+K) rows of 512 B"),
+                             (TOPK_CLS, "crd_bank_topk", "crd_bank_topk_kernel (+ merge): 2 banks x n_data rows of 512 B, each once"),
+                             (9, "crd_loss_grad", "crd_loss_grad_kernel (+ reduce): 2 banks x B x (P2+K2) rows of 512 B")):
+            n, ms, by = buf[4 * cls], buf[4 * cls + 1], buf[4 * cls + 2]
+            if n == 0:
+                continue
+            gbs = by / (ms * 1e-3) / 1e9
+            row = {"kernel": nm, "launches": int(n), "avg_launch_us": round(1000.0 * ms / n, 2),
+                   "algorithmic_mb_per_launch": round(by / n / 1e6, 2), "achieved_gbs": round(gbs, 1), "peak_gbs": HBM_PEAK_GBS,
+                   "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            t = traffic.get(key)
+            if t:   # counter bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) and the rate they give
+                row["traffic"] = t["bytes_per_launch"]
+                row["traffic_gbs"] = round(t["bytes_per_launch"] / (1000.0 * ms / n) / 1e3, 1)
+                row["traffic_frac"] = round(row["traffic_gbs"] / HBM_PEAK_GBS, 4)
+            rows.append(row)
+        res["crd_hbm"] = rows
+    for attr in ("model", "ema_model"):
+        mod = getattr(step, attr, None)
+        for sub in (mod.modules() if mod is not None else ()):
+            if hasattr(sub, "release_workspaces"):
+                sub.release_workspaces()
+    fm = getattr(step, "fix_model", None)
+    if fm is not None:
+        fm.path_net.release_workspaces()
+    del step, bts
+    torch.cuda.empty_cache()
     return res
 
 
@@ -257,6 +383,10 @@ def main():
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
                     "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
+    ap.add_argument("--variant", default="miccai2022", choices=["miccai2022", "mia2022", "mia2023", "tsvd"],
+                    help="run another batch body as the measured step (profiling aid; the default line already carries "
+                         "5-step figures of all three in `variants`)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (configs[3] / configs[4] legs)")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.north_star:
@@ -283,6 +413,35 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
         sync = m.dist.ReplicaSync()
     m.set_precision("bf16")
+    if args.variant != "miccai2022":
+        # profiling aid: another batch body through the same timing protocol (rocprofv3 -- python3 bench.py --variant ...)
+        torch.manual_seed(0)
+        np.random.seed(2019 + rank)
+        L = m.lib()
+        step, batches, desc = variant_setup(args.variant, 128 if (args.variant == "tsvd" and args.batch == 64) else args.batch,
+                                            args.size, device, rank, sync)
+        graph = hasattr(step, "enable_graph") and not args.eager
+        if graph:
+            step.enable_graph()
+        for i in range(max(args.warmup, 4)):
+            step.step(batches[i % 2], epoch=5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step.step(batches[i % 2], epoch=5)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        Bv = batches[0][0][0].shape[0]
+        if rank == 0:
+            print(json.dumps({"metric": "ROI-tiles/sec (variant step)", "value": round(Bv * world * args.steps / dt, 2), "unit": "tiles/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                              "config": {"workload": desc, "tiles_per_gpu": Bv, "final_loss": round(float(out["loss"]), 4),
+                                         "launch": "one captured HIP graph per step" if graph else "eager"}}), flush=True)
+        if sync is not None:
+            torch.distributed.destroy_process_group()
+        return
     opt = m.stage2_opt(dropout_rate=0.1, batch_size=args.batch)
     opt.fused_loss_head = not args.generic_loss_head
     n_data = 1024
@@ -382,6 +541,18 @@ def main():
                                 "of the reference)", "value": round(args.batch * psteps / d2, 2), "unit": "tiles/s",
                   "ms_per_step": round(1000.0 * d2 / psteps, 3), "steps": psteps, "final_loss": round(l2, 4)}
 
+    variants = None
+    if world == 1 and not args.no_variants and not args.device_loader and (args.batch, args.size) == (64, 512):
+        # driver-timed legs of BASELINE configs[3] / configs[4] (VERDICT r02 missing 2) and the CRD kernels against the
+        # HBM roofline at the bank size of configs[4]; the headline step's buffers are released first
+        for mod in (step.model, step.ema_model, step.fix_model.path_net):
+            mod.release_workspaces()
+        step._slots = None; step._static = None
+        torch.cuda.empty_cache()
+        variants = {"mia2022": run_variant("mia2022", 64, args.size, device, L),
+                    "mia2023": run_variant("mia2023", 64, args.size, device, L),
+                    "tsvd_stage1": run_variant("tsvd", 128, args.size, device, L)}
+
     if rank == 0:
         tiles = args.batch * world * args.steps
         res = {"metric": "ROI-tiles/sec (teacher+student distill step)", "value": round(tiles / dt, 2),
@@ -473,6 +644,8 @@ def main():
             res["north_star_global_256"] = strong
         if parity is not None:
             res["parity_mode"] = parity
+        if variants is not None:
+            res["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

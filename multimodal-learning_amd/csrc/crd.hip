@@ -509,10 +509,14 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
   if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX || !workspace) return PH_EINVAL;
   float* cv = reinterpret_cast<float*>(workspace);
   int* ci = reinterpret_cast<int*>(cv + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
+  void* tok = nullptr;
+  if (ph_prof_on())   // algorithmic bytes: every row of both banks once + the row labels + the 2 x B x num_pos results
+    ph_prof_begin(PH_CLS_CRD_TOPK, 2.0 * n_data * D * 4 + 4.0 * n_data + 2.0 * B * num_pos * 12, st, &tok);
   hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2, TOPK_SPLIT), dim3(256), 0, st, mem1, mem2, labels, idx, PK, batch_label,
                      n_data, cv, ci);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(crd_bank_topk_merge_kernel, dim3(B, 2), dim3(256), 0, st, cv, ci, num_pos, nb1, nb2, sim1, sim2);
+  ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -21,7 +21,8 @@
 #define PH_CLS_TAPCONV2_MASKED 12   // tapconv2_kernel<2,2,4,false,MASKED>: stride-2 fwd / merged-class dgrad as masked stride-1 grids
 #define PH_CLS_TAPCONV2_FUSEDIN 13   // class 6 launches that also apply their input's BatchNorm + ReLU in LDS (PhTapConv::in_scale)
 #define PH_CLS_TAPCONV2_RES_FUSEDIN 14   // class 7 (layer-1 kernel) launches that do
-#define PH_NCLS 15
+#define PH_CLS_CRD_TOPK 15      // crd_bank_topk (+ merge): class-masked full-bank cosine KNN, 2 banks x n_data rows of 512 B (each once)
+#define PH_NCLS 16
 #define PH_NUM_CLS 6
 bool ph_prof_on();
 int ph_num_cus();   // compute units of the current device (cached)
