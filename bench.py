@@ -381,6 +381,9 @@ def main():
                     help="A/B switch: first-generation kernel for the 3x3 stride-2 convolutions (not the masked tap grid)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
+    ap.add_argument("--no-stem-pool", action="store_true",
+                    help="A/B: separate stem conv + BatchNorm/ReLU/max-pool passes in the forward-only networks instead of "
+                         "the stem kernel with the pooled epilogue")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the replica-sync code path even "
                     "with one rank (exercises the collectives inside graph capture on a 1-GPU box)")
     ap.add_argument("--variant", default="miccai2022", choices=["miccai2022", "mia2022", "mia2023", "tsvd"],
@@ -456,6 +459,9 @@ def main():
     if args.no_masked:
         for net in (step.model, step.ema_model, step.fix_model.path_net):
             net._no_masked = True
+    if args.no_stem_pool:
+        step.ema_model._no_stem_pool = True
+        step.fix_model.path_net._no_stem_pool = True
     batches = [make_batch(args.batch, args.size, n_data, opt, device, seed=rank * 100 + i) for i in range(2)]
     if sync is not None:
         np.random.seed(2019)   # the 'mid' rank draw is host RNG state shared by all replicas

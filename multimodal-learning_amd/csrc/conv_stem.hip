@@ -232,6 +232,216 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv 7x7/2 + max-pool 3x3/2 of the raw output in one kernel (forward-only networks, perf mode; ph_kernels.h PhStemPool).
+// A workgroup owns a STRIP: image b, 14 conv columns (7 pooled columns) - its 16-column tiles start one column to the left
+// of the owned ones, so every pooling window's three columns lie inside the tile (2 of 16 columns are computed by two
+// strips: 12.5 % more MFMA work on a kernel that was bound by writing 537 MB) - and walks down the image tile by tile;
+// the last conv row of a tile stays in LDS for the first pooling row of the next tile, so no row is recomputed (a strip
+// cut into `nsplit` pieces recomputes one tile per cut for that row).  Per tile: the same MFMA stream as stem_fwd_kernel,
+// then the bf16-rounded outputs go to an LDS staging tile [9 rows][16][64] instead of HBM, one barrier, and 224 threads
+// pool 4 x 7 x 64 outputs from it (16-byte LDS reads, sign-aware max) while the next tile's halo loads are in flight.
+// Staging rows 1..7 are double-buffered and the last row triple-buffered: one barrier per tile protects everything.
+// The staging tile holds ORDER KEYS, not bf16 values: key = bits ^ ((bits >> 15 arithmetic) | 0x8000) is monotone in the
+// bf16 value as an UNSIGNED 16-bit integer, and for a channel with gamma < 0 all 16 bits are flipped once more, so the
+// pooled raw value is always the unsigned MAXIMUM of keys: one v_pk_max_u16 per two channels and tap, no conversions in
+// the pooling loop (the first version converted to fp32 and multiplied by the sign per tap: twice the VALU work of the
+// MFMA stream).  Out-of-image pixels are staged as key 0, the identity of the unsigned maximum.
+constexpr int PCOLS = 14;
+#ifndef PH_STEM_ABL      // ablation builds (`make trace TRACE_TAG=_sN EXTRA=-DPH_STEM_ABL=N`, tests/bench_stem_pool_gpu.py):
+#define PH_STEM_ABL 0    // 1 no halo loads after the first, 2 no pooling phase, 4 no MFMAs, 8 no staging writes
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ unsigned key_of(unsigned bits2, unsigned flip2) {
+  const s16x2 sg = __builtin_bit_cast(s16x2, bits2) >> (short)15;
+  return bits2 ^ ((__builtin_bit_cast(unsigned, sg) | 0x80008000u) ^ flip2);
+}
+__device__ __forceinline__ unsigned bits_of(unsigned key2, unsigned flip2) {
+  const unsigned k = key2 ^ flip2;
+  const s16x2 sg = __builtin_bit_cast(s16x2, ~k) >> (short)15;
+  return k ^ (__builtin_bit_cast(unsigned, sg) | 0x80008000u);
+}
+__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+constexpr int PROWB = TW * 64;   // bf16 elements of one staged conv row
+
+__global__ __launch_bounds__(256) void stem_fwd_pool_kernel(PhStemPool p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ldsX = smem;                 // 2 x XB
+  unsigned char* ldsW = smem + 2 * XB;        // WB
+  bf16* mid = reinterpret_cast<bf16*>(smem + 2 * XB + WB);   // [2][7][16][64]
+  bf16* last = mid + 2 * 7 * PROWB;                          // [3][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncs = (p.OW + PCOLS - 1) / PCOLS;
+  int blk = blockIdx.x;
+  const int split = blk % p.nsplit; blk /= p.nsplit;
+  const int cs = blk % ncs, b = blk / ncs;
+  const int tiles_h = (p.OH + TH - 1) / TH, per = (tiles_h + p.nsplit - 1) / p.nsplit;
+  const int tr_own0 = split * per, tr_end = min(tiles_h, tr_own0 + per);
+  const int tr_begin = tr_own0 > 0 ? tr_own0 - 1 : 0;       // (a cut strip recomputes the tile above for its last row)
+  const int x0 = cs * PCOLS - 1;
+  const bf16* x4 = reinterpret_cast<const bf16*>(p.x4);
+
+  for (int i = tid; i < 7 * 64 * 4; i += 256) {
+    const int ch = i & 3, row = i >> 2;
+    *reinterpret_cast<u32x4*>(ldsW + row * 64 + (wsw(row, ch) << 4)) = reinterpret_cast<const u32x4*>(p.w)[i];
+  }
+  const int m = wave * 32 + (lane & 31), khalf = lane >> 5;
+  const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  constexpr int HCH = (HP + 255) / 256;
+  u32x2 hreg[HCH];
+  const int ix_base = x0 * 2 - 3;
+  auto load_halo_regs = [&](int tr) {
+    const int iy_base = tr * TH * 2 - 3;
+#pragma unroll
+    for (int e = 0; e < HCH; ++e) {
+      const int i = tid + e * 256;
+      const int hr = i / HPW, hc = i - hr * HPW;
+      const int iy = iy_base + hr, ix = ix_base + hc;
+      const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+      const bf16* src = ok ? x4 + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const bf16*>(stem_zero8);
+      hreg[e] = *reinterpret_cast<const u32x2*>(src);
+    }
+  };
+  auto store_halo_regs = [&](unsigned char* dst) {
+#pragma unroll
+    for (int e = 0; e < HCH; ++e) {
+      const int i = tid + e * 256;
+      if (i < HP) *reinterpret_cast<u32x2*>(dst + i * 8) = hreg[e];
+    }
+  };
+  // pooling role of this thread: (pooled row prl of 4, pooled column pcl of 7, 8-channel group cg)
+  const int cg = tid & 7, pcl = (tid >> 3) % 7, prl = (tid >> 3) / 7;
+  unsigned pflip[4];      // pooling role: per channel pair of the 8-channel group, 0xFFFF in the half whose gamma < 0
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    pflip[k] = (p.gamma[cg * 8 + 2 * k] < 0.f ? 0xFFFFu : 0u) | (p.gamma[cg * 8 + 2 * k + 1] < 0.f ? 0xFFFF0000u : 0u);
+  unsigned eflip[2];      // epilogue role: the lane's channel pair (lane & 30, + 1) of each 32-channel half j
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c0 = j * 32 + ((lane & 31) & ~1);
+    eflip[j] = (p.gamma[c0] < 0.f ? 0xFFFFu : 0u) | (p.gamma[c0 + 1] < 0.f ? 0xFFFF0000u : 0u);
+  }
+  // a strip that starts at the top of the image reads a "row above" that does not exist: key 0 = identity of the maximum
+  for (int i = tid; i < 3 * PROWB / 2; i += 256) reinterpret_cast<unsigned*>(last)[i] = 0u;
+
+  if (tr_begin < tr_end) {
+    load_halo_regs(tr_begin);
+    store_halo_regs(ldsX);
+  }
+  __syncthreads();
+  for (int tr = tr_begin; tr < tr_end; ++tr) {
+    const int tpar = tr - tr_begin;
+    const unsigned char* ldsXc = ldsX + (tpar & 1) * XB;
+    if (!(PH_STEM_ABL & 1) && tr + 1 < tr_end) load_halo_regs(tr + 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int chunk = s * 2 + khalf;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsXc + (pbase + kh * HPW + 4 * s + 2 * khalf) * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = kh * 64 + j * 32 + (lane & 31);
+          const bf16x8 bq = *reinterpret_cast<const bf16x8*>(ldsW + row * 64 + (wsw(row, chunk) << 4));
+          if (PH_STEM_ABL & 4) { asm volatile("" ::"v"(a), "v"(bq)); acc[j][0] += 1.f; }
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue 1: statistics of the OWNED pixels (fp32 accumulators), order keys of the bf16 outputs to the staging tile
+    const bool own_tile = tr >= tr_own0;
+    const int r0 = tr * TH;
+    bf16* midb = mid + (tpar & 1) * 7 * PROWB;
+    bf16* lastb = last + (tpar % 3) * PROWB;
+    const bf16* prevb = last + ((tpar + 2) % 3) * PROWB;
+    {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+#pragma unroll
+      for (int q2 = 0; q2 < 8; ++q2) {
+        const int mm = wave * 32 + ((2 * q2) & 3) + 8 * ((2 * q2) >> 2) + 4 * khalf;   // pixel of column 2*q2 (even)
+        const int rl = mm >> 4, cl = mm & 15;
+        const int r = r0 + rl, c = x0 + cl;
+        const bool rok = own_tile && r < p.OH;
+        const bool m0 = rok && cl >= 1 && c < p.OW;                  // owned: local columns 1..14 (cl is even: 2..14)
+        const bool m1 = rok && cl + 1 <= PCOLS && c + 1 < p.OW;      // cl + 1 is odd: 1..13
+        const int cmine = c + (lane & 1);                            // the pixel whose channel pair this lane stages
+        const bool inimg = r < p.OH && cmine >= 0 && cmine < p.OW;
+        bf16* rowp = (rl < 7 ? midb + rl * PROWB : lastb) + (cl + (lane & 1)) * 64 + ((lane & 31) & ~1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float v0 = acc[j][2 * q2], v1 = acc[j][2 * q2 + 1];
+          const float w0 = m0 ? v0 : 0.f, w1 = m1 ? v1 : 0.f;
+          s1[j] += w0 + w1;
+          s2[j] += w0 * w0 + w1 * w1;
+          bf16x2 own;
+          own[0] = (bf16)v0;
+          own[1] = (bf16)v1;
+          const unsigned x = __builtin_bit_cast(unsigned, own);
+          const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+          const unsigned word = __builtin_amdgcn_perm(y, x, psel);                               // [even channel, odd channel]
+          if (PH_STEM_ABL & 8) asm volatile("" ::"v"(word));
+          else *reinterpret_cast<unsigned*>(rowp + j * 32) = inimg ? key_of(word, eflip[j]) : 0u;
+        }
+      }
+    }
+    if (tr + 1 < tr_end) store_halo_regs(ldsX + ((tpar & 1) ^ 1) * XB);
+    __syncthreads();
+    // ---- epilogue 2: 4 x 7 pooled pixels x 64 channels from the staging tile (+ the previous tile's last row)
+    if (!(PH_STEM_ABL & 2) && own_tile && tid < 224) {
+      const int ph = tr * 4 + prl, pw = cs * 7 + pcl;
+      if (ph < p.PH && pw < p.PW) {
+        u32x4 best = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int R = 2 * prl + kh;              // staging row: 0 = last row of the tile above, 1..8 = this tile
+          const bf16* rowp = R == 0 ? prevb : (R <= 7 ? midb + (R - 1) * PROWB : lastb);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(rowp + (2 * pcl + kw) * 64 + cg * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) best[k] = pkmax(best[k], v[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) best[k] = bits_of(best[k], pflip[k]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.pooled) + ((((size_t)b * p.PH + ph) * p.PW + pw) * 64 + cg * 8)) = best;
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][64] (the halo buffers are dead)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
+      const float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (khalf == 0) {
+        red[(wave * 2 + 0) * 64 + j * 32 + (lane & 31)] = a1;
+        red[(wave * 2 + 1) * 64 + j * 32 + (lane & 31)] = a2;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, n = tid & 63;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * 64 + n];
+      p.stats[((size_t)blockIdx.x * 2 + which) * 64 + n] = v;
+    }
+  }
+}
+
 __device__ __forceinline__ int sw_piece(int pix, int piece) { return piece ^ (((pix >> 1) & 1) << 1); }
 
 __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, int off1) {
@@ -414,6 +624,35 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
   } else {
     return PH_EINVAL;
   }
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+
+namespace {
+int stem_pool_nsplit(int B, int OH, int OW) {
+  const int ncs = cdiv(OW, PCOLS), th = cdiv(OH, TH);
+  int ns = 1;
+  while (B * ncs * ns < 2048 && th / (ns * 2) >= 4) ns *= 2;   // >= 8 workgroups per CU; a cut costs one recomputed tile
+  return ns;
+}
+}  // namespace
+
+int ph_stem_pool_stat_parts(int B, int OH, int OW) { return B * cdiv(OW, PCOLS) * stem_pool_nsplit(B, OH, OW); }
+
+int ph_stem_fwd_pool_launch(const PhStemPool* p_, hipStream_t st) {
+  PhStemPool p = *p_;
+  if (!p.x4 || !p.w || !p.pooled || !p.gamma) return PH_EINVAL;
+  p.nsplit = stem_pool_nsplit(p.B, p.OH, p.OW);
+  void* tok = nullptr;
+  if (ph_prof_on())   // bytes: the packed image once + the pooled 64-channel output
+    ph_prof_begin2(PH_CLS_STEM_FWD, 2.0 * p.B * p.OH * p.OW * 64.0 * 147.0,
+                   ((double)p.B * p.IH * p.IW * 4 + (double)p.B * p.PH * p.PW * 64) * 2.0, st, &tok);
+  struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
+  static bool done = false;
+  const int lds = 2 * XB + WB + (2 * 7 + 3) * PROWB * 2;
+  if (set_lds(stem_fwd_pool_kernel, lds, done)) return PH_ELAUNCH;
+  hipLaunchKernelGGL(stem_fwd_pool_kernel, dim3(ph_stem_pool_stat_parts(p.B, p.OH, p.OW)), dim3(256), lds, st, p);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -99,6 +99,19 @@ struct PhStem {
 };
 int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st);
 int ph_stem_stat_parts(int B, int OH, int OW);
+// forward-only networks, perf mode: the same convolution with the 3x3 / stride-2 / pad-1 max-pool applied to its RAW
+// output in the epilogue - the [B][OH][OW][64] conv output is never written.  pooled [B][PH][PW][64] bf16 receives, per
+// channel, the window's MAXIMUM of the bf16-rounded conv output where gamma >= 0 and its MINIMUM where gamma < 0:
+// relu(scale * y + shift) is monotone in y with the sign of scale = gamma * invstd = the sign of gamma, so BatchNorm +
+// ReLU applied to this tensor afterwards (bn_apply, in place) gives bitwise the separate pooling pass's result.
+// stats: BatchNorm partial sums over ALL conv pixels (each counted once), ph_stem_pool_stat_parts() rows of [2][64].
+struct PhStemPool {
+  const void* x4; const void* w; size_t wplane;
+  void* pooled; float* stats; const float* gamma;
+  int B, IH, IW, OH, OW, PH, PW, nsplit;
+};
+int ph_stem_fwd_pool_launch(const PhStemPool* p, hipStream_t st);
+int ph_stem_pool_stat_parts(int B, int OH, int OW);
 
 struct PhStemWgrad {
   const void* x4; const void* dy; float* slab;   // slab [nchunks][7][64][32]

@@ -89,7 +89,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   P->PH0 = (s.OH + 1) / 2; P->PW0 = (s.OW + 1) / 2;
   P->p0_off = take((size_t)B * P->PH0 * P->PW0 * 64 * es);
   P->idx_off = take((size_t)B * P->PH0 * P->PW0 * 64);
-  size_t parts_max = (size_t)ph_stem_stat_parts(B, s.OH, s.OW) * 2 * 64 * sizeof(float);
+  size_t parts_max = (size_t)std::max(ph_stem_stat_parts(B, s.OH, s.OW), ph_stem_pool_stat_parts(B, s.OH, s.OW)) * 2 * 64 * sizeof(float);
   size_t slab_max = 0;
   { int tpc; int nc = stem_chunks(B, s.OH, s.OW, &tpc); slab_max = (size_t)nc * 7 * 64 * 32 * sizeof(float); }
   size_t act_max = (size_t)B * P->PH0 * P->PW0 * 64 * es;
@@ -325,7 +325,9 @@ extern "C" {
 // perf mode bn1 + ReLU of every block is then applied by conv2 itself while it stages its input (conv_tap2.hip,
 // PhTapConv::in_scale): the a1 tensor is neither written nor read, 8 bn_apply launches per forward disappear;
 // bit3 = A/B and test switch: separate bn_apply passes although bit2 is set;
-// bit4 = A/B and test switch: the first-generation kernel for the 3x3 stride-2 convolutions (not the masked grid)
+// bit4 = A/B and test switch: the first-generation kernel for the 3x3 stride-2 convolutions (not the masked grid);
+// bit5 = A/B and test switch: separate stem conv and BatchNorm + ReLU + max-pool passes although bit2 is set (perf mode
+// otherwise pools the raw conv output inside the stem kernel, PhStemPool)
 int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const void* packed, const float* x_nchw,
                       void* ws_, float* f3, float* f4, int flags, hipStream_t st) {
   if (!P || !params || !packed || !x_nchw || !ws_) return PH_EINVAL;
@@ -348,6 +350,27 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     }
     if ((rc = ph_bn_eval_params_launch(&t, 1e-5f, st))) return rc;
   }
+  if ((flags & 4) && !(flags & 32) && P->prec == PH_PREC_BF16) {
+    // forward-only network, perf mode: the stem conv pools its own raw output (sign-aware max / min, conv_stem.hip
+    // stem_fwd_pool_kernel) - the 537 MB conv output (B = 64, 512 x 512) is never written - and BatchNorm + ReLU is
+    // applied to the pooled tensor in place; bitwise the separate passes' result (relu(scale * y + shift) is monotone)
+    const Unit& u = P->units[0];
+    PhStemPool s{};
+    s.x4 = ws + P->x4_off; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
+    s.pooled = ws + P->p0_off; s.stats = c.eval ? nullptr : reinterpret_cast<float*>(ws + P->parts_off);
+    s.gamma = (const float*)params[1];
+    s.B = P->B; s.IH = P->H; s.IW = P->W; s.OH = u.OH; s.OW = u.OW; s.PH = P->PH0; s.PW = P->PW0;
+    if ((rc = ph_stem_fwd_pool_launch(&s, st))) return rc;
+    float* rm = c.update_running ? (float*)params[3] : nullptr;
+    if (!c.eval && (rc = ph_bn_finalize_launch(s.stats, ph_stem_pool_stat_parts(P->B, u.OH, u.OW), 64, (double)P->B * u.OH * u.OW,
+                                    1e-5f, 0.1f, (const float*)params[1], (const float*)params[2], c.stat(u, 0),
+                                    c.stat(u, 1), c.stat(u, 2), c.stat(u, 3), rm, (float*)params[4],
+                                    (int64_t*)params[5], st)))
+      return rc;
+    if ((rc = ph_bn_apply_launch(ws + P->p0_off, c.stat(u, 2), c.stat(u, 3), nullptr, nullptr, nullptr, nullptr,
+                                 ws + P->p0_off, (size_t)P->B * P->PH0 * P->PW0, 64, 1, P->prec, st)))
+      return rc;
+  } else
   {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
     const Unit& u = P->units[0];
     PhStem s{};

@@ -94,8 +94,9 @@ class _TrunkFn(torch.autograd.Function):
         # teacher networks of the distillation step) - the trunk then fuses bn1 + ReLU into conv2's operand staging;
         # +8 (`net._no_fuse`, an A/B and test switch) keeps the separate passes; +16 (`net._no_masked`, likewise) keeps the
         # first-generation kernel for the 3x3 stride-2 convolutions
+        # +32 (`net._no_stem_pool`, likewise) keeps the separate stem conv and pooling passes in forward-only networks
         flags = (1 if net.training else 2) | (0 if any(ctx.needs_input_grad) else 4) | (8 if getattr(net, "_no_fuse", False) else 0) | \
-            (16 if getattr(net, "_no_masked", False) else 0)
+            (16 if getattr(net, "_no_masked", False) else 0) | (32 if getattr(net, "_no_stem_pool", False) else 0)
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4), flags, stream()),
               "ph_resnet_forward")
         ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table

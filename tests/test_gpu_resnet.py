@@ -481,6 +481,65 @@ def test_fused_input_batchnorm_equals_separate_pass(B, H):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H", [(4, 64), (3, 160), (2, 224), (5, 72), (8, 512)])
+def test_stem_conv_with_pooled_epilogue_equals_separate_passes(B, H):
+    """Forward-only networks in perf mode never write the stem's conv output: stem_fwd_pool_kernel pools the bf16-rounded
+    RAW output inside the conv kernel (maximum where gamma >= 0, minimum where gamma < 0) and BatchNorm + ReLU is applied to
+    the pooled tensor - relu(scale * y + shift) is monotone in y, so this equals pooling the activated tensor
+    (resnets.py:219-222: conv1 - bn1 - relu - maxpool).  Checked against the separate passes (`_no_stem_pool`):
+      * eval mode (fixed running statistics, some gamma negative, one zero): the pooled activation and every output BITWISE;
+      * train mode: the BatchNorm sums are taken over other workgroup tiles (strips of 14 columns with a recomputed halo
+        column that must be counted once) - batch statistics to 1e-6, pooled activation within one bf16 step, and the
+        running statistics to 1e-6;
+      * ragged maps (72 -> 36 x 36 conv pixels: strips of 14 + 8, 160 -> 80: a cut strip at the larger batch), odd sizes."""
+    import ctypes as C
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd._lib import lib, check
+    from oracle.step import synthetic_batch
+    m.set_precision("bf16")
+    x = synthetic_batch(B, H, seed=37)["x_path"].cuda()
+    for training in (False, True):
+        outs = {}
+        for no_pool in (True, False, False):
+            net = _student()
+            with torch.no_grad():
+                g = net.bn1.weight
+                g[::5] = -g[::5].abs() - 0.1          # negative gamma: the pooled raw value must be the window's MINIMUM
+                g[7] = 0.0
+                net.bn1.running_mean.normal_(0, 0.3, generator=torch.Generator(device="cuda").manual_seed(1))
+                net.bn1.running_var.uniform_(0.5, 2.0, generator=torch.Generator(device="cuda").manual_seed(2))
+            net.train(training)
+            net._no_stem_pool = no_pool
+            with torch.no_grad():
+                f3, feat, hazard, pred, _ = net(x_path=x)
+            plan = net._get_plan(B, H, H)
+            ws = net._get_workspace(plan, False)
+            off = C.c_size_t(0); dims = (C.c_int * 4)()
+            check(lib().ph_resnet_tensor_info(plan.h, 3, 0, C.byref(off), dims), "tensor_info")
+            n = dims[0] * dims[1] * dims[2] * dims[3]
+            pooled = ws[off.value: off.value + 2 * n].view(torch.bfloat16).clone()
+            check(lib().ph_resnet_tensor_info(plan.h, 8, 0, C.byref(off), dims), "tensor_info")
+            stats = ws[off.value: off.value + 16 * 64].view(torch.float32).clone()
+            key = "separate" if no_pool else ("pooled" if "pooled" not in outs else "pooled again")
+            outs[key] = (pooled, stats, f3.clone(), feat.clone(), hazard.clone(), net.bn1.running_mean.clone(), net.bn1.running_var.clone())
+        sep = outs["separate"]
+        assert torch.equal(outs["pooled"][0], outs["pooled again"][0]) and torch.equal(outs["pooled"][4], outs["pooled again"][4])
+        got = outs["pooled"]
+        if not training:
+            for a, b in zip(sep, got):
+                assert torch.equal(a, b), (training, (a.float() - b.float()).abs().max().item())
+        else:
+            assert ((sep[1] - got[1]).abs() <= 1e-6 * sep[1].abs() + 1e-6).all(), "batch statistics"
+            for a, b in zip(sep[5:], got[5:]):
+                assert ((a - b).abs() <= 1e-6 * a.abs() + 1e-7).all(), "running statistics"
+            a, b = sep[0].float(), got[0].float()
+            assert ((a - b).abs() <= a.abs() * 2.0 ** -7 + 1e-30).all(), (a - b).abs().max().item()      # one bf16 step
+            assert (a != b).float().mean().item() <= 1e-3
+            for a, b in zip(sep[2:5], got[2:5]):
+                assert (a - b).norm() <= 2e-2 * a.norm()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H", [(4, 128), (6, 160)])
 def test_masked_stride2_grid_vs_first_generation_kernel(B, H):
     """The 3x3 stride-2 convolutions (conv1 of layers 2-4) run in perf mode as a MASKED stride-1 grid over the four
