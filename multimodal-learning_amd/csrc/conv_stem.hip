@@ -243,38 +243,45 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
 // then the bf16-rounded outputs go to an LDS staging tile [9 rows][16][64] instead of HBM, one barrier, and 224 threads
 // pool 4 x 7 x 64 outputs from it (16-byte LDS reads, sign-aware max) while the next tile's halo loads are in flight.
 // Staging rows 1..7 are double-buffered and the last row triple-buffered: one barrier per tile protects everything.
-// The staging tile holds ORDER KEYS, not bf16 values: key = bits ^ ((bits >> 15 arithmetic) | 0x8000) is monotone in the
-// bf16 value as an UNSIGNED 16-bit integer, and for a channel with gamma < 0 all 16 bits are flipped once more, so the
-// pooled raw value is always the unsigned MAXIMUM of keys: one v_pk_max_u16 per two channels and tap, no conversions in
-// the pooling loop (the first version converted to fp32 and multiplied by the sign per tap: twice the VALU work of the
-// MFMA stream).  Out-of-image pixels are staged as key 0, the identity of the unsigned maximum.
+// The staging tile holds the bf16 bit patterns themselves and the pooling loop compares them with v_pk_max_f16: bf16 and
+// fp16 are both sign-magnitude formats, so for finite values the fp16 ordering of two bit patterns IS the bf16 ordering
+// (patterns that fp16 reads as inf / NaN are bf16 magnitudes >= 2^121, fp16 denormals - preserved by the default float
+// mode - bf16 magnitudes < 2^-119).  Channels with gamma < 0 are staged with their sign bit flipped, which turns the
+// minimum they need into a maximum; the flip is undone on the pooled value.  Out-of-image pixels are staged as 0xFC00,
+// fp16's -inf, the identity of the maximum.  One v_pk_max_f16 per two channels and tap, no conversions: the first version
+// (fp32 compares, a sign multiply per tap, per-element masks everywhere) issued ~1000 vector instructions per tile and
+// wave against 28 MFMAs and was bound by exactly that (ablation builds: every phase cost its full time, nothing overlapped).
 constexpr int PCOLS = 14;
 #ifndef PH_STEM_ABL      // ablation builds (`make trace TRACE_TAG=_sN EXTRA=-DPH_STEM_ABL=N`, tests/bench_stem_pool_gpu.py):
 #define PH_STEM_ABL 0    // 1 no halo loads after the first, 2 no pooling phase, 4 no MFMAs, 8 no staging writes
 #endif
-typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-__device__ __forceinline__ unsigned key_of(unsigned bits2, unsigned flip2) {
-  const s16x2 sg = __builtin_bit_cast(s16x2, bits2) >> (short)15;
-  return bits2 ^ ((__builtin_bit_cast(unsigned, sg) | 0x80008000u) ^ flip2);
-}
-__device__ __forceinline__ unsigned bits_of(unsigned key2, unsigned flip2) {
-  const unsigned k = key2 ^ flip2;
-  const s16x2 sg = __builtin_bit_cast(s16x2, ~k) >> (short)15;
-  return k ^ (__builtin_bit_cast(unsigned, sg) | 0x80008000u);
-}
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 __device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)));
+}
+constexpr unsigned POOL_IDENT = 0xFC00FC00u;
+// scalar fp32 add / fused multiply-add the SLP vectoriser cannot pair: hipcc -O3 turned the BatchNorm sums of the epilogue
+// into v_pk_add_f32 / v_pk_mul_f32, which cost ~16 cycles each beside an MFMA stream (the staging phase: 2200 cycles for
+// ~200 instructions, interval tracer) - MI355X_MICROARCH.md, "price of one filler beside MFMAs"
+__device__ __forceinline__ float fadd_s(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float ffma_s(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 constexpr int PROWB = TW * 64;   // bf16 elements of one staged conv row
 
-__global__ __launch_bounds__(256) void stem_fwd_pool_kernel(PhStemPool p) {
+__global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsX = smem;                 // 2 x XB
-  unsigned char* ldsW = smem + 2 * XB;        // WB
-  bf16* mid = reinterpret_cast<bf16*>(smem + 2 * XB + WB);   // [2][7][16][64]
-  bf16* last = mid + 2 * 7 * PROWB;                          // [3][16][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* mid = smem + 2 * XB;         // [2][7][16][64] bf16
+  unsigned char* last = mid + 2 * 7 * PROWB * 2;   // [3][16][64] bf16
+  // (the wave number read through readfirstlane lives in an SGPR: branches and row addresses derived from it are scalar)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ncs = (p.OW + PCOLS - 1) / PCOLS;
   int blk = blockIdx.x;
   const int split = blk % p.nsplit; blk /= p.nsplit;
@@ -285,25 +292,46 @@ __global__ __launch_bounds__(256) void stem_fwd_pool_kernel(PhStemPool p) {
   const int x0 = cs * PCOLS - 1;
   const bf16* x4 = reinterpret_cast<const bf16*>(p.x4);
 
-  for (int i = tid; i < 7 * 64 * 4; i += 256) {
-    const int ch = i & 3, row = i >> 2;
-    *reinterpret_cast<u32x4*>(ldsW + row * 64 + (wsw(row, ch) << 4)) = reinterpret_cast<const u32x4*>(p.w)[i];
-  }
   const int m = wave * 32 + (lane & 31), khalf = lane >> 5;
+  // ALL weight fragments of the lane live in registers for the whole strip (7 x 2 x 2 fragments of 16 bytes = 112 VGPRs):
+  // with the weights in LDS a tile needed 28 + 14 ds_read_b128 per wave for its 28 MFMAs and the LDS array, not the
+  // matrix pipe, set the tile time (ablation with everything but the operand reads removed: 111 of 291 us)
+  bf16x8 wfrag[7][2][2];
+#pragma unroll
+  for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wfrag[kh][s2][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.w) +
+                                                            ((size_t)(kh * 64 + j * 32 + (lane & 31)) * 32 + (s2 * 2 + khalf) * 8));
   const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  // ---- halo: the thread's (up to) four pixels of the 21 x 38 halo keep their offsets for the whole strip; only the row
+  // validity changes from tile to tile
   constexpr int HCH = (HP + 255) / 256;
   u32x2 hreg[HCH];
-  const int ix_base = x0 * 2 - 3;
-  auto load_halo_regs = [&](int tr) {
-    const int iy_base = tr * TH * 2 - 3;
+  int hrow[HCH];            // halo row of element e, or a large value when the element does not exist / its column is outside
+  long hoff[HCH];           // element offset from the tile's first halo row
+  {
+    const int ix_base = x0 * 2 - 3;
 #pragma unroll
     for (int e = 0; e < HCH; ++e) {
       const int i = tid + e * 256;
       const int hr = i / HPW, hc = i - hr * HPW;
-      const int iy = iy_base + hr, ix = ix_base + hc;
-      const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-      const bf16* src = ok ? x4 + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const bf16*>(stem_zero8);
+      const int ix = ix_base + hc;
+      hrow[e] = (i < HP && ix >= 0 && ix < p.IW) ? hr : (1 << 28);
+      hoff[e] = ((long)hr * p.IW + ix) * 4;
+    }
+  }
+  const bf16* ximg = x4 + (size_t)b * p.IH * p.IW * 4;
+  auto load_halo_regs = [&](int tr) {
+    const int iy_base = tr * TH * 2 - 3;
+    const bf16* rowbase = ximg + (long)iy_base * p.IW * 4;
+#pragma unroll
+    for (int e = 0; e < HCH; ++e) {
+      const unsigned iy = (unsigned)(iy_base + hrow[e]);      // (invalid elements: a huge row)
+      const bf16* src = iy < (unsigned)p.IH ? rowbase + hoff[e] : reinterpret_cast<const bf16*>(stem_zero8);
       hreg[e] = *reinterpret_cast<const u32x2*>(src);
     }
   };
@@ -314,107 +342,143 @@ __global__ __launch_bounds__(256) void stem_fwd_pool_kernel(PhStemPool p) {
       if (i < HP) *reinterpret_cast<u32x2*>(dst + i * 8) = hreg[e];
     }
   };
-  // pooling role of this thread: (pooled row prl of 4, pooled column pcl of 7, 8-channel group cg)
+  // ---- pooling role of this thread: (pooled row prl of 4, pooled column pcl of 7, 8-channel group cg)
   const int cg = tid & 7, pcl = (tid >> 3) % 7, prl = (tid >> 3) / 7;
-  unsigned pflip[4];      // pooling role: per channel pair of the 8-channel group, 0xFFFF in the half whose gamma < 0
+  unsigned pflip[4];      // sign-bit flips of the group's channel pairs (gamma < 0)
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    pflip[k] = (p.gamma[cg * 8 + 2 * k] < 0.f ? 0xFFFFu : 0u) | (p.gamma[cg * 8 + 2 * k + 1] < 0.f ? 0xFFFF0000u : 0u);
-  unsigned eflip[2];      // epilogue role: the lane's channel pair (lane & 30, + 1) of each 32-channel half j
+    pflip[k] = (p.gamma[cg * 8 + 2 * k] < 0.f ? 0x8000u : 0u) | (p.gamma[cg * 8 + 2 * k + 1] < 0.f ? 0x80000000u : 0u);
+  const int poff = (2 * pcl * 64 + cg * 8) * 2;               // byte offset of the window's first column in a staged row
+  // ---- epilogue role: the lane's channel pair (lane & 30, + 1) of each 32-channel half j; its staging byte offset
+  unsigned eflip[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c0 = j * 32 + ((lane & 31) & ~1);
-    eflip[j] = (p.gamma[c0] < 0.f ? 0xFFFFu : 0u) | (p.gamma[c0 + 1] < 0.f ? 0xFFFF0000u : 0u);
+    eflip[j] = (p.gamma[c0] < 0.f ? 0x8000u : 0u) | (p.gamma[c0 + 1] < 0.f ? 0x80000000u : 0u);
   }
-  // a strip that starts at the top of the image reads a "row above" that does not exist: key 0 = identity of the maximum
-  for (int i = tid; i < 3 * PROWB / 2; i += 256) reinterpret_cast<unsigned*>(last)[i] = 0u;
+  const int eoff = ((4 * khalf + (lane & 1)) * 64 + ((lane & 31) & ~1)) * 2;
+  // local columns 0 and 15 of a tile belong to the neighbouring strips: registers (khalf 0: q = 0, 8), (khalf 1: q = 7, 15)
+  const float own_lo = khalf == 0 ? 0.f : 1.f, own_hi = khalf == 1 ? 0.f : 1.f;
+  // a strip that starts at the top of the image reads a "row above" that does not exist
+  for (int i = tid; i < 3 * PROWB / 2; i += 256) reinterpret_cast<unsigned*>(last)[i] = POOL_IDENT;
 
   if (tr_begin < tr_end) {
     load_halo_regs(tr_begin);
     store_halo_regs(ldsX);
   }
   __syncthreads();
+  const bool strip_inside = x0 >= 0 && x0 + TW <= p.OW;
   for (int tr = tr_begin; tr < tr_end; ++tr) {
     const int tpar = tr - tr_begin;
     const unsigned char* ldsXc = ldsX + (tpar & 1) * XB;
     if (!(PH_STEM_ABL & 1) && tr + 1 < tr_end) load_halo_regs(tr + 1);
     f32x16 acc[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-#pragma unroll
     for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int chunk = s * 2 + khalf;
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsXc + (pbase + kh * HPW + 4 * s + 2 * khalf) * 8);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int row = kh * 64 + j * 32 + (lane & 31);
-          const bf16x8 bq = *reinterpret_cast<const bf16x8*>(ldsW + row * 64 + (wsw(row, chunk) << 4));
-          if (PH_STEM_ABL & 4) { asm volatile("" ::"v"(a), "v"(bq)); acc[j][0] += 1.f; }
-          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[j], 0, 0, 0);
+          if (kh == 0 && s == 0) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wfrag[0][0][j], zero, 0, 0, 0);   // (C = inline constant 0)
+          } else if (PH_STEM_ABL & 4) { asm volatile("" ::"v"(a), "v"(wfrag[kh][s][j])); acc[j][0] += 1.f; }
+          else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wfrag[kh][s][j], acc[j], 0, 0, 0);
         }
       }
     }
-    // ---- epilogue 1: statistics of the OWNED pixels (fp32 accumulators), order keys of the bf16 outputs to the staging tile
+    // ---- epilogue 1: statistics of the OWNED pixels (fp32 accumulators), bf16 outputs to the staging tile
     const bool own_tile = tr >= tr_own0;
     const int r0 = tr * TH;
-    bf16* midb = mid + (tpar & 1) * 7 * PROWB;
-    bf16* lastb = last + (tpar % 3) * PROWB;
-    const bf16* prevb = last + ((tpar + 2) % 3) * PROWB;
-    {
-      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-      const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+    unsigned char* midb = mid + (tpar & 1) * 7 * PROWB * 2;
+    unsigned char* lastb = last + (tpar % 3) * PROWB * 2;
+    const unsigned char* prevb = last + ((tpar + 2) % 3) * PROWB * 2;
+    // the wave's two conv rows of the tile: 2 * wave and 2 * wave + 1 (the tile's row 7 is the carried one)
+    unsigned char* erow0 = midb + (2 * wave) * PROWB * 2 + eoff;
+    unsigned char* erow1 = (wave < 3 ? midb + (2 * wave + 1) * PROWB * 2 : lastb) + eoff;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+    // (out-of-image pixels are staged like any other: the pooling pass skips them by coordinate)
+    auto stage = [&](auto insidec) {
+      constexpr bool INSIDE = decltype(insidec)::value;
+      if constexpr (!INSIDE) asm volatile("; edge tile: masked statistics" ::: "memory");   // keeps the two paths apart
 #pragma unroll
       for (int q2 = 0; q2 < 8; ++q2) {
-        const int mm = wave * 32 + ((2 * q2) & 3) + 8 * ((2 * q2) >> 2) + 4 * khalf;   // pixel of column 2*q2 (even)
-        const int rl = mm >> 4, cl = mm & 15;
-        const int r = r0 + rl, c = x0 + cl;
-        const bool rok = own_tile && r < p.OH;
-        const bool m0 = rok && cl >= 1 && c < p.OW;                  // owned: local columns 1..14 (cl is even: 2..14)
-        const bool m1 = rok && cl + 1 <= PCOLS && c + 1 < p.OW;      // cl + 1 is odd: 1..13
-        const int cmine = c + (lane & 1);                            // the pixel whose channel pair this lane stages
-        const bool inimg = r < p.OH && cmine >= 0 && cmine < p.OW;
-        bf16* rowp = (rl < 7 ? midb + rl * PROWB : lastb) + (cl + (lane & 1)) * 64 + ((lane & 31) & ~1);
+        constexpr int CO[4] = {0, 2, 8, 10};
+        const int clc = CO[q2 & 3];                      // + 4 * khalf (in eoff): local column of register 2 * q2
+        unsigned char* dst = (q2 < 4 ? erow0 : erow1) + clc * 128;
+        float k0 = 1.f, k1 = 1.f;
+        if constexpr (!INSIDE) {
+          const int r = r0 + 2 * wave + (q2 >> 2), c = x0 + clc + 4 * khalf;
+          k0 = (r < p.OH && c >= 0 && c < p.OW) ? 1.f : 0.f;
+          k1 = (r < p.OH && c + 1 >= 0 && c + 1 < p.OW) ? 1.f : 0.f;
+        }
+        if (q2 == 0 || q2 == 4) k0 *= own_lo;            // register 0 / 8: local column 0 when khalf == 0
+        if (q2 == 3 || q2 == 7) k1 *= own_hi;            // register 7 / 15: local column 15 when khalf == 1
+        const bool edge0 = !INSIDE || q2 == 0 || q2 == 4, edge1 = !INSIDE || q2 == 3 || q2 == 7;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v0 = acc[j][2 * q2], v1 = acc[j][2 * q2 + 1];
-          const float w0 = m0 ? v0 : 0.f, w1 = m1 ? v1 : 0.f;
-          s1[j] += w0 + w1;
-          s2[j] += w0 * w0 + w1 * w1;
+          if (own_tile && !(PH_STEM_ABL & 32)) {
+            const float w0 = edge0 ? v0 * k0 : v0, w1 = edge1 ? v1 * k1 : v1;
+            s1[j] = fadd_s(fadd_s(s1[j], w0), w1);
+            s2[j] = ffma_s(w1, w1, ffma_s(w0, w0, s2[j]));
+          }
+          if (PH_STEM_ABL & 64) { asm volatile("" ::"v"(v0), "v"(v1)); continue; }
           bf16x2 own;
           own[0] = (bf16)v0;
           own[1] = (bf16)v1;
           const unsigned x = __builtin_bit_cast(unsigned, own);
           const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-          const unsigned word = __builtin_amdgcn_perm(y, x, psel);                               // [even channel, odd channel]
+          const unsigned word = __builtin_amdgcn_perm(y, x, psel) ^ eflip[j];                    // [even channel, odd channel]
           if (PH_STEM_ABL & 8) asm volatile("" ::"v"(word));
-          else *reinterpret_cast<unsigned*>(rowp + j * 32) = inimg ? key_of(word, eflip[j]) : 0u;
+          else *reinterpret_cast<unsigned*>(dst + j * 64) = word;
         }
       }
-    }
+    };
+    if (strip_inside && r0 + TH <= p.OH) stage(std::true_type{});
+    else stage(std::false_type{});
     if (tr + 1 < tr_end) store_halo_regs(ldsX + ((tpar & 1) ^ 1) * XB);
-    __syncthreads();
+    // LDS-only barrier (__syncthreads() would also drain the vector-memory counter: the pooled stores of the tile before)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // ---- epilogue 2: 4 x 7 pooled pixels x 64 channels from the staging tile (+ the previous tile's last row)
     if (!(PH_STEM_ABL & 2) && own_tile && tid < 224) {
       const int ph = tr * 4 + prl, pw = cs * 7 + pcl;
       if (ph < p.PH && pw < p.PW) {
-        u32x4 best = {0u, 0u, 0u, 0u};
+        u32x4 best = {POOL_IDENT, POOL_IDENT, POOL_IDENT, POOL_IDENT};
+        // a window leaves the image only at column -1 (pw == 0), at column OW (last pw of an odd OW) and at row OH (last
+        // ph of an odd OH); row -1 (ph == 0) reads the identity rows `last` was initialised with
+        const bool cut_l = pw == 0, cut_r = 2 * pw + 1 >= p.OW, cut_b = 2 * ph + 1 >= p.OH;
+        auto pool = [&](auto edgec) {
+          constexpr bool EDGE = decltype(edgec)::value;
+          if constexpr (EDGE) asm volatile("; edge window" ::: "memory");
+          u32x4 v[3][3];       // all nine 16-byte reads are issued before the first compare (the accumulators are dead here)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int R = 2 * prl + kh;              // staging row: 0 = last row of the tile above, 1..8 = this tile
-          const bf16* rowp = R == 0 ? prevb : (R <= 7 ? midb + (R - 1) * PROWB : lastb);
+          for (int kh = 0; kh < 3; ++kh) {
+            const int R = 2 * prl + kh;              // staging row: 0 = last row of the tile above, 1..8 = this tile
+            const unsigned char* rowp = (R == 0 ? prevb : (R <= 7 ? midb + (R - 1) * PROWB * 2 : lastb)) + poff;
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(rowp + (2 * pcl + kw) * 64 + cg * 8);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) best[k] = pkmax(best[k], v[k]);
+            for (int kw = 0; kw < 3; ++kw) v[kh][kw] = *reinterpret_cast<const u32x4*>(rowp + kw * 128);
           }
-        }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) best[k] = bits_of(best[k], pflip[k]);
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              if constexpr (EDGE) {
+                const bool skip = (kw == 0 && cut_l) || (kw == 2 && cut_r) || (kh == 2 && cut_b);
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) v[kh][kw][kq] = skip ? POOL_IDENT : v[kh][kw][kq];
+              }
+#pragma unroll
+              for (int kq = 0; kq < 4; ++kq) best[kq] = pkmax(best[kq], v[kh][kw][kq]);
+            }
+        };
+        if (cut_l || cut_r || cut_b) pool(std::true_type{});
+        else pool(std::false_type{});
+#pragma unroll
+        for (int k = 0; k < 4; ++k) best[k] ^= pflip[k];
         *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(p.pooled) + ((((size_t)b * p.PH + ph) * p.PW + pw) * 64 + cg * 8)) = best;
       }
     }
@@ -650,7 +714,7 @@ int ph_stem_fwd_pool_launch(const PhStemPool* p_, hipStream_t st) {
                    ((double)p.B * p.IH * p.IW * 4 + (double)p.B * p.PH * p.PW * 64) * 2.0, st, &tok);
   struct EndGuard { void* t; hipStream_t s; ~EndGuard() { ph_prof_end(t, s); } } guard{tok, st};
   static bool done = false;
-  const int lds = 2 * XB + WB + (2 * 7 + 3) * PROWB * 2;
+  const int lds = 2 * XB + (2 * 7 + 3) * PROWB * 2;
   if (set_lds(stem_fwd_pool_kernel, lds, done)) return PH_ELAUNCH;
   hipLaunchKernelGGL(stem_fwd_pool_kernel, dim3(ph_stem_pool_stat_parts(p.B, p.OH, p.OW)), dim3(256), lds, st, p);
   PH_LAUNCH_CHECK();

@@ -29,10 +29,12 @@ def main():
     stats = torch.empty(16384 * 128, device="cuda")
     gamma = torch.ones(64, device="cuda")
     libs = [os.path.join(PKG, "libpathomic_hip.so")] + sorted(glob.glob(os.path.join(PKG, "libpathomic_hip_trace_s*.so")))
+    if os.environ.get("ONLY_MAIN"):
+        libs = libs[:1]
     st = torch.cuda.current_stream().cuda_stream
     for path in libs:
         L = C.CDLL(path)
-        fn = L.ph_stem_fwd_pool_launch
+        fn = getattr(L, "_Z23ph_stem_fwd_pool_launchPK10PhStemPoolP12ihipStream_t")   # library-internal C++ symbol
         fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_void_p]
         p = PhStemPool(x4.data_ptr(), w.data_ptr(), 7 * 64 * 32, pooled.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                        B, H, H, OH, OH, PH, PH, 0)
@@ -46,6 +48,18 @@ def main():
             fn(C.byref(p), st)
         e1.record(); torch.cuda.synchronize()
         print(f"{os.path.basename(path):40s} {e0.elapsed_time(e1) / R * 1e3:8.1f} us")
+        if "trace_st" in path:      # PH_STEM_TRACE build: s_memtime stamps (interval start, before barrier, after barrier)
+            tr = stats.view(torch.int32)[(1 << 20):(1 << 20) + 8 * 256].cpu().view(8, 256).long() & 0xffffffff
+            for row in (0, 1, 2, 3):
+                t = tr[row]
+                t0 = int(t[0])
+                print("wg", row // 2, "group", row % 2, "work / barrier-wait cycles per interval:")
+                print("   ", " ".join(f"{int(t[3 * k + 1] - t[3 * k]) & 0xffffffff}/{int(t[3 * k + 2] - t[3 * k + 1]) & 0xffffffff}" for k in range(37)))
+                print("    total", (int(t[3 * 36 + 2]) - t0) & 0xffffffff)
+                ks = [k for k in range(6, 30) if (k - row % 2) % 2 == 1]
+                print("    S+P intervals: stage / halo store / halo load issue / pool:",
+                      " ".join(f"{int(t[128 + 3 * k] - t[3 * k]) & 0xffffffff}/{int(t[128 + 3 * k + 1] - t[128 + 3 * k]) & 0xffffffff}/"
+                               f"{int(t[128 + 3 * k + 2] - t[128 + 3 * k + 1]) & 0xffffffff}/{int(t[3 * k + 1] - t[128 + 3 * k + 2]) & 0xffffffff}" for k in ks[:6]))
 
 
 if __name__ == "__main__":
