@@ -76,7 +76,8 @@ __global__ void bn_eval_params_kernel(PhBnEvalTable t, float eps) {
   }
 }
 
-// out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] ), 8 channels per thread
+// out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r | relu(y_r*scale_r + shift_r)] ), 8 channels per thread;
+// relu bit0: ReLU on the sum, bit1: ReLU (and rounding to T) on the shortcut term
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const T* __restrict__ res,
@@ -95,10 +96,20 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
     for (int k = 0; k < 8; ++k) v[k] += r[k];
   } else if (y_r) {
     load8(y_r + i * 8, r);
+    if (relu & 2) {
+      // the shortcut is relu(bn(y_r)) (the stem's pooled RAW output feeding layer1.0, forward-only networks): rounded to the
+      // activation type exactly as the separate pass that used to materialise it did, so the sum is bitwise the same
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] += r[k] * scale_r[c + k] + shift_r[c + k];
+      for (int k = 0; k < 8; ++k) {
+        const float t = r[k] * scale_r[c + k] + shift_r[c + k];
+        v[k] += (float)(T)(t > 0.f ? t : 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k] * scale_r[c + k] + shift_r[c + k];
+    }
   }
-  if (relu) {
+  if (relu & 1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
   }

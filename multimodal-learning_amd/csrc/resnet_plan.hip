@@ -350,6 +350,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     }
     if ((rc = ph_bn_eval_params_launch(&t, 1e-5f, st))) return rc;
   }
+  bool p0_raw = false;
   if ((flags & 4) && !(flags & 32) && P->prec == PH_PREC_BF16) {
     // forward-only network, perf mode: the stem conv pools its own raw output (sign-aware max / min, conv_stem.hip
     // stem_fwd_pool_kernel) - the 537 MB conv output (B = 64, 512 x 512) is never written - and BatchNorm + ReLU is
@@ -367,8 +368,12 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
                                     c.stat(u, 1), c.stat(u, 2), c.stat(u, 3), rm, (float*)params[4],
                                     (int64_t*)params[5], st)))
       return rc;
-    if ((rc = ph_bn_apply_launch(ws + P->p0_off, c.stat(u, 2), c.stat(u, 3), nullptr, nullptr, nullptr, nullptr,
-                                 ws + P->p0_off, (size_t)P->B * P->PH0 * P->PW0, 64, 1, P->prec, st)))
+    // BatchNorm + ReLU of the pooled tensor is applied by its two consumers - layer1.0.conv1 while it stages its input
+    // (PhTapConv::in_scale, like conv2 of the forward-only blocks) and layer1.0's output pass on its shortcut term - so the
+    // pooled tensor stays RAW and no pass over it remains (bit 3 of the flags keeps the separate pass, as for the blocks)
+    p0_raw = !(flags & 8);
+    if (!p0_raw && (rc = ph_bn_apply_launch(ws + P->p0_off, c.stat(u, 2), c.stat(u, 3), nullptr, nullptr, nullptr, nullptr,
+                                            ws + P->p0_off, (size_t)P->B * P->PH0 * P->PW0, 64, 1, P->prec, st)))
       return rc;
   } else
   {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
@@ -396,7 +401,9 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     const Unit& u1 = P->units[b.u1];
     const Unit& u2 = P->units[b.u2];
     const size_t npix = (size_t)P->B * b.OH * b.OW;
-    if ((rc = conv_fwd(c, b.u1, ws + b.in_off))) return rc;
+    const Unit& u0 = P->units[0];
+    const bool raw_in = bi == 0 && p0_raw;      // block 0 reads the stem's pooled RAW output
+    if ((rc = raw_in ? conv_fwd(c, b.u1, ws + b.in_off, c.stat(u0, 2), c.stat(u0, 3)) : conv_fwd(c, b.u1, ws + b.in_off))) return rc;
     // (measured per launch, B = 64, 512^2: the in-LDS pass costs the conv +10 us in layer 1 and +13 us in layers 2-4 - it
     // runs with the matrix pipe idle - against bn_apply launches of 49 / 25 / 13 / 8 us: fused where it pays)
     if (fuse_a1 && b.Cout <= 128) {
@@ -413,8 +420,10 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
       rc = ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + ud.y_off, c.stat(ud, 2),
                               c.stat(ud, 3), ws + b.out_off, npix, b.Cout, 1, P->prec, st);
     } else {
-      rc = ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), ws + b.in_off, nullptr, nullptr, nullptr,
-                              ws + b.out_off, npix, b.Cout, 1, P->prec, st);
+      rc = raw_in ? ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + b.in_off, c.stat(u0, 2),
+                                       c.stat(u0, 3), ws + b.out_off, npix, b.Cout, 3, P->prec, st)
+                  : ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), ws + b.in_off, nullptr, nullptr, nullptr,
+                                       ws + b.out_off, npix, b.Cout, 1, P->prec, st);
     }
     if (rc) return rc;
     if (bi == 5 && f3) { if ((rc = ph_avgpool_launch(ws + b.out_off, f3, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }

@@ -95,7 +95,10 @@ class _TrunkFn(torch.autograd.Function):
         # +8 (`net._no_fuse`, an A/B and test switch) keeps the separate passes; +16 (`net._no_masked`, likewise) keeps the
         # first-generation kernel for the 3x3 stride-2 convolutions
         # +32 (`net._no_stem_pool`, likewise) keeps the separate stem conv and pooling passes in forward-only networks
-        flags = (1 if net.training else 2) | (0 if any(ctx.needs_input_grad) else 4) | (8 if getattr(net, "_no_fuse", False) else 0) | \
+        # (`needs_input_grad` mirrors requires_grad even under torch.no_grad(), and grad mode is always off inside
+        # Function.forward: the caller's grad mode is recorded by _forward_impl - a forward under no_grad is forward-only)
+        fwd_only = not (getattr(net, "_caller_grad_mode", True) and any(ctx.needs_input_grad))
+        flags = (1 if net.training else 2) | (4 if fwd_only else 0) | (8 if getattr(net, "_no_fuse", False) else 0) | \
             (16 if getattr(net, "_no_masked", False) else 0) | (32 if getattr(net, "_no_stem_pool", False) else 0)
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4), flags, stream()),
               "ph_resnet_forward")
@@ -301,6 +304,7 @@ class ResNet(nn.Module):
     # ------------------------------------------------------------------ reference API
     def _forward_impl(self, x):
         lin, bn = self.fc_new1[0], self.fc_new1[1]
+        self._caller_grad_mode = torch.is_grad_enabled()
         if not self.training and torch.is_grad_enabled() and x.requires_grad:
             # eval-mode net with a gradient to the IMAGE (MIA-2023 superpixel attention, train_test_MT_SP_Masking.py:62-75)
             f3, f4 = _TrunkFn.apply(x, self, *self._trunk_params())

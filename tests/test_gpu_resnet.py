@@ -520,23 +520,34 @@ def test_stem_conv_with_pooled_epilogue_equals_separate_passes(B, H):
             pooled = ws[off.value: off.value + 2 * n].view(torch.bfloat16).clone()
             check(lib().ph_resnet_tensor_info(plan.h, 8, 0, C.byref(off), dims), "tensor_info")
             stats = ws[off.value: off.value + 16 * 64].view(torch.float32).clone()
+            if not no_pool:
+                # the fused path leaves the pooled tensor RAW: BatchNorm + ReLU is applied by its two consumers (layer1.0.conv1
+                # while it stages its input, layer1.0's output pass on its shortcut).  Activate it here for the comparison;
+                # torch may round the multiply-add differently from the kernels' fused multiply-add: one bf16 step allowed
+                sc, sh = stats[128:192], stats[192:256]
+                raw_pooled = pooled
+                pooled = torch.relu(pooled.float().view(-1, 64) * sc + sh).bfloat16().view(-1)
             key = "separate" if no_pool else ("pooled" if "pooled" not in outs else "pooled again")
             outs[key] = (pooled, stats, f3.clone(), feat.clone(), hazard.clone(), net.bn1.running_mean.clone(), net.bn1.running_var.clone())
         sep = outs["separate"]
         assert torch.equal(outs["pooled"][0], outs["pooled again"][0]) and torch.equal(outs["pooled"][4], outs["pooled again"][4])
         got = outs["pooled"]
         if not training:
-            for a, b in zip(sep, got):
+            for a, b in zip(sep[1:], got[1:]):
                 assert torch.equal(a, b), (training, (a.float() - b.float()).abs().max().item())
+            a, b = sep[0].float(), got[0].float()      # (+ 1e-5: a pre-activation within rounding of zero)
+            assert ((a - b).abs() <= torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-5).all() and (a != b).float().mean().item() <= 1e-3
         else:
             assert ((sep[1] - got[1]).abs() <= 1e-6 * sep[1].abs() + 1e-6).all(), "batch statistics"
             for a, b in zip(sep[5:], got[5:]):
                 assert ((a - b).abs() <= 1e-6 * a.abs() + 1e-7).all(), "running statistics"
             a, b = sep[0].float(), got[0].float()
-            assert ((a - b).abs() <= a.abs() * 2.0 ** -7 + 1e-30).all(), (a - b).abs().max().item()      # one bf16 step
+            assert ((a - b).abs() <= torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-5).all(), (a - b).abs().max().item()      # one bf16 step
             assert (a != b).float().mean().item() <= 1e-3
-            for a, b in zip(sep[2:5], got[2:5]):
-                assert (a - b).norm() <= 2e-2 * a.norm()
+            # (one-step differences of the activation propagate through 17 bf16 layers; the head sits behind a BatchNorm1d
+            # over B <= 8 samples, which amplifies them - the eval-mode pass above is the bitwise check of the whole network)
+            for (a, b), tol in zip(zip(sep[2:5], got[2:5]), (2e-2, 1e-1, 1e-1)):
+                assert (a - b).norm() <= tol * a.norm(), ((a - b).norm() / a.norm()).item()
 
 
 @pytest.mark.gpu
