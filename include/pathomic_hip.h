@@ -62,7 +62,12 @@ int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, 
  * statistics; bit1: eval mode (normalise with the running statistics; no backward); bit2: forward only - no
  * ph_resnet_backward will read this workspace (the no_grad EMA / teacher forwards of train_test_path_multi_distill.py:
  * 253-256): bn1 + ReLU of every BasicBlock (resnets.py:61-63) is then applied by conv2 while it stages its input and the
- * a1 tensor is not materialised (perf mode); bit3: keep the separate passes nevertheless (A/B and test switch) */
+ * a1 tensor is not materialised (perf mode); bit3: keep the separate passes nevertheless (A/B and test switch); bit4 /
+ * bit5: A/B and test switches (first-generation stride-2 kernel / separate stem conv and pooling passes); bit6: `x_nchw`
+ * is the NHWC4 tensor ph_pack_input made of the image (the student and the teacher read the same x_path,
+ * train_test_path_multi_distill.py:249,256: packed once) - it must stay valid until the matching backward has run */
+int ph_pack_input(const float* x_nchw, void* x4 /* B*H*W*4 elements of the mode's activation type */, int B, int H, int W,
+                  int prec, ph_stream_t stream);
 int ph_resnet_forward(const PhResnetPlan* plan, const void* const* params, const void* packed, const float* x_nchw,
                       void* workspace, float* f3, float* f4, int flags, ph_stream_t stream);
 int ph_resnet_backward(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
@@ -78,7 +83,7 @@ int ph_resnet_backward_part(const PhResnetPlan* plan, const void* const* params,
  * BasicBlock bn2 / wgrad(conv2) / dgrad(conv2) / bn1 / wgrad(conv1) / dgrad(conv1) [+ bn / wgrad / dgrad of the
  * downsample branch], then the stem's BatchNorm reduction, its apply pass, its weight gradient) - autograd of
  * resnets.py:58-74,219-222 one node at a time.  Only scratch buffers are written, so it can be re-run; with
- * ph_resnet_tensor_info (what 4-9: the scratch buffers, the BatchNorm statistics, the pool arg codes) a harness compares
+ * the tensor-info call below - its `what` 4-9 are the scratch buffers, the BatchNorm statistics and the pool arg codes - a harness compares
  * every stage with a reference computed from that stage's own inputs (tests/test_gpu_fullsize.py). */
 int ph_resnet_backward_debug(const PhResnetPlan* plan, const void* const* params, const void* packed, void* workspace,
                              const float* g_f3, const float* g_f4, void* const* grads, int stop_after, ph_stream_t stream);

@@ -23,6 +23,7 @@ SIGNATURES = {
     "ph_resnet_num_units": (i32, [vp]),
     "ph_resnet_unit_shape": (i32, [vp, i32, vp]),
     "ph_resnet_pack_weights": (i32, [vp, vp, vp, vp]),
+    "ph_pack_input": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ph_resnet_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ph_resnet_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "ph_bn1d_eval_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, i32, vp]),

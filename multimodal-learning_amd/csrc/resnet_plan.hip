@@ -43,6 +43,7 @@ struct PhResnetPlan {
   int PH0, PW0;   // pooled dims
   size_t act_max;   // max block-level activation bytes
   mutable int no_masked = 0;   // A/B and test switch, set by the last forward's flag bit3 and followed by its backward
+  mutable const void* x4_ext = nullptr;   // the last forward's pre-packed input (flag bit6), read again by its backward (stem wgrad)
 };
 
 namespace {
@@ -336,8 +337,12 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   P->no_masked = (flags & 16) ? 1 : 0;
   c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
-  int rc = ph_pack_input_launch(x_nchw, ws + P->x4_off, P->B, P->H, P->W, P->prec, st);
-  if (rc) return rc;
+  // bit6: `x_nchw` is not the image but an NHWC4 tensor of the mode's activation type that ph_pack_input produced from it
+  // (the student and the teacher of the distillation step read the same x_path: packed once, train_test_path_multi_distill.py:249,256)
+  int rc = PH_OK;
+  P->x4_ext = (flags & 64) ? reinterpret_cast<const void*>(x_nchw) : nullptr;
+  const unsigned char* x4p = (flags & 64) ? reinterpret_cast<const unsigned char*>(x_nchw) : ws + P->x4_off;
+  if (!(flags & 64) && (rc = ph_pack_input_launch(x_nchw, ws + P->x4_off, P->B, P->H, P->W, P->prec, st))) return rc;
   if (c.eval) {
     PhBnEvalTable t{};
     t.n = (int)P->units.size();
@@ -357,7 +362,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     // applied to the pooled tensor in place; bitwise the separate passes' result (relu(scale * y + shift) is monotone)
     const Unit& u = P->units[0];
     PhStemPool s{};
-    s.x4 = ws + P->x4_off; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
+    s.x4 = x4p; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
     s.pooled = ws + P->p0_off; s.stats = c.eval ? nullptr : reinterpret_cast<float*>(ws + P->parts_off);
     s.gamma = (const float*)params[1];
     s.B = P->B; s.IH = P->H; s.IW = P->W; s.OH = u.OH; s.OW = u.OW; s.PH = P->PH0; s.PW = P->PW0;
@@ -379,7 +384,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
     const Unit& u = P->units[0];
     PhStem s{};
-    s.x4 = ws + P->x4_off; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
+    s.x4 = x4p; s.w = c.pk + u.wf_off; s.wplane = u.wplane;
     s.out = ws + u.y_off; s.stats = c.eval ? nullptr : reinterpret_cast<float*>(ws + P->parts_off);
     s.B = P->B; s.IH = P->H; s.IW = P->W; s.OH = u.OH; s.OW = u.OW;
     if ((rc = ph_stem_fwd_launch(&s, P->prec, st))) return rc;
@@ -501,7 +506,7 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
                                       c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64,
                                       P->prec, st));
     PhStemWgrad w{};
-    w.x4 = ws + P->x4_off; w.dy = dyb; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
+    w.x4 = P->x4_ext ? P->x4_ext : ws + P->x4_off; w.dy = dyb; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
     w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
     if ((rc = ph_stem_wgrad_launch(&w, P->prec, st))) return rc;
@@ -514,6 +519,13 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
 }  // namespace
 
 extern "C" {
+
+// image [B,3,H,W] f32 -> NHWC4 (channel 3 = 0) of the mode's activation type, B * H * W * 4 elements: the trunk's input
+// layout, for ph_resnet_forward flag bit6
+int ph_pack_input(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st) {
+  if (!x_nchw || !x4 || B < 1 || H < 1 || W < 1 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X6)) return PH_EINVAL;
+  return ph_pack_input_launch(x_nchw, x4, B, H, W, prec, st);
+}
 
 // grads: per unit 3 pointers [dw (OIHW f32), dgamma, dbeta]; g_f3 may be null.  Needs the activations the
 // matching ph_resnet_forward left in `ws`.

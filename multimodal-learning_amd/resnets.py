@@ -100,8 +100,16 @@ class _TrunkFn(torch.autograd.Function):
         fwd_only = not (getattr(net, "_caller_grad_mode", True) and any(ctx.needs_input_grad))
         flags = (1 if net.training else 2) | (4 if fwd_only else 0) | (8 if getattr(net, "_no_fuse", False) else 0) | \
             (16 if getattr(net, "_no_masked", False) else 0) | (32 if getattr(net, "_no_stem_pool", False) else 0)
-        check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x), ptr(ws), ptr(f3), ptr(f4), flags, stream()),
-              "ph_resnet_forward")
+        # an image that has been packed already (pack_shared_input: the student and the teacher of the distillation step read
+        # the same x_path) enters as its NHWC4 tensor, flag +64; the tensor is kept alive for the backward's stem wgrad
+        shared = getattr(net, "_x4_shared", None)
+        x4 = None
+        if shared is not None and shared[0] == (x.data_ptr(), tuple(x.shape), ops.get_precision()):
+            x4 = shared[1]
+            flags |= 64
+        check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x4 if x4 is not None else x), ptr(ws), ptr(f3), ptr(f4), flags,
+                                      stream()), "ph_resnet_forward")
+        ctx.x4 = x4
         ctx.net, ctx.plan, ctx.ws, ctx.packed, ctx.table = net, plan, ws, packed, table
         ctx.input_only = not net.training      # eval mode: the backward produces the image gradient only
         ctx.set_materialize_grads(False)
@@ -142,6 +150,23 @@ class _TrunkFn(torch.autograd.Function):
                     hook()
         ctx.ws = None
         return (None, None) + tuple(grads)
+
+
+def pack_shared_input(x, nets):
+    """Pack the image batch `x` [B,3,H,W] f32 ONCE into the trunk's NHWC4 input layout for several networks that read it
+    (the reference feeds the same x_path to the student and to the teacher, train_test_path_multi_distill.py:249,256, and
+    each of its ResNets starts from the NCHW tensor).  The next forward of each net on this very tensor skips its own
+    packing pass.  Must run on a stream the consumers are ordered after."""
+    x = require_cuda(x, "x_path")
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        return None
+    B, Cc, H, W = x.shape
+    prec = ops.get_precision()
+    x4 = torch.empty(B, H, W, 4, device=x.device, dtype=torch.bfloat16 if prec == ops.PREC_BF16 else torch.float32)
+    check(lib().ph_pack_input(ptr(x), ptr(x4), B, H, W, prec, stream()), "ph_pack_input")
+    for net in nets:
+        net._x4_shared = ((x.data_ptr(), tuple(x.shape), prec), x4)
+    return x4
 
 
 class ResNet(nn.Module):

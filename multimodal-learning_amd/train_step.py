@@ -400,6 +400,10 @@ class DistillStep:
         # of the captured graph) so their small-kernel tails overlap the student's convolutions.
         main = torch.cuda.current_stream()
         side = self._side_stream
+        # the student and the teacher read the same x_path (:249, :256): one packing pass into the trunk's input layout
+        # serves both (before the streams fork, so both consumers are ordered after it)
+        from .resnets import pack_shared_input
+        pack_shared_input(x_path, (self.model, self.fix_model.path_net))
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad():
