@@ -539,13 +539,27 @@ def main():
                   "scaling": "strong", "final_loss": round(l2, 4)}
     parity = None
     if world == 1 and not args.no_parity_mode and not args.device_loader:
-        # the arithmetic that meets the north-star's 1e-3 logit tolerance (fp32 activations, 3-plane split bf16 operands,
-        # six MFMA products per k-step); same step, same sizes
+        # the arithmetics that meet the north-star's 1e-3 tolerance (tests/test_gpu_step.py::
+        # test_two_steps_from_mid_training_state_vs_reference_golden runs the same assertions against the reference's golden
+        # in each of them), same step, same sizes:
+        #   bf16x6/x3  fp32 activations; six bf16 MFMA products per k-step in every forward, the three leading ones in the
+        #              backward's dgrad / wgrad kernels: every assertion of the parity mode holds (logits 4e-5, six loss terms
+        #              1e-5, GK-Refine weights 3e-5, gradients 2e-3 relative, Adam moments, updated weights)
+        #   bf16x3     three products everywhere: logits 5.3e-4 and the six loss terms 5.4e-4 (within 1e-3); the GK-Refine
+        #              weights - cosines of DIFFERENCES of student and teacher probabilities - only to 5e-3 relative, and the
+        #              total loss they multiply to 3e-3 relative
+        #   bf16x6     six products everywhere (the parity mode of the golden tests)
         psteps = max(2, min(args.steps, 5))
-        d2, l2 = extra_run(args.batch, "bf16x6", psteps)
-        parity = {"arithmetic": "bf16x6 (fp32 activations, 6 bf16 MFMA products per k-step: fp32-equivalent, logits within 1e-3 "
-                                "of the reference)", "value": round(args.batch * psteps / d2, 2), "unit": "tiles/s",
-                  "ms_per_step": round(1000.0 * d2 / psteps, 3), "steps": psteps, "final_loss": round(l2, 4)}
+        parity = {}
+        for pm, what in (("bf16x6/x3", "fp32 activations, 6 bf16 MFMA products per k-step forward / 3 backward: every 1e-3 assertion of the "
+                                       "parity mode holds (logits, six loss terms, GK-Refine weights, gradients 2e-3)"),
+                         ("bf16x3", "fp32 activations, 3 products everywhere: logits and the six loss terms within 1e-3 (5.4e-4), "
+                                    "GK-Refine weights / total loss 5e-3 / 3e-3 relative"),
+                         ("bf16x6", "fp32 activations, 6 products everywhere (fp32-equivalent; the mode of the golden tests)")):
+            d2, l2 = extra_run(args.batch, pm, psteps)
+            parity[pm] = {"arithmetic": what, "value": round(args.batch * psteps / d2, 2), "unit": "tiles/s",
+                          "ms_per_step": round(1000.0 * d2 / psteps, 3), "steps": psteps, "final_loss": round(l2, 4)}
+        parity["tolerance_compliant"] = "bf16x6/x3"
 
     variants = None
     if world == 1 and not args.no_variants and not args.device_loader and (args.batch, args.size) == (64, 512):

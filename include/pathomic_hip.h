@@ -23,6 +23,7 @@ typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
 
 #define PH_PREC_BF16 0   /* perf mode: bf16 operands + activations, fp32 accumulate/statistics */
 #define PH_PREC_BF16X6 1 /* parity mode: fp32 activations, 3-plane split-bf16 (6-product, fp32-equivalent) MFMA */
+#define PH_PREC_BF16X3 2 /* fp32 activations, the 3 leading split-bf16 products (16-bit operands): half the matrix work */
 
 #define PH_ACT_NONE 0
 #define PH_ACT_RELU 1
@@ -66,6 +67,9 @@ int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, 
  * bit5: A/B and test switches (first-generation stride-2 kernel / separate stem conv and pooling passes); bit6: `x_nchw`
  * is the NHWC4 tensor ph_pack_input made of the image (the student and the teacher read the same x_path,
  * train_test_path_multi_distill.py:249,256: packed once) - it must stay valid until the matching backward has run */
+/* Arithmetic of the backward's dgrad / wgrad launches where it differs from the plan's (PH_PREC_BF16X3 on a PH_PREC_BF16X6
+ * plan: parity-mode forward, three-product backward; -1 = follow the plan) */
+int ph_resnet_plan_set_backward_prec(const PhResnetPlan* plan, int prec);
 int ph_pack_input(const float* x_nchw, void* x4 /* B*H*W*4 elements of the mode's activation type */, int B, int H, int W,
                   int prec, ph_stream_t stream);
 int ph_resnet_forward(const PhResnetPlan* plan, const void* const* params, const void* packed, const float* x_nchw,

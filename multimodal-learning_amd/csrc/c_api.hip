@@ -172,7 +172,7 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, in
 }
 
 int ph_stem_dgrad(const void* dy_nhwc, const float* w_oihw, float* dx_nchw, int B, int H, int W, int prec, hipStream_t st) {
-  if (!dy_nhwc || !w_oihw || !dx_nchw || B < 1 || H < 2 || W < 2 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X6))
+  if (!dy_nhwc || !w_oihw || !dx_nchw || B < 1 || H < 2 || W < 2 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec)))
     return PH_EINVAL;
   return ph_stem_dgrad_launch(dy_nhwc, w_oihw, dx_nchw, B, H, W, prec, st);
 }

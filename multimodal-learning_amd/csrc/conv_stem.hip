@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
 #define PH_MM(PI, PJ)                                                                               \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ][j], acc[j], 0, 0, 0);
-          PH_SPLIT_PAIRS(PH_MM)
+          if (p.prod6) { PH_SPLIT_PAIRS_LO(PH_MM) }
+          PH_SPLIT_PAIRS_HI(PH_MM)
 #undef PH_MM
         } else {
 #pragma unroll
@@ -599,7 +600,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
 #define PH_MM(PI, PJ)                                                                                       \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
       acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI][j], bq[PJ], acc[ai][j], 0, 0, 0);
-            PH_SPLIT_PAIRS(PH_MM)
+            if (p.prod6) { PH_SPLIT_PAIRS_LO(PH_MM) }
+            PH_SPLIT_PAIRS_HI(PH_MM)
 #undef PH_MM
           } else {
 #pragma unroll
@@ -680,11 +682,13 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     const int lds = 2 * XB + WB;
     if (set_lds(stem_fwd_kernel<bf16>, lds, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, *p);
-  } else if (prec == PH_PREC_BF16X6) {
+  } else if (PH_IS_SPLIT_PREC(prec)) {
     static bool done = false;
     const int lds = PH_NPLANES * (XB + WB);
     if (set_lds(stem_fwd_kernel<float>, lds, done)) return PH_ELAUNCH;
-    hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, *p);
+    PhStem q = *p;
+    q.prod6 = prec == PH_PREC_BF16X6;
+    hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, q);
   } else {
     return PH_EINVAL;
   }
@@ -733,10 +737,12 @@ int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
     static bool done = false;
     if (set_lds(stem_wgrad_kernel<bf16>, base, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_wgrad_kernel<bf16>, grid, dim3(256), base, st, *p);
-  } else if (prec == PH_PREC_BF16X6) {
+  } else if (PH_IS_SPLIT_PREC(prec)) {
     static bool done = false;
     if (set_lds(stem_wgrad_kernel<float>, PH_NPLANES * base, done)) return PH_ELAUNCH;
-    hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), PH_NPLANES * base, st, *p);
+    PhStemWgrad q = *p;
+    q.prod6 = prec == PH_PREC_BF16X6;
+    hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), PH_NPLANES * base, st, q);
   } else {
     return PH_EINVAL;
   }

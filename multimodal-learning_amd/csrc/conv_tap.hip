@@ -204,20 +204,23 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       for (int ks = 0; ks < 4; ++ks) {
         const int chunk = ks * 2 + khalf;
         bf16x8 a[NP][FM], bq[NP][FN];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
+        auto load_plane = [&](int pl) {
 #pragma unroll
           for (int i = 0; i < FM; ++i)
             a[pl][i] = *reinterpret_cast<const bf16x8*>(ldsA + pl * C::A_BYTES + lds_off(hp[i], chunk));
 #pragma unroll
           for (int j = 0; j < FN; ++j)
             bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsBcur + pl * C::B_BYTES + t * BNT * 128 + lds_off(nrow[j], chunk));
-        }
+        };
+        // (the third plane's fragments are only read where its products are issued: bf16x3 skips a third of the LDS reads)
+#pragma unroll
+        for (int pl = 0; pl < (SPLIT ? 2 : 1); ++pl) load_plane(pl);
         if constexpr (SPLIT) {
 #define PH_MM(PI, PJ)                                                                                   \
   _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < FN; ++j)          \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI][i], bq[PJ][j], acc[i][j], 0, 0, 0);
-          PH_SPLIT_PAIRS(PH_MM)
+          if (p.prod6) { load_plane(2); PH_SPLIT_PAIRS_LO(PH_MM) }
+          PH_SPLIT_PAIRS_HI(PH_MM)
 #undef PH_MM
         } else {
 #pragma unroll
@@ -497,7 +500,11 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
   if (p->in_scale || p->m_groups) return PH_EINVAL;   // in-LDS BatchNorm + ReLU / masked tap grids: second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
-  if (prec == PH_PREC_BF16X6) return launch_T<float>(*p, S, st);
+  if (PH_IS_SPLIT_PREC(prec)) {
+    PhTapConv q = *p;
+    q.prod6 = prec == PH_PREC_BF16X6;
+    return launch_T<float>(q, S, st);
+  }
   return PH_EINVAL;
 }
 

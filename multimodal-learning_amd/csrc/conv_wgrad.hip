@@ -108,9 +108,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       const int t0 = kk * 16 + 8 * khalf + q4, t1 = t0 + 4;
       const int offA0 = t0 * 128 + sw_piece(t0, pieceA) * 32 + p4 * 8;
       const int offA1 = t1 * 128 + sw_piece(t1, pieceA) * 32 + p4 * 8;
-      bf16x8 a[NP];
+      bf16x8 a[NP];      // (third plane: only in the six-product mode)
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) a[pl] = tr_pair(dD + pl * C::D_BYTES, offA0, offA1);
+      for (int pl = 0; pl < NP; ++pl)
+        if (pl < 2 || p.prod6) a[pl] = tr_pair(dD + pl * C::D_BYTES, offA0, offA1);
       const int hb0 = ((t0 >> 4) * S) * HPW + (t0 & 15) * S;
       const int hb1 = ((t1 >> 4) * S) * HPW + (t1 & 15) * S;
 #pragma unroll
@@ -121,10 +122,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int offB1 = h1 * 128 + sw_piece(h1, pieceB) * 32 + p4 * 8;
         bf16x8 bq[NP];
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) bq[pl] = tr_pair(dX + pl * C::X_BYTES, offB0, offB1);
+        for (int pl = 0; pl < NP; ++pl)
+          if (pl < 2 || p.prod6) bq[pl] = tr_pair(dX + pl * C::X_BYTES, offB0, offB1);
         if constexpr (SPLIT) {
 #define PH_MM(PI, PJ) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ], acc[t], 0, 0, 0);
-          PH_SPLIT_PAIRS(PH_MM)
+          if (p.prod6) { PH_SPLIT_PAIRS_LO(PH_MM) }
+          PH_SPLIT_PAIRS_HI(PH_MM)
 #undef PH_MM
         } else {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[t], 0, 0, 0);
@@ -402,7 +405,11 @@ int ph_wgrad_tile_h(int S) { return S == 1 ? 8 : 4; }
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->nchunks < 1) return PH_EINVAL;
   if (prec == PH_PREC_BF16) return launch_wg_T<bf16>(*p, st);
-  if (prec == PH_PREC_BF16X6) return launch_wg_T<float>(*p, st);
+  if (PH_IS_SPLIT_PREC(prec)) {
+    PhWgrad q = *p;
+    q.prod6 = prec == PH_PREC_BF16X6;
+    return launch_wg_T<float>(q, st);
+  }
   return PH_EINVAL;
 }
 

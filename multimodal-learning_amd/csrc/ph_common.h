@@ -21,6 +21,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // precision modes of the C-ABI (activation storage type follows the mode)
 #define PH_PREC_BF16 0    // perf mode: bf16 operands+activations, fp32 accumulate / statistics
 #define PH_PREC_BF16X6 1  // parity mode: fp32 activations, operands split into 3 bf16 planes, 6 MFMA products
+#define PH_PREC_BF16X3 2  // fp32 activations, the 3 leading products only (hi*hi, hi*mid, mid*hi: 16-bit operands, ~2^-16 per
+                          // product): half the matrix work of the parity mode; same kernels, same packed weights
 
 #define PH_LAUNCH_CHECK()                                  \
   do {                                                     \
@@ -75,7 +77,10 @@ __device__ __forceinline__ void split3_bf16(float x, bf16& p0, bf16& p1, bf16& p
 }
 constexpr int PH_NPLANES = 3;
 // the (i, j) plane pairs, least significant first
-#define PH_SPLIT_PAIRS(X) X(2, 0) X(0, 2) X(1, 1) X(1, 0) X(0, 1) X(0, 0)
+#define PH_SPLIT_PAIRS_LO(X) X(2, 0) X(0, 2) X(1, 1)
+#define PH_SPLIT_PAIRS_HI(X) X(1, 0) X(0, 1) X(0, 0)
+#define PH_SPLIT_PAIRS(X) PH_SPLIT_PAIRS_LO(X) PH_SPLIT_PAIRS_HI(X)
+#define PH_IS_SPLIT_PREC(p) ((p) == PH_PREC_BF16X6 || (p) == PH_PREC_BF16X3)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

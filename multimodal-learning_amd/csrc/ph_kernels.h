@@ -63,6 +63,7 @@ struct PhTapConv {
   int m_mask[4];         // bit t: grid tap t (row-major, dy = t / 3, dx = t % 3) is live (fixed sets, see the kernel)
   int m_slab[4][9];      // weight slab of every grid tap (any valid slab for dead taps)
   long m_in_off[4];
+  int prod6;             // split-plane modes (first-generation kernel): six products or the three leading ones (set by the launcher)
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 double ph_tapconv_bytes(const PhTapConv& p, int S, int es);
@@ -83,6 +84,7 @@ struct PhWgrad {
   int S, pad, KS;
   int nchunks, tiles_per_chunk;
   long x_pix_stride, x_row_stride, x_img_stride;   // element strides of the x view (0 = dense NHWC)
+  int prod6;             // split-plane modes: 1 = all six products (bf16x6), 0 = the three leading ones (bf16x3); set by the launcher
 };
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st);
 int ph_wgrad_tile_h(int S);
@@ -96,6 +98,7 @@ struct PhStem {
   void* out;             // [B][OH][OW][64]
   float* stats;          // [B*tiles][2][64]
   int B, IH, IW, OH, OW;
+  int prod6;             // split-plane modes: six products or the three leading ones (set by the launcher)
 };
 int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st);
 int ph_stem_stat_parts(int B, int OH, int OW);
@@ -117,6 +120,7 @@ struct PhStemWgrad {
   const void* x4; const void* dy; float* slab;   // slab [nchunks][7][64][32]
   int B, IH, IW, OH, OW;
   int nchunks, tiles_per_chunk;
+  int prod6;
 };
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st);
 // input gradient of the 7x7/2 stem conv: dy [B][H/2][W/2][64] (type of the mode) -> dx [B][3][H][W] f32 (stem_dgrad.hip)

@@ -43,6 +43,7 @@ struct PhResnetPlan {
   int PH0, PW0;   // pooled dims
   size_t act_max;   // max block-level activation bytes
   mutable int no_masked = 0;   // A/B and test switch, set by the last forward's flag bit3 and followed by its backward
+  mutable int bwd_prec = -1;   // >= 0: arithmetic of the backward's dgrad / wgrad launches where it differs from `prec` (both split-plane)
   mutable const void* x4_ext = nullptr;   // the last forward's pre-packed input (flag bit6), read again by its backward (stem wgrad)
 };
 
@@ -71,7 +72,7 @@ int stem_chunks(int B, int OH, int OW, int* tpc) {
 extern "C" {
 
 PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
-  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X6)) return nullptr;
+  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec))) return nullptr;
   PhResnetPlan* P = new (std::nothrow) PhResnetPlan();
   if (!P) return nullptr;
   P->B = B; P->H = H; P->W = W; P->prec = prec; P->es = prec == PH_PREC_BF16 ? 2 : 4;
@@ -201,6 +202,7 @@ struct Ctx {
   float* stat(const Unit& u, int which) const {
     return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
   }
+  int bprec() const { return (P->bwd_prec >= 0 && P->prec != PH_PREC_BF16) ? P->bwd_prec : P->prec; }
 };
 
 int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullptr, const float* in_shift = nullptr) {
@@ -247,7 +249,7 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
       const int dyy = k / u.KS, dxx = k % u.KS;
       t.dy[k] = dyy; t.dx[k] = dxx; t.wtap[k] = (u.KS - 1 - dyy) * u.KS + (u.KS - 1 - dxx);
     }
-    return ph_tapconv_launch(&t, 1, P->prec, c.st);
+    return ph_tapconv_launch(&t, 1, c.bprec(), c.st);
   }
   // stride 2: one launch per output parity class (a,b); x row 2i+a receives kh with (a + pad - kh) even
   for (int a = 0; a < 2; ++a)
@@ -272,7 +274,7 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
           if (dhs[i] < 0 || dws[j] < 0 || dhs[i] > 2 || dws[j] > 2) return PH_EINVAL;
           t.dy[q] = dhs[i]; t.dx[q] = dws[j]; t.wtap[q] = khs[i] * u.KS + kws[j]; ++q;
         }
-      int rc = ph_tapconv_launch(&t, 1, P->prec, c.st);
+      int rc = ph_tapconv_launch(&t, 1, c.bprec(), c.st);
       if (rc) return rc;
     }
   return PH_OK;
@@ -291,7 +293,7 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
     w.IH = u.OH; w.IW = u.OW; w.S = 1;
   }
   w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk);
-  int rc = ph_wgrad_launch(&w, P->prec, c.st);
+  int rc = ph_wgrad_launch(&w, c.bprec(), c.st);
   if (rc) return rc;
   return ph_wgrad_reduce_launch(w.slab, dw, w.nchunks, u.KS, u.Cout, u.Cin, c.st);
 }
@@ -509,7 +511,7 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     w.x4 = P->x4_ext ? P->x4_ext : ws + P->x4_off; w.dy = dyb; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
     w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
-    if ((rc = ph_stem_wgrad_launch(&w, P->prec, st))) return rc;
+    if ((rc = ph_stem_wgrad_launch(&w, c.bprec(), st))) return rc;
     PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, st));
   }
   return PH_OK;
@@ -520,10 +522,20 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
 
 extern "C" {
 
+// Arithmetic of the BACKWARD's matrix kernels (dgrad / wgrad) where it differs from the plan's: PH_PREC_BF16X3 on a
+// PH_PREC_BF16X6 plan = six-product forward (logits, losses and GK-Refine weights at parity-mode accuracy), three-product
+// backward (gradients at ~1e-3 relative); -1 = follow the plan.  Both arithmetics read the same fp32 activations and the
+// same packed weight planes.
+int ph_resnet_plan_set_backward_prec(const PhResnetPlan* P, int prec) {
+  if (!P || (prec != -1 && !PH_IS_SPLIT_PREC(prec)) || (prec != -1 && P->prec == PH_PREC_BF16)) return PH_EINVAL;
+  P->bwd_prec = prec;
+  return PH_OK;
+}
+
 // image [B,3,H,W] f32 -> NHWC4 (channel 3 = 0) of the mode's activation type, B * H * W * 4 elements: the trunk's input
 // layout, for ph_resnet_forward flag bit6
 int ph_pack_input(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st) {
-  if (!x_nchw || !x4 || B < 1 || H < 1 || W < 1 || (prec != PH_PREC_BF16 && prec != PH_PREC_BF16X6)) return PH_EINVAL;
+  if (!x_nchw || !x4 || B < 1 || H < 1 || W < 1 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec))) return PH_EINVAL;
   return ph_pack_input_launch(x_nchw, x4, B, H, W, prec, st);
 }
 

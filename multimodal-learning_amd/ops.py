@@ -10,9 +10,11 @@ from ._lib import lib, check, ptr, stream, require_cuda
 
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD, EW_ELU_BWD, EW_MUL = 0, 1, 2, 3, 4, 5
-PREC_BF16, PREC_BF16X6 = 0, 1
+PREC_BF16, PREC_BF16X6, PREC_BF16X3 = 0, 1, 2
 
 _precision = PREC_BF16
+_fwd_only_precision = None      # optional other arithmetic for forward-only (no_grad) trunk forwards, see set_precision
+_backward_precision = None      # optional other arithmetic for the backward's dgrad / wgrad kernels
 _weight_epoch = 0
 
 
@@ -28,13 +30,34 @@ def weight_epoch():
 
 
 def set_precision(mode):
-    """'bf16' (perf mode) or 'bf16x6' (parity mode: fp32 activations, 3-plane split-bf16 6-product MFMA, fp32-equivalent)."""
-    global _precision
-    _precision = {"bf16": PREC_BF16, "bf16x6": PREC_BF16X6, PREC_BF16: PREC_BF16, PREC_BF16X6: PREC_BF16X6}[mode]
+    """Arithmetic of the ResNet trunk:
+      'bf16'      perf mode: bf16 operands and activations, fp32 accumulation and statistics;
+      'bf16x6'    parity mode: fp32 activations, operands split into three bf16 planes, six MFMA products (fp32-equivalent);
+      'bf16x3'    fp32 activations, the three leading products only (16-bit operands, ~2^-16 per product): half the matrix work;
+      'bf16x6/x3' parity mode for every forward, three products in the backward's dgrad / wgrad kernels;
+      'bf16x6+x3' parity mode for every forward that is followed by a backward (the student), 'bf16x3' for the forward-only
+                  networks (the no_grad EMA / teacher forwards of train_test_path_multi_distill.py:253-256)."""
+    global _precision, _fwd_only_precision, _backward_precision
+    _backward_precision = None
+    names = {"bf16": PREC_BF16, "bf16x6": PREC_BF16X6, "bf16x3": PREC_BF16X3, PREC_BF16: PREC_BF16, PREC_BF16X6: PREC_BF16X6,
+             PREC_BF16X3: PREC_BF16X3}
+    if mode == "bf16x6+x3":
+        _precision, _fwd_only_precision = PREC_BF16X6, PREC_BF16X3
+    elif mode == "bf16x6/x3":
+        # every FORWARD in parity arithmetic (logits, losses, GK-Refine weights as in 'bf16x6'), the backward's dgrad /
+        # wgrad kernels with three products
+        _precision, _fwd_only_precision, _backward_precision = PREC_BF16X6, None, PREC_BF16X3
+    else:
+        _precision, _fwd_only_precision = names[mode], None
 
 
-def get_precision():
-    return _precision
+def get_backward_precision():
+    return _backward_precision
+
+
+def get_precision(fwd_only=False):
+    """The trunk arithmetic in force (for a forward-only forward when `fwd_only`)."""
+    return _fwd_only_precision if (fwd_only and _fwd_only_precision is not None) else _precision
 
 
 def _f32(t):

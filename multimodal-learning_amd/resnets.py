@@ -75,7 +75,10 @@ class _TrunkFn(torch.autograd.Function):
         B, Cc, H, W = x.shape
         if Cc != 3:
             raise RuntimeError("x_path must be [B,3,H,W]")
-        plan = net._get_plan(B, H, W)
+        # (`needs_input_grad` mirrors requires_grad even under torch.no_grad(), and grad mode is always off inside
+        # Function.forward: the caller's grad mode is recorded by _forward_impl - a forward under no_grad is forward-only)
+        fwd_only = not (getattr(net, "_caller_grad_mode", True) and any(ctx.needs_input_grad))
+        plan = net._get_plan(B, H, W, ops.get_precision(fwd_only))
         packed = net._get_packed(plan)
         table = net._param_table()
         want_dx = ctx.needs_input_grad[0]
@@ -95,16 +98,13 @@ class _TrunkFn(torch.autograd.Function):
         # +8 (`net._no_fuse`, an A/B and test switch) keeps the separate passes; +16 (`net._no_masked`, likewise) keeps the
         # first-generation kernel for the 3x3 stride-2 convolutions
         # +32 (`net._no_stem_pool`, likewise) keeps the separate stem conv and pooling passes in forward-only networks
-        # (`needs_input_grad` mirrors requires_grad even under torch.no_grad(), and grad mode is always off inside
-        # Function.forward: the caller's grad mode is recorded by _forward_impl - a forward under no_grad is forward-only)
-        fwd_only = not (getattr(net, "_caller_grad_mode", True) and any(ctx.needs_input_grad))
         flags = (1 if net.training else 2) | (4 if fwd_only else 0) | (8 if getattr(net, "_no_fuse", False) else 0) | \
             (16 if getattr(net, "_no_masked", False) else 0) | (32 if getattr(net, "_no_stem_pool", False) else 0)
         # an image that has been packed already (pack_shared_input: the student and the teacher of the distillation step read
         # the same x_path) enters as its NHWC4 tensor, flag +64; the tensor is kept alive for the backward's stem wgrad
         shared = getattr(net, "_x4_shared", None)
         x4 = None
-        if shared is not None and shared[0] == (x.data_ptr(), tuple(x.shape), ops.get_precision()):
+        if shared is not None and shared[0] == (x.data_ptr(), tuple(x.shape), plan.key[3] == ops.PREC_BF16):
             x4 = shared[1]
             flags |= 64
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x4 if x4 is not None else x), ptr(ws), ptr(f3), ptr(f4), flags,
@@ -135,6 +135,9 @@ class _TrunkFn(torch.autograd.Function):
             ctx.ws = None
             return (dx, None) + (None,) * ctx.nparams
         grads, gptrs = net._alloc_trunk_grads()
+        bp = ops.get_backward_precision()
+        if plan.key[3] != ops.PREC_BF16:
+            check(lib().ph_resnet_plan_set_backward_prec(plan.h, -1 if bp is None else bp), "ph_resnet_plan_set_backward_prec")
         hook = getattr(net, "_grad_ready_hook", None)
         if hook is None:
             check(lib().ph_resnet_backward(plan.h, ctx.table, ptr(ctx.packed), ptr(ctx.ws), ptr(g3), ptr(g4),
@@ -161,11 +164,11 @@ def pack_shared_input(x, nets):
     if x.dtype != torch.float32 or not x.is_contiguous():
         return None
     B, Cc, H, W = x.shape
-    prec = ops.get_precision()
+    prec = ops.get_precision()      # (every split-plane mode reads fp32 activations: one packed tensor serves bf16x6 and bf16x3)
     x4 = torch.empty(B, H, W, 4, device=x.device, dtype=torch.bfloat16 if prec == ops.PREC_BF16 else torch.float32)
     check(lib().ph_pack_input(ptr(x), ptr(x4), B, H, W, prec, stream()), "ph_pack_input")
     for net in nets:
-        net._x4_shared = ((x.data_ptr(), tuple(x.shape), prec), x4)
+        net._x4_shared = ((x.data_ptr(), tuple(x.shape), prec == ops.PREC_BF16), x4)
     return x4
 
 
@@ -253,8 +256,8 @@ class ResNet(nn.Module):
             self._table_key = key
         return self._table
 
-    def _get_plan(self, B, H, W):
-        key = (B, H, W, ops.get_precision())
+    def _get_plan(self, B, H, W, prec=None):
+        key = (B, H, W, ops.get_precision() if prec is None else prec)
         if key not in self._plans:
             self._plans[key] = _Plan(*key)
         return self._plans[key]

@@ -728,7 +728,8 @@ def test_mia2022_distill_baselines(distill):
         m.set_precision("bf16")
 
 
-def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("mode,gtol", [("bf16x6", 1.0), ("bf16x6/x3", 1.0), ("bf16x3", 8.0)])
+def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir, mode, gtol):
     """Post-update parity as a REAL check.  tests/golden/make_golden_midstate.py runs the reference
     for two steps from a mid-training state: Adam step count 7 with non-zero moments (per-tensor recipe scaled by the
     reference's own gradient scale), an EMA model of its own, iter_num 7, CRD constants Z already set.  There the Adam
@@ -736,14 +737,21 @@ def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
     asserted at the north-star tolerance: step 0's pre-update quantities AND its update (parameters, EMA, Adam moments,
     bank rows at ~1e-6), and - the point - step 1's logits / losses / GK-Refine weights, which depend on every piece of
     the update path.  The optimiser state enters through FusedAdam.load_state_dict in torch.optim.Adam's own layout
-    (what a checkpoint written by the reference holds)."""
+    (what a checkpoint written by the reference holds).
+
+    Three arithmetics (the cheapest one that meets 1e-3): `bf16x6` (six split-bf16 products everywhere),
+    `bf16x6/x3` (six in every forward, the three leading ones in the backward's dgrad / wgrad kernels) - held to the SAME
+    tolerances, gradients and Adam moments included - and `bf16x3` (three everywhere): its logits and six loss terms are
+    held to the same 1e-3, but the GK-Refine weights are cosines of DIFFERENCES of student and teacher probabilities and
+    amplify its 3e-4 logit error to 5e-3 relative, which the total loss inherits (mode-specific tolerances below:
+    weights 1e-2, total loss 5e-3, gradients / moments 8 x the parity mode's, touched bank rows 1e-4)."""
     import multimodal_learning_amd as m
     from oracle import weights as W
     from oracle.step import default_opt, synthetic_batch
     from tests.gpu_util import Report
     g = np.load(os.path.join(golden_dir, "midstate_b8_h96.npz"))
     seed, n_data, t0 = int(g["seed"]), int(g["n_data"]), int(g["t0"])
-    m.set_precision("bf16x6")
+    m.set_precision(mode)
     try:
         step = _mk_step(default_opt(), n_data, seed=seed)
         # ---- the mid-training state
@@ -767,7 +775,7 @@ def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
         for crd, key in ((step.criterion_kd, "Z0"), (step.criterion_kd_path, "Z1")):
             crd.contrast.params[2:4] = torch.as_tensor(g[key]).cuda()
             crd.contrast._z_set = True
-        R = Report("2 distill steps from a mid-training state, parity mode vs REFERENCE golden (B=8, 96x96)")
+        R = Report(f"2 distill steps from a mid-training state, arithmetic {mode} vs REFERENCE golden (B=8, 96x96)")
         cut = lambda t: t.detach().reshape(-1)[:4096]      # noqa: E731
         watch = ("conv1.weight", "layer2.0.conv1.weight", "layer4.1.bn2.weight", "fc_new1.0.weight", "fc_new2.weight",
                  "fc_new2.bias")
@@ -792,22 +800,22 @@ def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
                 R.close(g[f"{key}{it}"], out[k], 1e-3, 0, f"{k} step {it}")
             for k in ("loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2", "loss"):
                 ref = g[f"{k}{it}"] * (1.0 if k in ("loss_cls", "loss") else (step.opt.alpha if "div" in k else step.opt.beta))
-                R.close(ref, out[k], 1e-3, 1e-4, f"{k} step {it}")
-            R.close(g[f"scale{it}"], out["scale"], 2e-3, 1e-3, f"GK-Refine scale step {it}")
+                R.close(ref, out[k], 1e-3, 5e-3 if (k == "loss" and mode == "bf16x3") else 1e-4, f"{k} step {it}")
+            R.close(g[f"scale{it}"], out["scale"], 2e-3, 1e-2 if mode == "bf16x3" else 1e-3, f"GK-Refine scale step {it}")
             for k in watch:
                 if it == 0:
-                    R.close(g["g0_" + k], cut(grads0[k]), 1e-6, 2e-3, f"grad {k}")
-                R.close(g[f"p{it}_{k}"], cut(named[k]), 5e-6, 0, f"param {k} after step {it}")
-                R.close(g[f"e{it}_{k}"], cut(enamed[k]), 5e-6, 0, f"EMA {k} after step {it}")
+                    R.close(g["g0_" + k], cut(grads0[k]), 1e-6, 2e-3 * gtol, f"grad {k}")
+                R.close(g[f"p{it}_{k}"], cut(named[k]), 5e-6 * gtol, 0, f"param {k} after step {it}")
+                R.close(g[f"e{it}_{k}"], cut(enamed[k]), 5e-6 * gtol, 0, f"EMA {k} after step {it}")
                 o = off[id(named[k])]
                 n = named[k].numel()
                 # (exp_avg carries 0.1 x the fresh gradient: the step-1 gradient of the first layers is the most sensitive
                 # quantity of the net - 18 train-mode BatchNorms back-propagated through weights that differ by ~4e-6 - and
                 # sits at 4e-3 of its scale, the oracle's CPU run at 2e-3; everything downstream of it stays at 1e-3)
-                R.close(g[f"m{it}_{k}"], cut(step.optimizer._m[o:o + n]), 1e-7, 2e-3 if it == 0 else 6e-3, f"exp_avg {k} after step {it}")
-                R.close(g[f"v{it}_{k}"], cut(step.optimizer._v[o:o + n]), 1e-10, 2e-3, f"exp_avg_sq {k} after step {it}")
+                R.close(g[f"m{it}_{k}"], cut(step.optimizer._m[o:o + n]), 1e-7, (2e-3 if it == 0 else 6e-3) * gtol, f"exp_avg {k} after step {it}")
+                R.close(g[f"v{it}_{k}"], cut(step.optimizer._v[o:o + n]), 1e-10, 2e-3 * gtol, f"exp_avg_sq {k} after step {it}")
             if it == 0:
-                R.close(g["g0_embed_s0"], cut(grads0["embed_s0"]), 1e-6, 2e-3, "grad embed_s0")
+                R.close(g["g0_embed_s0"], cut(grads0["embed_s0"]), 1e-6, 2e-3 * gtol, "grad embed_s0")
             sdm, sde = step.model.state_dict(), step.ema_model.state_dict()
             R.close(g[f"p_abs_sum{it}"], sum(v.double().abs().sum() for v in sdm.values() if v.dtype.is_floating_point), 0, 2e-6,
                     f"sum|student| after step {it}")
@@ -816,8 +824,9 @@ def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir):
             R.close(g[f"rm_bn1_{it}"], sdm["bn1.running_mean"], 1e-5, 1e-4, f"bn1 running_mean after step {it}")
             R.close(g[f"rv_l4_{it}"], sdm["layer4.1.bn2.running_var"], 1e-5, 1e-3, f"layer4.1.bn2 running_var after step {it}")
             ix = bt["index"].cuda()
-            R.close(g[f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[ix], 1e-5, 0, f"bank0 v1 rows step {it}")
-            R.close(g[f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[ix], 1e-5, 0, f"bank1 v2 rows step {it}")
+            btol = 1e-4 if mode == "bf16x3" else 1e-5
+            R.close(g[f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[ix], btol, 0, f"bank0 v1 rows step {it}")
+            R.close(g[f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[ix], btol, 0, f"bank1 v2 rows step {it}")
             R.close(g[f"params0_{it}"], step.criterion_kd.contrast.params, 1e-3, 1e-6, f"CRD params / Z step {it}")
         R.finish()
     finally:
