@@ -194,7 +194,7 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
 size_t ph_crd_loss_grad_workspace_bytes(int B);
 /* MIA-2023 v10 KNN positives (CRD_criterion_v10.py:72-79,110-116): class-masked full-bank cosine top-num_pos of each
  * query's own bank row, for both banks; labels = class of every bank row (int32 [n_data]) */
-size_t ph_crd_bank_topk_workspace_bytes(int B);
+size_t ph_crd_bank_topk_workspace_bytes(int B, int n_data);
 int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, const int64_t* idx, int PK,
                      const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
                      int64_t* nb2, float* sim1, float* sim2, void* workspace, ph_stream_t stream);

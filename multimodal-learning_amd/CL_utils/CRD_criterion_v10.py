@@ -112,7 +112,7 @@ class CRDLoss(nn.Module):
             return self._forward_centers(sample_weights, v1, v2, batch_label, idx, contrast_idx)
         nb1 = torch.empty(B, NP, device=dev, dtype=torch.int64); nb2 = torch.empty_like(nb1)
         sim1 = torch.empty(B, NP, device=dev, dtype=torch.float32); sim2 = torch.empty_like(sim1)
-        ws = torch.empty(lib().ph_crd_bank_topk_workspace_bytes(B), device=dev, dtype=torch.uint8)
+        ws = torch.empty(lib().ph_crd_bank_topk_workspace_bytes(B, mem.nLem), device=dev, dtype=torch.uint8)
         check(lib().ph_crd_bank_topk(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(mem.all_sample_labels),
                                      ptr(contrast_idx), K + 1, ptr(batch_label), B, mem.nLem, NP, v1.shape[1], ptr(nb1),
                                      ptr(nb2), ptr(sim1), ptr(sim2), ptr(ws), stream()), "ph_crd_bank_topk")

@@ -76,7 +76,7 @@ SIGNATURES = {
     "ph_tsvd_update_aux": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
     "ph_crd_score": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "ph_crd_select": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "ph_crd_bank_topk_workspace_bytes": (sz, [i32]),
+    "ph_crd_bank_topk_workspace_bytes": (sz, [i32, i32]),
     "ph_crd_bank_topk": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "ph_kl_rows_fwd": (i32, [vp, vp, vp, i32, i32, f32, vp]),
     "ph_kl_rows_bwd": (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),

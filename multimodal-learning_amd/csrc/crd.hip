@@ -288,47 +288,74 @@ __device__ __forceinline__ void block_argbest(const float* sv, const int* si, in
   __syncthreads();
 }
 
-// stage 1: block (query b, bank, slice z) scans its slice of the bank; every thread keeps a private top list over its rows
-// (same per-row arithmetic and order as ever: the similarities are bitwise those of the single-block version), the block
-// picks its TOPK_MAX best by parallel arg-max rounds and leaves them in the workspace
-__global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restrict__ mem1,
-                                                            const float* __restrict__ mem2,
-                                                            const int* __restrict__ labels,
-                                                            const int64_t* __restrict__ idx, int PK,
-                                                            const int64_t* __restrict__ batch_label, int n_data,
-                                                            float* __restrict__ cand_v, int* __restrict__ cand_i) {
-  const int b = blockIdx.x, bank = blockIdx.y, z = blockIdx.z;
+// stage 0: the B query rows of each bank (the bank row of the sample itself, idx[b][0]) copied next to their norms
+__global__ __launch_bounds__(64) void crd_topk_queries_kernel(const float* __restrict__ mem1, const float* __restrict__ mem2,
+                                                              const int64_t* __restrict__ idx, int PK, float* __restrict__ qbuf,
+                                                              float* __restrict__ qnorm) {
+  const int b = blockIdx.x, bank = blockIdx.y, t = threadIdx.x;
   const float* mem = bank ? mem2 : mem1;
   const int64_t qrow = idx[(size_t)b * PK];
-  const int lab = (int)batch_label[b];
-  __shared__ float q[D];
-  __shared__ float qn;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) q[d] = mem[qrow * D + d];
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    float s = q[threadIdx.x] * q[threadIdx.x] + q[threadIdx.x + 64] * q[threadIdx.x + 64];
-    s = wave_sum(s);
-    if (threadIdx.x == 0) qn = sqrtf(s);
+  const float q0 = mem[qrow * D + t], q1 = mem[qrow * D + t + 64];
+  float* q = qbuf + ((size_t)bank * gridDim.x + b) * D;
+  q[t] = q0; q[t + 64] = q1;
+  const float s = wave_sum(q0 * q0 + q1 * q1);
+  if (t == 0) qnorm[bank * gridDim.x + b] = sqrtf(s);
+}
+
+// stage 1: class-masked cosine similarity of EVERY bank row with EVERY query, S[bank][b][j] (CRD_criterion_v10.py:72-79: the
+// reference's cosine_similarity(bank[idx], bank) * class_mask).  One thread per bank row: the row's 128 features live in
+// registers (read ONCE from HBM: 512 B per row, the algorithmic traffic), the queries are wave-uniform and enter the
+// fused multiply-adds as scalar operands (scalar loads, no LDS), the similarity column of a query leaves as one
+// coalesced 256-B store per wave.  The first version scanned the bank once per QUERY (64 x 2 x 21 845 rows of 512 B =
+// 1.4 GB through L2 per call at B = 64: 278 us, 0.03 of the HBM roofline for the 67 MB the call needs).  Same per-pair
+// arithmetic and order as before (sequential dot product over the features, norms as before): the similarities are
+// bitwise those of the per-query scan.
+__global__ __launch_bounds__(256) void crd_bank_sim_kernel(const float* __restrict__ mem1, const float* __restrict__ mem2,
+                                                           const int* __restrict__ labels, const float* __restrict__ qbuf,
+                                                           const float* __restrict__ qnorm,
+                                                           const int64_t* __restrict__ batch_label, int B, int n_data,
+                                                           float* __restrict__ S) {
+  const int bank = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < n_data;
+  const float* mem = bank ? mem2 : mem1;
+  float m[D];
+  float nn = 0.f;
+  const f32x4* r = reinterpret_cast<const f32x4*>(mem + (size_t)(live ? j : 0) * D);
+#pragma unroll
+  for (int d4 = 0; d4 < D / 4; ++d4) {
+    const f32x4 v = r[d4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { m[d4 * 4 + k] = v[k]; nn += v[k] * v[k]; }
   }
-  __syncthreads();
+  const float rn = sqrtf(nn);
+  const int lab = live ? labels[j] : -1;
+  const float* q = qbuf + (size_t)bank * B * D;
+  float* Sb = S + (size_t)bank * B * n_data;
+  for (int b = 0; b < B; ++b) {
+    const float* qb = q + (size_t)b * D;      // wave-uniform address: scalar loads
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) dot += m[d] * qb[d];
+    const float den = rn * qnorm[bank * B + b];
+    float v = den > 0.f ? dot / den : 0.f;
+    if (lab != (int)batch_label[b]) v = 0.f;                 // other classes are masked to similarity 0 (class_mask *)
+    if (live) Sb[(size_t)b * n_data + j] = v;
+  }
+}
+
+// stage 2: block (query b, bank, slice z) scans its slice of the similarity row; every thread keeps a private top list over
+// its columns, the block picks its TOPK_MAX best by parallel arg-max rounds and leaves them in the workspace
+__global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restrict__ S, int B, int n_data,
+                                                            float* __restrict__ cand_v, int* __restrict__ cand_i) {
+  const int b = blockIdx.x, bank = blockIdx.y, z = blockIdx.z;
+  const float* row = S + ((size_t)bank * B + b) * n_data;
   float bv[TOPK_MAX]; int bi[TOPK_MAX];
 #pragma unroll
   for (int k = 0; k < TOPK_MAX; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
   const int chunk = (n_data + TOPK_SPLIT - 1) / TOPK_SPLIT, lo = z * chunk, hi = min(n_data, lo + chunk);
   for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    float v = 0.f;                                   // other classes are masked to similarity 0 (class_mask *)
-    if (labels[j] == lab) {
-      float dot = 0.f, nn = 0.f;
-      const f32x4* r = reinterpret_cast<const f32x4*>(mem + (size_t)j * D);
-#pragma unroll 8
-      for (int d4 = 0; d4 < D / 4; ++d4) {
-        const f32x4 m = r[d4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { dot += m[k] * q[d4 * 4 + k]; nn += m[k] * m[k]; }
-      }
-      const float den = sqrtf(nn) * qn;
-      v = den > 0.f ? dot / den : 0.f;
-    }
+    const float v = row[j];
     // insert (v, j) into the descending private list (ties: lower index first)
     if (v > bv[TOPK_MAX - 1] || (v == bv[TOPK_MAX - 1] && j < bi[TOPK_MAX - 1])) {
       int pos = TOPK_MAX - 1;
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restr
   }
 }
 
-// stage 2: the NP best of the TOPK_SPLIT * TOPK_MAX candidates of a (query, bank)
+// stage 3: the NP best of the TOPK_SPLIT * TOPK_MAX candidates of a (query, bank)
 __global__ __launch_bounds__(256) void crd_bank_topk_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
                                                                   int NP, int64_t* __restrict__ nb1, int64_t* __restrict__ nb2,
                                                                   float* __restrict__ sim1, float* __restrict__ sim2) {
@@ -501,19 +528,30 @@ __global__ __launch_bounds__(256) void contrast_loss_v2_kernel(const float* __re
 
 }  // namespace
 
-size_t ph_crd_bank_topk_workspace_bytes(int B) { return (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX * (sizeof(float) + sizeof(int)); }
+// workspace: similarity rows S [2][B][n_data] f32 | candidates | query rows [2][B][128] + norms [2][B]
+static inline size_t topk_cand_bytes(int B) { return (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX * (sizeof(float) + sizeof(int)); }
+size_t ph_crd_bank_topk_workspace_bytes(int B, int n_data) {
+  return (size_t)2 * B * n_data * sizeof(float) + topk_cand_bytes(B) + (size_t)2 * B * (D + 1) * sizeof(float) + 256;
+}
 
 int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, const int64_t* idx, int PK,
                      const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
                      int64_t* nb2, float* sim1, float* sim2, void* workspace, hipStream_t st) {
-  if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX || !workspace) return PH_EINVAL;
-  float* cv = reinterpret_cast<float*>(workspace);
+  if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX || !workspace || B < 1 || n_data < 1) return PH_EINVAL;
+  float* S = reinterpret_cast<float*>(workspace);
+  float* cv = S + (size_t)2 * B * n_data;
   int* ci = reinterpret_cast<int*>(cv + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
+  float* qbuf = reinterpret_cast<float*>(ci + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
+  float* qnorm = qbuf + (size_t)2 * B * D;
   void* tok = nullptr;
   if (ph_prof_on())   // algorithmic bytes: every row of both banks once + the row labels + the 2 x B x num_pos results
     ph_prof_begin(PH_CLS_CRD_TOPK, 2.0 * n_data * D * 4 + 4.0 * n_data + 2.0 * B * num_pos * 12, st, &tok);
-  hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2, TOPK_SPLIT), dim3(256), 0, st, mem1, mem2, labels, idx, PK, batch_label,
-                     n_data, cv, ci);
+  hipLaunchKernelGGL(crd_topk_queries_kernel, dim3(B, 2), dim3(64), 0, st, mem1, mem2, idx, PK, qbuf, qnorm);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(crd_bank_sim_kernel, dim3(cdiv(n_data, 256), 2), dim3(256), 0, st, mem1, mem2, labels, qbuf, qnorm,
+                     batch_label, B, n_data, S);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2, TOPK_SPLIT), dim3(256), 0, st, S, B, n_data, cv, ci);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(crd_bank_topk_merge_kernel, dim3(B, 2), dim3(256), 0, st, cv, ci, num_pos, nb1, nb2, sim1, sim2);
   ph_prof_end(tok, st);

@@ -345,7 +345,7 @@ def test_mia2023_bank_topk_bit_exact():
     nb1 = torch.empty(B, NP, dtype=torch.int64, device="cuda"); nb2 = torch.empty_like(nb1)
     s1 = torch.empty(B, NP, device="cuda"); s2 = torch.empty_like(s1)
     m1, m2, lb, ix, blc = d(mem1), d(mem2), d(labels), d(idx), d(bl)     # keep the device tensors alive across the launch
-    ws = torch.empty(L.ph_crd_bank_topk_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    ws = torch.empty(L.ph_crd_bank_topk_workspace_bytes(B, n), dtype=torch.uint8, device="cuda")
     check(L.ph_crd_bank_topk(ptr(m1), ptr(m2), ptr(lb), ptr(ix), 5, ptr(blc), B, n, NP, 128,
                              ptr(nb1), ptr(nb2), ptr(s1), ptr(s2), ptr(ws), stream()), "topk")
     for mem, nb, s in ((mem1, nb1, s1), (mem2, nb2, s2)):
