@@ -609,7 +609,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = None
             tname = None
-            for tname in ("r02_traffic.json", "r01_traffic.json"):
+            for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 tf = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tf):
                     try:

@@ -120,7 +120,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
 template <typename T, bool IDX>
 __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                        const float* __restrict__ shift, T* __restrict__ out,
-                                       uint8_t* __restrict__ idx, int B, int H, int W, int C8) {
+                                       uint8_t* __restrict__ idx, T* __restrict__ raw, int B, int H, int W, int C8) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;   // floor((H + 2 - 3)/2) + 1
   const size_t n = (size_t)B * OH * OW * C8;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,10 +131,10 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __r
   const int oh = (int)(pix % OH);
   const int b = (int)(pix / OH);
   const int c = cg * 8;
-  float sc[8], sh[8], best[8];
+  float sc[8], sh[8], best[8], braw[8];
   int bi[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { sc[k] = scale[c + k]; sh[k] = shift[c + k]; best[k] = -INFINITY; bi[k] = 0; }
+  for (int k = 0; k < 8; ++k) { sc[k] = scale[c + k]; sh[k] = shift[c + k]; best[k] = -INFINITY; bi[k] = 0; braw[k] = 0.f; }
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int ih = oh * 2 - 1 + kh;
@@ -151,7 +151,7 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __r
         // the pooled value equals pooling the stored bf16 activation; only an exact-vs-rounded tie can pick another
         // - equally large after rounding - tap.  Rounding every tap cost a third of this VALU-bound kernel.)
         const float a = fmaxf(v[k] * sc[k] + sh[k], 0.f);
-        if constexpr (IDX) { if (a > best[k]) { best[k] = a; bi[k] = kh * 3 + kw; } }
+        if constexpr (IDX) { if (a > best[k]) { best[k] = a; bi[k] = kh * 3 + kw; braw[k] = v[k]; } }
         else best[k] = fmaxf(best[k], a);
       }
     }
@@ -162,6 +162,9 @@ __global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __r
 #pragma unroll
     for (int k = 0; k < 8; ++k) packed |= (uint64_t)(bi[k] & 0xff) << (8 * k);
     *reinterpret_cast<uint64_t*>(idx + i * 8) = packed;
+    // the conv output AT the arg-max (exact: a stored value, not re-rounded): the backward's BatchNorm sums over pooled
+    // pixels read it instead of gathering 2-byte values out of the full-resolution tensor
+    if (raw) store8(raw + i * 8, braw);
   }
 }
 
@@ -453,6 +456,51 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __
   }
 }
 
+// The same sums from the conv output AT the arg-max, which the forward's pooling pass saved per window (`raw`): no arg codes,
+// no gather - two streamed tensors of the pooled size.  Same thread -> window mapping, same arithmetic and summation
+// order as stem_bwd_reduce_pooled_kernel: bitwise the same partial rows (186 -> ~60 us at B = 64, 512 x 512).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bwd_reduce_raw_kernel(const T* __restrict__ dpool, const T* __restrict__ raw,
+                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  float* __restrict__ parts, int B, int H, int W) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const int cg = threadIdx.x & 7, wl = threadIdx.x >> 3, c = cg * 8;
+  float sc[8], sf[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean[c + k]; is[k] = invstd[c + k];
+    s1[k] = 0.f; s2[k] = 0.f;
+  }
+  constexpr int PROWS = STEM_ROWS / 2;
+  const int row0 = blockIdx.x * PROWS, row1 = min(B * OH, row0 + PROWS);
+  for (int prow = row0; prow < row1; ++prow) {
+    for (int pw = wl; pw < OW; pw += 32) {
+      const size_t o8 = ((size_t)prow * OW + pw) * 8 + cg;
+      float g8[8], z8[8];
+      load8(dpool + o8 * 8, g8);
+      load8(raw + o8 * 8, z8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = z8[k];
+        const float dz = (z * sc[k] + sf[k]) > 0.f ? g8[k] : 0.f;
+        s1[k] += dz;
+        s2[k] += dz * ((z - mu[k]) * is[k]);
+      }
+    }
+  }
+  __shared__ float sh[2][256][9];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
+    float t = 0.f;
+    for (int q = 0; q < 32; ++q) t += sh[which][q * 8 + (ch >> 3)][ch & 7];
+    parts[((size_t)blockIdx.x * 2 + which) * 64 + ch] = t;
+  }
+}
+
 inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -498,12 +546,12 @@ int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, co
   return PH_OK;
 }
 
-int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int B,
-                              int H, int W, int C, int prec, hipStream_t st) {
+int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* raw,
+                              int B, int H, int W, int C, int prec, hipStream_t st) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const size_t n = (size_t)B * OH * OW * (C / 8);
 #define PH_POOL_LAUNCH(T, IDX) \
-  hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, IDX>), dim3(nblk(n)), dim3(256), 0, st, (const T*)y, scale, shift, (T*)out, idx, B, H, W, C / 8)
+  hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, IDX>), dim3(nblk(n)), dim3(256), 0, st, (const T*)y, scale, shift, (T*)out, idx, (T*)raw, B, H, W, C / 8)
   if (prec == PH_PREC_BF16) { if (idx) PH_POOL_LAUNCH(bf16, true); else PH_POOL_LAUNCH(bf16, false); }
   else { if (idx) PH_POOL_LAUNCH(float, true); else PH_POOL_LAUNCH(float, false); }
 #undef PH_POOL_LAUNCH
@@ -575,11 +623,21 @@ int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const fl
 
 int ph_stem_bwd_parts(int B, int H) { return (B * H + STEM_ROWS - 1) / STEM_ROWS; }
 
-int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
+int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const void* raw, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
                               int W, int C, int prec, hipStream_t st) {
   if (C != 64) return PH_EINVAL;
   const int nb = ph_stem_bwd_parts(B, H);
+  if (raw && H % 2 == 0) {   // the forward saved the conv output at every window's arg-max
+    if (prec == PH_PREC_BF16)
+      hipLaunchKernelGGL((stem_bwd_reduce_raw_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, (const bf16*)raw,
+                         scale, shift, mean, invstd, parts, B, H, W);
+    else
+      hipLaunchKernelGGL((stem_bwd_reduce_raw_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dpool, (const float*)raw,
+                         scale, shift, mean, invstd, parts, B, H, W);
+    PH_LAUNCH_CHECK();
+    return PH_OK;
+  }
 #ifndef PH_STEM_BWD_PER_PIXEL   // (A/B switch: the per-input-pixel form of the reduction, 246 us against 190 us)
   if (H % 2 == 0) {   // (the block -> pooled-row mapping reuses the partial-row count of the per-pixel kernel)
     if (prec == PH_PREC_BF16)

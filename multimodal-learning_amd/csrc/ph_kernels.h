@@ -161,8 +161,9 @@ int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st);
 int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
                        const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,
                        hipStream_t st);
-int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, int B,
-                              int H, int W, int C, int prec, hipStream_t st);
+// raw (optional, with idx): the conv output at every window's arg-max, [B][OH/2][OW/2][C] of the mode's type
+int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* raw,
+                              int B, int H, int W, int C, int prec, hipStream_t st);
 int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st);
 // d_x (+)= g / HW  broadcast
 int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int accumulate, int prec, hipStream_t st);
@@ -180,7 +181,7 @@ int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const fl
                            const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
                            int prec, const float* mscale, const float* mshift, hipStream_t st);
 // stem: da0 = scatter of d_pool through the saved argmax, dz = da0 * (bn(y0) > 0)
-int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
+int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const void* raw_at_argmax, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
                               int W, int C, int prec, hipStream_t st);
 int ph_stem_bwd_apply_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,

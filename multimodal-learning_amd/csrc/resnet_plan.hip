@@ -37,7 +37,7 @@ struct PhResnetPlan {
   int B, H, W, prec, es;
   std::vector<Unit> units;
   std::vector<Block> blocks;
-  size_t x4_off, p0_off, idx_off, parts_off, parts_bytes;
+  size_t x4_off, p0_off, p0raw_off, idx_off, parts_off, parts_bytes;
   size_t g0_off, g1_off, dy_off, da_off, slab_off, slab_bytes, bparts_off, cc_off, zero_off;
   size_t ws_bytes, packed_bytes;
   int PH0, PW0;   // pooled dims
@@ -91,6 +91,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   P->PH0 = (s.OH + 1) / 2; P->PW0 = (s.OW + 1) / 2;
   P->p0_off = take((size_t)B * P->PH0 * P->PW0 * 64 * es);
   P->idx_off = take((size_t)B * P->PH0 * P->PW0 * 64);
+  P->p0raw_off = take((size_t)B * P->PH0 * P->PW0 * 64 * es);   // conv output at every pooling window's arg-max (training forwards)
   size_t parts_max = (size_t)std::max(ph_stem_stat_parts(B, s.OH, s.OW), ph_stem_pool_stat_parts(B, s.OH, s.OW)) * 2 * 64 * sizeof(float);
   size_t slab_max = 0;
   { int tpc; int nc = stem_chunks(B, s.OH, s.OW, &tpc); slab_max = (size_t)nc * 7 * 64 * 32 * sizeof(float); }
@@ -398,7 +399,8 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
       return rc;
     // (forward only: nobody scatters a gradient through the pooling windows - the argmax codes are not produced)
     if ((rc = ph_bn_relu_maxpool_launch(ws + u.y_off, c.stat(u, 2), c.stat(u, 3), ws + P->p0_off,
-                                        (flags & 4) ? nullptr : ws + P->idx_off, P->B, u.OH, u.OW, 64, P->prec, st)))
+                                        (flags & 4) ? nullptr : ws + P->idx_off, (flags & 4) ? nullptr : ws + P->p0raw_off,
+                                        P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
   }
   // conv2 of every block is 3x3 / stride 1 with Cin = Cout in {64, 128, 256, 512}: always a second-generation kernel in perf mode
@@ -499,8 +501,8 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     float* parts = reinterpret_cast<float*>(ws + P->bparts_off);
     float* c1 = reinterpret_cast<float*>(ws + P->cc_off);
     float* c2 = c1 + 512;
-    if ((rc = ph_stem_bwd_reduce_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
-                                        c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, st)))
+    if ((rc = ph_stem_bwd_reduce_launch(gcur, ws + P->idx_off, ws + u.y_off, ws + P->p0raw_off, c.stat(u, 0), c.stat(u, 1),
+                                        c.stat(u, 2), c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
     PH_STAGE(ph_bn_bwd_finalize_launch(parts, ph_stem_bwd_parts(P->B, u.OH), 64, (double)npix, (float*)grads[1],
                                        (float*)grads[2], c1, c2, st));

@@ -9,10 +9,15 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 T=gpurun_out/$TAG
 mkdir -p "$T"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode > "$T/bench_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants > "$T/bench_stats.log" 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 \
-  --output-format csv -d "$T/sq" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --eager --no-kernel-timer > "$T/bench_sq.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --eager --no-kernel-timer > "$T/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$T/write" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --eager --no-kernel-timer > "$T/bench_write.log" 2>&1
+  --output-format csv -d "$T/sq" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_sq.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$T/write" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_write.log" 2>&1
+# CRD kernels at the bank sizes of BASELINE configs[3] / configs[4] (counter bytes for the `variants` block of the bench line)
+for V in mia2022 mia2023; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch_$V" -- python3 bench.py --variant $V --steps 3 --warmup 3 --eager > "$T/bench_fetch_$V.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$T/write_$V" -- python3 bench.py --variant $V --steps 3 --warmup 3 --eager > "$T/bench_write_$V.log" 2>&1
+done
 python3 bench.py > "$T/bench_default.log" 2>&1
 tail -1 "$T/bench_default.log" | cut -c1-300

@@ -131,6 +131,37 @@ def main():
         json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
         open(os.path.join(out, f"{tag}_traffic.txt"), "w").write(
             "# HBM traffic per launch (FETCH_SIZE x2 correction, WRITE_SIZE exact; separate --pmc passes)\n" + "\n".join(lines) + "\n")
+    # ---- CRD kernels of the variant steps (bench.py --variant mia2022 / mia2023): counter bytes per CALL of each kernel family
+    crd = {}
+    for var in ("mia2022", "mia2023"):
+        ff = glob.glob(os.path.join(src, f"fetch_{var}", "*", "*counter_collection.csv"))
+        fw = glob.glob(os.path.join(src, f"write_{var}", "*", "*counter_collection.csv"))
+        if not (ff and fw):
+            continue
+        fa, fc = load_pmc(ff[0])
+        fdur = dict(dur)
+        wa, wc = load_pmc(fw[0])
+        fam = {"crd_score": ("crd_score_kernel",), "crd_loss_grad": ("crd_loss_grad_kernel", "crd_loss_grad_reduce_kernel"),
+               "crd_bank_topk": ("crd_topk_queries_kernel", "crd_bank_sim_kernel", "crd_bank_topk_kernel", "crd_bank_topk_merge_kernel")}
+        crd[var] = {}
+        for name, kerns in fam.items():
+            rd = wr = t = 0.0
+            calls = 0
+            for k in fa:
+                if any(q in k for q in kerns):
+                    rd += 2.0 * fa[k].get("FETCH_SIZE", 0.0) * 1024
+                    t += fdur.get(k, 0)
+                    if kerns[0] in k:
+                        calls = fc[k]
+            for k in wa:
+                if any(q in k for q in kerns):
+                    wr += wa[k].get("WRITE_SIZE", 0.0) * 1024
+            if calls:
+                crd[var][name] = {"read_bytes_per_launch": round(rd / calls), "write_bytes_per_launch": round(wr / calls),
+                                  "bytes_per_launch": round((rd + wr) / calls), "launches_sampled": calls,
+                                  "avg_us_under_profiler": round(t / calls / 1e3, 2)}
+    if crd:
+        json.dump(crd, open(os.path.join(out, f"{tag}_crd_traffic.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(out)))
 
 
