@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void crd_update_kernel(float* __restrict__ mem
 // the query's class with the largest cosine similarity to the query's OWN bank row.  One block per (query, bank);
 // every thread scans a strided slice keeping a private top-NP list, the lists are merged through LDS.  The
 // reference copies the whole bank to the host and calls sklearn per step; here the bank is read once from L2/HBM.
-constexpr int TOPK_MAX = 8, TOPK_SPLIT = 32;
+constexpr int TOPK_MAX = 8, TOPK_SPLIT = 8;     // (32 slices: 4096 selection workgroups of 8 arg-max rounds each, 83 us at B = 64)
 
 // block-wide pick of the best (value desc, index asc) live candidate among n entries of (sv, si); every thread gets it
 __device__ __forceinline__ void block_argbest(const float* sv, const int* si, int n, float* rv, int* ri, int* rs, float& best,
@@ -303,44 +303,101 @@ __global__ __launch_bounds__(64) void crd_topk_queries_kernel(const float* __res
 }
 
 // stage 1: class-masked cosine similarity of EVERY bank row with EVERY query, S[bank][b][j] (CRD_criterion_v10.py:72-79: the
-// reference's cosine_similarity(bank[idx], bank) * class_mask).  One thread per bank row: the row's 128 features live in
-// registers (read ONCE from HBM: 512 B per row, the algorithmic traffic), the queries are wave-uniform and enter the
-// fused multiply-adds as scalar operands (scalar loads, no LDS), the similarity column of a query leaves as one
-// coalesced 256-B store per wave.  The first version scanned the bank once per QUERY (64 x 2 x 21 845 rows of 512 B =
-// 1.4 GB through L2 per call at B = 64: 278 us, 0.03 of the HBM roofline for the 67 MB the call needs).  Same per-pair
-// arithmetic and order as before (sequential dot product over the features, norms as before): the similarities are
-// bitwise those of the per-query scan.
+// reference's cosine_similarity(bank[idx], bank) * class_mask) - a [B x 128] x [128 x n_data] product per bank on the EXACT
+// fp32 matrix instruction (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain, so every similarity is the
+// sequential dot product the scalar kernels computed).  A wave owns tiles of 32 bank rows: the rows arrive by coalesced
+// 16-byte loads (next tile prefetched into registers during the matrix loop) and sit in LDS with an odd row stride; the
+// queries sit in LDS once per workgroup; queries are the M side, bank rows the N side, so a lane's results are 32 consecutive
+// bank rows of one query: 128-byte stores.  History: one workgroup per (query, bank, slice) re-read the bank per query
+// (1.4 GB through L2, 278 us); a thread per bank row with the queries as scalar operands read the bank once but ran 120-132 us
+// (scalar-load latency per 128-feature query and one dependent fmac chain per pair; four interleaved chains and coalesced
+// row loads moved it by 10 %).
+constexpr int SIM_RS = 129;     // dwords per staged row (odd: the 32 lanes of a ds_read_b32 group hit 32 different banks)
+
+template <int NQ>
 __global__ __launch_bounds__(256) void crd_bank_sim_kernel(const float* __restrict__ mem1, const float* __restrict__ mem2,
                                                            const int* __restrict__ labels, const float* __restrict__ qbuf,
                                                            const float* __restrict__ qnorm,
                                                            const int64_t* __restrict__ batch_label, int B, int n_data,
                                                            float* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) float sim_lds[];
+  float* Qs = sim_lds;                                   // [NQ * 32][SIM_RS]
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* Rs = sim_lds + NQ * 32 * SIM_RS + wv * 32 * SIM_RS;   // this wave's [32][SIM_RS]
   const int bank = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool live = j < n_data;
   const float* mem = bank ? mem2 : mem1;
-  float m[D];
-  float nn = 0.f;
-  const f32x4* r = reinterpret_cast<const f32x4*>(mem + (size_t)(live ? j : 0) * D);
-#pragma unroll
-  for (int d4 = 0; d4 < D / 4; ++d4) {
-    const f32x4 v = r[d4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { m[d4 * 4 + k] = v[k]; nn += v[k] * v[k]; }
-  }
-  const float rn = sqrtf(nn);
-  const int lab = live ? labels[j] : -1;
   const float* q = qbuf + (size_t)bank * B * D;
   float* Sb = S + (size_t)bank * B * n_data;
-  for (int b = 0; b < B; ++b) {
-    const float* qb = q + (size_t)b * D;      // wave-uniform address: scalar loads
-    float dot = 0.f;
+  for (int e = threadIdx.x; e < NQ * 32 * D; e += 256) {
+    const int qi = e / D, d = e - qi * D;
+    Qs[qi * SIM_RS + d] = qi < B ? q[(size_t)qi * D + d] : 0.f;
+  }
+  // per lane: norm and label of the 16 * NQ queries its accumulator registers belong to
+  float qn[NQ][16];
+  int ql[NQ][16];
 #pragma unroll
-    for (int d = 0; d < D; ++d) dot += m[d] * qb[d];
-    const float den = rn * qnorm[bank * B + b];
-    float v = den > 0.f ? dot / den : 0.f;
-    if (lab != (int)batch_label[b]) v = 0.f;                 // other classes are masked to similarity 0 (class_mask *)
-    if (live) Sb[(size_t)b * n_data + j] = v;
+  for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      qn[nq][r] = qi < B ? qnorm[bank * B + qi] : 0.f;
+      ql[nq][r] = qi < B ? (int)batch_label[qi] : -2;
+    }
+  __syncthreads();
+  const int ntiles = (n_data + 31) / 32;
+  const int stride = gridDim.x * 4;
+  f32x4 pre[16];
+  auto load_tile = [&](int t) {       // 32 rows x 512 B: instruction e covers rows 2e, 2e + 1
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = t * 32 + e * 2 + (lane >> 5);
+      pre[e] = *reinterpret_cast<const f32x4*>(mem + (size_t)(row < n_data ? row : 0) * D + (lane & 31) * 4);
+    }
+  };
+  auto stage_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float* dst = Rs + (e * 2 + (lane >> 5)) * SIM_RS + (lane & 31) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst[k] = pre[e][k];
+    }
+  };
+  int t = blockIdx.x * 4 + wv;
+  if (t < ntiles) load_tile(t);
+  for (; t < ntiles; t += stride) {
+    stage_tile();
+    if (t + stride < ntiles) load_tile(t + stride);
+    __builtin_amdgcn_wave_barrier();
+    const int j = lane & 31, kk = lane >> 5, row = t * 32 + j;
+    // norm of the lane's bank row, features in index order (bitwise the scalar kernels' value)
+    float nn = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < D; ++d) { const float v = Rs[j * SIM_RS + d]; nn += v * v; }
+    const float rn = sqrtf(nn);
+    const int lab = row < n_data ? labels[row] : -1;
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nq][r] = 0.f;
+#pragma unroll 8
+    for (int k0 = 0; k0 < D; k0 += 2) {
+      const float bv = Rs[j * SIM_RS + k0 + kk];
+#pragma unroll
+      for (int nq = 0; nq < NQ; ++nq)
+        acc[nq] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(nq * 32 + j) * SIM_RS + k0 + kk], bv, acc[nq], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const float den = rn * qn[nq][r];
+        float v = den > 0.f ? acc[nq][r] / den : 0.f;
+        if (lab != ql[nq][r]) v = 0.f;                       // other classes are masked to similarity 0 (class_mask *)
+        if (qi < B && row < n_data) Sb[(size_t)qi * n_data + row] = v;
+      }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -367,22 +424,48 @@ __global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restr
       bv[pos] = v; bi[pos] = j;
     }
   }
-  __shared__ float sv[256 * TOPK_MAX];
-  __shared__ int si[256 * TOPK_MAX];
-  __shared__ float rv[256];
-  __shared__ int ri[256], rs[256];
+  // The block's TOPK_MAX best out of its 256 sorted private lists: every wave pops the best list head TOPK_MAX times
+  // (butterfly arg-max over the lanes: value descending, index ascending - a total order, so the result does not depend on
+  // how the elements are dealt to threads), the four waves' winners meet in LDS and wave 0 repeats the selection on those
+  // 32.  (The first version kept all 2048 candidates in LDS and ran TOPK_MAX block-wide arg-max rounds of nine barriers
+  // each: 62 us at 65 536 rows x 64 queries.)
+  auto better = [](float v, int i, float v2, int i2) { return v2 > v || (v2 == v && i2 < i); };
+  auto wave_pop_best = [&](float& ov, int& oi) {
+    float v = bv[0]; int i = bi[0];
 #pragma unroll
-  for (int k = 0; k < TOPK_MAX; ++k) { sv[threadIdx.x * TOPK_MAX + k] = bv[k]; si[threadIdx.x * TOPK_MAX + k] = bi[k]; }
-  __syncthreads();
-  const size_t base = (((size_t)b * 2 + bank) * TOPK_SPLIT + z) * TOPK_MAX;
-  for (int pick = 0; pick < TOPK_MAX; ++pick) {
-    float best; int besti, slot;
-    block_argbest(sv, si, 256 * TOPK_MAX, rv, ri, rs, best, besti, slot);
-    if (threadIdx.x == 0) {
-      if (slot >= 0) si[slot] = 0x7fffffff;
-      cand_v[base + pick] = best; cand_i[base + pick] = besti;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(v, o, 64); const int i2 = __shfl_xor(i, o, 64);
+      if (better(v, i, v2, i2)) { v = v2; i = i2; }
     }
-    __syncthreads();
+    ov = v; oi = i;
+    if (bi[0] == i && i != 0x7fffffff) {      // the owner drops its head (indices are unique within the block)
+#pragma unroll
+      for (int k = 0; k + 1 < TOPK_MAX; ++k) { bv[k] = bv[k + 1]; bi[k] = bi[k + 1]; }
+      bv[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
+    }
+  };
+  __shared__ float wv_[4 * TOPK_MAX];
+  __shared__ int wi_[4 * TOPK_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int pick = 0; pick < TOPK_MAX; ++pick) {
+    float v; int i;
+    wave_pop_best(v, i);
+    if (lane == 0) { wv_[wave * TOPK_MAX + pick] = v; wi_[wave * TOPK_MAX + pick] = i; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    bv[0] = lane < 4 * TOPK_MAX ? wv_[lane] : -INFINITY;
+    bi[0] = lane < 4 * TOPK_MAX ? wi_[lane] : 0x7fffffff;
+#pragma unroll
+    for (int k = 1; k < TOPK_MAX; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
+    const size_t base = (((size_t)b * 2 + bank) * TOPK_SPLIT + z) * TOPK_MAX;
+#pragma unroll
+    for (int pick = 0; pick < TOPK_MAX; ++pick) {
+      float v; int i;
+      wave_pop_best(v, i);
+      if (lane == 0) { cand_v[base + pick] = v; cand_i[base + pick] = i; }
+    }
   }
 }
 
@@ -548,8 +631,28 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
     ph_prof_begin(PH_CLS_CRD_TOPK, 2.0 * n_data * D * 4 + 4.0 * n_data + 2.0 * B * num_pos * 12, st, &tok);
   hipLaunchKernelGGL(crd_topk_queries_kernel, dim3(B, 2), dim3(64), 0, st, mem1, mem2, idx, PK, qbuf, qnorm);
   PH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(crd_bank_sim_kernel, dim3(cdiv(n_data, 256), 2), dim3(256), 0, st, mem1, mem2, labels, qbuf, qnorm,
-                     batch_label, B, n_data, S);
+  {
+    const int nq = cdiv(B, 32);
+    if (nq > 4) return PH_EINVAL;      // up to 128 queries per call
+    const int ntiles = cdiv(n_data, 32);
+    int gx = cdiv(ntiles, 4);
+    const int cus = ph_num_cus();
+    if (gx > cus / 2) gx = cus / 2;     // one workgroup per CU over the two banks; a wave walks its tiles
+    const size_t lds = (size_t)(nq * 32 + 4 * 32) * SIM_RS * sizeof(float);
+#define PH_SIM_LAUNCH(N)                                                                                                    \
+  do {                                                                                                                      \
+    static bool done = false;                                                                                               \
+    if (!done) {                                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(crd_bank_sim_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess) return PH_ELAUNCH;                                                   \
+      done = true;                                                                                                          \
+    }                                                                                                                       \
+    hipLaunchKernelGGL(crd_bank_sim_kernel<N>, dim3(gx, 2), dim3(256), lds, st, mem1, mem2, labels, qbuf, qnorm, batch_label, B, \
+                       n_data, S);                                                                                          \
+  } while (0)
+    if (nq == 1) PH_SIM_LAUNCH(1); else if (nq == 2) PH_SIM_LAUNCH(2); else if (nq == 3) PH_SIM_LAUNCH(3); else PH_SIM_LAUNCH(4);
+#undef PH_SIM_LAUNCH
+  }
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2, TOPK_SPLIT), dim3(256), 0, st, S, B, n_data, cv, ci);
   PH_LAUNCH_CHECK();

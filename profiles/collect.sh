@@ -14,6 +14,8 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES 
   --output-format csv -d "$T/sq" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_sq.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$T/write" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_write.log" 2>&1
+# L2 view of the same step (do the re-reads of the layer-1 kernel's halos reach the fabric?): hits / misses / fabric read requests
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d "$T/tcc" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_tcc.log" 2>&1
 # CRD kernels at the bank sizes of BASELINE configs[3] / configs[4] (counter bytes for the `variants` block of the bench line)
 for V in mia2022 mia2023; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch_$V" -- python3 bench.py --variant $V --steps 3 --warmup 3 --eager > "$T/bench_fetch_$V.log" 2>&1

@@ -131,6 +131,26 @@ def main():
         json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
         open(os.path.join(out, f"{tag}_traffic.txt"), "w").write(
             "# HBM traffic per launch (FETCH_SIZE x2 correction, WRITE_SIZE exact; separate --pmc passes)\n" + "\n".join(lines) + "\n")
+    # ---- L2 (TCC) view per MFMA kernel class: hit rate and fabric read requests
+    ft = glob.glob(os.path.join(src, "tcc", "*", "*counter_collection.csv"))
+    if ft:
+        ta, tc = load_pmc(ft[0])
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        for k in ta:
+            c = cls_of(k)
+            if c is not None:
+                for name, v in ta[k].items():
+                    per[c][name] += v
+                per[c]["n"] += tc[k]
+        with open(os.path.join(out, f"{tag}_tcc.txt"), "w") as o:
+            o.write("# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum (eager bench); per launch of each kernel class\n")
+            o.write("# l2_hit = HIT / (HIT + MISS) over 128-B request granules; rdreq = read requests the L2 sent to the fabric "
+                    "(Infinity Cache / HBM); rdreq_dram = those addressed to device memory\n")
+            for c, d in sorted(per.items()):
+                n = max(d["n"], 1)
+                o.write(f"class {c}: l2_hit {d['TCC_HIT_sum'] / max(d['TCC_HIT_sum'] + d['TCC_MISS_sum'], 1):.3f}  "
+                        f"hit {d['TCC_HIT_sum'] / n:12.0f}  miss {d['TCC_MISS_sum'] / n:12.0f}  rdreq {d['TCC_EA0_RDREQ_sum'] / n:12.0f}  "
+                        f"rdreq_dram {d['TCC_EA0_RDREQ_DRAM_sum'] / n:12.0f}  ({int(n)} launches)\n")
     # ---- CRD kernels of the variant steps (bench.py --variant mia2022 / mia2023): counter bytes per CALL of each kernel family
     crd = {}
     for var in ("mia2022", "mia2023"):
