@@ -407,13 +407,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
+    if os.environ.get("PH_BENCH_ONE_GPU"):
+        local_rank = 0     # testing aid: every replica on GPU 0 (with PH_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import multimodal_learning_amd as m
     sync = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("PH_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
         sync = m.dist.ReplicaSync()
     m.set_precision("bf16")
     if args.variant != "miccai2022":
