@@ -969,6 +969,8 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
 #ifdef PH_ABL_NOSTORE
           asm volatile("" ::"v"(w));
 #else
+          // (write-through `sc1` stores, tried so that the output lines would not occupy the XCD's L2 beside the halos:
+          // the layer-1 launches ran 43 % slower on the same box - profiles/EXPERIMENTS.md)
           if (mine) *reinterpret_cast<u32x4*>(out + o + j * 32 + gp * 16) = w;
 #endif
         }
