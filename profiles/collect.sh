@@ -23,3 +23,5 @@ for V in mia2022 mia2023; do
 done
 python3 bench.py > "$T/bench_default.log" 2>&1
 tail -1 "$T/bench_default.log" | cut -c1-300
+python3 bench.py --north-star --no-parity-mode --no-cpu-baseline --no-variants > "$T/bench_b256.log" 2>&1
+tail -1 "$T/bench_b256.log" | cut -c1-200

@@ -216,3 +216,22 @@ def test_distill_step_fed_by_the_resident_loader_inside_its_graph():
     assert sorted(rows.tolist()) == list(range(n_data))
     assert not torch.equal(seen[12].cpu(), seen[0].cpu())  # the next epoch uses another permutation
     assert int(ld.batch_no.item()) == 14
+
+
+def test_caller_supplied_params_validate_the_disabled_step_mask():
+    """column 13 of a caller-supplied parameter block is the bit mask of disabled colour steps (0..15); anything
+    else - a block from before the layout change, garbage - must raise instead of silently skipping jitter steps."""
+    import types
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.augment import DeviceAugment, NPARAM
+    opt = types.SimpleNamespace(input_size_path=32)
+    aug = DeviceAugment(opt, "cuda", seed=1)
+    src = torch.randint(0, 256, (2, 64, 64, 3), dtype=torch.uint8, device="cuda")
+    aug(src)
+    good = aug.last_params.clone()
+    aug(src, params=good)                       # a block the kernel produced itself is accepted
+    for bad in (99.0, -1.0, 2.5):
+        p = good.clone()
+        p[0, 1, 13] = bad
+        with pytest.raises(ValueError):
+            aug(src, params=p)

@@ -577,3 +577,43 @@ def test_masked_stride2_grid_vs_first_generation_kernel(B, H):
     ga, gb = res[True][2], res[False][2]
     assert torch.isfinite(gb).all()
     assert torch.dot(ga, gb) >= 0.70 * ga.norm() * gb.norm()
+
+
+@pytest.mark.gpu
+def test_workspace_cache_is_bounded_and_pins_what_a_capture_uses():
+    """one trunk workspace per (B, H, W, arithmetic) used to stay alive for good (2.7 GB each at the benchmark
+    size).  Un-pinned workspaces now live in a 2-entry LRU per network; a workspace requested while a stream capture is
+    running is pinned (the graph holds its raw pointer) and survives any number of other shapes."""
+    import multimodal_learning_amd as m
+    m.set_precision("bf16")
+    net = _student()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    xs = {h: torch.rand(2, 3, h, h, device="cuda") * 2 - 1 for h in (64, 96, 128, 160)}
+    with torch.no_grad():
+        for h in (64, 96, 128):
+            net(x_path=xs[h])
+    assert len(net._ws_cache) == 2 and [k[1] for k in net._ws_cache] == [96, 128]      # least recently used first
+    with torch.no_grad():
+        net(x_path=xs[96])
+        net(x_path=xs[160])
+    assert [k[1] for k in net._ws_cache] == [96, 160]
+    # a capture pins its workspace
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        with torch.cuda.graph(g):
+            out = net(x_path=xs[64])
+    ptr64 = net._ws_cache[(2, 64, 64, m.get_precision())].data_ptr()
+    with torch.no_grad():
+        for h in (96, 128, 160, 96, 128):
+            net(x_path=xs[h])
+    assert (2, 64, 64, m.get_precision()) in net._ws_cache and net._ws_cache[(2, 64, 64, m.get_precision())].data_ptr() == ptr64
+    assert len([k for k in net._ws_cache if k[1] != 64]) == 2
+    g.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = net(x_path=xs[64])
+    assert torch.equal(out[2], ref[2])
+    net.release_workspaces()
+    assert not net._ws_cache and not net._ws_pinned
