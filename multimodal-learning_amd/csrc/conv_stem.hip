@@ -401,8 +401,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
     const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
     // (out-of-image pixels are staged like any other: the pooling pass skips them by coordinate)
-    auto stage = [&](auto insidec) {
+    // (`OWN` - does the tile count for the statistics - is a template argument, not a branch around each of the 16 updates:
+    // the inline-asm statistics ops cannot be hoisted, so hipcc had emitted one s_cbranch per register pair, and ~30 scalar
+    // branches per tile are what made this phase cost ~12 cycles per vector instruction)
+    auto stage = [&](auto insidec, auto ownc) {
       constexpr bool INSIDE = decltype(insidec)::value;
+      constexpr bool OWN = decltype(ownc)::value;
       if constexpr (!INSIDE) asm volatile("; edge tile: masked statistics" ::: "memory");   // keeps the two paths apart
 #pragma unroll
       for (int q2 = 0; q2 < 8; ++q2) {
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v0 = acc[j][2 * q2], v1 = acc[j][2 * q2 + 1];
-          if (own_tile && !(PH_STEM_ABL & 32)) {
+          if constexpr (OWN && !(PH_STEM_ABL & 32)) {
             const float w0 = edge0 ? v0 * k0 : v0, w1 = edge1 ? v1 * k1 : v1;
             s1[j] = fadd_s(fadd_s(s1[j], w0), w1);
             s2[j] = ffma_s(w1, w1, ffma_s(w0, w0, s2[j]));
@@ -438,8 +442,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
         }
       }
     };
-    if (strip_inside && r0 + TH <= p.OH) stage(std::true_type{});
-    else stage(std::false_type{});
+    if (own_tile) {
+      if (strip_inside && r0 + TH <= p.OH) stage(std::true_type{}, std::true_type{});
+      else stage(std::false_type{}, std::true_type{});
+    } else {
+      stage(std::false_type{}, std::false_type{});
+    }
     if (tr + 1 < tr_end) store_halo_regs(ldsX + ((tpar & 1) ^ 1) * XB);
     // LDS-only barrier (__syncthreads() would also drain the vector-memory counter: the pooled stores of the tile before)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
