@@ -273,7 +273,7 @@ def launch_replicas(n, argv, timeout_s=None):
     the replicas are killed by PID and attempt 2 runs eagerly (PH_BENCH_LAUNCH tells the children what to report)."""
     import socket
     import subprocess
-    timeout_s = timeout_s or float(os.environ.get("PH_BENCH_LAUNCH_TIMEOUT", "600"))
+    timeout_s = timeout_s or float(os.environ.get("PH_BENCH_LAUNCH_TIMEOUT", "300"))
     attempts = [("self-launched", [])]
     if "--eager" not in argv:
         attempts.append(("self-launched, eager fallback (the graph-replayed attempt failed or timed out)", ["--eager"]))
