@@ -104,9 +104,11 @@ class _TrunkFn(torch.autograd.Function):
         # the same x_path) enters as its NHWC4 tensor, flag +64; the tensor is kept alive for the backward's stem wgrad
         shared = getattr(net, "_x4_shared", None)
         x4 = None
-        if shared is not None and shared[0] == (x.data_ptr(), tuple(x.shape), plan.key[3] == ops.PREC_BF16):
-            x4 = shared[1]
-            flags |= 64
+        if shared is not None:
+            net._x4_shared = None      # single use: a later forward on recycled memory at the same address must not find it
+            if shared[0] == (x.data_ptr(), tuple(x.shape), plan.key[3] == ops.PREC_BF16):
+                x4 = shared[1]
+                flags |= 64
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x4 if x4 is not None else x), ptr(ws), ptr(f3), ptr(f4), flags,
                                       stream()), "ph_resnet_forward")
         ctx.x4 = x4
