@@ -451,7 +451,7 @@ def test_image_gradient_perf_mode_tracks_parity_mode():
     assert 0.8 < float(b.norm() / a.norm()) < 1.25
 
 
-@pytest.mark.parametrize("B,H", [(6, 160), (3, 96), (20, 224)])
+@pytest.mark.parametrize("B,H", [(6, 160), (3, 96), (20, 224), (64, 512)])
 def test_fused_input_batchnorm_equals_separate_pass(B, H):
     """Forward-only networks (the EMA student and the teacher) run conv2 of every block on the RAW conv1 output and apply
     bn1 + ReLU to each halo tile in LDS (conv_tap2.hip, PhTapConv::in_scale; padding enters as NaN and leaves the ReLU
@@ -481,7 +481,7 @@ def test_fused_input_batchnorm_equals_separate_pass(B, H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,H", [(4, 64), (3, 160), (2, 224), (5, 72), (2, 70), (3, 102), (8, 512)])
+@pytest.mark.parametrize("B,H", [(4, 64), (3, 160), (2, 224), (5, 72), (2, 70), (3, 102), (8, 512), (64, 512)])
 def test_stem_conv_with_pooled_epilogue_equals_separate_passes(B, H):
     """Forward-only networks in perf mode never write the stem's conv output: stem_fwd_pool_kernel pools the bf16-rounded
     RAW output inside the conv kernel (maximum where gamma >= 0, minimum where gamma < 0) and BatchNorm + ReLU is applied to
