@@ -183,7 +183,8 @@ class DropoutFn(torch.autograd.Function):
         y = _f32(x).clone()
         check(lib().ph_dropout_dev(ptr(y), y.numel(), p, seed, site_offset, ptr(step_counter), int(alpha), stream()),
               "ph_dropout_dev")
-        ctx.save_for_backward(step_counter.clone())
+        if ctx.needs_input_grad[0]:      # (the frozen teacher's dropouts never run a backward: no 8-byte copy kernel for them)
+            ctx.save_for_backward(step_counter.clone())
         ctx.args = (p, seed, site_offset, int(alpha))
         return y
 
