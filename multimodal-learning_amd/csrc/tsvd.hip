@@ -229,19 +229,52 @@ __global__ __launch_bounds__(256) void tsvd_slice_kernel(const float* __restrict
 // at B = 128; the slice is 128 KB.  Column pairs (p, q) of A (initially X) are rotated until all columns are mutually
 // orthogonal: A = X V = U Sigma, so sigma_j = ||a_j|| and the thresholded slice is
 //   Y = U max(Sigma - tau, 0) V^H = A diag(f_j / sigma_j^2) A^H X,   f_j = max(1 - tau / sigma_j, 0),
-// which needs neither V nor U explicitly.  A lives in LDS column-major; X, T = A^H X and Y go through the workspace.
-// One workgroup (1024 threads = 64 teams of 16 lanes, one team per column pair) per frequency slice.
-constexpr int TB_MAXB = 128, TB_LD = TB_MAXB + 1, TB_ROWS = TB_MAXB / 16;
+// which needs neither V nor U explicitly.  X, T = A^H X and Y go through the workspace.
+// One workgroup (1024 threads = 64 teams of 16 lanes, one team per column pair) per frequency slice - the launch is
+// V / 2 + 1 workgroups, so the time of a call is the time of ONE compute unit walking 127 rotation steps per sweep: the
+// step body is what matters.  A lives in LDS column-major as interleaved (re, im) pairs; rows >= B are zero and stay
+// zero, so the body has no bounds checks.  Lane l of a team owns the row pairs 2 (l + 16 m), m < 4: each ds_read_b128 /
+// ds_write_b128 of a team covers 256 contiguous bytes.  The arithmetic is packed fp32 on (re, im) pairs (v_pk_fma_f32),
+// the four dot products are reduced over the team's 16 lanes with DPP butterflies (quad_perm / row_half_mirror /
+// row_mirror: both partners of an exchange add the same two numbers, so all 16 lanes hold bitwise the same sums and
+// apply the same rotation).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+// Column stride exactly 1 KiB: the lane groups of a ds_read_b128 mix lanes of two teams (MI355X_MICROARCH.md, LDS), and with
+// every column base = 0 (mod 256 B) the pieces of the two columns still fall on disjoint banks.  Everything the kernel keeps in
+// LDS sits in the DYNAMIC region (statics in front of it would leave A off its 16-byte alignment: replayed accesses).
+constexpr int TB_MAXB = 128, TB_CS = 2 * TB_MAXB;
+constexpr int TB_LDS_FLOATS = TB_MAXB * TB_CS + TB_MAXB + 1024 + 4;
+#ifndef TB_TOL2
+#define TB_TOL2 1e-12f
+#endif
+#ifndef TB_MAX_SWEEPS
+#define TB_MAX_SWEEPS 30
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, the same bits in every lane
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_xchg<0xB1>(x);      // quad_perm [1,0,3,2]
+  x += dpp_xchg<0x4E>(x);      // quad_perm [2,3,0,1]
+  x += dpp_xchg<0x141>(x);     // row_half_mirror
+  x += dpp_xchg<0x140>(x);     // row_mirror
+  return x;
+}
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __restrict__ adj, float* __restrict__ yre,
                                                               float* __restrict__ yim, float* __restrict__ tre,
                                                               float* __restrict__ tim, float* __restrict__ tnn_k, int V,
                                                               int B, float tau) {
   extern __shared__ float sm[];
-  float* Are = sm;                       // [n][TB_LD]  column-major: Are[col * TB_LD + row]
-  float* Aim = sm + TB_MAXB * TB_LD;
-  __shared__ float dj[TB_MAXB], red[1024];
-  __shared__ int rotated;
+  float* A = sm;                         // [n][TB_CS]: column j at A + j * TB_CS, row r at floats 2r (re), 2r + 1 (im)
+  float* dj = sm + TB_MAXB * TB_CS;      // [TB_MAXB]
+  float* red = dj + TB_MAXB;             // [1024]
+  int& rotated = *reinterpret_cast<int*>(red + 1024);
   const int tid = threadIdx.x, k = blockIdx.x;
   const int n = B + (B & 1);             // an odd B gets a zero column that never rotates
   const size_t bb = (size_t)B * B;
@@ -249,17 +282,16 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
   float* Xim = yim + (size_t)k * bb;
   float* Tre = tre + (size_t)k * bb;
   float* Tim = tim + (size_t)k * bb;
+  for (int e = tid; e < TB_MAXB * TB_CS / 4; e += 1024) reinterpret_cast<v4f*>(A)[e] = v4f{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
   float part = 0.f;
-  for (int e = tid; e < n * B; e += 1024) {
-    const int i = e / n, b = e % n;
-    float re = 0.f, im = 0.f;
-    if (b < B) {
-      dft_elem(adj, V, bb, (size_t)i * B + b, k, re, im);
-      Xre[(size_t)i * B + b] = re;
-      Xim[(size_t)i * B + b] = im;
-    }
-    Are[b * TB_LD + i] = re;
-    Aim[b * TB_LD + i] = im;
+  for (int e = tid; e < B * B; e += 1024) {
+    const int i = e / B, b = e % B;
+    float re, im;
+    dft_elem(adj, V, bb, (size_t)e, k, re, im);
+    Xre[e] = re;
+    Xim[e] = im;
+    *reinterpret_cast<v2f*>(A + b * TB_CS + 2 * i) = v2f{re, im};
     part += re * re + im * im;
   }
   red[tid] = part;
@@ -273,45 +305,54 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
   const float col_floor = 1e-14f * nrm2;  // columns below the rounding noise of the slice are left alone (and dropped)
   __syncthreads();
   const int team = tid >> 4, l = tid & 15, half = n / 2;
-  for (int sweep = 0; sweep < 30; ++sweep) {
+  const int nm = (B + 31) >> 5;          // row chunks of 32 that hold data
+  int sweeps_done = 0;
+  for (int sweep = 0; sweep < TB_MAX_SWEEPS; ++sweep) {
+    ++sweeps_done;
     for (int step = 0; step < n - 1; ++step) {
       if (team < half) {
         const int j1 = n - 1 - team;
         const int p = team == 0 ? n - 1 : (step + team - 1) % (n - 1);
         const int q = (step + j1 - 1) % (n - 1);
-        float ar[TB_ROWS], ai[TB_ROWS], br[TB_ROWS], bi[TB_ROWS];
-        float al = 0.f, be = 0.f, gr = 0.f, gi = 0.f;
+        v4f* cp = reinterpret_cast<v4f*>(A + p * TB_CS) + l;
+        v4f* cq = reinterpret_cast<v4f*>(A + q * TB_CS) + l;
+        v4f a[4], b[4];
+        v2f saa = {0.f, 0.f}, sbb = {0.f, 0.f}, sab = {0.f, 0.f}, sax = {0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < TB_ROWS; ++m) {
-          const int r = l + 16 * m;
-          const bool in = r < B;
-          ar[m] = in ? Are[p * TB_LD + r] : 0.f; ai[m] = in ? Aim[p * TB_LD + r] : 0.f;
-          br[m] = in ? Are[q * TB_LD + r] : 0.f; bi[m] = in ? Aim[q * TB_LD + r] : 0.f;
-          al += ar[m] * ar[m] + ai[m] * ai[m];
-          be += br[m] * br[m] + bi[m] * bi[m];
-          gr += ar[m] * br[m] + ai[m] * bi[m];     // conj(a_p) . a_q
-          gi += ar[m] * bi[m] - ai[m] * br[m];
+        for (int m = 0; m < 4; ++m) {
+          if (m < nm) {
+            a[m] = cp[16 * m];
+            b[m] = cq[16 * m];
+            const v2f a0 = a[m].xy, a1 = a[m].zw, b0 = b[m].xy, b1 = b[m].zw;
+            saa = pk_fma(a0, a0, saa); saa = pk_fma(a1, a1, saa);
+            sbb = pk_fma(b0, b0, sbb); sbb = pk_fma(b1, b1, sbb);
+            sab = pk_fma(a0, b0, sab); sab = pk_fma(a1, b1, sab);        // (ar br, ai bi)
+            sax = pk_fma(a0, b0.yx, sax); sax = pk_fma(a1, b1.yx, sax);  // (ar bi, ai br)
+          }
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-          al += __shfl_xor(al, o, 16); be += __shfl_xor(be, o, 16);
-          gr += __shfl_xor(gr, o, 16); gi += __shfl_xor(gi, o, 16);
-        }
+        const float al = row16_sum(saa.x + saa.y), be = row16_sum(sbb.x + sbb.y);
+        const float gr = row16_sum(sab.x + sab.y);      // conj(a_p) . a_q
+        const float gi = row16_sum(sax.x - sax.y);
         const float g2 = gr * gr + gi * gi;
-        if (fminf(al, be) > col_floor && g2 > 1e-12f * al * be) {
-          const float g = sqrtf(g2), er = gr / g, ei = gi / g;
-          const float ze = (be - al) / (2.f * g);
+        if (fminf(al, be) > col_floor && g2 > TB_TOL2 * al * be) {
+          const float rg = __frsqrt_rn(g2), g = g2 * rg;
+          const float ze = (be - al) * (0.5f * rg);
           const float t = copysignf(1.f, ze) / (fabsf(ze) + sqrtf(1.f + ze * ze));
-          const float c = 1.f / sqrtf(1.f + t * t), s = c * t;
+          const float c = __frsqrt_rn(1.f + t * t), s = c * t;
+          const float ser = s * gr * rg, sei = s * gi * rg;
+          (void)g;
+          // a_p' = c a_p - s e^{-i phi} a_q ;  a_q' = s e^{i phi} a_p + c a_q ;  e^{i phi} = (gr + i gi) / |g|
+          const v2f c2 = {c, c}, s2 = {ser, ser}, ns2 = {-ser, -ser}, k1 = {-sei, sei};
 #pragma unroll
-          for (int m = 0; m < TB_ROWS; ++m) {
-            const int r = l + 16 * m;
-            if (r < B) {
-              // a_p' = c a_p - s e^{-i phi} a_q ;  a_q' = s e^{i phi} a_p + c a_q
-              Are[p * TB_LD + r] = c * ar[m] - s * (er * br[m] + ei * bi[m]);
-              Aim[p * TB_LD + r] = c * ai[m] - s * (er * bi[m] - ei * br[m]);
-              Are[q * TB_LD + r] = s * (er * ar[m] - ei * ai[m]) + c * br[m];
-              Aim[q * TB_LD + r] = s * (er * ai[m] + ei * ar[m]) + c * bi[m];
+          for (int m = 0; m < 4; ++m) {
+            if (m < nm) {
+              const v2f a0 = a[m].xy, a1 = a[m].zw, b0 = b[m].xy, b1 = b[m].zw;
+              const v2f p0 = pk_fma(c2, a0, pk_fma(ns2, b0, k1 * b0.yx));
+              const v2f p1 = pk_fma(c2, a1, pk_fma(ns2, b1, k1 * b1.yx));
+              const v2f q0 = pk_fma(c2, b0, pk_fma(s2, a0, k1 * a0.yx));
+              const v2f q1 = pk_fma(c2, b1, pk_fma(s2, a1, k1 * a1.yx));
+              cp[16 * m] = v4f{p0.x, p0.y, p1.x, p1.y};
+              cq[16 * m] = v4f{q0.x, q0.y, q1.x, q1.y};
             }
           }
           if (l == 0) rotated = 1;
@@ -329,7 +370,7 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
   part = 0.f;
   if (tid < n) {
     float a2 = 0.f;
-    for (int r = 0; r < B; ++r) a2 += Are[tid * TB_LD + r] * Are[tid * TB_LD + r] + Aim[tid * TB_LD + r] * Aim[tid * TB_LD + r];
+    for (int r = 0; r < 2 * B; ++r) a2 += A[tid * TB_CS + r] * A[tid * TB_CS + r];
     const float sig = sqrtf(a2);
     const bool keep = a2 > 100.f * col_floor && sig > tau;
     dj[tid] = keep ? (1.f - tau / sig) / a2 : 0.f;
@@ -341,29 +382,34 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
     if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0) tnn_k[k] = red[0];
-  // T = A^H X
+  if (tid == 0) {
+    tnn_k[k] = red[0];
+    tnn_k[8 + k] = (float)sweeps_done;  // diagnostic: sweeps this slice took (tests/bench_tsvd_gpu.py)
+  }
+  // T = D A^H X
   for (int e = tid; e < B * B; e += 1024) {
     const int j = e / B, b = e % B;
     float tr = 0.f, ti = 0.f;
     for (int i = 0; i < B; ++i) {
-      const float ar = Are[j * TB_LD + i], ai = Aim[j * TB_LD + i], xr = Xre[(size_t)i * B + b], xi = Xim[(size_t)i * B + b];
-      tr += ar * xr + ai * xi;
-      ti += ar * xi - ai * xr;
+      const v2f av = *reinterpret_cast<const v2f*>(A + j * TB_CS + 2 * i);
+      const float xr = Xre[(size_t)i * B + b], xi = Xim[(size_t)i * B + b];
+      tr += av.x * xr + av.y * xi;
+      ti += av.x * xi - av.y * xr;
     }
     Tre[e] = tr * dj[j];
     Tim[e] = ti * dj[j];
   }
   __threadfence_block();
   __syncthreads();
-  // Y = A (D T)
+  // Y = A T
   for (int e = tid; e < B * B; e += 1024) {
     const int i = e / B, b = e % B;
     float yr = 0.f, yi = 0.f;
     for (int j = 0; j < B; ++j) {
-      const float ar = Are[j * TB_LD + i], ai = Aim[j * TB_LD + i], tr = Tre[(size_t)j * B + b], ti = Tim[(size_t)j * B + b];
-      yr += ar * tr - ai * ti;
-      yi += ar * ti + ai * tr;
+      const v2f av = *reinterpret_cast<const v2f*>(A + j * TB_CS + 2 * i);
+      const float tr = Tre[(size_t)j * B + b], ti = Tim[(size_t)j * B + b];
+      yr += av.x * tr - av.y * ti;
+      yi += av.x * ti + av.y * tr;
     }
     Xre[e] = yr;
     Xim[e] = yi;
@@ -429,7 +475,7 @@ int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn, int V, int B, f
   float* tim = tre + (size_t)(V / 2 + 1) * bb;
   float* tk = tim + (size_t)(V / 2 + 1) * bb;
   if (B > TS_MAXB) {
-    const int ldsb = 2 * TB_MAXB * TB_LD * (int)sizeof(float);
+    const int ldsb = TB_LDS_FLOATS * (int)sizeof(float);
     static bool attr_big = false;
     if (!attr_big) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(tsvd_slice_big_kernel),
