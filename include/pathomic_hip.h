@@ -369,6 +369,9 @@ int ph_prof_reset(void);
 int ph_prof_summary(double* out, int nclasses);
 /* out[cls*4 + {0,1,2,3}] = {launches, total ms, total algorithmic work, total algorithmic HBM bytes} */
 int ph_prof_summary4(double* out, int nclasses);
+/* Phase marker: a one-thread launch that stores the device's 100 MHz wall clock into *out (device memory) when `stream`
+ * reaches it - capturable in a HIP graph, unlike events, so the phases of a replayed step can be timed. */
+int ph_prof_stamp(unsigned long long* out, ph_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ SIGNATURES = {
     "ph_prof_reset": (i32, []),
     "ph_prof_summary": (i32, [vp, i32]),
     "ph_prof_summary4": (i32, [vp, i32]),
+    "ph_prof_stamp": (i32, [vp, vp]),
     "ph_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32]),
     "ph_conv2d_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ph_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),

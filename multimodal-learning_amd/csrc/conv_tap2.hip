@@ -261,6 +261,13 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   }
 
   f32x16 acc[FM][FN];
+#ifdef PH_ABL_MFMA16   // timing ablation only (results are garbage): same FLOPs through v_mfma_f32_16x16x32_bf16
+  f32x4 abl[FM][FN][2];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) { abl[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; abl[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#endif
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -487,6 +494,10 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
   // (Macros, not lambdas: clang rejects asm operands that name captured variables inside a generic lambda.)
 #ifdef PH_ABL_NOMFMA   // timing ablation only
 #define PH_MM(CB, I, J) asm volatile("" : "+a"(acc[I][J]) : "v"(fa[CB][I]), "v"(fb[CB][J]))
+#elif defined(PH_ABL_MFMA16)
+#define PH_MM(CB, I, J)                                                                                         \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %2, %3, %1"               \
+               : "+a"(abl[I][J][0]), "+a"(abl[I][J][1]) : "v"(fa[CB][I]), "v"(fb[CB][J]))
 #else
 #define PH_MM(CB, I, J)                                                                                  \
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(fa[CB][I]), "v"(fb[CB][J]))

@@ -96,6 +96,17 @@ int ph_prof_summary(double* out, int nclasses) {
   return PH_OK;
 }
 
+// a one-thread kernel that stores the 100 MHz wall clock: a launch like any other, so it can sit inside a captured graph
+// and mark when the stream reached that point of a replayed step (tests/bench_phases_gpu.py)
+__global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
+
+int ph_prof_stamp(unsigned long long* out, hipStream_t st) {
+  if (!out) return PH_EINVAL;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, out);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
 }  // extern "C"
 
 int ph_num_cus() {

@@ -358,6 +358,7 @@ class DistillStep:
         self._static = None
         self._slots = None
         self._side_stream = torch.cuda.Stream(device=self.device) if getattr(opt, "overlap_teachers", True) else None
+        self._stamps = None      # int64 [16] device tensor: set BEFORE enable_graph() to have the body mark its phases
         self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
         # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
         flat = self.optimizer.flat
@@ -392,6 +393,11 @@ class DistillStep:
                 lo = next(o for t, o in zip(flat.tensors, flat.offsets) if t is first)
                 self.model._grad_ready_hook = lambda: self.sync.begin_grad_slice(self.optimizer.flat, lo)
 
+    def _stamp(self, k):
+        """Phase marker k (ph_prof_stamp: the device wall clock when the current stream gets here; also inside a graph)."""
+        if self._stamps is not None:
+            check(lib().ph_prof_stamp(self._stamps.data_ptr() + 8 * k, stream()), "ph_prof_stamp")
+
     # ------------------------------------------------------------------ one step
     def _device_body(self, x_path, ema_x_path, x_omic, grade, index, sample_idx, bnorm, e, r1, r2):
         """Everything of the step that runs on the device (capturable in one HIP graph)."""
@@ -403,21 +409,28 @@ class DistillStep:
         # the student and the teacher read the same x_path (:249, :256): one packing pass into the trunk's input layout
         # serves both (before the streams fork, so both consumers are ordered after it)
         from .resnets import pack_shared_input
+        self._stamp(0)
         pack_shared_input(x_path, (self.model, self.fix_model.path_net))
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad():
                 _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
+                self._stamp(8)
                 fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
+                self._stamp(9)
                 for t in (ema_path_feat, ema_logit_path, fuse_feat, logits[-1]):
                     t.record_stream(main)
         _, path_feat, logit_path, pred_path, _ = self.model(x_path=x_path)                                   # :249
+        self._stamp(1)
+        if self._stamps is not None and path_feat.requires_grad:
+            path_feat.register_hook(lambda g: (self._stamp(4), g)[1])
         if side is not None:
             main.wait_stream(side)
         else:
             with torch.no_grad():
                 _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
                 fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
+        self._stamp(2)
         if self._fused_head_ok():
             # :262-313 as one function of the student feature (loss_head.py): same values, ~50 launches instead of ~125
             from .loss_head import FusedDistillLossFn, LossHeadCtx
@@ -426,10 +439,13 @@ class DistillStep:
             loss = FusedDistillLossFn.apply(path_feat, Hc)
             loss = self._add_reg(loss)                                                                      # :312-313
             self.optimizer.zero_grad()                                                                      # :326
+            self._stamp(3)
             loss.backward()                                                                                 # :327
+            self._stamp(5)
             if self.sync is not None:
                 self.sync.all_reduce_grads(self.optimizer.flat)
             self.optimizer.step()                                                                           # :328 (+ :329 fused)
+            self._stamp(6)
             o = Hc.out
             return dict(loss=loss.detach(), loss_cls=o["loss_cls"], loss_div1=o["loss_div1"], loss_div2=o["loss_div2"],
                         loss_kd1=o["loss_kd1"], loss_kd2=o["loss_kd2"], scale=o["scale"], logit_path=o["logit_path"],
