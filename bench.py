@@ -381,6 +381,10 @@ def main():
                     help="A/B switch: first-generation kernel for the 3x3 stride-2 convolutions (not the masked tap grid)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
+    ap.add_argument("--teacher-streams", type=int, default=2,
+                    help="A/B switch: 1 = the fused teacher's forward behind the mean teacher's on one side stream (round 2)")
+    ap.add_argument("--no-bwd-overlap", action="store_true",
+                    help="A/B switch: the student's backward on one stream (weight gradients not on the plan's side stream)")
     ap.add_argument("--no-stem-pool", action="store_true",
                     help="A/B: separate stem conv + BatchNorm/ReLU/max-pool passes in the forward-only networks instead of "
                          "the stem kernel with the pooled epilogue")
@@ -453,6 +457,7 @@ def main():
         return
     opt = m.stage2_opt(dropout_rate=0.1, batch_size=args.batch)
     opt.fused_loss_head = not args.generic_loss_head
+    opt.teacher_streams = args.teacher_streams
     n_data = 1024
     torch.manual_seed(0)
     np.random.seed(2019 + rank)
@@ -465,6 +470,8 @@ def main():
     if args.no_masked:
         for net in (step.model, step.ema_model, step.fix_model.path_net):
             net._no_masked = True
+    if args.no_bwd_overlap:
+        step.model._no_bwd_overlap = True
     if args.no_stem_pool:
         step.ema_model._no_stem_pool = True
         step.fix_model.path_net._no_stem_pool = True

@@ -24,6 +24,7 @@ SIGNATURES = {
     "ph_resnet_unit_shape": (i32, [vp, i32, vp]),
     "ph_resnet_pack_weights": (i32, [vp, vp, vp, vp]),
     "ph_resnet_plan_set_backward_prec": (i32, [vp, i32]),
+    "ph_resnet_plan_set_backward_overlap": (i32, [vp, i32]),
     "ph_pack_input": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "ph_resnet_forward": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     "ph_resnet_backward": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -45,15 +45,31 @@ struct PhResnetPlan {
   mutable int no_masked = 0;   // A/B and test switch, set by the last forward's flag bit3 and followed by its backward
   mutable int bwd_prec = -1;   // >= 0: arithmetic of the backward's dgrad / wgrad launches where it differs from `prec` (both split-plane)
   mutable const void* x4_ext = nullptr;   // the last forward's pre-packed input (flag bit6), read again by its backward (stem wgrad)
+  // Backward on two streams (backward_impl): the weight-gradient launches run on `side` beside the BatchNorm-backward /
+  // dgrad chain.  Stream and event pool are created by the first backward that is NOT being captured into a graph.
+  size_t dy2_off = 0;
+  mutable int bwd_overlap = 1;
+  mutable hipStream_t side = nullptr;
+  mutable std::vector<hipEvent_t> evs;
+  mutable size_t ev_next = 0;
+  ~PhResnetPlan() {
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 namespace {
 
-int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk) {
+// Workgroups a weight-gradient launch aims for.  Alone on the chip ~2 per CU is best (A/B on one box: 256 -> +0.2 ms / step,
+// 384 and 768 -> +0.33).  On the side stream of the two-stream backward (backward_impl) ONE per CU: the BatchNorm-backward
+// passes it runs beside need the other half of every SIMD's registers and wave slots (same box, ms per step: one stream
+// 12.76 / two streams with 512: 12.63, 384: 12.47, 256: 12.31, 192: 12.2 on a box where 256 gave 11.95, 128: 13.3).
+constexpr int WG_WANT_ALONE = 512, WG_WANT_BESIDE = 256;
+int wgrad_chunks(const Unit& u, int B, int* tiles_per_chunk, int wg_want = WG_WANT_ALONE) {
   const int th = ph_wgrad_tile_h((u.KS == 1) ? 1 : u.S);
   const int ntiles = B * cdiv(u.OH, th) * cdiv(u.OW, 16);
   const int blocks = (u.Cout / 64) * (u.Cin / 64);
-  int want = cdiv(512, blocks);            // ~2 workgroups per CU (A/B on one box: 256 -> +0.2 ms / step, 384 and 768 -> +0.33)
+  int want = cdiv(wg_want, blocks);
   if (want > ntiles) want = ntiles;
   if (want < 1) want = 1;
   int tpc = cdiv(ntiles, want);
@@ -140,6 +156,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   P->g1_off = take(act_max);
   P->da_off = take(act_max);
   P->dy_off = take((size_t)B * s.OH * s.OW * 64 * es);
+  P->dy2_off = take(act_max);      // second dz buffer of the two-stream backward (every unit but the stem fits)
   P->slab_bytes = slab_max;
   P->slab_off = take(slab_max);
   {  // BN-backward partial rows: ph_bn_bwd_parts() <= 1024 rows of [2][C <= 512]; the stem writes its own count of [2][64]
@@ -200,6 +217,7 @@ struct Ctx {
   int update_running;
   int eval;
   int no_masked = 0;      // A/B and test switch (forward flag bit3): first-generation kernels for the stride-2 convolutions
+  int wg_want = WG_WANT_ALONE;   // workgroups a weight-gradient launch aims for (wgrad_chunks)
   float* stat(const Unit& u, int which) const {
     return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
   }
@@ -293,7 +311,7 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
     w.x_pix_stride = 2L * u.Cin; w.x_row_stride = 2L * u.IW * u.Cin; w.x_img_stride = (long)u.IH * u.IW * u.Cin;
     w.IH = u.OH; w.IW = u.OW; w.S = 1;
   }
-  w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk);
+  w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk, c.wg_want);
   int rc = ph_wgrad_launch(&w, c.bprec(), c.st);
   if (rc) return rc;
   return ph_wgrad_reduce_launch(w.slab, dw, w.nchunks, u.KS, u.Cout, u.Cin, c.st);
@@ -454,6 +472,36 @@ namespace {
     if (stop > 0 && ++nst == stop) return PH_OK;         \
   } while (0)
 
+// The backward runs on TWO streams: BatchNorm backward and dgrad form the dependent chain on the caller's stream; every
+// weight gradient (wgrad + its slab reduction, 1.9 of the 5.6 ms) only needs its unit's dz and a saved activation and feeds
+// nothing but the optimizer, so it goes to the plan's side stream: its matrix-pipe work overlaps the HBM-bound BatchNorm
+// passes and the tails of the chain's launches.  dz buffers alternate (dy / dy2) so that the chain can produce the next dz
+// while the side stream still reads the last one; events order producer -> wgrad and wgrad -> the buffer's next writer.
+// Both streams are joined before the call returns (also at the end of part 0: its gradients are then final).  Inside a
+// stream capture the side stream joins the capture through the event waits (a parallel branch of the graph).  A weight
+// gradient starts when the dgrad that reads the same dz is done (event after it): started earlier it takes CUs from the
+// dgrad - a persistent kernel sized for the whole chip, one 512-register wave per SIMD - and the step gets SLOWER (same box:
+// 12.4 one stream, 12.55-12.8 two streams); started there it runs beside the next unit's BatchNorm-backward passes.
+// The chain's kernels and arguments are those of the one-stream sequence (BatchNorm gradients bitwise the same); the weight
+// gradients are cut into half as many chunks (WG_WANT_BESIDE), i.e. the same sums in another fp32 order.
+bool overlap_ready(const PhResnetPlan* P, hipStream_t st) {
+  if (!P->bwd_overlap) return false;
+  if (P->side) return true;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // not while capturing
+  hipStream_t sd = nullptr;
+  if (hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess) return false;
+  std::vector<hipEvent_t> ev(64);
+  for (size_t i = 0; i < ev.size(); ++i)
+    if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+      for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
+      (void)hipStreamDestroy(sd);
+      return false;
+    }
+  P->side = sd; P->evs.swap(ev); P->ev_next = 0;
+  return true;
+}
+
 int backward_impl(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_, const float* g_f3,
                   const float* g_f4, void* const* grads, int part, int stop, hipStream_t st) {
   if (!P || !params || !packed || !ws_ || !g_f4 || !grads || part < -1 || part > 1) return PH_EINVAL;
@@ -463,8 +511,37 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   unsigned char* ws = c.ws;
   unsigned char* gcur = ws + P->g0_off;
   unsigned char* gnext = ws + P->g1_off;
-  unsigned char* dyb = ws + P->dy_off;
   unsigned char* dab = ws + P->da_off;
+  const bool ov = stop == 0 && overlap_ready(P, st);
+  Ctx cs = c;                       // the weight-gradient launches' context
+  if (ov) { cs.st = P->side; cs.wg_want = WG_WANT_BESIDE; }
+  unsigned char* dzb[2] = {ws + P->dy_off, ov ? ws + P->dy2_off : ws + P->dy_off};
+  hipEvent_t rd[2] = {nullptr, nullptr};    // recorded on the side stream after the last reader of dzb[k]
+  int k = 0;
+  auto next_ev = [&]() { hipEvent_t e = P->evs[P->ev_next]; P->ev_next = (P->ev_next + 1) % P->evs.size(); return e; };
+  // the chain is about to overwrite dzb[k]: wait for the weight gradient that read it
+  auto claim = [&](int kk) -> int {
+    if (ov && rd[kk]) { if (hipStreamWaitEvent(st, rd[kk], 0) != hipSuccess) return PH_ELAUNCH; rd[kk] = nullptr; }
+    return PH_OK;
+  };
+  // dz of unit ui is in dzb[kk] (produced on st): its weight gradient
+  auto wgrad_of = [&](int ui, const void* x, int kk) -> int {
+    if (!ov) return conv_wgrad(c, ui, x, dzb[kk], (float*)grads[ui * 3 + 0]);
+    hipEvent_t e = next_ev();
+    if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(P->side, e, 0) != hipSuccess) return PH_ELAUNCH;
+    int r = conv_wgrad(cs, ui, x, dzb[kk], (float*)grads[ui * 3 + 0]);
+    if (r) return r;
+    hipEvent_t d = next_ev();
+    if (hipEventRecord(d, P->side) != hipSuccess) return PH_ELAUNCH;
+    rd[kk] = d;
+    return PH_OK;
+  };
+  auto join = [&]() -> int {
+    if (!ov) return PH_OK;
+    hipEvent_t e = next_ev();
+    if (hipEventRecord(e, P->side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) return PH_ELAUNCH;
+    return PH_OK;
+  };
   int rc, nst = 0;
   if (part != 1) {
     if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
@@ -478,20 +555,31 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     const void* a1 = ws + b.a1_off;
     const void* xin = ws + b.in_off;
     // bn2 <- d_out * (out > 0)
-    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dyb, (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]));
-    PH_STAGE(conv_wgrad(c, b.u2, a1, dyb, (float*)grads[b.u2 * 3 + 0]));
-    PH_STAGE(conv_dgrad(c, b.u2, dyb, dab, nullptr, nullptr));
+    if ((rc = claim(k))) return rc;
+    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dzb[k], (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]));
+    if (!ov) PH_STAGE(wgrad_of(b.u2, a1, k));
+    PH_STAGE(conv_dgrad(c, b.u2, dzb[k], dab, nullptr, nullptr));
+    if (ov) PH_STAGE(wgrad_of(b.u2, a1, k));
+    k ^= 1;
     // bn1 <- d_a1 * (a1 > 0)
-    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dyb, (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true));
-    PH_STAGE(conv_wgrad(c, b.u1, xin, dyb, (float*)grads[b.u1 * 3 + 0]));
+    if ((rc = claim(k))) return rc;
+    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dzb[k], (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true));
+    if (!ov) PH_STAGE(wgrad_of(b.u1, xin, k));
     if (b.uds < 0) {
       // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
-      PH_STAGE(conv_dgrad(c, b.u1, dyb, gnext, gcur, out));
+        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, gcur, out));
+      if (ov) PH_STAGE(wgrad_of(b.u1, xin, k));
+      k ^= 1;
     } else {
-      PH_STAGE(conv_dgrad(c, b.u1, dyb, gnext, nullptr, nullptr));
-      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dyb, (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]));
-      PH_STAGE(conv_wgrad(c, b.uds, xin, dyb, (float*)grads[b.uds * 3 + 0]));
-      PH_STAGE(conv_dgrad(c, b.uds, dyb, gnext, gnext, nullptr));   // in-place accumulate
+        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, nullptr, nullptr));
+      if (ov) PH_STAGE(wgrad_of(b.u1, xin, k));
+      k ^= 1;
+      if ((rc = claim(k))) return rc;
+      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dzb[k], (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]));
+      if (!ov) PH_STAGE(wgrad_of(b.uds, xin, k));
+        PH_STAGE(conv_dgrad(c, b.uds, dzb[k], gnext, gnext, nullptr));   // in-place accumulate
+      if (ov) PH_STAGE(wgrad_of(b.uds, xin, k));
+      k ^= 1;
     }
     unsigned char* t = gcur; gcur = gnext; gnext = t;
   }
@@ -506,17 +594,22 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
       return rc;
     PH_STAGE(ph_bn_bwd_finalize_launch(parts, ph_stem_bwd_parts(P->B, u.OH), 64, (double)npix, (float*)grads[1],
                                        (float*)grads[2], c1, c2, st));
+    if ((rc = claim(0))) return rc;       // the stem's dz is full resolution: only the first buffer holds it
     PH_STAGE(ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
-                                      c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64,
+                                      c.stat(u, 3), (const float*)params[1], c1, c2, dzb[0], P->B, u.OH, u.OW, 64,
                                       P->prec, st));
     PhStemWgrad w{};
-    w.x4 = P->x4_ext ? P->x4_ext : ws + P->x4_off; w.dy = dyb; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
+    w.x4 = P->x4_ext ? P->x4_ext : ws + P->x4_off; w.dy = dzb[0]; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
     w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
-    if ((rc = ph_stem_wgrad_launch(&w, c.bprec(), st))) return rc;
-    PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, st));
+    if (ov) {      // same stream as the other weight gradients: they share the slab
+      hipEvent_t e = next_ev();
+      if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(P->side, e, 0) != hipSuccess) return PH_ELAUNCH;
+    }
+    if ((rc = ph_stem_wgrad_launch(&w, c.bprec(), cs.st))) return rc;
+    PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, cs.st));
   }
-  return PH_OK;
+  return join();
 }
 #undef PH_STAGE
 
@@ -531,6 +624,14 @@ extern "C" {
 int ph_resnet_plan_set_backward_prec(const PhResnetPlan* P, int prec) {
   if (!P || (prec != -1 && !PH_IS_SPLIT_PREC(prec)) || (prec != -1 && P->prec == PH_PREC_BF16)) return PH_EINVAL;
   P->bwd_prec = prec;
+  return PH_OK;
+}
+
+// A/B and test switch: 0 = the whole backward on the caller's stream (the round-2 sequence), 1 (default) = weight
+// gradients on the plan's side stream
+int ph_resnet_plan_set_backward_overlap(const PhResnetPlan* P, int on) {
+  if (!P) return PH_EINVAL;
+  P->bwd_overlap = on ? 1 : 0;
   return PH_OK;
 }
 

@@ -358,6 +358,9 @@ class DistillStep:
         self._static = None
         self._slots = None
         self._side_stream = torch.cuda.Stream(device=self.device) if getattr(opt, "overlap_teachers", True) else None
+        # the fused teacher on a third stream (opt.teacher_streams = 1: behind the mean teacher on the second)
+        self._side_stream2 = (torch.cuda.Stream(device=self.device)
+                              if self._side_stream is not None and getattr(opt, "teacher_streams", 2) == 2 else None)
         self._stamps = None      # int64 [16] device tensor: set BEFORE enable_graph() to have the body mark its phases
         self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
         # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
@@ -411,21 +414,27 @@ class DistillStep:
         from .resnets import pack_shared_input
         self._stamp(0)
         pack_shared_input(x_path, (self.model, self.fix_model.path_net))
+        side2 = self._side_stream2 if side is not None else None
         if side is not None:
             side.wait_stream(main)
             with torch.cuda.stream(side), torch.no_grad():
                 _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254
                 self._stamp(8)
+            if side2 is not None:
+                side2.wait_stream(main)
+            with torch.cuda.stream(side2 if side2 is not None else side), torch.no_grad():
                 fuse_feat, _, _, _, logits, pred, _, _, _, _, _ = self.fix_model(x_path=x_path, x_omic=x_omic)  # :256
                 self._stamp(9)
-                for t in (ema_path_feat, ema_logit_path, fuse_feat, logits[-1]):
-                    t.record_stream(main)
+            for t in (ema_path_feat, ema_logit_path, fuse_feat, logits[-1]):
+                t.record_stream(main)
         _, path_feat, logit_path, pred_path, _ = self.model(x_path=x_path)                                   # :249
         self._stamp(1)
         if self._stamps is not None and path_feat.requires_grad:
             path_feat.register_hook(lambda g: (self._stamp(4), g)[1])
         if side is not None:
             main.wait_stream(side)
+            if side2 is not None:
+                main.wait_stream(side2)
         else:
             with torch.no_grad():
                 _, ema_path_feat, ema_logit_path, _, _ = self.ema_model(x_path=ema_x_path)                  # :254

@@ -617,3 +617,66 @@ def test_workspace_cache_is_bounded_and_pins_what_a_capture_uses():
     assert torch.equal(out[2], ref[2])
     net.release_workspaces()
     assert not net._ws_cache and not net._ws_pinned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,mode", [(4, 128, "bf16"), (6, 160, "bf16"), (2, 96, "bf16x6"), (64, 512, "bf16")])
+def test_two_stream_backward_equals_one_stream(B, H, mode):
+    """The trunk's backward runs its weight gradients on a second stream beside the BatchNorm-backward / dgrad chain
+    (csrc/resnet_plan.hip: backward_impl; dz buffers alternate, events order every producer and reader).  The chain's
+    kernels are unchanged: BatchNorm gradients are BITWISE the one-stream sequence's.  The weight gradients are split into
+    half as many partial sums per launch (one workgroup per CU beside the chain instead of two): equal up to the fp32
+    summation order.  Eager and captured-and-replayed (the side stream becomes a parallel branch) agree bitwise."""
+    import multimodal_learning_amd as m
+    from oracle.step import synthetic_batch
+    m.set_precision(mode)
+    try:
+        x = synthetic_batch(B, H, seed=35)["x_path"].cuda()
+        res = {}
+        for one_stream in (True, False):
+            net = _student()
+            net.train()
+            net._no_bwd_overlap = one_stream
+            # (torch's capture recipe: eager passes on a side stream, no autograd graph of theirs alive at capture time)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for rep in range(2):         # the second pass re-uses buffers the side stream may still be reading
+                    for p in net.parameters():
+                        p.grad = None
+                    f3, feat, hazard, pred, _ = net(x_path=x)
+                    (feat.square().mean() + hazard.sum()).backward()
+                    del f3, feat, hazard, pred
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            res[one_stream] = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+            if not one_stream:
+                # the same forward + backward captured and replayed
+                static_x = x.clone()
+                for p in net.parameters():
+                    p.grad = None
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    f3, feat, hazard, pred, _ = net(x_path=static_x)
+                    (feat.square().mean() + hazard.sum()).backward()
+                del f3, feat, hazard, pred
+                for p in net.parameters():
+                    if p.grad is not None:
+                        p.grad.zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                res["graph"] = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+        assert len(res[True]) == len(res[False]) == len(res["graph"]) > 60
+        nbit = 0
+        for a, b, c in zip(res[True], res[False], res["graph"]):
+            assert torch.isfinite(a).all()
+            assert torch.equal(b, c)
+            if a.dim() == 4:      # a convolution weight
+                assert (a - b).abs().max() <= 2e-5 * a.abs().max() + 1e-12, ((a - b).abs().max() / a.abs().max()).item()
+            else:
+                assert torch.equal(a, b)
+                nbit += 1
+        assert nbit >= 40
+    finally:
+        m.set_precision("bf16")
