@@ -1028,11 +1028,21 @@ class TeacherStage1Step:
                 ema_m1 = self.ema_model(x_path=x_path_m_v1.to(dev), x_omic=x_omic)[5]             # :211-215
                 ema_m2 = self.ema_model(x_path=x_path_m_v2.to(dev), x_omic=x_omic)[5]
             loss_masking = self.pred_KD_loss(pred_m1, ema_m1, B) + self.pred_KD_loss(pred_m2, ema_m2, B)   # :217-220
-        fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
-            x_path=x_path, x_omic=x_omic)                                                        # :137
-        with torch.no_grad():
+        # the mean teacher's forward (no_grad, :143-145) does not depend on the student's (:137): a second stream, joined
+        # before the losses, as in DistillStep._device_body
+        main = torch.cuda.current_stream()
+        if getattr(self, "_ema_side", None) is None:
+            self._ema_side = torch.cuda.Stream(device=dev)
+        eside = self._ema_side
+        eside.wait_stream(main)
+        with torch.cuda.stream(eside), torch.no_grad():
             ema_fuse_feat, ema_path_feat, ema_omic_feat, _, _, ema_pred, ema_pred_path, ema_pred_omic, _, _, _ = self.ema_model(
                 x_path=ema_x_path, x_omic=x_omic)                                                # :143-145
+            for t in (ema_fuse_feat, ema_path_feat, ema_omic_feat, ema_pred, ema_pred_path, ema_pred_omic):
+                t.record_stream(main)
+        fuse_feat, path_feat, omic_feat, _, _, pred, pred_path, pred_omic, _, _, _ = self.model(
+            x_path=x_path, x_omic=x_omic)                                                        # :137
+        main.wait_stream(eside)
         loss_CRD = torch.zeros((), device=dev)
         if self.crd_on:                                                                          # :157-165
             self.CRD_criterion_fuse.contrast.batch_norm_size = B
