@@ -383,6 +383,10 @@ def main():
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
     ap.add_argument("--teacher-streams", type=int, default=2,
                     help="A/B switch: 1 = the fused teacher's forward behind the mean teacher's on one side stream (round 2)")
+    ap.add_argument("--serial", action="store_true",
+                    help="everything on ONE stream (no teacher streams, no side-stream weight gradients): the command "
+                         "profiles/collect.sh traces for per-kernel durations - with the streams on, a launch's wall "
+                         "duration includes time it shares the chip with other kernels")
     ap.add_argument("--no-bwd-overlap", action="store_true",
                     help="A/B switch: the student's backward on one stream (weight gradients not on the plan's side stream)")
     ap.add_argument("--no-stem-pool", action="store_true",
@@ -470,8 +474,10 @@ def main():
     if args.no_masked:
         for net in (step.model, step.ema_model, step.fix_model.path_net):
             net._no_masked = True
-    if args.no_bwd_overlap:
+    if args.no_bwd_overlap or args.serial:
         step.model._no_bwd_overlap = True
+    if args.serial:
+        step._side_stream = None
     if args.no_stem_pool:
         step.ema_model._no_stem_pool = True
         step.fix_model.path_net._no_stem_pool = True
@@ -501,7 +507,8 @@ def main():
         # the in-library HIP-event timer brackets individual launches, which a graph replay does not expose:
         # time the same kernels in 3 eager steps right after the timed region (same data, same shapes)
         step._want_graph = False
-        step._side_stream = None         # one stream: un-overlapped per-kernel durations
+        step._side_stream = None         # one stream, forward and backward: un-overlapped per-kernel durations
+        step.model._no_bwd_overlap = True
         step.step(batches[0], epoch=1)
         L.ph_prof_reset(); L.ph_prof_enable(1)
         for i in range(3):

@@ -9,7 +9,11 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 T=gpurun_out/$TAG
 mkdir -p "$T"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants > "$T/bench_stats.log" 2>&1
+# per-kernel durations: the step on ONE stream (--serial).  In the product step three forwards run on three streams and the
+# weight gradients beside the BatchNorm-backward passes, and a launch's wall duration includes the time it shares the chip;
+# that run is traced too (stats_concurrent) - its total is the honest one, its per-kernel averages are not kernel quality.
+rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants > "$T/bench_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats_concurrent" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants > "$T/bench_stats_concurrent.log" 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 \
   --output-format csv -d "$T/sq" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_sq.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch" -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --eager --no-kernel-timer > "$T/bench_fetch.log" 2>&1

@@ -69,13 +69,18 @@ def load_pmc(path):
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     out = os.path.dirname(os.path.abspath(__file__))
-    # ---- kernel stats
-    f = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
-    if f:
+    # ---- kernel stats: the one-stream run (per-kernel durations) and the product run (three forward streams, weight
+    # gradients beside the BatchNorm-backward passes: a launch's wall duration includes time it shares the chip)
+    for sub, suffix, cmd in (("stats", "", "python3 bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
+                             ("stats_concurrent", "_concurrent", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants")):
+        f = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
+        if not f:
+            continue
         rows = list(csv.DictReader(open(f[0])))
         tot = sum(int(r["TotalDurationNs"]) for r in rows)
-        with open(os.path.join(out, f"{tag}_kernel_stats.txt"), "w") as o:
-            o.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode   (total kernel time {tot/1e6:.1f} ms)\n")
+        with open(os.path.join(out, f"{tag}_kernel_stats{suffix}.txt"), "w") as o:
+            o.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}   (sum of kernel durations {tot/1e6:.1f} ms"
+                    + (": kernels overlap, durations include shared time" if suffix else "") + ")\n")
             o.write(f"{'kernel':<100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}\n")
             for r in rows[:45]:
                 o.write(f"{short(r['Name'])[:100]:<100s} {r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} "
