@@ -381,6 +381,8 @@ def main():
                     help="A/B switch: first-generation kernel for the 3x3 stride-2 convolutions (not the masked tap grid)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="A/B: separate bn_apply passes in the forward-only networks instead of the in-LDS BatchNorm + ReLU")
+    ap.add_argument("--no-head-overlap", action="store_true",
+                    help="A/B switch: the fused loss head on one stream (second CRD chain and head weight gradients not on a side stream)")
     ap.add_argument("--teacher-streams", type=int, default=2,
                     help="A/B switch: 1 = the fused teacher's forward behind the mean teacher's on one side stream (round 2)")
     ap.add_argument("--serial", action="store_true",
@@ -462,6 +464,7 @@ def main():
     opt = m.stage2_opt(dropout_rate=0.1, batch_size=args.batch)
     opt.fused_loss_head = not args.generic_loss_head
     opt.teacher_streams = args.teacher_streams
+    opt.overlap_head = not (args.no_head_overlap or args.serial)
     n_data = 1024
     torch.manual_seed(0)
     np.random.seed(2019 + rank)
@@ -508,6 +511,7 @@ def main():
         # time the same kernels in 3 eager steps right after the timed region (same data, same shapes)
         step._want_graph = False
         step._side_stream = None         # one stream, forward and backward: un-overlapped per-kernel durations
+        step._head_side = None
         step.model._no_bwd_overlap = True
         step.step(batches[0], epoch=1)
         L.ph_prof_reset(); L.ph_prof_enable(1)

@@ -73,22 +73,42 @@ class FusedDistillLossFn(torch.autograd.Function):
               "ph_logit_losses")
         G = torch.empty(5, B, D, device=dev, dtype=torch.float32)
         ops.sgemm(dl, W2, None, G, 3 * B, D, Cc, Cc, 1, D, 1)          # rows 0..2: d{div1, div2, CE}/d feat = dlogit @ W2
-        crd_saved = []
-        for k, (crd, tf, rk) in enumerate(((step.criterion_kd, H.fuse_feat, H.r1), (step.criterion_kd_path, H.ema_feat, H.r2))):
+        crd_saved = [None, None]
+
+        def crd_chain(k, crd, tf, rk):
+            stc = stream()
             tf = ops._f32(tf).contiguous()
             es, et = crd.embed_s.linear, crd.embed_t.linear
             v1 = torch.empty(B, es.weight.shape[0], device=dev, dtype=torch.float32); n1 = torch.empty(B, device=dev)
             v2 = torch.empty_like(v1); n2 = torch.empty_like(n1)
             pre_s = ops.linear_fwd(feat, es.weight, es.bias)
-            check(L.ph_l2norm_fwd(ptr(pre_s), ptr(v1), ptr(n1), B, v1.shape[1], st), "ph_l2norm_fwd")
+            check(L.ph_l2norm_fwd(ptr(pre_s), ptr(v1), ptr(n1), B, v1.shape[1], stc), "ph_l2norm_fwd")
             pre_t = ops.linear_fwd(tf, et.weight, et.bias)
-            check(L.ph_l2norm_fwd(ptr(pre_t), ptr(v2), ptr(n2), B, v2.shape[1], st), "ph_l2norm_fwd")
+            check(L.ph_l2norm_fwd(ptr(pre_t), ptr(v2), ptr(n2), B, v2.shape[1], stc), "ph_l2norm_fwd")
             _, dv1, dv2 = crd_core(v1, v2, crd.contrast, H.index, H.sample_idx, rk, False, loss_out=Lb[3 + k])
             dps = torch.empty_like(v1)
-            check(L.ph_l2norm_bwd(ptr(dv1), ptr(v1), ptr(n1), ptr(dps), B, v1.shape[1], st), "ph_l2norm_bwd")
+            check(L.ph_l2norm_bwd(ptr(dv1), ptr(v1), ptr(n1), ptr(dps), B, v1.shape[1], stc), "ph_l2norm_bwd")
             Do = es.weight.shape[0]
             ops.sgemm(dps, es.weight, None, G[3 + k], B, D, Do, Do, 1, D, 1)      # d CRD_k / d feat
-            crd_saved.append((dps, dv2, v2, n2, tf))
+            crd_saved[k] = (dps, dv2, v2, n2, tf)
+            return (tf, v1, n1, v2, n2, pre_s, pre_t, dv1, dv2, dps)
+
+        chains = ((step.criterion_kd, H.fuse_feat, H.r1), (step.criterion_kd_path, H.ema_feat, H.r2))
+        # the two CRD terms are independent chains of ~10 short launches (two banks, two pairs of heads): the second runs on a
+        # side stream beside the first (not under data parallelism: its all-gathers must keep one issue order on every rank)
+        hs = step._head_stream() if step.sync is None and hasattr(step, "_head_stream") else None
+        if hs is not None:
+            main_s = torch.cuda.current_stream()
+            hs.wait_stream(main_s)
+            with torch.cuda.stream(hs):
+                made = crd_chain(1, *chains[1])
+                for t in made:
+                    t.record_stream(main_s)
+            crd_chain(0, *chains[0])
+            main_s.wait_stream(hs)
+        else:
+            for k, (crd, tf, rk) in enumerate(chains):
+                crd_chain(k, crd, tf, rk)
         gram = torch.empty(25, device=dev, dtype=torch.float32)
         check(L.ph_gram(ptr(G), ptr(gram), 5, B * D, st), "ph_gram")
         if step.sync is not None:
@@ -119,21 +139,36 @@ class FusedDistillLossFn(torch.autograd.Function):
         ops.sgemm(w, G, None, dfeat, 1, B * D, 5, 5, 1, B * D, 1)                       # sum_i w_i G_i
         dlt = torch.empty(B, Cc, device=dev, dtype=torch.float32)
         ops.sgemm(w, dl, None, dlt, 1, B * Cc, 3, 3, 1, B * Cc, 1)                      # w[0:3] . {dl_div1, dl_div2, dl_CE}
-        ones = ops._ones(B, dev)
-        ops.sgemm(dlt, feat, None, _grad_dst(model.fc_new2.weight), Cc, D, B, 1, Cc, D, 1)      # dW2 = dlogit^T feat
-        ops.sgemm(ones, dlt, None, _grad_dst(model.fc_new2.bias), 1, Cc, B, 0, 1, Cc, 1)
-        for k, (crd, (dps, dv2, v2, n2, tf)) in enumerate(zip((step.criterion_kd, step.criterion_kd_path), ctx.crd_saved)):
-            wk = w[3 + k:4 + k]
-            es, et = crd.embed_s.linear, crd.embed_t.linear
-            Do = es.weight.shape[0]
-            gs = dps * wk
-            ops.sgemm(gs, feat, None, _grad_dst(es.weight), Do, D, B, 1, Do, D, 1)
-            ops.sgemm(ones, gs, None, _grad_dst(es.bias), 1, Do, B, 0, 1, Do, 1)
-            dpt = torch.empty_like(v2)
-            check(L.ph_l2norm_bwd(ptr(dv2), ptr(v2), ptr(n2), ptr(dpt), B, v2.shape[1], st), "ph_l2norm_bwd")
-            gt = dpt * wk
-            Dt = tf.shape[1]
-            ops.sgemm(gt, tf, None, _grad_dst(et.weight), Do, Dt, B, 1, Do, Dt, 1)
-            ops.sgemm(ones, gt, None, _grad_dst(et.bias), 1, Do, B, 0, 1, Do, 1)
+        # Only dfeat feeds the trunk backward: the gradients of fc_new2 and of the four CRD heads (14 short launches) go to the
+        # side stream, beside the trunk backward; DistillStep joins it before the optimiser step
+        # (not under data parallelism: the all-reduce of the late gradient slice starts inside the trunk backward and reads them)
+        hs = step._head_stream() if step.sync is None and hasattr(step, "_head_stream") else None
+        main_s = torch.cuda.current_stream()
+        if hs is not None:
+            hs.wait_stream(main_s)
+        with torch.cuda.stream(hs if hs is not None else main_s):
+            stb = stream()
+            ones = ops._ones(B, dev)
+            ops.sgemm(dlt, feat, None, _grad_dst(model.fc_new2.weight), Cc, D, B, 1, Cc, D, 1)      # dW2 = dlogit^T feat
+            ops.sgemm(ones, dlt, None, _grad_dst(model.fc_new2.bias), 1, Cc, B, 0, 1, Cc, 1)
+            for k, (crd, (dps, dv2, v2, n2, tf)) in enumerate(zip((step.criterion_kd, step.criterion_kd_path), ctx.crd_saved)):
+                wk = w[3 + k:4 + k]
+                es, et = crd.embed_s.linear, crd.embed_t.linear
+                Do = es.weight.shape[0]
+                gs = dps * wk
+                ops.sgemm(gs, feat, None, _grad_dst(es.weight), Do, D, B, 1, Do, D, 1)
+                ops.sgemm(ones, gs, None, _grad_dst(es.bias), 1, Do, B, 0, 1, Do, 1)
+                dpt = torch.empty_like(v2)
+                check(L.ph_l2norm_bwd(ptr(dv2), ptr(v2), ptr(n2), ptr(dpt), B, v2.shape[1], stb), "ph_l2norm_bwd")
+                gt = dpt * wk
+                Dt = tf.shape[1]
+                ops.sgemm(gt, tf, None, _grad_dst(et.weight), Do, Dt, B, 1, Do, Dt, 1)
+                ops.sgemm(ones, gt, None, _grad_dst(et.bias), 1, Do, B, 0, 1, Do, 1)
+            if hs is not None:
+                for t in (dlt, feat, w, dl):
+                    t.record_stream(hs)
+                for dps, dv2, v2, n2, tf in ctx.crd_saved:
+                    for t in (dps, dv2, v2, n2, tf):
+                        t.record_stream(hs)
         ctx.crd_saved = None
         return dfeat, None

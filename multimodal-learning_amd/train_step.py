@@ -362,6 +362,9 @@ class DistillStep:
         self._side_stream2 = (torch.cuda.Stream(device=self.device)
                               if self._side_stream is not None and getattr(opt, "teacher_streams", 2) == 2 else None)
         self._stamps = None      # int64 [16] device tensor: set BEFORE enable_graph() to have the body mark its phases
+        # side stream of the fused loss head (loss_head.py: second CRD chain, head weight gradients); opt.overlap_head = False: off
+        self._head_side = (torch.cuda.Stream(device=self.device)
+                           if self.device.type == "cuda" and getattr(opt, "overlap_head", True) else None)
         self.module_list.train(); self.fix_model.train()                           # :231-232 (EMA stays in train mode)
         # flat EMA storage with the student's layout -> EMA is fused into the Adam kernel
         flat = self.optimizer.flat
@@ -395,6 +398,9 @@ class DistillStep:
                 first = self.model.layer3[0].conv1.weight
                 lo = next(o for t, o in zip(flat.tensors, flat.offsets) if t is first)
                 self.model._grad_ready_hook = lambda: self.sync.begin_grad_slice(self.optimizer.flat, lo)
+
+    def _head_stream(self):
+        return self._head_side
 
     def _stamp(self, k):
         """Phase marker k (ph_prof_stamp: the device wall clock when the current stream gets here; also inside a graph)."""
@@ -450,6 +456,8 @@ class DistillStep:
             self.optimizer.zero_grad()                                                                      # :326
             self._stamp(3)
             loss.backward()                                                                                 # :327
+            if self._head_side is not None:
+                torch.cuda.current_stream().wait_stream(self._head_side)     # the heads' weight gradients (loss_head.py)
             self._stamp(5)
             if self.sync is not None:
                 self.sync.all_reduce_grads(self.optimizer.flat)
