@@ -402,6 +402,24 @@ class DistillStep:
     def _head_stream(self):
         return self._head_side
 
+    def _two_chains(self, f1, f2):
+        """Two independent launch chains (the two CRD criteria: separate banks, separate heads): the second on the head's side
+        stream, joined before anything reads its result; autograd replays each backward on the stream its forward used.  One
+        stream under data parallelism (the criteria's all-gathers must keep one issue order on every rank)."""
+        hs = self._head_side if self.sync is None else None
+        if hs is None:
+            return f1(), f2()
+        main = torch.cuda.current_stream()
+        hs.wait_stream(main)
+        with torch.cuda.stream(hs):
+            r2 = f2()
+        r1 = f1()
+        main.wait_stream(hs)
+        for t in (r2 if isinstance(r2, (tuple, list)) else (r2,)):
+            if torch.is_tensor(t):
+                t.record_stream(main)
+        return r1, r2
+
     def _stamp(self, k):
         """Phase marker k (ph_prof_stamp: the device wall clock when the current stream gets here; also inside a graph)."""
         if self._stamps is not None:
@@ -479,11 +497,13 @@ class DistillStep:
         loss_div2 = self.criterion_div(logit_path, ema_logit_path.detach())                                 # :265
         if self.variant == "mia2022":
             # v2 trainer :436-437: the first argument is the epoch weight of the per-sample CRD loss; result shape [1]
-            loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx).reshape(())
-            loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx).reshape(())
+            loss_kd1, loss_kd2 = self._two_chains(
+                lambda: self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx).reshape(()),
+                lambda: self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx).reshape(()))
         else:
-            loss_kd1 = self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx, ranks=r1)         # :278
-            loss_kd2 = self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx, ranks=r2)  # :279
+            loss_kd1, loss_kd2 = self._two_chains(
+                lambda: self.criterion_kd(e, path_feat, fuse_feat.detach(), index, sample_idx, ranks=r1),         # :278
+                lambda: self.criterion_kd_path(e, path_feat, ema_path_feat.detach(), index, sample_idx, ranks=r2))  # :279
         loss_div1 = opt.alpha * loss_div1; loss_div2 = opt.alpha * loss_div2                                # :293-294
         loss_kd1 = opt.beta * loss_kd1; loss_kd2 = opt.beta * loss_kd2                                      # :296-297
         KD_loss_list = [loss_div1, loss_div2, loss_kd1, loss_kd2]
@@ -588,8 +608,9 @@ class DistillStep:
         w1 = assign_sample_weights(logit_path, logits[-1], grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
         w2 = assign_sample_weights(logit_path, ema_logit_path, grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
         w1 = (1.0 + rw * w1).view(-1, 1); w2 = (1.0 + rw * w2).view(-1, 1)                                  # :373-382
-        loss_kd1, rows_kd1 = self.criterion_kd(w1, path_feat, fuse_feat.detach(), grade, index, sample_idx)         # :386
-        loss_kd2, rows_kd2 = self.criterion_kd_path(w2, path_feat, ema_path_feat.detach(), grade, index, sample_idx)  # :388
+        (loss_kd1, rows_kd1), (loss_kd2, rows_kd2) = self._two_chains(
+            lambda: self.criterion_kd(w1, path_feat, fuse_feat.detach(), grade, index, sample_idx),            # :386
+            lambda: self.criterion_kd_path(w2, path_feat, ema_path_feat.detach(), grade, index, sample_idx))    # :388
         KD_loss_list = [opt.alpha * rows_div1, opt.alpha * rows_div2, opt.beta * rows_kd1, opt.beta * rows_kd2]  # :407-414
         if opt.assign_weights == "True":
             if getattr(opt, "loss_weighting", "GK_refine") != "GK_refine":
