@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpathomic_hip.so")
+# PH_LIB_VARIANT=<tag>: load libpathomic_hip<tag>.so instead (same-box A/B of two builds, profiles/scripts/ab_lib.sh)
+LIB_PATH = os.path.join(_HERE, "libpathomic_hip%s.so" % os.environ.get("PH_LIB_VARIANT", ""))
 CSRC = os.path.join(_HERE, "csrc")
 
 vp, i32, i64, f32, f64, sz, u64, lng = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t, C.c_uint64, C.c_long
