@@ -109,9 +109,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       const int offA0 = t0 * 128 + sw_piece(t0, pieceA) * 32 + p4 * 8;
       const int offA1 = t1 * 128 + sw_piece(t1, pieceA) * 32 + p4 * 8;
       bf16x8 a[NP];      // (third plane: only in the six-product mode)
+#ifdef PH_ABL_WG_NOLDS   // timing ablation only (garbage results): no fragment reads
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) { bf16x8 z; asm volatile("" : "=v"(z)); a[pl] = z; }
+#else
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl)
         if (pl < 2 || p.prod6) a[pl] = tr_pair(dD + pl * C::D_BYTES, offA0, offA1);
+#endif
       const int hb0 = ((t0 >> 4) * S) * HPW + (t0 & 15) * S;
       const int hb1 = ((t1 >> 4) * S) * HPW + (t1 & 15) * S;
 #pragma unroll
@@ -121,9 +126,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int offB0 = h0 * 128 + sw_piece(h0, pieceB) * 32 + p4 * 8;
         const int offB1 = h1 * 128 + sw_piece(h1, pieceB) * 32 + p4 * 8;
         bf16x8 bq[NP];
+#ifdef PH_ABL_WG_NOLDS
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) { bf16x8 z; asm volatile("" : "=v"(z) : "v"(offB0 + offB1)); bq[pl] = z; }
+#else
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
           if (pl < 2 || p.prod6) bq[pl] = tr_pair(dX + pl * C::X_BYTES, offB0, offB1);
+#endif
         if constexpr (SPLIT) {
 #define PH_MM(PI, PJ) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ], acc[t], 0, 0, 0);
           if (p.prod6) { PH_SPLIT_PAIRS_LO(PH_MM) }
@@ -204,7 +214,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
     __syncthreads();
     int buf = 0;
     for (int tt = t_begin; tt < t_end; ++tt) {
+#ifndef PH_ABL_WG_NODMA   // timing ablation only (garbage results): no operand traffic
       if (tt + 1 < t_end) issue(tt + 1, buf ^ 1);
+#endif
       compute(smem + buf * BUF, smem + buf * BUF + C::D_BYTES);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile tt+1 have landed
       __syncthreads();                                    // ... and everybody's; buffer buf is free again
@@ -219,7 +231,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
     for (int q = 0; q < 16; ++q) {
       const int row = co0 + cf * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
       const int col = ci0 + kf * 32 + (lane & 31);
+#ifdef PH_ABL_WG_NOSLAB   // timing ablation only
+      asm volatile("" ::"v"(acc[t][q]), "v"(row + col));
+#else
       slab[((size_t)t * p.Cout + row) * p.Cin + col] = acc[t][q];
+#endif
     }
 }
 
