@@ -385,6 +385,9 @@ def main():
                     help="A/B switch: the fused loss head on one stream (second CRD chain and head weight gradients not on a side stream)")
     ap.add_argument("--teacher-streams", type=int, default=2,
                     help="A/B switch: 1 = the fused teacher's forward behind the mean teacher's on one side stream (round 2)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3", "bf16x6/x3", "bf16x6"],
+                    help="arithmetic of the headline run (default: the perf mode BASELINE configs[1] names); the split-plane "
+                         "modes are what `parity_mode` reports - this flag exists to profile them")
     ap.add_argument("--serial", action="store_true",
                     help="everything on ONE stream (no teacher streams, no side-stream weight gradients): the command "
                          "profiles/collect.sh traces for per-kernel durations - with the streams on, a launch's wall "
@@ -431,7 +434,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
         sync = m.dist.ReplicaSync()
-    m.set_precision("bf16")
+    m.set_precision(args.precision)
     if args.variant != "miccai2022":
         # profiling aid: another batch body through the same timing protocol (rocprofv3 -- python3 bench.py --variant ...)
         torch.manual_seed(0)
@@ -455,7 +458,7 @@ def main():
             print(json.dumps({"metric": "ROI-tiles/sec (variant step)", "value": round(Bv * world * args.steps / dt, 2), "unit": "tiles/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(1000.0 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-                              "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                              "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                               "config": {"workload": desc, "tiles_per_gpu": Bv, "final_loss": round(float(out["loss"]), 4),
                                          "launch": "one captured HIP graph per step" if graph else "eager"}}), flush=True)
         if sync is not None:
