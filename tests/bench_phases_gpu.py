@@ -30,6 +30,15 @@ for i in range(24):
     torch.cuda.synchronize()
     if i >= 4:
         rows.append(step._stamps.cpu().numpy().astype(np.int64).copy())
+# back-to-back replays (no host sync in between): the idle time between the end of one step's graph and the start of the next
+# is (time per step) - (marker 6 - marker 0); a second stamp buffer is not needed for that
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for i in range(30):
+    step.step(bts[i % 2], epoch=5)
+torch.cuda.synchronize()
+per_step_us = (time.perf_counter() - t0) / 30 * 1e6
 t = np.stack(rows)
 rel = (t - t[:, :1]) * 0.01      # us since marker 0
 names = {1: "student forward done (main stream)", 8: "mean-teacher forward done (side stream)",
@@ -38,5 +47,8 @@ names = {1: "student forward done (main stream)", 8: "mean-teacher forward done 
 for k in (1, 8, 9, 2, 3, 4, 5, 6):
     print("  %-62s %9.1f us   (p10 %.1f  p90 %.1f)" % (names[k], np.median(rel[:, k]), np.percentile(rel[:, k], 10),
                                                         np.percentile(rel[:, k], 90)))
+body = np.median(rel[:, 6])
+print("  back-to-back: %.1f us per step, graph body (marker 0 -> 6) %.1f us -> %.1f us per step outside the body (input copies, "
+      "graph launch, idle)" % (per_step_us, body, per_step_us - body))
 print("  head phase (join -> feature gradient): %.1f us;  trunk backward: %.1f us" %
       (np.median(rel[:, 4] - rel[:, 2]), np.median(rel[:, 5] - rel[:, 4])))
