@@ -52,6 +52,9 @@ struct PhResnetPlan {
   mutable hipStream_t side = nullptr;
   mutable std::vector<hipEvent_t> evs;
   mutable size_t ev_next = 0;
+  PhResnetPlan() = default;
+  PhResnetPlan(const PhResnetPlan&) = delete;              // owns a stream and events
+  PhResnetPlan& operator=(const PhResnetPlan&) = delete;
   ~PhResnetPlan() {
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
