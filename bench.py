@@ -393,7 +393,7 @@ def main():
                          "profiles/collect.sh traces for per-kernel durations - with the streams on, a launch's wall "
                          "duration includes time it shares the chip with other kernels")
     ap.add_argument("--no-bwd-overlap", action="store_true",
-                    help="A/B switch: the student's backward on one stream (weight gradients not on the plan's side stream)")
+                    help="A/B switch: the student's backward on one stream (weight gradients not on the side stream)")
     ap.add_argument("--no-stem-pool", action="store_true",
                     help="A/B: separate stem conv + BatchNorm/ReLU/max-pool passes in the forward-only networks instead of "
                          "the stem kernel with the pooled epilogue")

@@ -70,9 +70,10 @@ int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, 
 /* Arithmetic of the backward's dgrad / wgrad launches where it differs from the plan's (PH_PREC_BF16X3 on a PH_PREC_BF16X6
  * plan: parity-mode forward, three-product backward; -1 = follow the plan) */
 int ph_resnet_plan_set_backward_prec(const PhResnetPlan* plan, int prec);
-/* Scheduling of ph_resnet_backward / _part: 1 (default) = the weight-gradient launches run on a second stream owned by the
- * plan beside the BatchNorm-backward / dgrad chain and are joined before the call returns (inside a stream capture: a
- * parallel branch of the graph); 0 = everything on the caller's stream.  Same kernels; BatchNorm gradients bitwise the same,
+/* Scheduling of ph_resnet_backward / _part: 1 (default) = the weight-gradient launches run on a second, process-wide
+ * stream of the library (created once per device, never destroyed) beside the BatchNorm-backward / dgrad chain and are
+ * joined before the call returns (inside a stream capture: a parallel branch of the graph); 0 = everything on the
+ * caller's stream.  Same kernels; BatchNorm gradients bitwise the same,
  * weight gradients summed from half as many partial slabs (autograd of resnets.py:58-74 has no order between a layer's
  * weight and input gradients either). */
 int ph_resnet_plan_set_backward_overlap(const PhResnetPlan* plan, int on);

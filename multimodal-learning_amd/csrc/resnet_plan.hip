@@ -6,6 +6,8 @@
 // writes its RAW output y plus per-workgroup BN partial sums; BN is finalised per channel (fp64
 // combine) into scale/shift; the consumer-side elementwise kernel applies BN(+residual)+ReLU.
 // Saved for backward per BasicBlock: x_in, y1, a1, y2, (y_ds), out.
+#include <atomic>
+#include <mutex>
 #include <new>
 #include <vector>
 #include "ph_common.h"
@@ -45,20 +47,10 @@ struct PhResnetPlan {
   mutable int no_masked = 0;   // A/B and test switch, set by the last forward's flag bit3 and followed by its backward
   mutable int bwd_prec = -1;   // >= 0: arithmetic of the backward's dgrad / wgrad launches where it differs from `prec` (both split-plane)
   mutable const void* x4_ext = nullptr;   // the last forward's pre-packed input (flag bit6), read again by its backward (stem wgrad)
-  // Backward on two streams (backward_impl): the weight-gradient launches run on `side` beside the BatchNorm-backward /
-  // dgrad chain.  Stream and event pool are created by the first backward that is NOT being captured into a graph.
+  // Backward on two streams (backward_impl): the weight-gradient launches run on a side stream beside the BatchNorm-backward /
+  // dgrad chain; `dy2_off` is the second dz buffer they need.
   size_t dy2_off = 0;
   mutable int bwd_overlap = 1;
-  mutable hipStream_t side = nullptr;
-  mutable std::vector<hipEvent_t> evs;
-  mutable size_t ev_next = 0;
-  PhResnetPlan() = default;
-  PhResnetPlan(const PhResnetPlan&) = delete;              // owns a stream and events
-  PhResnetPlan& operator=(const PhResnetPlan&) = delete;
-  ~PhResnetPlan() {
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
-    if (side) (void)hipStreamDestroy(side);
-  }
 };
 
 namespace {
@@ -477,7 +469,7 @@ namespace {
 
 // The backward runs on TWO streams: BatchNorm backward and dgrad form the dependent chain on the caller's stream; every
 // weight gradient (wgrad + its slab reduction, 1.9 of the 5.6 ms) only needs its unit's dz and a saved activation and feeds
-// nothing but the optimizer, so it goes to the plan's side stream: its matrix-pipe work overlaps the HBM-bound BatchNorm
+// nothing but the optimizer, so it goes to the library's side stream: its matrix-pipe work overlaps the HBM-bound BatchNorm
 // passes and the tails of the chain's launches.  dz buffers alternate (dy / dy2) so that the chain can produce the next dz
 // while the side stream still reads the last one; events order producer -> wgrad and wgrad -> the buffer's next writer.
 // Both streams are joined before the call returns (also at the end of part 0: its gradients are then final).  Inside a
@@ -487,22 +479,41 @@ namespace {
 // 12.4 one stream, 12.55-12.8 two streams); started there it runs beside the next unit's BatchNorm-backward passes.
 // The chain's kernels and arguments are those of the one-stream sequence (BatchNorm gradients bitwise the same); the weight
 // gradients are cut into half as many chunks (WG_WANT_BESIDE), i.e. the same sums in another fp32 order.
-bool overlap_ready(const PhResnetPlan* P, hipStream_t st) {
-  if (!P->bwd_overlap) return false;
-  if (P->side) return true;
+// The side stream and its events are PROCESS-WIDE (one set per device), created by the first backward that is not being
+// captured and never destroyed: a stream that has taken part in a capture as a forked branch must outlive every later capture
+// on the same origin stream (destroying the plan-owned stream of an earlier round-3 build produced rare segfaults inside
+// hipStreamEndCapture of LATER captures), and streams of the torch pool are not destroyed either.  Every call reserves its own
+// block of 64 events, so two backward passes in flight never share one.
+struct SideRes {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> evs;
+  std::atomic<size_t> cursor{0};
+};
+constexpr size_t EV_BLOCK = 64, EV_BLOCKS = 16;
+
+SideRes* overlap_ready(const PhResnetPlan* P, hipStream_t st) {
+  static SideRes* res[16] = {nullptr};
+  static std::mutex mu;
+  if (!P->bwd_overlap) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (res[dev]) return res[dev];
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // not while capturing
-  hipStream_t sd = nullptr;
-  if (hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess) return false;
-  std::vector<hipEvent_t> ev(64);
-  for (size_t i = 0; i < ev.size(); ++i)
-    if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
-      for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(ev[j]);
-      (void)hipStreamDestroy(sd);
-      return false;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // not while capturing
+  SideRes* r = new (std::nothrow) SideRes();
+  if (!r) return nullptr;
+  if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess) { delete r; return nullptr; }
+  r->evs.resize(EV_BLOCK * EV_BLOCKS);
+  for (size_t i = 0; i < r->evs.size(); ++i)
+    if (hipEventCreateWithFlags(&r->evs[i], hipEventDisableTiming) != hipSuccess) {
+      for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(r->evs[j]);
+      (void)hipStreamDestroy(r->side);      // (never used: safe to destroy)
+      delete r;
+      return nullptr;
     }
-  P->side = sd; P->evs.swap(ev); P->ev_next = 0;
-  return true;
+  res[dev] = r;
+  return r;
 }
 
 int backward_impl(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_, const float* g_f3,
@@ -515,13 +526,17 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   unsigned char* gcur = ws + P->g0_off;
   unsigned char* gnext = ws + P->g1_off;
   unsigned char* dab = ws + P->da_off;
-  const bool ov = stop == 0 && overlap_ready(P, st);
+  SideRes* const sr = stop == 0 ? overlap_ready(P, st) : nullptr;
+  const bool ov = sr != nullptr;
+  const hipStream_t side = ov ? sr->side : st;
   Ctx cs = c;                       // the weight-gradient launches' context
-  if (ov) { cs.st = P->side; cs.wg_want = WG_WANT_BESIDE; }
+  if (ov) { cs.st = side; cs.wg_want = WG_WANT_BESIDE; }
+  const size_t ev_base = ov ? (sr->cursor.fetch_add(1) % EV_BLOCKS) * EV_BLOCK : 0;
+  size_t ev_used = 0;
   unsigned char* dzb[2] = {ws + P->dy_off, ov ? ws + P->dy2_off : ws + P->dy_off};
   hipEvent_t rd[2] = {nullptr, nullptr};    // recorded on the side stream after the last reader of dzb[k]
   int k = 0;
-  auto next_ev = [&]() { hipEvent_t e = P->evs[P->ev_next]; P->ev_next = (P->ev_next + 1) % P->evs.size(); return e; };
+  auto next_ev = [&]() { return sr->evs[ev_base + (ev_used++ % EV_BLOCK)]; };      // (a call needs < 50)
   // the chain is about to overwrite dzb[k]: wait for the weight gradient that read it
   auto claim = [&](int kk) -> int {
     if (ov && rd[kk]) { if (hipStreamWaitEvent(st, rd[kk], 0) != hipSuccess) return PH_ELAUNCH; rd[kk] = nullptr; }
@@ -531,18 +546,18 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   auto wgrad_of = [&](int ui, const void* x, int kk) -> int {
     if (!ov) return conv_wgrad(c, ui, x, dzb[kk], (float*)grads[ui * 3 + 0]);
     hipEvent_t e = next_ev();
-    if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(P->side, e, 0) != hipSuccess) return PH_ELAUNCH;
+    if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return PH_ELAUNCH;
     int r = conv_wgrad(cs, ui, x, dzb[kk], (float*)grads[ui * 3 + 0]);
     if (r) return r;
     hipEvent_t d = next_ev();
-    if (hipEventRecord(d, P->side) != hipSuccess) return PH_ELAUNCH;
+    if (hipEventRecord(d, side) != hipSuccess) return PH_ELAUNCH;
     rd[kk] = d;
     return PH_OK;
   };
   auto join = [&]() -> int {
     if (!ov) return PH_OK;
     hipEvent_t e = next_ev();
-    if (hipEventRecord(e, P->side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) return PH_ELAUNCH;
+    if (hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) return PH_ELAUNCH;
     return PH_OK;
   };
   int rc, nst = 0;
@@ -607,7 +622,7 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
     if (ov) {      // same stream as the other weight gradients: they share the slab
       hipEvent_t e = next_ev();
-      if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(P->side, e, 0) != hipSuccess) return PH_ELAUNCH;
+      if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return PH_ELAUNCH;
     }
     if ((rc = ph_stem_wgrad_launch(&w, c.bprec(), cs.st))) return rc;
     PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, cs.st));
@@ -631,7 +646,7 @@ int ph_resnet_plan_set_backward_prec(const PhResnetPlan* P, int prec) {
 }
 
 // A/B and test switch: 0 = the whole backward on the caller's stream (the round-2 sequence), 1 (default) = weight
-// gradients on the plan's side stream
+// gradients on the side stream
 int ph_resnet_plan_set_backward_overlap(const PhResnetPlan* P, int on) {
   if (!P) return PH_EINVAL;
   P->bwd_overlap = on ? 1 : 0;

@@ -141,7 +141,7 @@ class _TrunkFn(torch.autograd.Function):
         if plan.key[3] != ops.PREC_BF16:
             check(lib().ph_resnet_plan_set_backward_prec(plan.h, -1 if bp is None else bp), "ph_resnet_plan_set_backward_prec")
         # `net._no_bwd_overlap` (A/B and test switch): the whole backward on one stream instead of weight gradients on the
-        # plan's side stream (csrc/resnet_plan.hip: backward_impl) - bitwise the same gradients
+        # library's side stream (csrc/resnet_plan.hip: backward_impl) - same kernels, same BatchNorm gradients bitwise
         check(lib().ph_resnet_plan_set_backward_overlap(plan.h, 0 if getattr(net, "_no_bwd_overlap", False) else 1),
               "ph_resnet_plan_set_backward_overlap")
         hook = getattr(net, "_grad_ready_hook", None)
