@@ -209,8 +209,10 @@ class PathomicNet(nn.Module):
         self.output_shift = Parameter(torch.FloatTensor([-3]), requires_grad=False)
 
     def forward(self, **kwargs):
-        path_vec_f3, path_vec, hazard_path, pred_path, path_grads = self.path_net(x_path=kwargs["x_path"])
+        # (the SNN first: its ~15 short launches are independent of the trunk; in front of it they are covered by the other
+        # networks' kernels of the distillation step, behind it they would be a latency-bound tail before the fusion)
         omic_vec, hazard_omic, pred_omic, omic_grads = self.omic_net(x_omic=kwargs["x_omic"])
+        path_vec_f3, path_vec, hazard_path, pred_path, path_grads = self.path_net(x_path=kwargs["x_path"])
         if self.fusion_type == "concat":
             raise NotImplementedError("fusion_type concat is not on the hot path (default pofusion)")
         if self.cut_fuse_grad:
