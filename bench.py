@@ -420,6 +420,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
+    ext_eager = False
+    if world > 1 and "PH_BENCH_LAUNCH" not in os.environ and not args.eager and not os.environ.get("PH_BENCH_DDP_GRAPH"):
+        # Replicas started by an EXTERNAL launcher (torch.distributed.run): eager launches.  A graph capture that fails (an
+        # RCCL call that cannot be captured on this stack) leaves the HIP streams in capture state for the rest of the process
+        # (tests/probe_capture_fallback_gpu.py) - `python bench.py --gpus N` recovers by restarting its replicas eagerly, a rank
+        # of someone else's launcher cannot.  Eager costs ~2 % at N = 1 (11.97 against 11.73 ms); PH_BENCH_DDP_GRAPH=1 opts in.
+        args.eager = True
+        ext_eager = True
     if os.environ.get("PH_BENCH_ONE_GPU"):
         local_rank = 0     # testing aid: every replica on GPU 0 (with PH_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)
     torch.cuda.set_device(local_rank)
@@ -622,7 +630,9 @@ def main():
                                          args.batch, args.size, args.size),
                           "tiles_per_gpu": args.batch, "tile": args.size, "global_batch": args.batch * world,
                           "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4),
-                          "launch": ("eager" if args.eager else "one captured HIP graph per step")
+                          "launch": (("eager (external launcher: a failed graph capture cannot be recovered in-process; "
+                                      "PH_BENCH_DDP_GRAPH=1 opts in)" if ext_eager else "eager") if args.eager
+                                     else "one captured HIP graph per step")
                                     + ("; replicas: " + os.environ["PH_BENCH_LAUNCH"] if "PH_BENCH_LAUNCH" in os.environ else ""),
                           "input_pipeline": ("on-device from resident uint8 tiles, inside the timed region and the graph"
                                              if args.device_loader else "inputs resident in HBM when the timed region starts")}}

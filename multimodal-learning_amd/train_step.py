@@ -810,6 +810,11 @@ class DistillStep:
                 import warnings
                 warnings.warn("HIP graph capture of the distill step failed (%r); continuing with eager launches" % (exc,))
                 torch.cuda.synchronize()
+                try:      # on this HIP runtime a failed capture can leave its streams in capture state for good
+                    torch.ones(1).to(self.device)
+                except Exception as exc2:
+                    raise RuntimeError("HIP graph capture of the distill step failed (%r) and the runtime did not leave capture "
+                                       "mode (%r): restart the process without enable_graph()" % (exc, exc2)) from exc
                 self._want_graph = False
                 self._static = None
                 self._slots = None
