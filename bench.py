@@ -243,7 +243,18 @@ def measure(step, batches, steps, warmup, sync, device, graph=True, loader=False
         # the two resident batches are adopted in place as the graph's input sets (no staging copy); the second set's
         # graph is captured here - capture executes nothing - so that the timed region only replays
         step.precapture(batches[1], epoch=1)
+    _flush_c_stdio()      # every rank: whatever native libraries printed while the communicators came up goes out NOW
     return step, batches
+
+
+def _flush_c_stdio():
+    """Flush the C library's stdio buffers (output of native libraries, e.g. RCCL's banner, is block-buffered when stdout is a
+    pipe and would otherwise appear at process exit, after the JSON line)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 def timed(step, batches, steps, sync, device):
@@ -613,6 +624,9 @@ def main():
                     "mia2023": run_variant("mia2023", 64, args.size, device, L),
                     "tsvd_stage1": run_variant("tsvd", 128, args.size, device, L)}
 
+    _flush_c_stdio()
+    if sync is not None:
+        torch.distributed.barrier()      # every rank's native output is out before rank 0 prints the line
     if rank == 0:
         tiles = args.batch * world * args.steps
         res = {"metric": "ROI-tiles/sec (teacher+student distill step)", "value": round(tiles / dt, 2),
@@ -709,6 +723,7 @@ def main():
             res["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        _flush_c_stdio()      # (RCCL prints its version banner through C stdio: without this it lands AFTER the JSON line)
         print(json.dumps(res), flush=True)
     if sync is not None:
         torch.distributed.destroy_process_group()
