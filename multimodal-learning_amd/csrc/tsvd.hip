@@ -307,8 +307,82 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
   const int team = tid >> 4, l = tid & 15, half = n / 2;
   const int nm = (B + 31) >> 5;          // row chunks of 32 that hold data
   int sweeps_done = 0;
+  // One rotation on the register copies of two columns (a = column p, b = column q); true if it rotated.
+  auto rotate = [&](v4f (&a)[4], v4f (&b)[4]) -> bool {
+    v2f saa = {0.f, 0.f}, sbb = {0.f, 0.f}, sab = {0.f, 0.f}, sax = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m < nm) {
+        const v2f a0 = a[m].xy, a1 = a[m].zw, b0 = b[m].xy, b1 = b[m].zw;
+        saa = pk_fma(a0, a0, saa); saa = pk_fma(a1, a1, saa);
+        sbb = pk_fma(b0, b0, sbb); sbb = pk_fma(b1, b1, sbb);
+        sab = pk_fma(a0, b0, sab); sab = pk_fma(a1, b1, sab);        // (ar br, ai bi)
+        sax = pk_fma(a0, b0.yx, sax); sax = pk_fma(a1, b1.yx, sax);  // (ar bi, ai br)
+      }
+    }
+    const float al = row16_sum(saa.x + saa.y), be = row16_sum(sbb.x + sbb.y);
+    const float gr = row16_sum(sab.x + sab.y);      // conj(a_p) . a_q
+    const float gi = row16_sum(sax.x - sax.y);
+    const float g2 = gr * gr + gi * gi;
+    if (!(fminf(al, be) > col_floor && g2 > TB_TOL2 * al * be)) return false;
+    const float rg = __frsqrt_rn(g2);
+    const float ze = (be - al) * (0.5f * rg);
+    const float t = copysignf(1.f, ze) / (fabsf(ze) + sqrtf(1.f + ze * ze));
+    const float c = __frsqrt_rn(1.f + t * t), sn = c * t;
+    const float ser = sn * gr * rg, sei = sn * gi * rg;
+    // a_p' = c a_p - s e^{-i phi} a_q ;  a_q' = s e^{i phi} a_p + c a_q ;  e^{i phi} = (gr + i gi) / |g|
+    const v2f c2 = {c, c}, s2 = {ser, ser}, ns2 = {-ser, -ser}, k1 = {-sei, sei};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (m < nm) {
+        const v2f a0 = a[m].xy, a1 = a[m].zw, b0 = b[m].xy, b1 = b[m].zw;
+        const v2f p0 = pk_fma(c2, a0, pk_fma(ns2, b0, k1 * b0.yx));
+        const v2f p1 = pk_fma(c2, a1, pk_fma(ns2, b1, k1 * b1.yx));
+        const v2f q0 = pk_fma(c2, b0, pk_fma(s2, a0, k1 * a0.yx));
+        const v2f q1 = pk_fma(c2, b1, pk_fma(s2, a1, k1 * a1.yx));
+        a[m] = v4f{p0.x, p0.y, p1.x, p1.y};
+        b[m] = v4f{q0.x, q0.y, q1.x, q1.y};
+      }
+    }
+    return true;
+  };
   for (int sweep = 0; sweep < TB_MAX_SWEEPS; ++sweep) {
     ++sweeps_done;
+#ifndef TB_NO_BIPARTITE
+    if (n == TB_MAXB) {
+      // n = 128 (BASELINE configs[3]): a recursive bipartite ordering.  Phase with sets of S = 128, 64, ... 2 columns: every
+      // set pairs its lower half with its upper half in S / 2 steps (team i of the set keeps lower column i and meets
+      // upper column (i + s) mod S / 2) - 64 + 32 + ... + 1 = 127 steps and every pair once, like the round robin below,
+      // but a team's FIRST column stays in its registers for the whole phase: per step one column is read and (if it
+      // rotated) written instead of two, i.e. half the LDS traffic of a step whose stores (~80 B / clk) weigh as much as
+      // its arithmetic.
+      for (int S = n; S >= 2; S >>= 1) {
+        const int h = S >> 1, g = team / h, i = team - g * h;
+        v4f* cp = reinterpret_cast<v4f*>(A + (g * S + i) * TB_CS) + l;
+        v4f a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = cp[16 * m];
+        bool moved = false;
+        for (int st = 0; st < h; ++st) {
+          v4f* cq = reinterpret_cast<v4f*>(A + (g * S + h + ((i + st) & (h - 1))) * TB_CS) + l;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) b[m] = cq[16 * m];
+          if (rotate(a, b)) {
+            moved = true;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) cq[16 * m] = b[m];
+          }
+          __syncthreads();      // column q is read by another team in the next step
+        }
+        if (moved) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) cp[16 * m] = a[m];
+          if (l == 0) rotated = 1;
+        }
+        __syncthreads();
+      }
+    } else
+#endif
     for (int step = 0; step < n - 1; ++step) {
       if (team < half) {
         const int j1 = n - 1 - team;
@@ -317,44 +391,13 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
         v4f* cp = reinterpret_cast<v4f*>(A + p * TB_CS) + l;
         v4f* cq = reinterpret_cast<v4f*>(A + q * TB_CS) + l;
         v4f a[4], b[4];
-        v2f saa = {0.f, 0.f}, sbb = {0.f, 0.f}, sab = {0.f, 0.f}, sax = {0.f, 0.f};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          if (m < nm) {
-            a[m] = cp[16 * m];
-            b[m] = cq[16 * m];
-            const v2f a0 = a[m].xy, a1 = a[m].zw, b0 = b[m].xy, b1 = b[m].zw;
-            saa = pk_fma(a0, a0, saa); saa = pk_fma(a1, a1, saa);
-            sbb = pk_fma(b0, b0, sbb); sbb = pk_fma(b1, b1, sbb);
-            sab = pk_fma(a0, b0, sab); sab = pk_fma(a1, b1, sab);        // (ar br, ai bi)
-            sax = pk_fma(a0, b0.yx, sax); sax = pk_fma(a1, b1.yx, sax);  // (ar bi, ai br)
-          }
-        }
-        const float al = row16_sum(saa.x + saa.y), be = row16_sum(sbb.x + sbb.y);
-        const float gr = row16_sum(sab.x + sab.y);      // conj(a_p) . a_q
-        const float gi = row16_sum(sax.x - sax.y);
-        const float g2 = gr * gr + gi * gi;
-        if (fminf(al, be) > col_floor && g2 > TB_TOL2 * al * be) {
-          const float rg = __frsqrt_rn(g2), g = g2 * rg;
-          const float ze = (be - al) * (0.5f * rg);
-          const float t = copysignf(1.f, ze) / (fabsf(ze) + sqrtf(1.f + ze * ze));
-          const float c = __frsqrt_rn(1.f + t * t), s = c * t;
-          const float ser = s * gr * rg, sei = s * gi * rg;
-          (void)g;
-          // a_p' = c a_p - s e^{-i phi} a_q ;  a_q' = s e^{i phi} a_p + c a_q ;  e^{i phi} = (gr + i gi) / |g|
-          const v2f c2 = {c, c}, s2 = {ser, ser}, ns2 = {-ser, -ser}, k1 = {-sei, sei};
+        for (int m = 0; m < 4; ++m)
+          if (m < nm) { a[m] = cp[16 * m]; b[m] = cq[16 * m]; }
+        if (rotate(a, b)) {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            if (m < nm) {
-              const v2f a0 = a[m].xy, a1 = a[m].zw, b0 = b[m].xy, b1 = b[m].zw;
-              const v2f p0 = pk_fma(c2, a0, pk_fma(ns2, b0, k1 * b0.yx));
-              const v2f p1 = pk_fma(c2, a1, pk_fma(ns2, b1, k1 * b1.yx));
-              const v2f q0 = pk_fma(c2, b0, pk_fma(s2, a0, k1 * a0.yx));
-              const v2f q1 = pk_fma(c2, b1, pk_fma(s2, a1, k1 * a1.yx));
-              cp[16 * m] = v4f{p0.x, p0.y, p1.x, p1.y};
-              cq[16 * m] = v4f{q0.x, q0.y, q1.x, q1.y};
-            }
-          }
+          for (int m = 0; m < 4; ++m)
+            if (m < nm) { cp[16 * m] = a[m]; cq[16 * m] = b[m]; }
           if (l == 0) rotated = 1;
         }
       }
