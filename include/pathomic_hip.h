@@ -24,6 +24,8 @@ typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
 #define PH_PREC_BF16 0   /* perf mode: bf16 operands + activations, fp32 accumulate/statistics */
 #define PH_PREC_BF16X6 1 /* parity mode: fp32 activations, 3-plane split-bf16 (6-product, fp32-equivalent) MFMA */
 #define PH_PREC_BF16X3 2 /* fp32 activations, the 3 leading split-bf16 products (16-bit operands): half the matrix work */
+#define PH_PREC_FP16X3 3 /* half-pair mode: tensors a convolution reads are fp16 pairs x = hi + lo * 2^-11 (4 B / element, 22
+                            significant bits), conv outputs / gradients fp32, 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi) */
 
 #define PH_ACT_NONE 0
 #define PH_ACT_RELU 1
@@ -272,6 +274,12 @@ int ph_l1_sign_axpy(const float* w, float* g, size_t n, const float* coef_dev, f
  * mode's type, weights OIHW f32.  `ws` must hold ph_conv2d_workspace_bytes().
  * ---------------------------------------------------------------------------------------------- */
 size_t ph_conv2d_workspace_bytes(int B, int Cin, int IH, int IW, int Cout, int KS, int stride, int pad);
+/* PH_PREC_FP16X3: the tensors a convolution READS (x of fwd / wgrad, dy of dgrad / wgrad) are half-pair tensors - layout
+ * [..][C / 64][2][64] fp16 (per 64-channel slice a 128-B line of hi values, then one of lo values), 256-B aligned, C % 64 == 0
+ * - and everything it writes is fp32.  These two convert (n elements, n % 64 == 0; `scale`: a power of two applied before the
+ * split, 1 for activations).  Replace nothing in the reference: they are the storage format of this arithmetic. */
+int ph_hp_pack(const float* src, void* dst, size_t n, float scale, ph_stream_t stream);
+int ph_hp_unpack(const void* src, float* dst, size_t n, ph_stream_t stream);
 int ph_conv2d_fwd(const void* x, const float* w_oihw, void* y, float* ch_sum /* [Cout] or NULL */,
                   float* ch_sumsq, int B, int Cin, int IH, int IW, int Cout, int KS, int stride, int pad, int prec,
                   void* ws, ph_stream_t stream);

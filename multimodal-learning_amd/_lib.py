@@ -110,6 +110,8 @@ SIGNATURES = {
     "ph_prof_summary4": (i32, [vp, i32]),
     "ph_prof_stamp": (i32, [vp, vp]),
     "ph_conv2d_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "ph_hp_pack": (i32, [vp, vp, sz, f32, vp]),
+    "ph_hp_unpack": (i32, [vp, vp, sz, vp]),
     "ph_conv2d_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ph_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ph_conv2d_dgrad_res": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -15,7 +15,18 @@ __global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ x
   const size_t hw = (size_t)H * W;
   const size_t b = i / hw, r = i - b * hw;
   const float c0 = x[(b * 3 + 0) * hw + r], c1 = x[(b * 3 + 1) * hw + r], c2 = x[(b * 3 + 2) * hw + r];
-  if constexpr (is_f32<T>::value) {
+  if constexpr (is_hp<T>::value) {
+    // NHWC4 half-pair planes [2][npix][4] fp16: plane 0 = hi, plane 1 = lo (the stem kernels stage them as they lie)
+    f16x4 h, l;
+    f16 a, b;
+    hp_split(c0, a, b); h[0] = a; l[0] = b;
+    hp_split(c1, a, b); h[1] = a; l[1] = b;
+    hp_split(c2, a, b); h[2] = a; l[2] = b;
+    h[3] = (f16)0.f; l[3] = (f16)0.f;
+    f16* base = reinterpret_cast<f16*>(x4);
+    *reinterpret_cast<f16x4*>(base + i * 4) = h;
+    *reinterpret_cast<f16x4*>(base + (npix + i) * 4) = l;
+  } else if constexpr (is_f32<T>::value) {
     f32x4 v = {c0, c1, c2, 0.f};
     *reinterpret_cast<f32x4*>(x4 + i * 4) = v;
   } else {
@@ -78,10 +89,11 @@ __global__ void bn_eval_params_kernel(PhBnEvalTable t, float eps) {
 
 // out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r | relu(y_r*scale_r + shift_r)] ), 8 channels per thread;
 // relu bit0: ReLU on the sum, bit1: ReLU (and rounding to T) on the shortcut term
-template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+// TY: type of the convolution outputs (y, y_r), T: type of the activations (res, out); they differ in PH_PREC_FP16X3 only
+template <typename T, typename TY>
+__global__ void bn_apply_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const T* __restrict__ res,
-                                const T* __restrict__ y_r, const float* __restrict__ scale_r,
+                                const TY* __restrict__ y_r, const float* __restrict__ scale_r,
                                 const float* __restrict__ shift_r, T* __restrict__ out, size_t n8, int C8, int relu) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
@@ -102,7 +114,8 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float t = r[k] * scale_r[c + k] + shift_r[c + k];
-        v[k] += (float)(T)(t > 0.f ? t : 0.f);
+        if constexpr (is_hp<T>::value) v[k] += (t > 0.f ? t : 0.f);
+        else v[k] += (float)(T)(t > 0.f ? t : 0.f);
       }
     } else {
 #pragma unroll
@@ -117,10 +130,10 @@ __global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict
 }
 
 // stem: relu(bn(y0)) -> maxpool 3x3/2 pad 1; argmax position code (kh*3+kw, first max wins) saved as u8
-template <typename T, bool IDX>
-__global__ void bn_relu_maxpool_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+template <typename T, typename TY, bool IDX>
+__global__ void bn_relu_maxpool_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
                                        const float* __restrict__ shift, T* __restrict__ out,
-                                       uint8_t* __restrict__ idx, T* __restrict__ raw, int B, int H, int W, int C8) {
+                                       uint8_t* __restrict__ idx, TY* __restrict__ raw, int B, int H, int W, int C8) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;   // floor((H + 2 - 3)/2) + 1
   const size_t n = (size_t)B * OH * OW * C8;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,9 +229,9 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ g, T* __restrict__ 
 // ---------------------------------------------------------------- BN backward
 // dz source of a plain block BN: dz = g * (a > 0).  (The stem - g scattered through the max-pool argmax - has its own
 // geometry-aware kernel below.)
-template <typename T>
+template <typename T, typename TY = T>
 struct DzPlain {
-  const T* g; const T* a; const T* y;
+  const TY* g; const T* a; const TY* y;
   // optional: the ReLU mask of a BatchNorm whose OWN output went through the ReLU (bn1 of a BasicBlock: a1 =
   // relu(y * scale + shift)) is a function of y, which the kernels read anyway - the activation tensor `a` is then not
   // read at all (2 of the 6 / 8 bytes per element of the reduce / apply pass)
@@ -240,14 +253,17 @@ struct DzPlain {
 
 constexpr int BWD_BLOCKS_MAX = 1024;
 
+// amax (optional, PH_PREC_FP16X3): amax[block] = max |dz| over the block's elements - the BatchNorm-backward output dz' is
+// stored as fp16 pairs and needs a per-tensor power-of-two scale, which bn_bwd_finalize_kernel derives from this bound
 template <typename T, typename Src>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
-                                                            float* __restrict__ parts, size_t npix, int C) {
+                                                            float* __restrict__ parts, size_t npix, int C,
+                                                            float* __restrict__ amax) {
   const int C8 = C >> 3;
   const int cg = threadIdx.x % C8, pl = threadIdx.x / C8, npl = 256 / C8;
   const int c = cg * 8;
-  float mu[8], is[8], s1[8], s2[8];
+  float mu[8], is[8], s1[8], s2[8], am = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) { mu[k] = mean[c + k]; is[k] = invstd[c + k]; s1[k] = 0.f; s2[k] = 0.f; }
   const size_t per = (npix + gridDim.x - 1) / gridDim.x;
@@ -259,9 +275,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float
     for (int k = 0; k < 8; ++k) {
       s1[k] += dz[k];
       s2[k] += dz[k] * (yy[k] - mu[k]) * is[k];
+      am = fmaxf(am, fabsf(dz[k]));
     }
   }
   __shared__ float sh[2][256][9];
+  if (amax) {      // (uniform)
+    __shared__ float sha[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0) sha[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
   __syncthreads();
@@ -273,10 +298,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float
   }
 }
 
+// dzs (optional, PH_PREC_FP16X3; with amax[namax], gamma, invstd): block 0 also writes the power-of-two scale of the dz' tensor
+// the apply pass is about to store as fp16 pairs: dzs[0] = 2^s (multiplier of the apply pass), dzs[1] = 2^-s (the consumers'
+// un-scale).  |dz'| = |gamma invstd (dz - c1 - xhat c2)| <= G A (2 + |xhat|) with A = max |dz|, G = max |gamma invstd| (|c1|,
+// |c2| <= A: means of dz and of dz xhat with E|xhat| <= 1); s puts G A at 2^9, so fp16 (max 65504) holds |xhat| up to 125 and
+// elements down to 2^-23 of the bound keep 11 + 11 significant bits.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C,
                                                               double count, float* dgamma, float* dbeta, float* c1,
-                                                              float* c2) {
+                                                              float* c2, const float* __restrict__ amax, int namax,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd, float* dzs) {
   const int c = blockIdx.x, tid = threadIdx.x;
+  if (dzs && c == 0) {
+    float a = 0.f, g = 0.f;
+    for (int i = tid; i < namax; i += 256) a = fmaxf(a, amax[i]);
+    for (int i = tid; i < C; i += 256) g = fmaxf(g, fabsf(gamma[i] * invstd[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o, 64)); g = fmaxf(g, __shfl_xor(g, o, 64)); }
+    __shared__ float sa[2][4];
+    if ((tid & 63) == 0) { sa[0][tid >> 6] = a; sa[1][tid >> 6] = g; }
+    __syncthreads();
+    if (tid == 0) {
+      a = fmaxf(fmaxf(sa[0][0], sa[0][1]), fmaxf(sa[0][2], sa[0][3]));
+      g = fmaxf(fmaxf(sa[1][0], sa[1][1]), fmaxf(sa[1][2], sa[1][3]));
+      const float bound = a * g;
+      int e = 0;
+      if (bound > 0.f && bound < INFINITY) e = 9 - ilogbf(bound);      // bound * 2^e in [2^9, 2^10)
+      e = e > 100 ? 100 : (e < -100 ? -100 : e);
+      dzs[0] = ldexpf(1.f, e);
+      dzs[1] = ldexpf(1.f, -e);
+    }
+  }
   double s1 = 0.0, s2 = 0.0;
   for (int p = tid; p < nparts; p += 256) {
     s1 += (double)parts[((size_t)p * 2 + 0) * C + c];
@@ -299,17 +351,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 template <typename T, typename Src>
 __global__ void bn_bwd_apply_kernel(Src src, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
-                                    const float* __restrict__ c2, T* __restrict__ dy, size_t n8, int C8) {
+                                    const float* __restrict__ c2, T* __restrict__ dy, size_t n8, int C8,
+                                    const float* __restrict__ dzs) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int c = (int)(i % C8) * 8;
   float dz[8], yy[8];
   src.get(i, c, dz, yy);
+  const float sc = dzs ? dzs[0] : 1.f;      // power of two (bn_bwd_finalize_kernel): the product is exact
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const float is = invstd[c + k];
     const float xh = (yy[k] - mean[c + k]) * is;
-    dz[k] = gamma[c + k] * is * (dz[k] - c1[c + k] - xh * c2[c + k]);
+    dz[k] = gamma[c + k] * is * (dz[k] - c1[c + k] - xh * c2[c + k]) * sc;
   }
   store8(dy + i * 8, dz);
 }
@@ -351,13 +405,14 @@ __device__ __forceinline__ void stem_dz(const T* __restrict__ dpool, const uint8
       dz[k] += (ok[q] && ((unsigned)(packed[q] >> (8 * k)) & 0xffu) == code[q]) ? g8[q][k] : 0.f;
 }
 
-template <typename T, bool APPLY>
-__global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx,
-                                                       const T* __restrict__ y, const float* __restrict__ scale,
+template <typename T, typename TY, bool APPLY>
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const TY* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                       const TY* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ c1, const float* __restrict__ c2,
-                                                       float* __restrict__ parts, T* __restrict__ dy, int B, int H, int W) {
+                                                       float* __restrict__ parts, T* __restrict__ dy, int B, int H, int W,
+                                                       const float* __restrict__ dzs) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const int cg = threadIdx.x & 7, wl = threadIdx.x >> 3, c = cg * 8;
   float sc[8], sf[8], mu[8], is[8], ga[8], k1[8], k2[8], s1[8], s2[8];
@@ -367,6 +422,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dpo
     s1[k] = 0.f; s2[k] = 0.f;
     if (APPLY) { ga[k] = gamma[c + k] * is[k]; k1[k] = c1[c + k]; k2[k] = c2[c + k]; }
   }
+  const float dsc = (APPLY && dzs) ? dzs[0] : 1.f;      // PH_PREC_FP16X3: power-of-two scale of the stored dz (exact)
   const int row0 = blockIdx.x * STEM_ROWS, row1 = min(B * H, row0 + STEM_ROWS);
   for (int row = row0; row < row1; ++row) {
     const size_t b = row / H;
@@ -380,7 +436,7 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const T* __restrict__ dpo
       for (int k = 0; k < 8; ++k) {
         dz[k] = (yy[k] * sc[k] + sf[k]) > 0.f ? dz[k] : 0.f;
         const float xh = (yy[k] - mu[k]) * is[k];
-        if (APPLY) dz[k] = ga[k] * (dz[k] - k1[k] - xh * k2[k]);
+        if (APPLY) dz[k] = ga[k] * (dz[k] - k1[k] - xh * k2[k]) * dsc;
         else { s1[k] += dz[k]; s2[k] += dz[k] * xh; }
       }
       if (APPLY) store8(dy + i8 * 8, dz);
@@ -413,10 +469,11 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __
                                                                      const float* __restrict__ shift,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd,
-                                                                     float* __restrict__ parts, int B, int H, int W) {
+                                                                     float* __restrict__ parts, int B, int H, int W,
+                                                                     float* __restrict__ amax) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const int cg = threadIdx.x & 7, wl = threadIdx.x >> 3, c = cg * 8;
-  float sc[8], sf[8], mu[8], is[8], s1[8], s2[8];
+  float sc[8], sf[8], mu[8], is[8], s1[8], s2[8], am = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean[c + k]; is[k] = invstd[c + k];
@@ -441,13 +498,21 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __
         const float dz = (z * sc[k] + sf[k]) > 0.f ? g8[k] : 0.f;
         s1[k] += dz;
         s2[k] += dz * ((z - mu[k]) * is[k]);
+        am = fmaxf(am, fabsf(dz));
       }
     }
   }
   __shared__ float sh[2][256][9];
+  __shared__ float sha[4];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0) sha[threadIdx.x >> 6] = am;
+  }
   __syncthreads();
+  if (amax && threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
     float t = 0.f;
@@ -463,10 +528,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void stem_bwd_reduce_raw_kernel(const T* __restrict__ dpool, const T* __restrict__ raw,
                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                  float* __restrict__ parts, int B, int H, int W) {
+                                                                  float* __restrict__ parts, int B, int H, int W,
+                                                                  float* __restrict__ amax) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const int cg = threadIdx.x & 7, wl = threadIdx.x >> 3, c = cg * 8;
-  float sc[8], sf[8], mu[8], is[8], s1[8], s2[8];
+  float sc[8], sf[8], mu[8], is[8], s1[8], s2[8], am = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     sc[k] = scale[c + k]; sf[k] = shift[c + k]; mu[k] = mean[c + k]; is[k] = invstd[c + k];
@@ -486,13 +552,21 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_raw_kernel(const T* __res
         const float dz = (z * sc[k] + sf[k]) > 0.f ? g8[k] : 0.f;
         s1[k] += dz;
         s2[k] += dz * ((z - mu[k]) * is[k]);
+        am = fmaxf(am, fabsf(dz));
       }
     }
   }
   __shared__ float sh[2][256][9];
+  __shared__ float sha[4];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sh[0][threadIdx.x][k] = s1[k]; sh[1][threadIdx.x][k] = s2[k]; }
+  if (amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+    if ((threadIdx.x & 63) == 0) sha[threadIdx.x >> 6] = am;
+  }
   __syncthreads();
+  if (amax && threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
     float t = 0.f;
@@ -505,10 +579,19 @@ inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t)
 
 }  // namespace
 
+// precision mode -> (activation type T, conv-output type TY): PH_DISPATCH(prec, CALL) expands CALL(T, TY)
+#define PH_DISPATCH(prec, CALL)                                  \
+  do {                                                           \
+    if ((prec) == PH_PREC_BF16) { CALL(bf16, bf16); }            \
+    else if ((prec) == PH_PREC_FP16X3) { CALL(hp16, float); }    \
+    else { CALL(float, float); }                                 \
+  } while (0)
+
 int ph_pack_input_launch(const float* x, void* x4, int B, int H, int W, int prec, hipStream_t st) {
   const size_t n = (size_t)B * H * W;
-  if (prec == PH_PREC_BF16) hipLaunchKernelGGL(pack_input_kernel<bf16>, dim3(nblk(n)), dim3(256), 0, st, x, (bf16*)x4, B, H, W);
-  else hipLaunchKernelGGL(pack_input_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, x, (float*)x4, B, H, W);
+#define PH_CALL(T, TY) hipLaunchKernelGGL(pack_input_kernel<T>, dim3(nblk(n)), dim3(256), 0, st, x, (T*)x4, B, H, W)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -535,12 +618,11 @@ int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, co
   void* tok = nullptr;
   if (ph_prof_on())
     ph_prof_begin(PH_CLS_BN_APPLY, (double)npix * C * (prec == PH_PREC_BF16 ? 2.0 : 4.0) * ((res || y_r) ? 3.0 : 2.0), st, &tok);
-  if (prec == PH_PREC_BF16)
-    hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(nblk(n8)), dim3(256), 0, st, (const bf16*)y, scale, shift,
-                       (const bf16*)res, (const bf16*)y_r, scale_r, shift_r, (bf16*)out, n8, C / 8, relu);
-  else
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(nblk(n8)), dim3(256), 0, st, (const float*)y, scale, shift,
-                       (const float*)res, (const float*)y_r, scale_r, shift_r, (float*)out, n8, C / 8, relu);
+#define PH_CALL(T, TY)                                                                                              \
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(nblk(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const T*)res, \
+                     (const TY*)y_r, scale_r, shift_r, (T*)out, n8, C / 8, relu)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
@@ -550,29 +632,34 @@ int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* sh
                               int B, int H, int W, int C, int prec, hipStream_t st) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const size_t n = (size_t)B * OH * OW * (C / 8);
-#define PH_POOL_LAUNCH(T, IDX) \
-  hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, IDX>), dim3(nblk(n)), dim3(256), 0, st, (const T*)y, scale, shift, (T*)out, idx, (T*)raw, B, H, W, C / 8)
-  if (prec == PH_PREC_BF16) { if (idx) PH_POOL_LAUNCH(bf16, true); else PH_POOL_LAUNCH(bf16, false); }
-  else { if (idx) PH_POOL_LAUNCH(float, true); else PH_POOL_LAUNCH(float, false); }
-#undef PH_POOL_LAUNCH
+#define PH_CALL(T, TY)                                                                                                          \
+  do {                                                                                                                          \
+    if (idx) hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, TY, true>), dim3(nblk(n)), dim3(256), 0, st, (const TY*)y, scale, shift, \
+                                (T*)out, idx, (TY*)raw, B, H, W, C / 8);                                                        \
+    else hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, TY, false>), dim3(nblk(n)), dim3(256), 0, st, (const TY*)y, scale, shift,   \
+                            (T*)out, idx, (TY*)raw, B, H, W, C / 8);                                                            \
+  } while (0)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 
 int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st) {
   dim3 grid(C / 64, B);
-  if (prec == PH_PREC_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, out, HW, C);
-  else hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, HW, C);
+#define PH_CALL(T, TY) hipLaunchKernelGGL(avgpool_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, HW, C)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 
+// dx: a GRADIENT buffer (conv-output type)
 int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int accumulate, int prec, hipStream_t st) {
   const size_t n8 = (size_t)B * HW * (C / 8);
-  if (prec == PH_PREC_BF16)
-    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(nblk(n8)), dim3(256), 0, st, g, (bf16*)dx, n8, HW, C / 8, accumulate);
-  else
-    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(nblk(n8)), dim3(256), 0, st, g, (float*)dx, n8, HW, C / 8, accumulate);
+#define PH_CALL(T, TY) hipLaunchKernelGGL(avgpool_bwd_kernel<TY>, dim3(nblk(n8)), dim3(256), 0, st, g, (TY*)dx, n8, HW, C / 8, accumulate)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -586,37 +673,40 @@ int ph_bn_bwd_parts(size_t npix, int C) {
 
 int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                             float* parts, size_t npix, int C, int prec, const float* mscale, const float* mshift,
-                            hipStream_t st) {
+                            float* amax, hipStream_t st) {
   const int nb = ph_bn_bwd_parts(npix, C);
-  if (prec == PH_PREC_BF16) {
-    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y, mscale, mshift};
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, DzPlain<bf16>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
-  } else {
-    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y, mscale, mshift};
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, DzPlain<float>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C);
-  }
+#define PH_CALL(T, TY)                                                                                                       \
+  do {                                                                                                                       \
+    DzPlain<T, TY> s{(const TY*)g, (const T*)a, (const TY*)y, mscale, mshift};                                               \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, DzPlain<T, TY>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C, amax); \
+  } while (0)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 
 int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
-                              float* c1, float* c2, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, dgamma, dbeta, c1, c2);
+                              float* c1, float* c2, const float* amax, int namax, const float* gamma, const float* invstd,
+                              float* dzs, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, dgamma, dbeta, c1, c2,
+                     amax, namax, gamma, invstd, dzs);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 
 int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
-                           int prec, const float* mscale, const float* mshift, hipStream_t st) {
+                           int prec, const float* mscale, const float* mshift, const float* dzs, hipStream_t st) {
   const size_t n8 = npix * (C / 8);
-  if (prec == PH_PREC_BF16) {
-    DzPlain<bf16> s{(const bf16*)g, (const bf16*)a, (const bf16*)y, mscale, mshift};
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, DzPlain<bf16>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (bf16*)dy, n8, C / 8);
-  } else {
-    DzPlain<float> s{(const float*)g, (const float*)a, (const float*)y, mscale, mshift};
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float, DzPlain<float>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, (float*)dy, n8, C / 8);
-  }
+#define PH_CALL(T, TY)                                                                                                       \
+  do {                                                                                                                       \
+    DzPlain<T, TY> s{(const TY*)g, (const T*)a, (const TY*)y, mscale, mshift};                                               \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DzPlain<T, TY>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, \
+                       (T*)dy, n8, C / 8, dzs);                                                                              \
+  } while (0)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -625,37 +715,35 @@ int ph_stem_bwd_parts(int B, int H) { return (B * H + STEM_ROWS - 1) / STEM_ROWS
 
 int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const void* raw, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
-                              int W, int C, int prec, hipStream_t st) {
+                              int W, int C, int prec, float* amax, hipStream_t st) {
   if (C != 64) return PH_EINVAL;
+  if (amax && (H & 1)) return PH_EINVAL;      // (the per-pixel form below does not produce the bound)
   const int nb = ph_stem_bwd_parts(B, H);
   if (raw && H % 2 == 0) {   // the forward saved the conv output at every window's arg-max
-    if (prec == PH_PREC_BF16)
-      hipLaunchKernelGGL((stem_bwd_reduce_raw_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, (const bf16*)raw,
-                         scale, shift, mean, invstd, parts, B, H, W);
-    else
-      hipLaunchKernelGGL((stem_bwd_reduce_raw_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dpool, (const float*)raw,
-                         scale, shift, mean, invstd, parts, B, H, W);
+#define PH_CALL(T, TY)                                                                                                      \
+  hipLaunchKernelGGL((stem_bwd_reduce_raw_kernel<TY>), dim3(nb), dim3(256), 0, st, (const TY*)dpool, (const TY*)raw, scale, shift, \
+                     mean, invstd, parts, B, H, W, amax)
+    PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
     PH_LAUNCH_CHECK();
     return PH_OK;
   }
 #ifndef PH_STEM_BWD_PER_PIXEL   // (A/B switch: the per-input-pixel form of the reduction, 246 us against 190 us)
   if (H % 2 == 0) {   // (the block -> pooled-row mapping reuses the partial-row count of the per-pixel kernel)
-    if (prec == PH_PREC_BF16)
-      hipLaunchKernelGGL((stem_bwd_reduce_pooled_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx,
-                         (const bf16*)y0, scale, shift, mean, invstd, parts, B, H, W);
-    else
-      hipLaunchKernelGGL((stem_bwd_reduce_pooled_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dpool, idx,
-                         (const float*)y0, scale, shift, mean, invstd, parts, B, H, W);
+#define PH_CALL(T, TY)                                                                                                      \
+  hipLaunchKernelGGL((stem_bwd_reduce_pooled_kernel<TY>), dim3(nb), dim3(256), 0, st, (const TY*)dpool, idx, (const TY*)y0, scale, \
+                     shift, mean, invstd, parts, B, H, W, amax)
+    PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
     PH_LAUNCH_CHECK();
     return PH_OK;
   }
 #endif
-  if (prec == PH_PREC_BF16)
-    hipLaunchKernelGGL((stem_bwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx, (const bf16*)y0,
-                       scale, shift, mean, invstd, nullptr, nullptr, nullptr, parts, (bf16*)nullptr, B, H, W);
-  else
-    hipLaunchKernelGGL((stem_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, (const float*)dpool, idx, (const float*)y0,
-                       scale, shift, mean, invstd, nullptr, nullptr, nullptr, parts, (float*)nullptr, B, H, W);
+#define PH_CALL(T, TY)                                                                                                         \
+  hipLaunchKernelGGL((stem_bwd_kernel<T, TY, false>), dim3(nb), dim3(256), 0, st, (const TY*)dpool, idx, (const TY*)y0, scale, shift, \
+                     mean, invstd, nullptr, nullptr, nullptr, parts, (T*)nullptr, B, H, W, nullptr)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -663,15 +751,14 @@ int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void*
 int ph_stem_bwd_apply_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
                              const float* invstd, const float* scale, const float* shift, const float* gamma,
                              const float* c1, const float* c2, void* dy0, int B, int H, int W, int C, int prec,
-                             hipStream_t st) {
+                             const float* dzs, hipStream_t st) {
   if (C != 64) return PH_EINVAL;
   const int nb = ph_stem_bwd_parts(B, H);
-  if (prec == PH_PREC_BF16)
-    hipLaunchKernelGGL((stem_bwd_kernel<bf16, true>), dim3(nb), dim3(256), 0, st, (const bf16*)dpool, idx, (const bf16*)y0,
-                       scale, shift, mean, invstd, gamma, c1, c2, nullptr, (bf16*)dy0, B, H, W);
-  else
-    hipLaunchKernelGGL((stem_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, st, (const float*)dpool, idx, (const float*)y0,
-                       scale, shift, mean, invstd, gamma, c1, c2, nullptr, (float*)dy0, B, H, W);
+#define PH_CALL(T, TY)                                                                                                        \
+  hipLaunchKernelGGL((stem_bwd_kernel<T, TY, true>), dim3(nb), dim3(256), 0, st, (const TY*)dpool, idx, (const TY*)y0, scale, shift, \
+                     mean, invstd, gamma, c1, c2, nullptr, (T*)dy0, B, H, W, dzs)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -17,6 +17,24 @@ __global__ void parts_sum_kernel(const float* __restrict__ parts, int nparts, in
   if (s2) s2[c] = (float)b;
 }
 
+// fp32 <-> half-pair tensors (ph_common.h), 8 channels per thread
+__global__ void hp_pack_kernel(const float* __restrict__ src, hp16* __restrict__ dst, size_t n8, float scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float v[8];
+  load8(src + i * 8, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] *= scale;
+  store8(dst + i * 8, v);
+}
+__global__ void hp_unpack_kernel(const hp16* __restrict__ src, float* __restrict__ dst, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float v[8];
+  load8(src + i * 8, v);
+  store8(dst + i * 8, v);
+}
+
 int chunks_for(int B, int OH, int OW, int S, int Cout, int Cin, int* tpc) {
   const int th = ph_wgrad_tile_h(S);
   const int ntiles = B * cdiv(OH, th) * cdiv(OW, 16);
@@ -46,7 +64,7 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
   unsigned char* ws = reinterpret_cast<unsigned char*>(ws_);
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws);
-  int rc = ph_pack_w_fwd_launch(w, hi, Cout, Cin, KS, st);
+  int rc = prec == PH_PREC_FP16X3 ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 0, st) : ph_pack_w_fwd_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
@@ -74,7 +92,7 @@ int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* re
   if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return PH_EINVAL;
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws_);
-  int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
+  int rc = prec == PH_PREC_FP16X3 ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
@@ -116,7 +134,7 @@ int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, in
   if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws_);
-  int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
+  int rc = prec == PH_PREC_FP16X3 ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
@@ -168,11 +186,27 @@ int ph_conv2d_wgrad(const void* x, const void* dy, float* dw, int B, int Cin, in
   g.nchunks = chunks_for(B, OH, OW, g.S, Cout, Cin, &g.tiles_per_chunk);
   int rc = ph_wgrad_launch(&g, prec, st);
   if (rc) return rc;
-  return ph_wgrad_reduce_launch(g.slab, dw, g.nchunks, KS, Cout, Cin, st);
+  return ph_wgrad_reduce_launch(g.slab, dw, g.nchunks, KS, Cout, Cin, nullptr, st);
 }
 
 int ph_stem_dgrad(const void* dy_nhwc, const float* w_oihw, float* dx_nchw, int B, int H, int W, int prec, hipStream_t st) {
   if (!dy_nhwc || !w_oihw || !dx_nchw || B < 1 || H < 2 || W < 2 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec)))
     return PH_EINVAL;
   return ph_stem_dgrad_launch(dy_nhwc, w_oihw, dx_nchw, B, H, W, prec, st);
+}
+
+// PH_PREC_FP16X3 storage of a tensor whose innermost extent is a multiple of 64 (NHWC activations, C % 64 == 0): fp32 -> the
+// half-pair layout [..][C / 64][2][64] fp16 (x * scale ~= hi + lo * 2^-11; `scale` a power of two, 1 for activations) and
+// back.  n = number of elements (multiple of 64), both pointers 256-B aligned, same byte size either way.
+int ph_hp_pack(const float* src, void* dst, size_t n, float scale, hipStream_t st) {
+  if (!src || !dst || (n & 63) || ((uintptr_t)dst & 255)) return PH_EINVAL;
+  hipLaunchKernelGGL(hp_pack_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, src, reinterpret_cast<hp16*>(dst), n / 8, scale);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_hp_unpack(const void* src, float* dst, size_t n, hipStream_t st) {
+  if (!src || !dst || (n & 63) || ((uintptr_t)src & 255)) return PH_EINVAL;
+  hipLaunchKernelGGL(hp_unpack_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const hp16*>(src), dst, n / 8);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
 }

@@ -23,15 +23,25 @@ constexpr int STEM_TPW = 8;           // output tiles per forward workgroup (wei
 
 __device__ __forceinline__ int wsw(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
+// (T = hp16: x4 = the two fp16 planes [2][B IH IW][4] of ph_pack_input_launch, staged as they lie; `nb` = batch size)
 template <typename T>
 __device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, int iy_base, int ix_base,
-                                           unsigned char* hi, int tid) {
+                                           unsigned char* hi, int tid, int nb = 0) {
   for (int i = tid; i < HP; i += 256) {
     const int hr = i / HPW, hc = i - hr * HPW;
     const int iy = iy_base + hr, ix = ix_base + hc;
     const bool ok = iy >= 0 && iy < IH && ix >= 0 && ix < IW;
     const size_t g = (((size_t)b * IH + iy) * IW + ix) * 4;
-    if constexpr (!is_f32<T>::value) {
+    if constexpr (is_hp<T>::value) {
+      const f16* xp = reinterpret_cast<const f16*>(x4);
+      u32x2 vh = {0u, 0u}, vl = {0u, 0u};
+      if (ok) {
+        vh = *reinterpret_cast<const u32x2*>(xp + g);
+        vl = *reinterpret_cast<const u32x2*>(xp + (size_t)nb * IH * IW * 4 + g);
+      }
+      *reinterpret_cast<u32x2*>(hi + i * 8) = vh;
+      *reinterpret_cast<u32x2*>(hi + XB + i * 8) = vl;
+    } else if constexpr (!is_f32<T>::value) {
       u32x2 v = {0u, 0u};
       if (ok) v = *reinterpret_cast<const u32x2*>(x4 + g);
       *reinterpret_cast<u32x2*>(hi + i * 8) = v;
@@ -50,8 +60,12 @@ __device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
-  constexpr bool SPLIT = is_f32<T>::value;
+  // SPLIT: the plane-staged path (three bf16 split planes of fp32 operands; T = hp16, PH_PREC_FP16X3: the two fp16 planes
+  // of the half-pair input against the three weight planes (hi 2^11, lo, hi), fp32 output = accumulators * 2^-11)
+  constexpr bool HPM = is_hp<T>::value;
+  constexpr bool SPLIT = is_f32<T>::value || HPM;
   constexpr int NP = SPLIT ? PH_NPLANES : 1;
+  typedef typename std::conditional<HPM, float, T>::type TO;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // perf mode: two halo buffers (tile t+1 is written while nobody reads it: one barrier per tile); parity: NP planes
   constexpr int XBUFS = SPLIT ? NP : 2;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     const unsigned char* ldsXc = ldsX;
     if constexpr (SPLIT) {
       __syncthreads();   // previous tile's fragment reads of ldsX are done (and, first time, nothing)
-      stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
+      stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid, p.B);
       __syncthreads();
     } else {
       ldsXc = ldsX + ((tt - t_begin) & 1) * XB;
@@ -138,14 +152,20 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         bf16x8 a[NP], bq[NP][2];
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
-          a[pl] = *reinterpret_cast<const bf16x8*>(ldsXc + pl * XB + aoff);
+          if (!HPM || pl < 2) a[pl] = *reinterpret_cast<const bf16x8*>(ldsXc + pl * XB + aoff);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int row = kh * 64 + j * 32 + (lane & 31);
             bq[pl][j] = *reinterpret_cast<const bf16x8*>(ldsW + pl * WB + row * 64 + (wsw(row, chunk) << 4));
           }
         }
-        if constexpr (SPLIT) {
+        if constexpr (HPM) {
+#define PH_MMH(PI, PJ)                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PI]), __builtin_bit_cast(f16x8, bq[PJ][j]), acc[j], 0, 0, 0);
+          PH_MMH(1, 2) PH_MMH(0, 1) PH_MMH(0, 0)
+#undef PH_MMH
+        } else if constexpr (SPLIT) {
 #define PH_MM(PI, PJ)                                                                               \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
       acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI], bq[PJ][j], acc[j], 0, 0, 0);
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     // lanes l, l^1 hold neighbouring channels of the same pixels, so they swap one value of each column pair by DPP and
     // each stores one [even channel, odd channel] word (half the store instructions of 2-byte stores, which bound the
     // kernel: 537 MB of output left the CU in 128-B wave-instructions)
-    T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * 64;
+    TO* out = reinterpret_cast<TO*>(p.out) + (size_t)b * p.OH * p.OW * 64;
     if constexpr (!SPLIT) {
       typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
       const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
@@ -203,7 +223,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         const bool valid = r < p.OH && c < p.OW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float v = valid ? acc[j][q] : 0.f;
+          const float v = valid ? (HPM ? acc[j][q] * PH_HP_LO_INV : acc[j][q]) : 0.f;
           s1[j] += v; s2[j] += v * v;
           if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
         }
@@ -528,8 +548,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, i
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
+  // T = hp16 (PH_PREC_FP16X3): two fp16 planes of dz' (a [hi 64 | lo 64] pixel record) and of the image; the leading product
+  // and the two cross products accumulate separately and are combined (cross * 2^-11) when the slab is written
+  constexpr bool HPM = is_hp<T>::value;
   constexpr bool SPLIT = is_f32<T>::value;
-  constexpr int NP = SPLIT ? PH_NPLANES : 1;
+  constexpr int NP = SPLIT ? PH_NPLANES : (HPM ? 2 : 1);
   constexpr int DB = TH * TW * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsD = smem;               // NP planes of DB
@@ -543,13 +566,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
   const T* DY = reinterpret_cast<const T*>(p.dy);
   // wave w owns kernel rows kh = w and w+4 (w+4 == 7 does not exist)
   const int nkh = (wave + 4 < 7) ? 2 : 1;
-  f32x16 acc[2][2];
+  f32x16 acc[2][2], accx[HPM ? 2 : 1][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[a][j][q] = 0.f;
+      for (int q = 0; q < 16; ++q) { acc[a][j][q] = 0.f; if (HPM) accx[HPM ? a : 0][j][q] = 0.f; }
   const int q4 = (lane & 15) >> 2, p4 = lane & 3, colhalf = (lane >> 4) & 1, khalf = lane >> 5;
 
   for (int tt = t_begin; tt < t_end; ++tt) {
@@ -562,7 +585,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
       const bool ok = r < p.OH && c < p.OW;
       const int off = pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16;
       const T* src = DY + (((size_t)b * p.OH + r) * p.OW + c) * 64 + ch * 8;
-      if constexpr (!SPLIT) {
+      if constexpr (HPM) {
+        const f16* sh = reinterpret_cast<const f16*>(p.dy) + (((size_t)b * p.OH + r) * p.OW + c) * 128 + ch * 8;
+        u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+        if (ok) { vh = *reinterpret_cast<const u32x4*>(sh); vl = *reinterpret_cast<const u32x4*>(sh + 64); }
+        *reinterpret_cast<u32x4*>(ldsD + off) = vh;
+        *reinterpret_cast<u32x4*>(ldsD + DB + off) = vl;
+      } else if constexpr (!SPLIT) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (ok) v = *reinterpret_cast<const u32x4*>(src);
         *reinterpret_cast<u32x4*>(ldsD + off) = v;
@@ -579,7 +608,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
         *reinterpret_cast<bf16x8*>(ldsD + 2 * DB + off) = p2;
       }
     }
-    stage_halo<T>(X, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid);
+    stage_halo<T>(X, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid, p.B);
     __syncthreads();
 #pragma unroll 2
     for (int kk = 0; kk < TH * TW / 16; ++kk) {
@@ -604,7 +633,16 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
           bf16x8 bq[NP];
 #pragma unroll
           for (int pl = 0; pl < NP; ++pl) bq[pl] = tr_pair(ldsX + pl * XB, o0, o1);
-          if constexpr (SPLIT) {
+          if constexpr (HPM) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f16x8 ah = __builtin_bit_cast(f16x8, a[0][j]), al = __builtin_bit_cast(f16x8, a[1][j]);
+              const f16x8 bh = __builtin_bit_cast(f16x8, bq[0]), bl = __builtin_bit_cast(f16x8, bq[1]);
+              accx[HPM ? ai : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[HPM ? ai : 0][j], 0, 0, 0);
+              accx[HPM ? ai : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[HPM ? ai : 0][j], 0, 0, 0);
+              acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ai][j], 0, 0, 0);
+            }
+          } else if constexpr (SPLIT) {
 #define PH_MM(PI, PJ)                                                                                       \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
       acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PI][j], bq[PJ], acc[ai][j], 0, 0, 0);
@@ -630,7 +668,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int row = j * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
-          slab[((size_t)kh * 64 + row) * 32 + (lane & 31)] = acc[ai][j][q];
+          slab[((size_t)kh * 64 + row) * 32 + (lane & 31)] =
+              HPM ? acc[ai][j][q] + accx[HPM ? ai : 0][j][q] * PH_HP_LO_INV : acc[ai][j][q];
         }
     }
   }
@@ -640,7 +679,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
 // partial sums per thread (loads in flight), fixed summation order (bitwise reproducible).  (One thread per output
 // walking all 512 chunks serially took 156 us for 29 MB.)
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                                int nchunks) {
+                                                                int nchunks, const float* __restrict__ unscale) {
   const int o = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
   const size_t n = (size_t)7 * 64 * 32;
@@ -660,7 +699,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __r
   __shared__ float sh[4][64];
   sh[cl][o] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (cl == 0 && i < 64 * 3 * 49) dw[i] = (sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o]);
+  if (cl == 0 && i < 64 * 3 * 49) dw[i] = ((sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o])) * (unscale ? unscale[1] : 1.f);
 }
 
 template <typename K>
@@ -697,6 +736,11 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     PhStem q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;
     hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, q);
+  } else if (prec == PH_PREC_FP16X3) {
+    static bool done = false;
+    const int lds = PH_NPLANES * (XB + WB);
+    if (set_lds(stem_fwd_kernel<hp16>, lds, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_fwd_kernel<hp16>, grid, dim3(256), lds, st, *p);
   } else {
     return PH_EINVAL;
   }
@@ -751,6 +795,10 @@ int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
     PhStemWgrad q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), PH_NPLANES * base, st, q);
+  } else if (prec == PH_PREC_FP16X3) {
+    static bool done = false;
+    if (set_lds(stem_wgrad_kernel<hp16>, 2 * base, done)) return PH_ELAUNCH;
+    hipLaunchKernelGGL(stem_wgrad_kernel<hp16>, grid, dim3(256), 2 * base, st, *p);
   } else {
     return PH_EINVAL;
   }
@@ -758,8 +806,8 @@ int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
   return PH_OK;
 }
 
-int ph_stem_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, hipStream_t st) {
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 147 + 63) / 64), dim3(256), 0, st, slab, dw, nchunks);
+int ph_stem_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, const float* unscale, hipStream_t st) {
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 147 + 63) / 64), dim3(256), 0, st, slab, dw, nchunks, unscale);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

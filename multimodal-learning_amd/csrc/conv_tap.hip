@@ -25,6 +25,7 @@ __device__ unsigned long long ph_tap_trace[PH_TRACE_WGS * 12];
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
 struct TapCfg {
   static constexpr bool SPLIT = is_f32<T>::value;
+  static constexpr bool HPM = is_hp<T>::value;   // PH_PREC_FP16X3: half-pair input, fp16 MFMA over 3 (A block, W block) pairs per slice, fp32 output
   static constexpr int TW = 16;
   static constexpr int HPH = (TH - 1) * S + 3;
   static constexpr int HPW = (TW - 1) * S + 3;
@@ -47,8 +48,11 @@ struct TapCfg {
 template <typename T, int S, int TH, int BNT, int WM, int WN, int FM, int FN, int TG>
 __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   using C = TapCfg<T, S, TH, BNT, WM, WN, FM, FN, TG>;
-  constexpr bool SPLIT = C::SPLIT;
+  constexpr bool SPLIT = C::SPLIT, HPM = C::HPM;
   constexpr int TW = C::TW, HPW = C::HPW, HP = C::HP, NP = C::NP, NTH = C::NTH;
+  typedef typename std::conditional<HPM, f16, T>::type TI;       // element type of the input as the staging code addresses it
+  typedef typename std::conditional<HPM, float, T>::type TO;     // output / residual-gradient type
+  constexpr int EW = HPM ? 2 : 1;                                // fp16 elements per input element
   constexpr int HCH = (HP * 8 + NTH - 1) / NTH;          // halo 16-B chunks per thread
   constexpr int WPT = BNT * 8 / NTH;                     // weight 16-B chunks per thread and tap
   constexpr int WCH = TG * WPT;                          // ... per stage (full tap group)
@@ -64,11 +68,16 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
   const int n0 = blockIdx.y * BNT;
   const int b = blockIdx.z;
-  const long pix_st = p.in_pix_stride ? p.in_pix_stride : p.Cin;
-  const long row_st = p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin;
-  const long img_st = p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin;
-  const T* in = reinterpret_cast<const T*>(p.in) + (size_t)b * img_st;
-  const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
+  const long pix_st = (p.in_pix_stride ? p.in_pix_stride : p.Cin) * EW;
+  const long row_st = (p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin) * EW;
+  const long img_st = (p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin) * EW;
+  const TI* in = reinterpret_cast<const TI*>(p.in) + (size_t)b * img_st;
+  const bf16* wbase = reinterpret_cast<const bf16*>(p.w);       // (2-byte elements: bf16, or fp16 in the half-pair mode)
+  const int wK = HPM ? 3 * p.Cin : p.Cin;                       // K extent of a packed weight row
+  // slice index -> element offset of its A block in a pixel's channel record / of its W block in a weight row.  Half-pair
+  // mode: slices 3c, 3c+1, 3c+2 of 64-channel group c pair the A blocks (hi, hi, lo) with the W blocks (hi 2^11, lo, hi).
+  auto slice_a = [&](int sl) { return HPM ? ((sl / 3) * 128 + ((sl % 3 == 2) ? 64 : 0)) : (sl << 6); };
+  auto slice_w = [&](int sl) { return sl << 6; };
   PH_TRACE(0);
   PH_TRACE_HWID();
   const int iy_base = r0 * S + p.iy0, ix_base = c0 * S + p.ix0;
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   for (int j = 0; j < FN; ++j) nrow[j] = (wn * FN + j) * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
-  const int nslices = p.Cin >> 6;
+  const int nslices = (p.Cin >> 6) * (HPM ? 3 : 1);
   const int ngroups = (p.ntaps + TG - 1) / TG;
   const int nstages = nslices * ngroups;
   // tap table in a VGPR (lane t holds tap t): the per-tap weight slab and halo offset are fetched with
@@ -108,12 +117,12 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
 #pragma unroll
   for (int e = 0; e < WPT; ++e) {
     const int i = tid + e * NTH;
-    w_goff[e] = (i >> 3) * p.Cin + (i & 7) * 8;
+    w_goff[e] = (i >> 3) * wK + (i & 7) * 8;
     w_loff[e] = lds_off(i >> 3, i & 7);
   }
 
   // ---- staging helpers ------------------------------------------------------------------------------
-  auto halo_src = [&](int i, int k0, bool& ok) -> const T* {
+  auto halo_src = [&](int i, int k0, bool& ok) -> const TI* {
     const int pix = i >> 3, ch = i & 7;
     const int hr = pix / HPW, hc = pix - hr * HPW;
     const int iy = iy_base + hr, ix = ix_base + hc;
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   auto stage_halo_sync = [&](int k0) {   // parity mode: load, split into 3 planes, store
     for (int i = tid; i < HP * 8; i += NTH) {
       bool ok;
-      const T* src = halo_src(i, k0, ok);
+      const TI* src = halo_src(i, k0, ok);
       const int off = lds_off(i >> 3, i & 7);
       if constexpr (SPLIT) {
         float v[8];
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   };
   auto stage_w_sync = [&](int k0, int tg0, int gcount) {
     for (int t = 0; t < gcount; ++t) {
-      const bf16* base = wbase + ((size_t)tap_slab(tg0 + t) * p.Cout + n0) * p.Cin + k0;
+      const bf16* base = wbase + ((size_t)tap_slab(tg0 + t) * p.Cout + n0) * wK + k0;
 #pragma unroll
       for (int e = 0; e < WPT; ++e)
 #pragma unroll
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     for (int e = 0; e < HCH; ++e) {
       const int i = tid + e * NTH;
       bool ok;
-      const T* src = halo_src(i, k0, ok);
+      const TI* src = halo_src(i, k0, ok);
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ok) v = *reinterpret_cast<const u32x4*>(src);
       hreg[e] = v;
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
       if (t < gcount) {   // uniform
-        const bf16* base = wbase + ((size_t)tap_slab(tg0 + t) * p.Cout + n0) * p.Cin + k0;
+        const bf16* base = wbase + ((size_t)tap_slab(tg0 + t) * p.Cout + n0) * wK + k0;
 #pragma unroll
         for (int e = 0; e < WPT; ++e) wreg[t * WPT + e] = *reinterpret_cast<const u32x4*>(base + w_goff[e]);
       }
@@ -222,6 +231,13 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
           if (p.prod6) { load_plane(2); PH_SPLIT_PAIRS_LO(PH_MM) }
           PH_SPLIT_PAIRS_HI(PH_MM)
 #undef PH_MM
+        } else if constexpr (HPM) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0][i]), __builtin_bit_cast(f16x8, bq[0][j]),
+                                                                 acc[i][j], 0, 0, 0);
         } else {
 #pragma unroll
           for (int i = 0; i < FM; ++i)
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   if constexpr (SPLIT) {
     // parity mode: simple synchronous staging (throughput is irrelevant here, LDS holds 3 planes)
     for (int sl = 0; sl < nslices; ++sl) {
-      const int k0 = sl << 6;
+      const int k0 = sl << 6;      // (split-plane modes: A and W blocks coincide)
       __syncthreads();
       stage_halo_sync(k0);
       for (int tg0 = 0; tg0 < p.ntaps; tg0 += TG) {
@@ -259,11 +275,11 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     auto gc = [&](int tg_) { return (p.ntaps - tg_) < TG ? (p.ntaps - tg_) : TG; };
     int sl = 0, tg0 = 0, sl1 = 0, tg1 = 0;
     advance(sl1, tg1);
-    load_halo_regs(0);
+    load_halo_regs(slice_a(0));
     load_w_regs(0, 0, gc(0));
     store_halo_regs();
     store_w_regs(gc(0), ldsB);
-    if (nstages > 1) load_w_regs(sl1 << 6, tg1, gc(tg1));
+    if (nstages > 1) load_w_regs(slice_w(sl1), tg1, gc(tg1));
     __syncthreads();
     PH_TRACE(1);
     unsigned long long cyc_a = 0, cyc_b = 0, cyc_c = 0, cyc_d = 0, cyc_e = 0;
@@ -279,8 +295,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       const unsigned long long q0_ = PH_CLK();
       if (has1) store_w_regs(gc(tg1), Bnext);
       const unsigned long long q1_ = PH_CLK();
-      if (has2) load_w_regs(sl2 << 6, tg2, gc(tg2));
-      if (new_slice) load_halo_regs(sl1 << 6);
+      if (has2) load_w_regs(slice_w(sl2), tg2, gc(tg2));
+      if (new_slice) load_halo_regs(slice_a(sl1));
       const unsigned long long q2_ = PH_CLK();
       compute(tg0, gc(tg0), Bcur);
       const unsigned long long q3_ = PH_CLK();
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     // perf mode: stage s = (slice, tap group).  While the MFMAs of stage s run, the global loads of stage
     // s+1 (weights, and the next slice's halo when the slice changes) are in flight into registers; they
     // are written to LDS after the barrier that ends stage s.
-    load_halo_regs(0);
+    load_halo_regs(slice_a(0));
     load_w_regs(0, 0, p.ntaps < TG ? p.ntaps : TG);
     store_halo_regs();
     store_w_regs(p.ntaps < TG ? p.ntaps : TG, ldsB);
@@ -317,8 +333,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       const bool has_next = st + 1 < nstages;
       const int ngcount = (p.ntaps - ntg0) < TG ? (p.ntaps - ntg0) : TG;
       if (has_next) {
-        load_w_regs(nsl << 6, ntg0, ngcount);
-        if (nsl != sl) load_halo_regs(nsl << 6);
+        load_w_regs(slice_w(nsl), ntg0, ngcount);
+        if (nsl != sl) load_halo_regs(slice_a(nsl));
       }
       const unsigned long long k0_ = PH_CLK();
       compute(tg0, gcount, ldsB);
@@ -343,16 +359,19 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   // accumulator register q of fragment (i,j) holds MFMA row (q&3) + 8*(q>>2) + 4*khalf, i.e. (see
   // frag_row_to_pixel) tile row 2*(wm*FM+i) + ((popc(q>>2) + khalf) & 1), column q; channel n0 + nrow[j].
   const bool full = (r0 + TH <= p.OHt) && (c0 + TW <= p.OWt);
-  T* out = reinterpret_cast<T*>(p.out) + (size_t)b * p.OH * p.OW * p.Cout;
-  const T* resg = p.res_g ? reinterpret_cast<const T*>(p.res_g) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
+  TO* out = reinterpret_cast<TO*>(p.out) + (size_t)b * p.OH * p.OW * p.Cout;
+  const TO* resg = p.res_g ? reinterpret_cast<const TO*>(p.res_g) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
   const T* resa = p.res_a ? reinterpret_cast<const T*>(p.res_a) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
+  // half-pair mode: the accumulators hold 2^11 x the sum (the W blocks' scaling) times the dz tensor's power-of-two scale
+  float osc = 1.f;
+  if constexpr (HPM) osc = PH_HP_LO_INV * (p.in_unscale ? p.in_unscale[1] : 1.f);
   float s1[FN], s2[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   constexpr int BM = TH * TW;
   constexpr int CROW = BNT * 2;                       // bytes of one pixel row of the bf16 C image in LDS
   unsigned char* ldsC = smem;                          // perf mode: [BM][BNT] bf16 (the main loop's LDS is free)
-  float* red = reinterpret_cast<float*>(smem + (SPLIT ? 0 : BM * CROW));   // [WM][2][BNT]
+  float* red = reinterpret_cast<float*>(smem + ((SPLIT || HPM) ? 0 : BM * CROW));   // [WM][2][BNT]
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -364,9 +383,10 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         float v = valid ? acc[i][j][q] : 0.f;
+        if constexpr (HPM) v *= osc;
         s1[j] += v;
         s2[j] += v * v;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT || HPM) {
           if (valid) {
             if (resg) {
               float g = ldf(resg + o + nrow[j]);
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       }
     }
   }
-  if constexpr (!SPLIT) {
+  if constexpr (!SPLIT && !HPM) {
     // coalesced store: the C tile is re-read from LDS as 16-B chunks, BNT/8 consecutive lanes per pixel
     __syncthreads();
     PH_TRACE(3);
@@ -408,7 +428,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   }
   PH_TRACE(4);
   if (p.stats) {
-    if constexpr (SPLIT) __syncthreads();   // all MFMA reads of LDS done; smem is reused as float[WM][2][BNT]
+    if constexpr (SPLIT || HPM) __syncthreads();   // all MFMA reads of LDS done; smem is reused as float[WM][2][BNT]
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
@@ -469,7 +489,7 @@ namespace {
 
 template <typename T>
 int launch_T(const PhTapConv& p, int S, hipStream_t st) {
-  constexpr bool SPLIT = is_f32<T>::value;
+  constexpr bool SPLIT = is_f32<T>::value;      // (T = hp16 runs the perf-mode configurations)
   constexpr int TG = SPLIT ? 1 : 3;   // parity mode stages one tap at a time (3 planes must fit 160 KB LDS)
   if (S == 1) {
     if (p.Cout % 128 == 0) {
@@ -491,7 +511,8 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_stat_parts(p);
-  const int TH = (S == 1) ? ((p->Cout % 128 == 0 && prec != PH_PREC_BF16) ? 8 : 16) : (prec == PH_PREC_BF16 ? 8 : 2);
+  const bool perf_cfg = prec == PH_PREC_BF16 || prec == PH_PREC_FP16X3;
+  const int TH = (S == 1) ? ((p->Cout % 128 == 0 && !perf_cfg) ? 8 : 16) : (perf_cfg ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
 }
 
@@ -500,6 +521,7 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
   if (p->in_scale || p->m_groups) return PH_EINVAL;   // in-LDS BatchNorm + ReLU / masked tap grids: second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
+  if (prec == PH_PREC_FP16X3) return launch_T<hp16>(*p, S, st);
   if (PH_IS_SPLIT_PREC(prec)) {
     PhTapConv q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;

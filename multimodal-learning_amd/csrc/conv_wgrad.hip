@@ -25,6 +25,7 @@ __device__ __forceinline__ int sw_piece(int pix, int piece) { return piece ^ (((
 template <typename T, int S, int TH, int KS>
 struct WgCfg {
   static constexpr bool SPLIT = is_f32<T>::value;
+  static constexpr bool HPM = is_hp<T>::value;   // PH_PREC_FP16X3: both operands are half-pair tensors, three passes over the chunk
   static constexpr int TW = 16, BM = TH * TW;
   static constexpr int HPH = (TH - 1) * S + KS, HPW = (TW - 1) * S + KS, HP = HPH * HPW;
   static constexpr int HPP = (HP + 7) / 8 * 8;            // halo pixels padded to whole 1-KiB LDS-DMA pieces
@@ -68,8 +69,10 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* base, int off0, i
 template <typename T, int S, int TH, int KS>
 __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   using C = WgCfg<T, S, TH, KS>;
-  constexpr bool SPLIT = C::SPLIT;
+  constexpr bool SPLIT = C::SPLIT, HPM = C::HPM;
   constexpr int TW = C::TW, BM = C::BM, HPW = C::HPW, HP = C::HP, NT = C::NT, NP = C::NP;
+  typedef typename std::conditional<HPM, f16, T>::type TI;       // element type as the staging code addresses it
+  constexpr int EW = HPM ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* ldsD = smem;                      // NP planes of D_BYTES
   unsigned char* ldsX = smem + C::D_BYTES * NP;    // NP planes of X_BYTES
@@ -84,11 +87,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * p.B;
   const int t_begin = chunk * p.tiles_per_chunk;
   const int t_end = min(ntiles, t_begin + p.tiles_per_chunk);
-  const T* X = reinterpret_cast<const T*>(p.x);
-  const T* DY = reinterpret_cast<const T*>(p.dy);
-  const long xpix = p.x_pix_stride ? p.x_pix_stride : p.Cin;
-  const long xrow = p.x_row_stride ? p.x_row_stride : (long)p.IW * p.Cin;
-  const long ximg = p.x_img_stride ? p.x_img_stride : (long)p.IH * p.IW * p.Cin;
+  const TI* X = reinterpret_cast<const TI*>(p.x);
+  const TI* DY = reinterpret_cast<const TI*>(p.dy);
+  const long xpix = (p.x_pix_stride ? p.x_pix_stride : p.Cin) * EW;
+  const long xrow = (p.x_row_stride ? p.x_row_stride : (long)p.IW * p.Cin) * EW;
+  const long ximg = (p.x_img_stride ? p.x_img_stride : (long)p.IH * p.IW * p.Cin) * EW;
+  const long dpix = (long)p.Cout * EW;      // elements per dy pixel record
 
   f32x16 acc[NT];
 #pragma unroll
@@ -139,6 +143,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
           if (p.prod6) { PH_SPLIT_PAIRS_LO(PH_MM) }
           PH_SPLIT_PAIRS_HI(PH_MM)
 #undef PH_MM
+        } else if constexpr (HPM) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, bq[0]), acc[t], 0, 0, 0);
         } else {
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], acc[t], 0, 0, 0);
         }
@@ -183,7 +189,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
     const unsigned lds0 = (unsigned)(size_t)(lds_uchar*)smem;
     constexpr int BUF = C::D_BYTES + C::X_BYTES;
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(p.zeros);
-    auto issue = [&](int tt, int buf) {
+    // Half-pair mode: dz' = dh + dl 2^-11 (times the tensor's power-of-two scale, undone by the reduce kernel), x = xh +
+    // xl 2^-11, so dW = sum dh xh + 2^-11 sum (dh xl + dl xh): the chunk's tiles are walked three times - (dh, xl), (dl, xh),
+    // then the accumulators are multiplied by 2^-11, then (dh, xh) - as ONE stream of 3 * ntiles items through the same
+    // two LDS buffers; a 64-channel block of a pixel record is [hi 64 | lo 64] fp16 (ph_common.h).
+    const int nt = t_end > t_begin ? t_end - t_begin : 0;
+    const int nitems = HPM ? 3 * nt : nt;
+    const int dblk = HPM ? (co0 >> 6) * 128 : co0, xblk = HPM ? (ci0 >> 6) * 128 : ci0;
+    auto issue = [&](int item, int buf) {
+      int pass = 0, tt = t_begin + item;
+      if constexpr (HPM) { pass = item / nt; tt = t_begin + (item - pass * nt); }
+      const int dpl = (HPM && pass == 1) ? 64 : 0, xpl = (HPM && pass == 0) ? 64 : 0;     // lo plane of dz' / of x
       const int b = tt / tiles_img, ti = tt - b * tiles_img;
       const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
       unsigned char* dD = smem + buf * BUF;
@@ -193,7 +209,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int ch = sw_piece(pix, pos >> 1) * 2 + (pos & 1);          // source chunk of this LDS slot
         const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
         const bool ok = r < p.OH && c < p.OW;
-        const void* src = ok ? (const void*)(DY + (((size_t)b * p.OH + r) * p.OW + c) * p.Cout + co0 + ch * 8)
+        const void* src = ok ? (const void*)(DY + (((size_t)b * p.OH + r) * p.OW + c) * dpix + dblk + dpl + ch * 8)
                              : (const void*)zero;
         lds_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dD - smem) + i0 * 16));
       }
@@ -204,21 +220,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int hr = pix / HPW, hc = pix - hr * HPW;
         const int iy = iy_base + hr, ix = ix_base + hc;
         const bool ok = pix < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const void* src = ok ? (const void*)(X + (size_t)b * ximg + (size_t)iy * xrow + (size_t)ix * xpix + ci0 + ch * 8)
+        const void* src = ok ? (const void*)(X + (size_t)b * ximg + (size_t)iy * xrow + (size_t)ix * xpix + xblk + xpl + ch * 8)
                              : (const void*)zero;
         lds_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(dX - smem) + i0 * 16));
       }
     };
-    if (t_begin < t_end) issue(t_begin, 0);
+    if (nitems > 0) issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int buf = 0;
-    for (int tt = t_begin; tt < t_end; ++tt) {
+    for (int it = 0; it < nitems; ++it) {
 #ifndef PH_ABL_WG_NODMA   // timing ablation only (garbage results): no operand traffic
-      if (tt + 1 < t_end) issue(tt + 1, buf ^ 1);
+      if (it + 1 < nitems) issue(it + 1, buf ^ 1);
 #endif
+      if constexpr (HPM) {
+        if (it == 2 * nt) {      // the cross terms are complete: weight them before the leading products accumulate
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] *= PH_HP_LO_INV;
+        }
+      }
       compute(smem + buf * BUF, smem + buf * BUF + C::D_BYTES);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile tt+1 have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next item have landed
       __syncthreads();                                    // ... and everybody's; buffer buf is free again
       buf ^= 1;
     }
@@ -274,7 +298,8 @@ int launch_wg_T(const PhWgrad& p, hipStream_t st) {
 // slab[nchunks][NT][Cout][Cin] -> OIHW.  64 outputs x 4 chunk-lanes per block, 4 independent partial sums per
 // thread (loads in flight), fixed summation order (bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
-                                                           int nchunks, int NT, int Cout, int Cin) {
+                                                           int nchunks, int NT, int Cout, int Cin,
+                                                           const float* __restrict__ unscale) {
   const size_t n = (size_t)NT * Cout * Cin;
   const int e = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const size_t i = (size_t)blockIdx.x * 64 + e;
@@ -293,7 +318,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   sh[cl][e] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (cl == 0 && i < n) {
-    const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+    float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+    if (unscale) s *= unscale[1];      // (power of two: exact)
     const int ci = i % Cin;
     const int co = (i / Cin) % Cout;
     const int t = i / ((size_t)Cin * Cout);
@@ -395,7 +421,80 @@ __global__ __launch_bounds__(256) void pack_all_tiled_kernel(PhPackAll t, PackTi
   }
 }
 
+// PH_PREC_FP16X3 layout: per (tap, output row) the K direction holds, for every 64-channel slice, the three fp16 blocks
+// [hi * 2^11 | lo | hi] of the weights' half-pair split (w ~= hi + lo * 2^-11): the K loop of a convolution multiplies them
+// with the activation blocks (hi, hi, lo) and accumulates 2^11 * (x * w) in ONE accumulator set.  |w| < 32 (hi * 2^11 is fp16).
+__device__ __forceinline__ size_t hp_k(int k) { return (size_t)(k >> 6) * 192 + (k & 63); }
+__device__ __forceinline__ void hp_w3(float v, f16& b0, f16& b1, f16& b2) {
+  hp_split(v, b2, b1);
+  b0 = (f16)((float)b2 * PH_HP_LO);
+}
+template <bool ONE>
+__global__ __launch_bounds__(256) void pack_all_tiled_hp_kernel(PhPackAll t, PackTiles pt, f16* __restrict__ packed, int dgrad_only) {
+  __shared__ float sh[32][32 * 9 + 1];
+  int u = 0;
+#pragma unroll 1
+  while (u + 1 < t.n && (int)blockIdx.x >= pt.tstart[u + 1]) ++u;
+  const int O = t.O[u], I = t.I[u], NT = t.NT[u];
+  const int tile = (int)blockIdx.x - pt.tstart[u];
+  const int itiles = I >> 5;
+  const int o0 = (tile / itiles) << 5, i0 = (tile % itiles) << 5;
+  const int run = 32 * NT;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int o = idx / run, r = idx - o * run;
+    sh[o][r] = t.w[u][((size_t)(o0 + o) * I + i0) * NT + r];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int x = idx & 31, y = (idx >> 5) & 31, tp = idx >> 10;
+    f16 b0, b1, b2;
+    if (!ONE || dgrad_only == 0) {   // forward layout [tap][O][3 I]: x = input channel (fastest), y = output channel
+      hp_w3(sh[y][x * NT + tp], b0, b1, b2);
+      f16* d = packed + t.dst_fwd[u] + ((size_t)tp * O + o0 + y) * (3 * (size_t)I) + hp_k(i0 + x);
+      d[0] = b0; d[64] = b1; d[128] = b2;
+    }
+    if (!ONE || dgrad_only == 1) {   // dgrad layout [tap][I][3 O]: x = output channel (fastest), y = input channel
+      hp_w3(sh[x][y * NT + tp], b0, b1, b2);
+      f16* d = packed + t.dst_dg[u] + ((size_t)tp * I + i0 + y) * (3 * (size_t)O) + hp_k(o0 + x);
+      d[0] = b0; d[64] = b1; d[128] = b2;
+    }
+  }
+}
+
+// stem, PH_PREC_FP16X3: three fp16 planes [3][kh 7][cout 64][kw 8 x ch 4] = w hi * 2^11, w lo, w hi (the layout of the
+// three bf16 split planes): the kernel multiplies them with the activation planes (hi, hi, lo)
+__global__ void pack_w_stem_hp_kernel(const float* __restrict__ w, f16* __restrict__ packed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 7 * 64 * 32) return;
+  const int k = i & 31, co = (i >> 5) & 63, kh = i >> 11;
+  const int kw = k >> 2, ch = k & 3;
+  float v = 0.f;
+  if (kw < 7 && ch < 3) v = w[((co * 3 + ch) * 7 + kh) * 7 + kw];
+  f16 b0, b1, b2;
+  hp_w3(v, b0, b1, b2);
+  packed[i] = b0; packed[7 * 64 * 32 + i] = b1; packed[2 * 7 * 64 * 32 + i] = b2;
+}
+
 }  // namespace
+
+int ph_pack_w_stem_hp_launch(const float* w, void* packed, hipStream_t st) {
+  hipLaunchKernelGGL(pack_w_stem_hp_kernel, dim3((7 * 64 * 32 + 255) / 256), dim3(256), 0, st, w, (f16*)packed);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+// one convolution in the PH_PREC_FP16X3 layout (forward or dgrad orientation) at the start of `packed` (test hooks)
+int ph_pack_w_hp_launch(const float* w, void* packed, int O, int I, int KS, int dgrad, hipStream_t st) {
+  if ((O & 31) || (I & 31) || (KS != 1 && KS != 3)) return PH_EINVAL;
+  PhPackAll t{};
+  t.n = 1; t.w[0] = w; t.O[0] = O; t.I[0] = I; t.NT[0] = KS * KS; t.dst_fwd[0] = 0; t.dst_dg[0] = 0;
+  t.start[0] = 0; t.start[1] = t.total = (size_t)KS * KS * O * I;
+  PackTiles pt;
+  pt.tstart[0] = 0; pt.tstart[1] = (O >> 5) * (I >> 5);
+  hipLaunchKernelGGL(pack_all_tiled_hp_kernel<true>, dim3(pt.tstart[1]), dim3(256), 0, st, t, pt, (f16*)packed, dgrad ? 1 : 0);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
 
 int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_t st) {
   bool tiled = t->n <= 20;
@@ -405,7 +504,10 @@ int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_
     if ((t->O[u] & 31) || (t->I[u] & 31) || t->NT[u] > 9) tiled = false;
     pt.tstart[u + 1] = pt.tstart[u] + (t->O[u] >> 5) * (t->I[u] >> 5);
   }
-  if (tiled && nplanes == 1)
+  if (nplanes == -3) {
+    if (!tiled) return PH_EINVAL;
+    hipLaunchKernelGGL(pack_all_tiled_hp_kernel<false>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (f16*)packed, 0);
+  } else if (tiled && nplanes == 1)
     hipLaunchKernelGGL(pack_all_tiled_kernel<1>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (bf16*)packed);
   else if (tiled && nplanes == 3)
     hipLaunchKernelGGL(pack_all_tiled_kernel<3>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (bf16*)packed);
@@ -421,6 +523,7 @@ int ph_wgrad_tile_h(int S) { return S == 1 ? 8 : 4; }
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->nchunks < 1) return PH_EINVAL;
   if (prec == PH_PREC_BF16) return launch_wg_T<bf16>(*p, st);
+  if (prec == PH_PREC_FP16X3) return launch_wg_T<hp16>(*p, st);
   if (PH_IS_SPLIT_PREC(prec)) {
     PhWgrad q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;
@@ -429,10 +532,11 @@ int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
   return PH_EINVAL;
 }
 
-int ph_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, int KS, int Cout, int Cin, hipStream_t st) {
+int ph_wgrad_reduce_launch(const float* slab, float* dw, int nchunks, int KS, int Cout, int Cin, const float* unscale,
+                           hipStream_t st) {
   const size_t n = (size_t)KS * KS * Cout * Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, dw, nchunks,
-                     KS * KS, Cout, Cin);
+                     KS * KS, Cout, Cin, unscale);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -24,6 +24,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define PH_PREC_BF16X3 2  // fp32 activations, the 3 leading products only (hi*hi, hi*mid, mid*hi: 16-bit operands, ~2^-16 per
                           // product): half the matrix work of the parity mode; same kernels, same packed weights
 
+#define PH_PREC_FP16X3 3  // "half-pair" mode: every tensor a convolution READS (activations, BatchNorm-backward dz) is stored as two fp16
+                          // planes x = hi + lo * 2^-11 (4 B per element, layout below); conv outputs / gradients stay fp32; three
+                          // fp16 MFMA products per k-step (hi*hi, hi*lo, lo*hi: 22-bit operands, ~2^-22 per product)
+#define PH_IS_F32_OUT_PREC(p) ((p) == PH_PREC_BF16X6 || (p) == PH_PREC_BF16X3 || (p) == PH_PREC_FP16X3)   // conv outputs are fp32
+
 #define PH_LAUNCH_CHECK()                                  \
   do {                                                     \
     hipError_t e__ = hipGetLastError();                    \
@@ -32,6 +37,27 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 template <typename T> struct is_f32 { static constexpr bool value = std::is_same<T, float>::value; };
 
+// ---- half-pair ("HP") storage of PH_PREC_FP16X3.  A tensor [..][C] (C % 64 == 0, base 256-B aligned) is stored as
+// [..][C / 64][2][64] fp16: per 64-channel slice one 128-B line of hi values followed by one 128-B line of lo values,
+//     x ~= hi + lo * 2^-11,   hi = fp16(x),   lo = fp16((x - hi) * 2^11)      (22 significant bits, |x| < 65504)
+// 4 bytes per element, so `hp16` is a 4-byte placeholder type: pointer arithmetic on `hp16*` is the fp32 tensor's, and the
+// address of element i's hi half follows from the pointer alone (the byte offset inside a 256-B slice record is halved).
+// A convolution's LDS-DMA reads the hi (or lo) plane of a slice as whole 128-B lines: no conversion while staging.
+struct hp16 { unsigned int raw; };
+template <typename T> struct is_hp { static constexpr bool value = std::is_same<T, hp16>::value; };
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+constexpr float PH_HP_LO = 2048.0f, PH_HP_LO_INV = 1.0f / 2048.0f;
+__device__ __forceinline__ const unsigned char* hp_hi_addr(const hp16* p) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  return reinterpret_cast<const unsigned char*>((a & ~(uintptr_t)255) + ((a & 255) >> 1));
+}
+__device__ __forceinline__ void hp_split(float x, f16& hi, f16& lo) {
+  hi = (f16)x;
+  lo = (f16)((x - (float)hi) * PH_HP_LO);
+}
+
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 
@@ -39,6 +65,16 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float ldf(const hp16* p) {
+  const f16* h = reinterpret_cast<const f16*>(hp_hi_addr(p));
+  return (float)h[0] + (float)h[64] * PH_HP_LO_INV;
+}
+__device__ __forceinline__ void stf(hp16* p, float v) {
+  f16* h = reinterpret_cast<f16*>(const_cast<unsigned char*>(hp_hi_addr(p)));
+  f16 a, b;
+  hp_split(v, a, b);
+  h[0] = a; h[64] = b;
+}
 
 // 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32); pointers must be 16-B aligned
 __device__ __forceinline__ void load8(const bf16* p, float (&v)[8]) {
@@ -64,6 +100,23 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[i + 4]; }
   *reinterpret_cast<f32x4*>(p) = a;
   *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+// 8 consecutive channels (p 32-B aligned in the fp32 view): one 16-B hi chunk + one 16-B lo chunk, 128 B apart
+__device__ __forceinline__ void load8(const hp16* p, float (&v)[8]) {
+  const unsigned char* a = hp_hi_addr(p);
+  const f16x8 h = *reinterpret_cast<const f16x8*>(a);
+  const f16x8 l = *reinterpret_cast<const f16x8*>(a + 128);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i] * PH_HP_LO_INV;
+}
+__device__ __forceinline__ void store8(hp16* p, const float (&v)[8]) {
+  unsigned char* a = const_cast<unsigned char*>(hp_hi_addr(p));
+  f16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { f16 x, y; hp_split(v[i], x, y); h[i] = x; l[i] = y; }
+  *reinterpret_cast<f16x8*>(a) = h;
+  *reinterpret_cast<f16x8*>(a + 128) = l;
 }
 
 // 3-way bf16 split of an fp32 value (parity mode "bf16x6"): x = p0 + p1 + p2 exactly (3 x 8 significant

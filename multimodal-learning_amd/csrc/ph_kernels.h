@@ -64,6 +64,11 @@ struct PhTapConv {
   int m_slab[4][9];      // weight slab of every grid tap (any valid slab for dead taps)
   long m_in_off[4];
   int prod6;             // split-plane modes (first-generation kernel): six products or the three leading ones (set by the launcher)
+  // PH_PREC_FP16X3: `in` is a half-pair tensor (ph_common.h), `w` holds per 64-channel slice of Cin the three fp16 blocks
+  // [hi * 2^11 | lo | hi] of the weights' half-pair split (ph_pack_all_launch, nplanes = -3), the K loop walks 3 * Cin / 64 (A block, W block) pairs
+  // (x hi, w hi 2^11), (x hi, w lo), (x lo, w hi) and the fp32 result is acc * 2^-11 * (in_unscale ? in_unscale[1] : 1):
+  // in_unscale = the {2^s, 2^-s} record of a dz tensor (ph_bn_bwd_finalize_launch), null for activations
+  const float* in_unscale;
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 double ph_tapconv_bytes(const PhTapConv& p, int S, int es);
@@ -88,8 +93,9 @@ struct PhWgrad {
 };
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st);
 int ph_wgrad_tile_h(int S);
-// slab -> OIHW fp32 gradient
-int ph_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, int KS, int Cout, int Cin, hipStream_t st);
+// slab -> OIHW fp32 gradient; unscale (optional): the {2^s, 2^-s} record of the dz tensor, the sums are multiplied by unscale[1]
+int ph_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, int KS, int Cout, int Cin, const float* unscale,
+                           hipStream_t st);
 
 struct PhStem {
   const void* x4;        // [B][IH][IW][4]
@@ -125,7 +131,7 @@ struct PhStemWgrad {
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st);
 // input gradient of the 7x7/2 stem conv: dy [B][H/2][W/2][64] (type of the mode) -> dx [B][3][H][W] f32 (stem_dgrad.hip)
 int ph_stem_dgrad_launch(const void* dy, const float* w_oihw, float* dx_nchw, int B, int H, int W, int prec, hipStream_t st);
-int ph_stem_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, hipStream_t st);
+int ph_stem_wgrad_reduce_launch(const float* slab, float* dw_oihw, int nchunks, const float* unscale, hipStream_t st);
 
 // weight packing (OIHW fp32 -> MFMA-friendly bf16, 3 split planes of `plane` elements each)
 int ph_pack_w_fwd_launch(const float* w, void* planes, int O, int I, int KS, hipStream_t st);   // [tap][O][I]
@@ -140,7 +146,10 @@ struct PhPackAll {
   int n;
   size_t total;
 };
+// nplanes: 1 (bf16), 3 (three bf16 split planes), -3 (PH_PREC_FP16X3: fp16 [hi 2^11 | lo | hi] per 64-channel K slice, (hi, lo) = the half-pair split)
 int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_t st);
+int ph_pack_w_hp_launch(const float* w, void* packed, int O, int I, int KS, int dgrad, hipStream_t st);   // one conv, same layout
+int ph_pack_w_stem_hp_launch(const float* w, void* packed, hipStream_t st);
 
 // ---- BatchNorm / elementwise (bn_act.hip).  `prec` selects the activation type (bf16 | float).
 int ph_pack_input_launch(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st);
@@ -171,20 +180,23 @@ int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int ac
 int ph_bn_bwd_parts(size_t npix, int C);   // <= 1024
 int ph_stem_bwd_parts(int B, int H);         // partial rows written by ph_stem_bwd_reduce_launch
 // mscale / mshift (optional, with a == null): mask = (y * mscale + mshift > 0), the ReLU of this BN's own output
+// amax (optional): [ph_bn_bwd_parts()] per-block max |dz|, the input of the dz scale below
 int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                             float* parts, size_t npix, int C, int prec, const float* mscale, const float* mshift,
-                            hipStream_t st);
-// parts -> dgamma, dbeta, c1 = mean(dz), c2 = mean(dz*xhat)
+                            float* amax, hipStream_t st);
+// parts -> dgamma, dbeta, c1 = mean(dz), c2 = mean(dz*xhat).  dzs (optional, PH_PREC_FP16X3, with amax[namax], gamma, invstd):
+// float[2] = {2^s, 2^-s}, the power-of-two scale under which the apply pass stores its output as fp16 pairs
 int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
-                              float* c1, float* c2, hipStream_t st);
+                              float* c1, float* c2, const float* amax, int namax, const float* gamma, const float* invstd,
+                              float* dzs, hipStream_t st);
 int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
-                           int prec, const float* mscale, const float* mshift, hipStream_t st);
+                           int prec, const float* mscale, const float* mshift, const float* dzs, hipStream_t st);
 // stem: da0 = scatter of d_pool through the saved argmax, dz = da0 * (bn(y0) > 0)
 int ph_stem_bwd_reduce_launch(const void* dpool, const uint8_t* idx, const void* y0, const void* raw_at_argmax, const float* mean,
                               const float* invstd, const float* scale, const float* shift, float* parts, int B, int H,
-                              int W, int C, int prec, hipStream_t st);
+                              int W, int C, int prec, float* amax, hipStream_t st);
 int ph_stem_bwd_apply_launch(const void* dpool, const uint8_t* idx, const void* y0, const float* mean,
                              const float* invstd, const float* scale, const float* shift, const float* gamma,
                              const float* c1, const float* c2, void* dy0, int B, int H, int W, int C, int prec,
-                             hipStream_t st);
+                             const float* dzs, hipStream_t st);

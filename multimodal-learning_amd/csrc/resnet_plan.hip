@@ -51,6 +51,8 @@ struct PhResnetPlan {
   // dgrad chain; `dy2_off` is the second dz buffer they need.
   size_t dy2_off = 0;
   mutable int bwd_overlap = 1;
+  // PH_PREC_FP16X3: per-block max |dz| of a BatchNorm-backward reduction, and the {2^s, 2^-s} scale records of the two dz buffers
+  size_t amax_off = 0, dzs_off = 0;
 };
 
 namespace {
@@ -83,7 +85,8 @@ int stem_chunks(int B, int OH, int OW, int* tpc) {
 extern "C" {
 
 PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
-  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec))) return nullptr;
+  if (B < 1 || H < 32 || W < 32 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec) && prec != PH_PREC_FP16X3)) return nullptr;
+  if (prec == PH_PREC_FP16X3 && ((H | W) & 3)) return nullptr;   // (even stem output: the pooled form of the stem's BatchNorm-backward sums)
   PhResnetPlan* P = new (std::nothrow) PhResnetPlan();
   if (!P) return nullptr;
   P->B = B; P->H = H; P->W = W; P->prec = prec; P->es = prec == PH_PREC_BF16 ? 2 : 4;
@@ -161,6 +164,11 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   }
   P->cc_off = take(2 * 512 * sizeof(float));
   P->zero_off = take(256);
+  {
+    const size_t rows = std::max((size_t)1024, (size_t)ph_stem_bwd_parts(B, s.OH));
+    P->amax_off = take(rows * sizeof(float));
+    P->dzs_off = take(256);
+  }
   P->ws_bytes = off;
   P->packed_bytes = woff * sizeof(bf16);
   return P;
@@ -181,7 +189,9 @@ int ph_resnet_unit_shape(const PhResnetPlan* P, int u, int* out4) {
 int ph_resnet_pack_weights(const PhResnetPlan* P, const void* const* params, void* packed, hipStream_t st) {
   if (!P || !params || !packed) return PH_EINVAL;
   bf16* pk = reinterpret_cast<bf16*>(packed);
-  int rc = ph_pack_w_stem_launch(reinterpret_cast<const float*>(params[0]), pk + P->units[0].wf_off, st);
+  int rc = P->prec == PH_PREC_FP16X3
+               ? ph_pack_w_stem_hp_launch(reinterpret_cast<const float*>(params[0]), pk + P->units[0].wf_off, st)
+               : ph_pack_w_stem_launch(reinterpret_cast<const float*>(params[0]), pk + P->units[0].wf_off, st);
   if (rc) return rc;
   PhPackAll t{};
   size_t acc = 0;
@@ -196,7 +206,7 @@ int ph_resnet_pack_weights(const PhResnetPlan* P, const void* const* params, voi
   }
   t.start[t.n] = acc;
   t.total = acc;
-  return ph_pack_all_launch(&t, pk, P->prec == PH_PREC_BF16 ? 1 : 3, st);
+  return ph_pack_all_launch(&t, pk, P->prec == PH_PREC_BF16 ? 1 : (P->prec == PH_PREC_FP16X3 ? -3 : 3), st);
 }
 
 }  // extern "C"
@@ -216,7 +226,10 @@ struct Ctx {
   float* stat(const Unit& u, int which) const {
     return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
   }
-  int bprec() const { return (P->bwd_prec >= 0 && P->prec != PH_PREC_BF16) ? P->bwd_prec : P->prec; }
+  int bprec() const { return (P->bwd_prec >= 0 && PH_IS_SPLIT_PREC(P->prec)) ? P->bwd_prec : P->prec; }
+  // PH_PREC_FP16X3: scale record {2^s, 2^-s} of dz buffer k (null in the other modes), and the amax scratch
+  float* dzs(int k) const { return P->prec == PH_PREC_FP16X3 ? reinterpret_cast<float*>(ws + P->dzs_off) + 2 * k : nullptr; }
+  float* amax() const { return P->prec == PH_PREC_FP16X3 ? reinterpret_cast<float*>(ws + P->amax_off) : nullptr; }
 };
 
 int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullptr, const float* in_shift = nullptr) {
@@ -247,12 +260,12 @@ int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullp
                                (int64_t*)c.params[ui * 6 + 5], c.st);
 }
 
-// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual)
-int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a) {
+// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual); dzs: dY's scale record (half-pair mode)
+int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a, const float* dzs = nullptr) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhTapConv t{};
-  t.in = dy; t.w = c.pk + u.wd_off; t.wplane = u.wplane;
+  t.in = dy; t.w = c.pk + u.wd_off; t.wplane = u.wplane; t.in_unscale = dzs;
   t.out = dx; t.stats = nullptr; t.res_g = res_g; t.res_a = res_a;
   t.B = P->B; t.IH = u.OH; t.IW = u.OW; t.Cin = u.Cout; t.Cout = u.Cin;
   t.OH = u.IH; t.OW = u.IW;
@@ -294,7 +307,7 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
   return PH_OK;
 }
 
-int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
+int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw, const float* dzs = nullptr) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhWgrad w{};
@@ -309,12 +322,13 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw) {
   w.nchunks = wgrad_chunks(u, P->B, &w.tiles_per_chunk, c.wg_want);
   int rc = ph_wgrad_launch(&w, c.bprec(), c.st);
   if (rc) return rc;
-  return ph_wgrad_reduce_launch(w.slab, dw, w.nchunks, u.KS, u.Cout, u.Cin, c.st);
+  return ph_wgrad_reduce_launch(w.slab, dw, w.nchunks, u.KS, u.Cout, u.Cin, dzs, c.st);
 }
 
 // BN backward of unit ui: dz = g * (a > 0) -> dgamma/dbeta, dy (into ws dy buffer).  self_mask: `a` is this unit's own
 // relu(bn(y)) (bn1 of a block) - the mask is recomputed from y and `a` is not read.
-int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta, bool self_mask = false) {
+int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta, bool self_mask = false,
+           float* dzs = nullptr) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   const size_t npix = (size_t)P->B * u.OH * u.OW;
@@ -325,12 +339,15 @@ int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* 
   const float* ms = self_mask ? c.stat(u, 2) : nullptr;
   const float* mh = self_mask ? c.stat(u, 3) : nullptr;
   if (self_mask) a = nullptr;
-  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, ms, mh, c.st);
+  float* amax = dzs ? c.amax() : nullptr;
+  const int nparts = ph_bn_bwd_parts(npix, u.Cout);
+  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, ms, mh, amax, c.st);
   if (rc) return rc;
-  rc = ph_bn_bwd_finalize_launch(parts, ph_bn_bwd_parts(npix, u.Cout), u.Cout, (double)npix, dgamma, dbeta, c1, c2, c.st);
+  rc = ph_bn_bwd_finalize_launch(parts, nparts, u.Cout, (double)npix, dgamma, dbeta, c1, c2, amax, nparts,
+                                 (const float*)c.params[ui * 6 + 1], c.stat(u, 1), dzs, c.st);
   if (rc) return rc;
   return ph_bn_bwd_apply_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), (const float*)c.params[ui * 6 + 1], c1, c2, dy, npix,
-                                u.Cout, P->prec, ms, mh, c.st);
+                                u.Cout, P->prec, ms, mh, dzs, c.st);
 }
 
 }  // namespace
@@ -544,10 +561,10 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   };
   // dz of unit ui is in dzb[kk] (produced on st): its weight gradient
   auto wgrad_of = [&](int ui, const void* x, int kk) -> int {
-    if (!ov) return conv_wgrad(c, ui, x, dzb[kk], (float*)grads[ui * 3 + 0]);
+    if (!ov) return conv_wgrad(c, ui, x, dzb[kk], (float*)grads[ui * 3 + 0], c.dzs(kk));
     hipEvent_t e = next_ev();
     if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return PH_ELAUNCH;
-    int r = conv_wgrad(cs, ui, x, dzb[kk], (float*)grads[ui * 3 + 0]);
+    int r = conv_wgrad(cs, ui, x, dzb[kk], (float*)grads[ui * 3 + 0], c.dzs(kk));
     if (r) return r;
     hipEvent_t d = next_ev();
     if (hipEventRecord(d, side) != hipSuccess) return PH_ELAUNCH;
@@ -574,28 +591,28 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     const void* xin = ws + b.in_off;
     // bn2 <- d_out * (out > 0)
     if ((rc = claim(k))) return rc;
-    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dzb[k], (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2]));
+    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dzb[k], (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2], false, c.dzs(k)));
     if (!ov) PH_STAGE(wgrad_of(b.u2, a1, k));
-    PH_STAGE(conv_dgrad(c, b.u2, dzb[k], dab, nullptr, nullptr));
+    PH_STAGE(conv_dgrad(c, b.u2, dzb[k], dab, nullptr, nullptr, c.dzs(k)));
     if (ov) PH_STAGE(wgrad_of(b.u2, a1, k));
     k ^= 1;
     // bn1 <- d_a1 * (a1 > 0)
     if ((rc = claim(k))) return rc;
-    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dzb[k], (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true));
+    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dzb[k], (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true, c.dzs(k)));
     if (!ov) PH_STAGE(wgrad_of(b.u1, xin, k));
     if (b.uds < 0) {
       // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
-        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, gcur, out));
+        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, gcur, out, c.dzs(k)));
       if (ov) PH_STAGE(wgrad_of(b.u1, xin, k));
       k ^= 1;
     } else {
-        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, nullptr, nullptr));
+        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, nullptr, nullptr, c.dzs(k)));
       if (ov) PH_STAGE(wgrad_of(b.u1, xin, k));
       k ^= 1;
       if ((rc = claim(k))) return rc;
-      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dzb[k], (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2]));
+      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dzb[k], (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2], false, c.dzs(k)));
       if (!ov) PH_STAGE(wgrad_of(b.uds, xin, k));
-        PH_STAGE(conv_dgrad(c, b.uds, dzb[k], gnext, gnext, nullptr));   // in-place accumulate
+        PH_STAGE(conv_dgrad(c, b.uds, dzb[k], gnext, gnext, nullptr, c.dzs(k)));   // in-place accumulate
       if (ov) PH_STAGE(wgrad_of(b.uds, xin, k));
       k ^= 1;
     }
@@ -608,14 +625,16 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     float* c1 = reinterpret_cast<float*>(ws + P->cc_off);
     float* c2 = c1 + 512;
     if ((rc = ph_stem_bwd_reduce_launch(gcur, ws + P->idx_off, ws + u.y_off, ws + P->p0raw_off, c.stat(u, 0), c.stat(u, 1),
-                                        c.stat(u, 2), c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, st)))
+                                        c.stat(u, 2), c.stat(u, 3), parts, P->B, u.OH, u.OW, 64, P->prec, c.amax(), st)))
       return rc;
+    if (c.dzs(0) && (rc = claim(0))) return rc;      // (half-pair mode: the finalize pass rewrites buffer 0's scale record)
     PH_STAGE(ph_bn_bwd_finalize_launch(parts, ph_stem_bwd_parts(P->B, u.OH), 64, (double)npix, (float*)grads[1],
-                                       (float*)grads[2], c1, c2, st));
+                                       (float*)grads[2], c1, c2, c.amax(), ph_stem_bwd_parts(P->B, u.OH),
+                                       (const float*)params[1], c.stat(u, 1), c.dzs(0), st));
     if ((rc = claim(0))) return rc;       // the stem's dz is full resolution: only the first buffer holds it
     PH_STAGE(ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
                                       c.stat(u, 3), (const float*)params[1], c1, c2, dzb[0], P->B, u.OH, u.OW, 64,
-                                      P->prec, st));
+                                      P->prec, c.dzs(0), st));
     PhStemWgrad w{};
     w.x4 = P->x4_ext ? P->x4_ext : ws + P->x4_off; w.dy = dzb[0]; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
@@ -625,7 +644,7 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
       if (hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) return PH_ELAUNCH;
     }
     if ((rc = ph_stem_wgrad_launch(&w, c.bprec(), cs.st))) return rc;
-    PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, cs.st));
+    PH_STAGE(ph_stem_wgrad_reduce_launch(w.slab, (float*)grads[0], w.nchunks, c.dzs(0), cs.st));
   }
   return join();
 }
@@ -656,7 +675,8 @@ int ph_resnet_plan_set_backward_overlap(const PhResnetPlan* P, int on) {
 // image [B,3,H,W] f32 -> NHWC4 (channel 3 = 0) of the mode's activation type, B * H * W * 4 elements: the trunk's input
 // layout, for ph_resnet_forward flag bit6
 int ph_pack_input(const float* x_nchw, void* x4, int B, int H, int W, int prec, hipStream_t st) {
-  if (!x_nchw || !x4 || B < 1 || H < 1 || W < 1 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec))) return PH_EINVAL;
+  if (!x_nchw || !x4 || B < 1 || H < 1 || W < 1 || (prec != PH_PREC_BF16 && !PH_IS_SPLIT_PREC(prec) && prec != PH_PREC_FP16X3))
+    return PH_EINVAL;
   return ph_pack_input_launch(x_nchw, x4, B, H, W, prec, st);
 }
 
@@ -692,6 +712,7 @@ int ph_resnet_backward_debug(const PhResnetPlan* P, const void* const* params, c
 int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, const void* packed, void* ws_,
                              const float* g_f3, const float* g_f4, float* dx_nchw, hipStream_t st) {
   if (!P || !params || !packed || !ws_ || !g_f4 || !dx_nchw) return PH_EINVAL;
+  if (P->prec == PH_PREC_FP16X3) return PH_EINVAL;      // (the image gradient is built for the bf16 / split-plane arithmetics)
   Ctx c{P, params, reinterpret_cast<const bf16*>(packed), reinterpret_cast<unsigned char*>(ws_), st, 0, 1};
   c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
@@ -707,7 +728,7 @@ int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, c
   auto bn_eval_bwd = [&](int ui, const void* g, const void* a, void* dy) -> int {
     const Unit& u = P->units[ui];
     return ph_bn_bwd_apply_launch(g, a, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), (const float*)params[ui * 6 + 1], c1, c2,
-                                  dy, (size_t)P->B * u.OH * u.OW, u.Cout, P->prec, nullptr, nullptr, st);
+                                  dy, (size_t)P->B * u.OH * u.OW, u.Cout, P->prec, nullptr, nullptr, nullptr, st);
   };
   {
     const Block& b = P->blocks[7];
@@ -733,7 +754,7 @@ int ph_resnet_backward_input(const PhResnetPlan* P, const void* const* params, c
   }
   const Unit& u = P->units[0];
   if ((rc = ph_stem_bwd_apply_launch(gcur, ws + P->idx_off, ws + u.y_off, c.stat(u, 0), c.stat(u, 1), c.stat(u, 2),
-                                     c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64, P->prec, st)))
+                                     c.stat(u, 3), (const float*)params[1], c1, c2, dyb, P->B, u.OH, u.OW, 64, P->prec, nullptr, st)))
     return rc;
   return ph_stem_dgrad_launch(dyb, (const float*)params[0], dx_nchw, P->B, P->H, P->W, P->prec, st);
 }

@@ -10,7 +10,7 @@ from ._lib import lib, check, ptr, stream, require_cuda
 
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD, EW_ELU_BWD, EW_MUL = 0, 1, 2, 3, 4, 5
-PREC_BF16, PREC_BF16X6, PREC_BF16X3 = 0, 1, 2
+PREC_BF16, PREC_BF16X6, PREC_BF16X3, PREC_FP16X3 = 0, 1, 2, 3
 
 _precision = PREC_BF16
 _fwd_only_precision = None      # optional other arithmetic for forward-only (no_grad) trunk forwards, see set_precision
@@ -34,13 +34,17 @@ def set_precision(mode):
       'bf16'      perf mode: bf16 operands and activations, fp32 accumulation and statistics;
       'bf16x6'    parity mode: fp32 activations, operands split into three bf16 planes, six MFMA products (fp32-equivalent);
       'bf16x3'    fp32 activations, the three leading products only (16-bit operands, ~2^-16 per product): half the matrix work;
+      'fp16x3'    half-pair mode: every tensor a convolution reads (activations, BatchNorm-backward dz under a per-tensor
+                  power-of-two scale) is stored as two fp16 planes x = hi + lo * 2^-11 (22 significant bits, 4 B per element),
+                  conv outputs and gradients stay fp32, three fp16 MFMA products per k-step (hi*hi, hi*lo, lo*hi: ~2^-22 per
+                  product, fp32 accumulation) - the cheapest arithmetic that meets the 1e-3 parity tolerance everywhere;
       'bf16x6/x3' parity mode for every forward, three products in the backward's dgrad / wgrad kernels;
       'bf16x6+x3' parity mode for every forward that is followed by a backward (the student), 'bf16x3' for the forward-only
                   networks (the no_grad EMA / teacher forwards of train_test_path_multi_distill.py:253-256)."""
     global _precision, _fwd_only_precision, _backward_precision
     _backward_precision = None
-    names = {"bf16": PREC_BF16, "bf16x6": PREC_BF16X6, "bf16x3": PREC_BF16X3, PREC_BF16: PREC_BF16, PREC_BF16X6: PREC_BF16X6,
-             PREC_BF16X3: PREC_BF16X3}
+    names = {"bf16": PREC_BF16, "bf16x6": PREC_BF16X6, "bf16x3": PREC_BF16X3, "fp16x3": PREC_FP16X3, PREC_BF16: PREC_BF16,
+             PREC_BF16X6: PREC_BF16X6, PREC_BF16X3: PREC_BF16X3, PREC_FP16X3: PREC_FP16X3}
     if mode == "bf16x6+x3":
         _precision, _fwd_only_precision = PREC_BF16X6, PREC_BF16X3
     elif mode == "bf16x6/x3":

@@ -106,7 +106,7 @@ class _TrunkFn(torch.autograd.Function):
         x4 = None
         if shared is not None:
             net._x4_shared = None      # single use: a later forward on recycled memory at the same address must not find it
-            if shared[0] == (x.data_ptr(), tuple(x.shape), plan.key[3] == ops.PREC_BF16):
+            if shared[0] == (x.data_ptr(), tuple(x.shape), _x4_format(plan.key[3])):
                 x4 = shared[1]
                 flags |= 64
         check(lib().ph_resnet_forward(plan.h, table, ptr(packed), ptr(x4 if x4 is not None else x), ptr(ws), ptr(f3), ptr(f4), flags,
@@ -161,6 +161,12 @@ class _TrunkFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def _x4_format(prec):
+    """Layout of the packed NHWC4 input per arithmetic: 0 = bf16, 1 = fp32 (every split-plane mode), 2 = the two fp16
+    planes of the half-pair mode (16 bytes per pixel, like fp32)."""
+    return {ops.PREC_BF16: 0, ops.PREC_FP16X3: 2}.get(prec, 1)
+
+
 def pack_shared_input(x, nets):
     """Pack the image batch `x` [B,3,H,W] f32 ONCE into the trunk's NHWC4 input layout for several networks that read it
     (the reference feeds the same x_path to the student and to the teacher, train_test_path_multi_distill.py:249,256, and
@@ -174,7 +180,7 @@ def pack_shared_input(x, nets):
     x4 = torch.empty(B, H, W, 4, device=x.device, dtype=torch.bfloat16 if prec == ops.PREC_BF16 else torch.float32)
     check(lib().ph_pack_input(ptr(x), ptr(x4), B, H, W, prec, stream()), "ph_pack_input")
     for net in nets:
-        net._x4_shared = ((x.data_ptr(), tuple(x.shape), prec == ops.PREC_BF16), x4)
+        net._x4_shared = ((x.data_ptr(), tuple(x.shape), _x4_format(prec)), x4)
     return x4
 
 

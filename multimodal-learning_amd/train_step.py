@@ -474,8 +474,11 @@ class DistillStep:
             self.optimizer.zero_grad()                                                                      # :326
             self._stamp(3)
             loss.backward()                                                                                 # :327
-            if self._head_side is not None:
-                torch.cuda.current_stream().wait_stream(self._head_side)     # the heads' weight gradients (loss_head.py)
+            # the heads' weight gradients (loss_head.py) - joined only where loss_head forks that stream (`hs = ... if
+            # step.sync is None`): under data parallelism it never joins the capture, and waiting on a stream outside a
+            # capture invalidates the capture (hipErrorStreamCaptureIsolation)
+            if self._head_side is not None and self.sync is None:
+                torch.cuda.current_stream().wait_stream(self._head_side)
             self._stamp(5)
             if self.sync is not None:
                 self.sync.all_reduce_grads(self.optimizer.flat)

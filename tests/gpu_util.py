@@ -9,6 +9,23 @@ def nhwc(x, dtype):
     return x.permute(0, 2, 3, 1).contiguous().to("cuda").to(dtype)
 
 
+def hp_pack(x, scale=1.0):
+    """fp32 cuda tensor whose innermost extent is a multiple of 64 -> the half-pair storage of PH_PREC_FP16X3 (same shape and
+    byte size, an opaque float32 container; include/pathomic_hip.h: ph_hp_pack)."""
+    from multimodal_learning_amd._lib import lib, ptr, stream, check
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib().ph_hp_pack(ptr(x), ptr(out), x.numel(), float(scale), stream()), "ph_hp_pack")
+    return out
+
+
+def hp_unpack(x):
+    from multimodal_learning_amd._lib import lib, ptr, stream, check
+    out = torch.empty_like(x)
+    check(lib().ph_hp_unpack(ptr(x), ptr(out), x.numel(), stream()), "ph_hp_unpack")
+    return out
+
+
 def nchw_cpu(y):
     return y.float().cpu().permute(0, 3, 1, 2).contiguous()
 

@@ -65,6 +65,55 @@ def test_conv_fwd_dgrad_wgrad(case, prec):
     assert_close(wr.grad, dw.cpu(), 1e-6, 2e-5 if prec == 1 else 2e-3, "conv wgrad")
 
 
+def test_half_pair_storage_round_trip():
+    """ph_hp_pack / ph_hp_unpack (PH_PREC_FP16X3 storage): x ~= hi + lo * 2^-11 keeps 22 significant bits over the fp16
+    exponent range, and a power-of-two scale applied before the split is exact."""
+    from tests.gpu_util import hp_pack, hp_unpack
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 7, 5, 128, generator=g) * torch.exp(torch.randn(3, 7, 5, 128, generator=g) * 3)).cuda()
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65000.0, 6e-5, 1e-7, -3.3e-6]).cuda()
+    y = hp_unpack(hp_pack(x))
+    rel = ((y - x).abs() / x.abs().clamp_min(1e-4)).max().item()
+    assert rel < 2.0 ** -21, rel                       # (|x| >= 1e-4: both halves normal or the residual below 2^-25 absolute)
+    assert (y - x).abs().max().item() <= 2.0 ** -21 * x.abs().max().item()
+    small = x.abs() < 1e-4
+    assert ((y - x).abs()[small] <= 2.0 ** -24).all()  # fp16 subnormal spacing of the hi half, absolute
+    z = hp_unpack(hp_pack(x * 2.0 ** -20, scale=2.0 ** 20))
+    assert torch.equal(z, y)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad_half_pair(case):
+    """The three convolution kernels in PH_PREC_FP16X3 (fp16 pairs in, three fp16 MFMA products, fp32 out) against fp32
+    F.conv2d on the same fp32 operands: 22-bit operands and fp32 accumulation leave ~1e-6 of the largest output."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close, hp_pack
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, KS, S, pad, B = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) * (2.0 / (Cin * KS * KS)) ** 0.5
+    OH = (H + 2 * pad - KS) // S + 1
+    dy = torch.randn(B, Cout, OH, OH, generator=g)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr.double(), wr.double(), None, S, pad)
+    y_ref.backward(dy.double())
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, KS, S, pad), device="cuda", dtype=torch.uint8)
+    xd = hp_pack(nhwc(x, torch.float32)); wd = w.cuda(); dyd = hp_pack(nhwc(dy, torch.float32))
+    y = torch.full((B, OH, OH, Cout), float("nan"), device="cuda")
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, KS, S, pad, 3, ptr(ws),
+                          stream()), "fwd")
+    assert_close(y_ref.detach(), nchw_cpu(y), 1e-6, 3e-6, "conv fwd")
+    assert_close(y_ref.detach().sum(dim=(0, 2, 3)), s1.cpu(), 1e-3, 2e-4, "channel sum")
+    assert_close((y_ref.detach() ** 2).sum(dim=(0, 2, 3)), s2.cpu(), 1e-3, 2e-4, "channel sumsq")
+    dx = torch.full((B, H, H, Cin), float("nan"), device="cuda")
+    check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx), B, Cin, H, H, Cout, KS, S, pad, 3, ptr(ws), stream()), "dgrad")
+    assert_close(xr.grad, nchw_cpu(dx), 1e-6, 3e-6, "conv dgrad")
+    dw = torch.empty_like(wd)
+    check(L.ph_conv2d_wgrad(ptr(xd), ptr(dyd), ptr(dw), B, Cin, H, H, Cout, KS, S, pad, 3, ptr(ws), stream()), "wgrad")
+    assert_close(wr.grad, dw.cpu(), 1e-6, 5e-6, "conv wgrad")
+
+
 # ---- second-generation kernel (conv_tap2.hip): persistent workgroups walking SEVERAL tiles each.  The cases above
 # give every workgroup one tile; these are sized past 256 tiles so that the cross-tile operand streams (next tile's
 # halo in the other A buffer, the weight ring running across the tile edge, the epilogue between two tiles) are

@@ -20,12 +20,13 @@ def _student(seed=1):
     return net.cuda().train()
 
 
-def test_student_forward_backward_parity_mode(golden_dir):
+@pytest.mark.parametrize("pmode", ["bf16x6", "fp16x3"])
+def test_student_forward_backward_parity_mode(golden_dir, pmode):
     import multimodal_learning_amd as m
     from oracle.step import synthetic_batch
     from tests.gpu_util import assert_close, Report
     g = np.load(os.path.join(golden_dir, "modules_b4_h64.npz"))
-    m.set_precision("bf16x6")
+    m.set_precision(pmode)
     R = Report("student fwd/bwd, parity mode vs reference golden (B=4, 64x64)")
     assert_close = R.close
     try:
@@ -85,13 +86,14 @@ def test_student_forward_perf_mode_noise_floor():
     assert e_gpu.max() <= 3.0 * e_emu.max() + 1e-3
 
 
-def test_teacher_forward_parity_mode(golden_dir):
+@pytest.mark.parametrize("pmode", ["bf16x6", "fp16x3"])
+def test_teacher_forward_parity_mode(golden_dir, pmode):
     import multimodal_learning_amd as m
     from oracle import weights as W
     from oracle.step import synthetic_batch, default_opt
     from tests.gpu_util import assert_close, Report
     g = np.load(os.path.join(golden_dir, "modules_b4_h64.npz"))
-    m.set_precision("bf16x6")
+    m.set_precision(pmode)
     try:
         t = m.define_net(default_opt(), 1)
         t.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))

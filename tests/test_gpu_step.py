@@ -36,7 +36,8 @@ def _tuple(bt):
             bt["grade"], bt["index"], bt["sample_idx"])
 
 
-def test_three_steps_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("pmode", ["bf16x6", "fp16x3"])
+def test_three_steps_vs_reference_golden(golden_dir, pmode):
     """Step 0 (before any parameter update): everything within 1e-3 of the REFERENCE's golden values.
     Steps 1-2 (after Adam updates): the reference's own fp32 run sits 1e-2..6e-2 from the fp64 truth on
     logits/loss (tests/golden/make_fp64_truth.py) because Adam's sign-like first steps amplify rounding, so the
@@ -49,7 +50,7 @@ def test_three_steps_vs_reference_golden(golden_dir):
     from tests.gpu_util import assert_close, maxerr, Report
     g = np.load(os.path.join(golden_dir, "step_b16_h224.npz"))
     t64 = np.load(os.path.join(golden_dir, "step_b16_h224_fp64.npz"))
-    m.set_precision("bf16x6")
+    m.set_precision(pmode)
     try:
         step = _mk_step(default_opt(), int(g["n_data"]), seed=int(g["seed"]))
         R = Report("3 distill steps, parity mode vs REFERENCE golden (B=16, 224x224)")
@@ -728,7 +729,7 @@ def test_mia2022_distill_baselines(distill):
         m.set_precision("bf16")
 
 
-@pytest.mark.parametrize("mode,gtol", [("bf16x6", 1.0), ("bf16x6/x3", 1.0), ("bf16x3", 8.0)])
+@pytest.mark.parametrize("mode,gtol", [("bf16x6", 1.0), ("bf16x6/x3", 1.0), ("bf16x3", 8.0), ("fp16x3", 1.0)])
 def test_two_steps_from_mid_training_state_vs_reference_golden(golden_dir, mode, gtol):
     """Post-update parity as a REAL check.  tests/golden/make_golden_midstate.py runs the reference
     for two steps from a mid-training state: Adam step count 7 with non-zero moments (per-tensor recipe scaled by the
