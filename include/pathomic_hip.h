@@ -7,8 +7,12 @@
  *
  * Conventions: plain pointers to DEVICE memory + sizes, no torch types; every call enqueues work on
  * `stream` and returns immediately; return 0 on success, negative errno-style code otherwise
- * (-22 invalid argument, -5 launch failure).  No allocation happens inside: callers pass workspaces.
- * Thread-compatible (one stream per call), no global mutable state.
+ * (-22 invalid argument, -5 launch failure, -16 busy).  No device memory is allocated inside: callers pass workspaces.
+ * Thread-compatible (one stream per call).  Process-wide state the library owns: per device ONE side stream and a pool of
+ * 16 x 64 events for the two-stream trunk backward (created by the first ph_resnet_backward* call outside a stream capture,
+ * never destroyed; a 17th backward in flight at once gets -16), the records of the in-library kernel timer (ph_prof_*), and
+ * per-kernel "attributes set" flags.  A plan (PhResnetPlan) additionally remembers, per workspace, the pre-packed input of
+ * the last forward that ran on it.
  */
 #ifndef PATHOMIC_HIP_H_
 #define PATHOMIC_HIP_H_

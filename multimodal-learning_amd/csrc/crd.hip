@@ -621,6 +621,18 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
                      const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
                      int64_t* nb2, float* sim1, float* sim2, void* workspace, hipStream_t st) {
   if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX || !workspace || B < 1 || n_data < 1) return PH_EINVAL;
+  if (B > 128) {
+    // the similarity kernel holds up to 128 normalised queries in LDS: larger batches (the reference has no limit; a replica
+    // batch of 256 is the north-star size) run in chunks of 128 queries through the same workspace, in stream order
+    for (int c0 = 0; c0 < B; c0 += 128) {
+      const int bc = B - c0 < 128 ? B - c0 : 128;
+      const int rc = ph_crd_bank_topk(mem1, mem2, labels, idx + (size_t)c0 * PK, PK, batch_label + c0, bc, n_data, num_pos, feat_dim,
+                                      nb1 + (size_t)c0 * num_pos, nb2 + (size_t)c0 * num_pos, sim1 + (size_t)c0 * num_pos,
+                                      sim2 + (size_t)c0 * num_pos, workspace, st);
+      if (rc) return rc;
+    }
+    return PH_OK;
+  }
   float* S = reinterpret_cast<float*>(workspace);
   float* cv = S + (size_t)2 * B * n_data;
   int* ci = reinterpret_cast<int*>(cv + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
@@ -632,8 +644,7 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
   hipLaunchKernelGGL(crd_topk_queries_kernel, dim3(B, 2), dim3(64), 0, st, mem1, mem2, idx, PK, qbuf, qnorm);
   PH_LAUNCH_CHECK();
   {
-    const int nq = cdiv(B, 32);
-    if (nq > 4) return PH_EINVAL;      // up to 128 queries per call
+    const int nq = cdiv(B, 32);      // <= 4 (chunked above)
     const int ntiles = cdiv(n_data, 32);
     int gx = cdiv(ntiles, 4);
     const int cus = ph_num_cus();

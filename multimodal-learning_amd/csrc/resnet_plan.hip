@@ -9,6 +9,7 @@
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 #include "ph_common.h"
 #include "ph_kernels.h"
@@ -46,7 +47,11 @@ struct PhResnetPlan {
   size_t act_max;   // max block-level activation bytes
   mutable int no_masked = 0;   // A/B and test switch, set by the last forward's flag bit3 and followed by its backward
   mutable int bwd_prec = -1;   // >= 0: arithmetic of the backward's dgrad / wgrad launches where it differs from `prec` (both split-plane)
-  mutable const void* x4_ext = nullptr;   // the last forward's pre-packed input (flag bit6), read again by its backward (stem wgrad)
+  // pre-packed inputs (forward flag bit6) by the WORKSPACE of the forward that read them: the backward on that workspace
+  // reads the same tensor again (stem wgrad).  Keyed by workspace, not cached per plan: a no_grad / eval forward or another
+  // taped forward of a `_multi_forward` net on the same plan must not redirect an earlier forward's backward.
+  mutable std::unordered_map<const void*, const void*> x4_by_ws;
+  mutable std::mutex x4_mu;
   // Backward on two streams (backward_impl): the weight-gradient launches run on a side stream beside the BatchNorm-backward /
   // dgrad chain; `dy2_off` is the second dz buffer they need.
   size_t dy2_off = 0;
@@ -373,7 +378,12 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   // bit6: `x_nchw` is not the image but an NHWC4 tensor of the mode's activation type that ph_pack_input produced from it
   // (the student and the teacher of the distillation step read the same x_path: packed once, train_test_path_multi_distill.py:249,256)
   int rc = PH_OK;
-  P->x4_ext = (flags & 64) ? reinterpret_cast<const void*>(x_nchw) : nullptr;
+  {
+    std::lock_guard<std::mutex> lk(P->x4_mu);
+    if ((flags & 64) && P->x4_by_ws.size() > 256) P->x4_by_ws.clear();      // (workspaces long gone: keep the table bounded)
+    if (flags & 64) P->x4_by_ws[ws_] = reinterpret_cast<const void*>(x_nchw);
+    else P->x4_by_ws.erase(ws_);
+  }
   const unsigned char* x4p = (flags & 64) ? reinterpret_cast<const unsigned char*>(x_nchw) : ws + P->x4_off;
   if (!(flags & 64) && (rc = ph_pack_input_launch(x_nchw, ws + P->x4_off, P->B, P->H, P->W, P->prec, st))) return rc;
   if (c.eval) {
@@ -504,9 +514,17 @@ namespace {
 struct SideRes {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> evs;
-  std::atomic<size_t> cursor{0};
+  // A backward call holds one block of EV_BLOCK events until the work it enqueued has run: `done[b]` is recorded on the
+  // caller's stream when the call returns and the block is handed out again only once that event has completed.  A call made
+  // inside a stream capture frees its block at once (the capture turns its event waits into graph edges and keeps no
+  // reference to the events) and only takes blocks that are known to be free (no event queries while a capture runs).
+  hipEvent_t done[16];
+  bool busy[16];
+  size_t cursor = 0;
+  std::mutex mu;
 };
 constexpr size_t EV_BLOCK = 64, EV_BLOCKS = 16;
+#define PH_EBUSY (-16)
 
 SideRes* overlap_ready(const PhResnetPlan* P, hipStream_t st) {
   static SideRes* res[16] = {nullptr};
@@ -521,7 +539,7 @@ SideRes* overlap_ready(const PhResnetPlan* P, hipStream_t st) {
   SideRes* r = new (std::nothrow) SideRes();
   if (!r) return nullptr;
   if (hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking) != hipSuccess) { delete r; return nullptr; }
-  r->evs.resize(EV_BLOCK * EV_BLOCKS);
+  r->evs.resize(EV_BLOCK * EV_BLOCKS + EV_BLOCKS);
   for (size_t i = 0; i < r->evs.size(); ++i)
     if (hipEventCreateWithFlags(&r->evs[i], hipEventDisableTiming) != hipSuccess) {
       for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(r->evs[j]);
@@ -529,6 +547,7 @@ SideRes* overlap_ready(const PhResnetPlan* P, hipStream_t st) {
       delete r;
       return nullptr;
     }
+  for (size_t b = 0; b < EV_BLOCKS; ++b) { r->done[b] = r->evs[EV_BLOCK * EV_BLOCKS + b]; r->busy[b] = false; }
   res[dev] = r;
   return r;
 }
@@ -548,7 +567,32 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   const hipStream_t side = ov ? sr->side : st;
   Ctx cs = c;                       // the weight-gradient launches' context
   if (ov) { cs.st = side; cs.wg_want = WG_WANT_BESIDE; }
-  const size_t ev_base = ov ? (sr->cursor.fetch_add(1) % EV_BLOCKS) * EV_BLOCK : 0;
+  // this call's block of events (see SideRes): -EBUSY when all 16 are held by backward passes still in flight
+  size_t ev_base = 0;
+  int ev_blk = -1;
+  bool capturing = false;
+  if (ov) {
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    capturing = hipStreamIsCapturing(st, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lk(sr->mu);
+    for (size_t i = 0; i < EV_BLOCKS && ev_blk < 0; ++i) {
+      const size_t b = (sr->cursor + i) % EV_BLOCKS;
+      if (!sr->busy[b]) ev_blk = (int)b;
+      else if (!capturing && hipEventQuery(sr->done[b]) == hipSuccess) { sr->busy[b] = false; ev_blk = (int)b; }
+    }
+    if (ev_blk < 0) return PH_EBUSY;
+    sr->busy[ev_blk] = true;      // (claimed; released below)
+    sr->cursor = (size_t)ev_blk + 1;
+    ev_base = (size_t)ev_blk * EV_BLOCK;
+  }
+  struct BlockGuard {      // every exit path: a captured call frees the block, an eager one marks it with `done` on the stream
+    SideRes* r; int b; bool cap; hipStream_t s;
+    ~BlockGuard() {
+      if (!r || b < 0) return;
+      std::lock_guard<std::mutex> lk(r->mu);
+      if (cap || hipEventRecord(r->done[b], s) != hipSuccess) r->busy[b] = false;
+    }
+  } guard{ov ? sr : nullptr, ev_blk, capturing, st};
   size_t ev_used = 0;
   unsigned char* dzb[2] = {ws + P->dy_off, ov ? ws + P->dy2_off : ws + P->dy_off};
   hipEvent_t rd[2] = {nullptr, nullptr};    // recorded on the side stream after the last reader of dzb[k]
@@ -636,7 +680,13 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
                                       c.stat(u, 3), (const float*)params[1], c1, c2, dzb[0], P->B, u.OH, u.OW, 64,
                                       P->prec, c.dzs(0), st));
     PhStemWgrad w{};
-    w.x4 = P->x4_ext ? P->x4_ext : ws + P->x4_off; w.dy = dzb[0]; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
+    const void* x4_ext = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(P->x4_mu);
+      auto it = P->x4_by_ws.find(ws_);
+      if (it != P->x4_by_ws.end()) x4_ext = it->second;
+    }
+    w.x4 = x4_ext ? x4_ext : ws + P->x4_off; w.dy = dzb[0]; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;
     w.nchunks = stem_chunks(P->B, u.OH, u.OW, &w.tiles_per_chunk);
     if (ov) {      // same stream as the other weight gradients: they share the slab

@@ -15,6 +15,7 @@
 #include "ph_common.h"
 #include "ph_kernels.h"
 
+constexpr int TSVD_MAX_V = 8;   // views admitted by ph_tsvd_update_aux (couples the workspace tail layout, see tsvd_slice_big_kernel)
 namespace {
 
 constexpr int TS_MAXB = 64, TS_MAXN = 2 * TS_MAXB, TS_LD = TS_MAXN + 1;
@@ -427,7 +428,10 @@ __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __res
   }
   if (tid == 0) {
     tnn_k[k] = red[0];
-    tnn_k[8 + k] = (float)sweeps_done;  // diagnostic: sweeps this slice took (tests/bench_tsvd_gpu.py)
+    // diagnostic: sweeps this slice took (tests/bench_tsvd_gpu.py).  Slots 8.. of the 16-float tail: ph_tsvd_update_aux
+    // admits V <= 8, i.e. k <= V / 2 <= 4 < 8, so the counters never meet the per-slice TNN values in slots 0 .. V / 2
+    static_assert(TSVD_MAX_V / 2 + 1 <= 8 && 8 + TSVD_MAX_V / 2 + 1 <= 16, "sweep counters share the 16-float tail with the TNN values");
+    tnn_k[8 + k] = (float)sweeps_done;
   }
   // T = D A^H X
   for (int e = tid; e < B * B; e += 1024) {
@@ -509,7 +513,7 @@ int ph_scaled_diff(const float* a, const float* b, const float* gscalar, float a
 }
 
 int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn, int V, int B, float tau, void* ws_, hipStream_t st) {
-  if (!adj || !aux || !ws_ || V < 2 || V > 8 || (V & 1) || B < 1 || B > TB_MAXB) return PH_EINVAL;
+  if (!adj || !aux || !ws_ || V < 2 || V > TSVD_MAX_V || (V & 1) || B < 1 || B > TB_MAXB) return PH_EINVAL;
   float* ws = reinterpret_cast<float*>(ws_);
   const size_t bb = (size_t)B * B;
   float* yre = ws;

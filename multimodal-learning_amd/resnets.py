@@ -311,10 +311,22 @@ class ResNet(nn.Module):
             for k in loose[:max(0, len(loose) - (self._WS_LRU - 1))]:      # dict order = least recently used first
                 del self._ws_cache[k]
             ws = torch.empty(plan.ws_bytes, device=dev, dtype=torch.uint8)
+        elif not torch.cuda.is_current_stream_capturing():
+            # the cached block goes back to the pool of the stream that allocated it when it is evicted: tell the allocator
+            # about every other stream whose kernels read it (the forward-only networks run on side streams), so that an
+            # eviction cannot recycle memory a side stream's kernels still use
+            ws.record_stream(torch.cuda.current_stream())
         self._ws_cache[key] = ws                                          # (re-)inserted last = most recently used
         return ws
 
     _WS_LRU = 2      # un-pinned workspaces kept per network
+
+    def pinned_workspaces(self):
+        """The workspace tensors a stream capture has pinned (a captured graph holds their raw pointers): DistillStep keeps
+        references to them next to the graph, so that release_workspaces() cannot return their memory to the allocator while
+        the graph can still be replayed."""
+        pinned = self.__dict__.get("_ws_pinned", set())
+        return [ws for k, ws in self._ws_cache.items() if k in pinned]
 
     def release_workspaces(self, keep=None):
         """Free the cached trunk workspaces (all, or all but the plan key `keep` = (B, H, W, precision)), pinned ones

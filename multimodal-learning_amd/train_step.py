@@ -808,6 +808,9 @@ class DistillStep:
                     st["out"] = self._device_body(st["x_path"], st["ema_x_path"], st["x_omic"], st["grade"],
                                                   st["index"], st["sample_idx"], bnorm, e, st["r"][0], st["r"][1])
                 st["graph"] = g
+                # the graph holds raw pointers into the trunk workspaces it was captured with: keep them alive with it
+                st["ws_refs"] = [ws for net in (self.model, self.ema_model, getattr(self.fix_model, "path_net", None))
+                                 if net is not None and hasattr(net, "pinned_workspaces") for ws in net.pinned_workspaces()]
                 self.optimizer._prepared = was_prepared   # capture does not execute anything
             except Exception as exc:     # e.g. a collective that cannot be captured on this stack: stay eager
                 import warnings

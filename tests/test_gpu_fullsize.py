@@ -455,7 +455,7 @@ def _variant_step(variant, B, seed):
         kw["variant"] = "mia2022"
     else:
         n_data, K = 65536, 4096
-        for k, v in dict(nce_k=4096, nce_p=4, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
+        for k, v in dict(nce_k=4096, nce_p=6, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
                          max_discrep=2.0, use_grads_thresh="True", grads_thresh=0.0, loss_weighting="GK_refine").items():
             setattr(opt, k, v)
         labels = torch.arange(n_data) % 3
