@@ -89,12 +89,16 @@ __global__ void bn_eval_params_kernel(PhBnEvalTable t, float eps) {
 
 // out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r | relu(y_r*scale_r + shift_r)] ), 8 channels per thread;
 // relu bit0: ReLU on the sum, bit1: ReLU (and rounding to T) on the shortcut term
-// TY: type of the convolution outputs (y, y_r), T: type of the activations (res, out); they differ in PH_PREC_FP16X3 only
+// TY: type of the convolution outputs (y, y_r) and of everything an ELEMENTWISE pass reads (res); T: type of the activation
+// as the next convolution reads it (out).  They differ in PH_PREC_FP16X3 only: there `out` is the half-pair MFMA operand
+// image and `out32` (optional) an fp32 copy of the same values for the elementwise readers (the next block's shortcut term,
+// the backward's ReLU masks, the average pool) - the identity path of the network then carries fp32 like the reference's.
 template <typename T, typename TY>
 __global__ void bn_apply_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
-                                const float* __restrict__ shift, const T* __restrict__ res,
+                                const float* __restrict__ shift, const TY* __restrict__ res,
                                 const TY* __restrict__ y_r, const float* __restrict__ scale_r,
-                                const float* __restrict__ shift_r, T* __restrict__ out, size_t n8, int C8, int relu) {
+                                const float* __restrict__ shift_r, T* __restrict__ out, TY* __restrict__ out32, size_t n8,
+                                int C8, int relu) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int c = (int)(i % C8) * 8;
@@ -127,13 +131,15 @@ __global__ void bn_apply_kernel(const TY* __restrict__ y, const float* __restric
     for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
   }
   store8(out + i * 8, v);
+  if constexpr (!std::is_same<T, TY>::value) { if (out32) store8(out32 + i * 8, v); }
 }
 
 // stem: relu(bn(y0)) -> maxpool 3x3/2 pad 1; argmax position code (kh*3+kw, first max wins) saved as u8
 template <typename T, typename TY, bool IDX>
 __global__ void bn_relu_maxpool_kernel(const TY* __restrict__ y, const float* __restrict__ scale,
                                        const float* __restrict__ shift, T* __restrict__ out,
-                                       uint8_t* __restrict__ idx, TY* __restrict__ raw, int B, int H, int W, int C8) {
+                                       uint8_t* __restrict__ idx, TY* __restrict__ raw, TY* __restrict__ out32, int B, int H,
+                                       int W, int C8) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;   // floor((H + 2 - 3)/2) + 1
   const size_t n = (size_t)B * OH * OW * C8;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,6 +176,7 @@ __global__ void bn_relu_maxpool_kernel(const TY* __restrict__ y, const float* __
     }
   }
   store8(out + i * 8, best);
+  if constexpr (!std::is_same<T, TY>::value) { if (out32) store8(out32 + i * 8, best); }
   if constexpr (IDX) {
     uint64_t packed = 0;
 #pragma unroll
@@ -231,7 +238,7 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ g, T* __restrict__ 
 // geometry-aware kernel below.)
 template <typename T, typename TY = T>
 struct DzPlain {
-  const TY* g; const T* a; const TY* y;
+  const TY* g; const TY* a; const TY* y;      // (a: a block output as the elementwise passes read it - the fp32 copy in PH_PREC_FP16X3)
   // optional: the ReLU mask of a BatchNorm whose OWN output went through the ReLU (bn1 of a BasicBlock: a1 =
   // relu(y * scale + shift)) is a function of y, which the kernels read anyway - the activation tensor `a` is then not
   // read at all (2 of the 6 / 8 bytes per element of the reduce / apply pass)
@@ -612,15 +619,15 @@ int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st) 
 }
 
 int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
-                       const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,
+                       const float* scale_r, const float* shift_r, void* out, void* out32, size_t npix, int C, int relu, int prec,
                        hipStream_t st) {
   const size_t n8 = npix * (C / 8);
   void* tok = nullptr;
   if (ph_prof_on())
     ph_prof_begin(PH_CLS_BN_APPLY, (double)npix * C * (prec == PH_PREC_BF16 ? 2.0 : 4.0) * ((res || y_r) ? 3.0 : 2.0), st, &tok);
 #define PH_CALL(T, TY)                                                                                              \
-  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(nblk(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const T*)res, \
-                     (const TY*)y_r, scale_r, shift_r, (T*)out, n8, C / 8, relu)
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(nblk(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const TY*)res, \
+                     (const TY*)y_r, scale_r, shift_r, (T*)out, (TY*)out32, n8, C / 8, relu)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
   ph_prof_end(tok, st);
@@ -629,15 +636,15 @@ int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, co
 }
 
 int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* raw,
-                              int B, int H, int W, int C, int prec, hipStream_t st) {
+                              void* out32, int B, int H, int W, int C, int prec, hipStream_t st) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const size_t n = (size_t)B * OH * OW * (C / 8);
 #define PH_CALL(T, TY)                                                                                                          \
   do {                                                                                                                          \
     if (idx) hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, TY, true>), dim3(nblk(n)), dim3(256), 0, st, (const TY*)y, scale, shift, \
-                                (T*)out, idx, (TY*)raw, B, H, W, C / 8);                                                        \
+                                (T*)out, idx, (TY*)raw, (TY*)out32, B, H, W, C / 8);                                            \
     else hipLaunchKernelGGL((bn_relu_maxpool_kernel<T, TY, false>), dim3(nblk(n)), dim3(256), 0, st, (const TY*)y, scale, shift,   \
-                            (T*)out, idx, (TY*)raw, B, H, W, C / 8);                                                            \
+                            (T*)out, idx, (TY*)raw, (TY*)out32, B, H, W, C / 8);                                                \
   } while (0)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
@@ -647,7 +654,7 @@ int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* sh
 
 int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st) {
   dim3 grid(C / 64, B);
-#define PH_CALL(T, TY) hipLaunchKernelGGL(avgpool_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, HW, C)
+#define PH_CALL(T, TY) hipLaunchKernelGGL(avgpool_kernel<TY>, grid, dim3(256), 0, st, (const TY*)x, out, HW, C)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
   PH_LAUNCH_CHECK();
@@ -677,7 +684,7 @@ int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const f
   const int nb = ph_bn_bwd_parts(npix, C);
 #define PH_CALL(T, TY)                                                                                                       \
   do {                                                                                                                       \
-    DzPlain<T, TY> s{(const TY*)g, (const T*)a, (const TY*)y, mscale, mshift};                                               \
+    DzPlain<T, TY> s{(const TY*)g, (const TY*)a, (const TY*)y, mscale, mshift};                                              \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, DzPlain<T, TY>>), dim3(nb), dim3(256), 0, st, s, mean, invstd, parts, npix, C, amax); \
   } while (0)
   PH_DISPATCH(prec, PH_CALL);
@@ -701,7 +708,7 @@ int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const fl
   const size_t n8 = npix * (C / 8);
 #define PH_CALL(T, TY)                                                                                                       \
   do {                                                                                                                       \
-    DzPlain<T, TY> s{(const TY*)g, (const T*)a, (const TY*)y, mscale, mshift};                                               \
+    DzPlain<T, TY> s{(const TY*)g, (const TY*)a, (const TY*)y, mscale, mshift};                                              \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DzPlain<T, TY>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, \
                        (T*)dy, n8, C / 8, dzs);                                                                              \
   } while (0)

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const bool full = (r0 + TH <= p.OHt) && (c0 + TW <= p.OWt);
   TO* out = reinterpret_cast<TO*>(p.out) + (size_t)b * p.OH * p.OW * p.Cout;
   const TO* resg = p.res_g ? reinterpret_cast<const TO*>(p.res_g) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
-  const T* resa = p.res_a ? reinterpret_cast<const T*>(p.res_a) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
+  // (res_a: a block output as the elementwise passes read it - the fp32 copy in the half-pair mode)
+  const TO* resa = p.res_a ? reinterpret_cast<const TO*>(p.res_a) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
   // half-pair mode: the accumulators hold 2^11 x the sum (the W blocks' scaling) times the dz tensor's power-of-two scale
   float osc = 1.f;
   if constexpr (HPM) osc = PH_HP_LO_INV * (p.in_unscale ? p.in_unscale[1] : 1.f);

@@ -166,13 +166,15 @@ struct PhBnEvalTable {
   int n;
 };
 int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st);
-// out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] )
+// out = relu?( y*scale + shift + [res | y_r*scale_r + shift_r] ).  PH_PREC_FP16X3: `out` is the half-pair operand image,
+// `out32` (optional) the fp32 copy the elementwise passes read; `res` is such an fp32 copy.  Other modes: out32 = null.
 int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
-                       const float* scale_r, const float* shift_r, void* out, size_t npix, int C, int relu, int prec,
+                       const float* scale_r, const float* shift_r, void* out, void* out32, size_t npix, int C, int relu, int prec,
                        hipStream_t st);
 // raw (optional, with idx): the conv output at every window's arg-max, [B][OH/2][OW/2][C] of the mode's type
 int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* raw,
-                              int B, int H, int W, int C, int prec, hipStream_t st);
+                              void* out32, int B, int H, int W, int C, int prec, hipStream_t st);
+// x: an activation as the elementwise passes read it (the fp32 copy in PH_PREC_FP16X3)
 int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st);
 // d_x (+)= g / HW  broadcast
 int ph_avgpool_bwd_launch(const float* g, void* dx, int B, int HW, int C, int accumulate, int prec, hipStream_t st);

@@ -28,6 +28,9 @@ struct Unit {
 struct Block {
   int u1, u2, uds;
   size_t in_off, a1_off, out_off;   // byte offsets of the block input / post-bn1-relu / output activations
+  // the same tensors as the ELEMENTWISE passes read them (shortcut term, ReLU masks, average pool): in PH_PREC_FP16X3 fp32
+  // copies beside the half-pair MFMA operand images, otherwise the tensors themselves
+  size_t in32_off, out32_off;
   int IH, IW, OH, OW, Cin, Cout;
 };
 
@@ -109,6 +112,8 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   P->units.push_back(s);
   P->PH0 = (s.OH + 1) / 2; P->PW0 = (s.OW + 1) / 2;
   P->p0_off = take((size_t)B * P->PH0 * P->PW0 * 64 * es);
+  const bool hp = prec == PH_PREC_FP16X3;
+  const size_t p032_off = hp ? take((size_t)B * P->PH0 * P->PW0 * 64 * es) : P->p0_off;
   P->idx_off = take((size_t)B * P->PH0 * P->PW0 * 64);
   P->p0raw_off = take((size_t)B * P->PH0 * P->PW0 * 64 * es);   // conv output at every pooling window's arg-max (training forwards)
   size_t parts_max = (size_t)std::max(ph_stem_stat_parts(B, s.OH, s.OW), ph_stem_pool_stat_parts(B, s.OH, s.OW)) * 2 * 64 * sizeof(float);
@@ -116,7 +121,7 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
   { int tpc; int nc = stem_chunks(B, s.OH, s.OW, &tpc); slab_max = (size_t)nc * 7 * 64 * 32 * sizeof(float); }
   size_t act_max = (size_t)B * P->PH0 * P->PW0 * 64 * es;
   int ih = P->PH0, iw = P->PW0, inpl = 64;
-  size_t in_off = P->p0_off;
+  size_t in_off = P->p0_off, in32_off = p032_off;
   const int planes[4] = {64, 128, 256, 512};
   for (int li = 0; li < 4; ++li)
     for (int bi = 0; bi < 2; ++bi) {
@@ -144,12 +149,13 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
       b.u1 = mk(inpl, pl, 3, stride, 1, ih, iw);
       b.u2 = mk(pl, pl, 3, 1, 1, b.OH, b.OW);
       b.uds = (stride != 1 || inpl != pl) ? mk(inpl, pl, 1, stride, 0, ih, iw) : -1;
-      b.in_off = in_off;
+      b.in_off = in_off; b.in32_off = in32_off;
       b.a1_off = take((size_t)B * b.OH * b.OW * pl * es);
       b.out_off = take((size_t)B * b.OH * b.OW * pl * es);
+      b.out32_off = hp ? take((size_t)B * b.OH * b.OW * pl * es) : b.out_off;
       act_max = std::max(act_max, (size_t)B * b.OH * b.OW * pl * es);
       P->blocks.push_back(b);
-      in_off = b.out_off; ih = b.OH; iw = b.OW; inpl = pl;
+      in_off = b.out_off; in32_off = b.out32_off; ih = b.OH; iw = b.OW; inpl = pl;
     }
   P->act_max = act_max;
   P->parts_bytes = parts_max;
@@ -375,6 +381,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   P->no_masked = (flags & 16) ? 1 : 0;
   c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
+  const bool hp = P->prec == PH_PREC_FP16X3;
   // bit6: `x_nchw` is not the image but an NHWC4 tensor of the mode's activation type that ph_pack_input produced from it
   // (the student and the teacher of the distillation step read the same x_path: packed once, train_test_path_multi_distill.py:249,256)
   int rc = PH_OK;
@@ -421,7 +428,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     // pooled tensor stays RAW and no pass over it remains (bit 3 of the flags keeps the separate pass, as for the blocks)
     p0_raw = !(flags & 8);
     if (!p0_raw && (rc = ph_bn_apply_launch(ws + P->p0_off, c.stat(u, 2), c.stat(u, 3), nullptr, nullptr, nullptr, nullptr,
-                                            ws + P->p0_off, (size_t)P->B * P->PH0 * P->PW0, 64, 1, P->prec, st)))
+                                            ws + P->p0_off, nullptr, (size_t)P->B * P->PH0 * P->PW0, 64, 1, P->prec, st)))
       return rc;
   } else
   {  // stem: conv7x7/2 -> BN stats -> fused BN+ReLU+maxpool
@@ -440,7 +447,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     // (forward only: nobody scatters a gradient through the pooling windows - the argmax codes are not produced)
     if ((rc = ph_bn_relu_maxpool_launch(ws + u.y_off, c.stat(u, 2), c.stat(u, 3), ws + P->p0_off,
                                         (flags & 4) ? nullptr : ws + P->idx_off, (flags & 4) ? nullptr : ws + P->p0raw_off,
-                                        P->B, u.OH, u.OW, 64, P->prec, st)))
+                                        hp ? ws + P->blocks[0].in32_off : nullptr, P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
   }
   // conv2 of every block is 3x3 / stride 1 with Cin = Cout in {64, 128, 256, 512}: always a second-generation kernel in perf mode
@@ -459,7 +466,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
       if ((rc = conv_fwd(c, b.u2, ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3)))) return rc;
     } else {
       if ((rc = ph_bn_apply_launch(ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3), nullptr, nullptr, nullptr, nullptr,
-                                   ws + b.a1_off, npix, b.Cout, 1, P->prec, st)))
+                                   ws + b.a1_off, nullptr, npix, b.Cout, 1, P->prec, st)))
         return rc;
       if ((rc = conv_fwd(c, b.u2, ws + b.a1_off))) return rc;
     }
@@ -467,16 +474,16 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
       const Unit& ud = P->units[b.uds];
       if ((rc = conv_fwd(c, b.uds, ws + b.in_off))) return rc;
       rc = ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + ud.y_off, c.stat(ud, 2),
-                              c.stat(ud, 3), ws + b.out_off, npix, b.Cout, 1, P->prec, st);
+                              c.stat(ud, 3), ws + b.out_off, hp ? ws + b.out32_off : nullptr, npix, b.Cout, 1, P->prec, st);
     } else {
       rc = raw_in ? ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + b.in_off, c.stat(u0, 2),
-                                       c.stat(u0, 3), ws + b.out_off, npix, b.Cout, 3, P->prec, st)
-                  : ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), ws + b.in_off, nullptr, nullptr, nullptr,
-                                       ws + b.out_off, npix, b.Cout, 1, P->prec, st);
+                                       c.stat(u0, 3), ws + b.out_off, nullptr, npix, b.Cout, 3, P->prec, st)
+                  : ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), ws + b.in32_off, nullptr, nullptr, nullptr,
+                                       ws + b.out_off, hp ? ws + b.out32_off : nullptr, npix, b.Cout, 1, P->prec, st);
     }
     if (rc) return rc;
-    if (bi == 5 && f3) { if ((rc = ph_avgpool_launch(ws + b.out_off, f3, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
-    if (bi == 7 && f4) { if ((rc = ph_avgpool_launch(ws + b.out_off, f4, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
+    if (bi == 5 && f3) { if ((rc = ph_avgpool_launch(ws + b.out32_off, f3, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
+    if (bi == 7 && f4) { if ((rc = ph_avgpool_launch(ws + b.out32_off, f4, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
   }
   return PH_OK;
 }
@@ -630,7 +637,7 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   for (int bi = bi_hi; bi >= bi_lo; --bi) {
     const Block& b = P->blocks[bi];
     if (bi == 5 && g_f3) PH_STAGE(ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st));
-    const void* out = ws + b.out_off;
+    const void* out = ws + b.out32_off;      // (ReLU masks: the tensor as the elementwise passes read it)
     const void* a1 = ws + b.a1_off;
     const void* xin = ws + b.in_off;
     // bn2 <- d_out * (out > 0)
