@@ -524,7 +524,7 @@ struct SideRes {
   // A backward call holds one block of EV_BLOCK events until the work it enqueued has run: `done[b]` is recorded on the
   // caller's stream when the call returns and the block is handed out again only once that event has completed.  A call made
   // inside a stream capture frees its block at once (the capture turns its event waits into graph edges and keeps no
-  // reference to the events) and only takes blocks that are known to be free (no event queries while a capture runs).
+  // reference to the events).
   hipEvent_t done[16];
   bool busy[16];
   size_t cursor = 0;
@@ -585,8 +585,13 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     for (size_t i = 0; i < EV_BLOCKS && ev_blk < 0; ++i) {
       const size_t b = (sr->cursor + i) % EV_BLOCKS;
       if (!sr->busy[b]) ev_blk = (int)b;
-      else if (!capturing && hipEventQuery(sr->done[b]) == hipSuccess) { sr->busy[b] = false; ev_blk = (int)b; }
     }
+    // none known free: ask the `done` events (recorded outside any capture, so the query is legal while `st` captures)
+    for (size_t i = 0; i < EV_BLOCKS && ev_blk < 0; ++i) {
+      const size_t b = (sr->cursor + i) % EV_BLOCKS;
+      if (hipEventQuery(sr->done[b]) == hipSuccess) { sr->busy[b] = false; ev_blk = (int)b; }
+    }
+    (void)hipGetLastError();      // (hipErrorNotReady of a pending block is not an error of this call)
     if (ev_blk < 0) return PH_EBUSY;
     sr->busy[ev_blk] = true;      // (claimed; released below)
     sr->cursor = (size_t)ev_blk + 1;
