@@ -74,7 +74,7 @@ def make_batch(B, H, n_data, opt, device, seed):
     return ((d(x_path), d(ema_x_path)), d(z), d(x_omic), d(z), d(z), d(grade), d(index), d(sample_idx))
 
 
-def cpu_baseline(nsteps=10, faithful_steps=3):
+def cpu_baseline(nsteps=10, faithful_steps=3, like_steps=2):
     """The CPU oracle (a port of the reference's algorithm, pinned to it by tests/test_oracle_golden.py) timed on
     this host for BASELINE config 1 (B=16, 224x224), 3 fwd + 1 bwd ("minimal") mode.  Threads are capped at 16:
     at B=16 torch's CPU kernels stop scaling there (with all 256 host threads of the GPU box the same step takes
@@ -94,6 +94,16 @@ def cpu_baseline(nsteps=10, faithful_steps=3):
            "sample": f"{nsteps} distill steps of BASELINE config 1 (B=16, 224x224, 320-d omic, fp32, 3 fwd + 1 bwd), "
                      f"{dt:.2f} s/step after 1 warm-up; NOT comparable per tile with the GPU figure (224x224 fp32 tiles "
                      f"against 512x512 bf16 tiles: 5.2x the FLOPs each)"}
+    if like_steps > 0:
+        # the GPU workload's tile size on the CPU: B = 16 tiles of 512 x 512 (5.2x the FLOPs of a 224 x 224 tile), same step
+        orc.step(synthetic_batch(16, 512, seed=70))
+        t0 = time.time()
+        for i in range(like_steps):
+            orc.step(synthetic_batch(16, 512, seed=71 + i))
+        dtl = (time.time() - t0) / like_steps
+        res["like_for_like"] = {"value": round(16.0 / dtl, 3), "unit": "tiles/s", "cores": cores,
+                                "sample": f"{like_steps} distill steps at the GPU workload's tile size (B=16, 512x512, fp32, 3 fwd + 1 bwd), "
+                                          f"{dtl:.2f} s/step after 1 warm-up: comparable per tile with the headline value"}
     if faithful_steps > 0:
         # what the reference executes: AEKD_loss runs one FULL backward per loss (train_test_path_multi_distill.py:49-56),
         # 3 forwards + 6 backwards per step for the same numbers
@@ -355,11 +365,20 @@ def stub_main(args):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    comm = None
+    if world > 1:
+        sys.path.insert(0, os.path.join(ROOT, "multimodal-learning_amd"))
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ph_dist", os.path.join(ROOT, "multimodal-learning_amd", "dist.py"))
+        pd = importlib.util.module_from_spec(spec); spec.loader.exec_module(pd)
+        comm = pd.comm_report(pd.ReplicaSync(), None, "gloo")      # every rank takes part
+        comm["launch"] = os.environ.get("PH_BENCH_LAUNCH", "external launcher")
     if rank == 0:
         print(json.dumps({"metric": "stub", "value": round(args.batch * world * args.steps / dt, 2), "unit": "tiles/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "stub",
-                          "sum": y.item(), "config": {"workload": "launcher self-test (CPU, gloo, stand-in step)",
-                                                      "launch": os.environ.get("PH_BENCH_LAUNCH", "external launcher")}}), flush=True)
+                          "sum": y.item(), "comm": comm,
+                          "config": {"workload": "launcher self-test (CPU, gloo, stand-in step)",
+                                     "launch": os.environ.get("PH_BENCH_LAUNCH", "external launcher")}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -380,6 +399,7 @@ def main():
     ap.add_argument("--north-star", action="store_true",
                     help="N = 1: batch 256 on one GPU - the single-GPU roofline point of the north-star (BASELINE.json)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the extra bf16x6 (parity arithmetic) measurement")
+    ap.add_argument("--no-north-star-block", action="store_true", help="skip the extra batch-256 single-GPU measurement (`north_star_b256`)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the extra global-batch-256 (configs[2]) measurement")
     ap.add_argument("--strong-batch", type=int, default=0,
                     help="testing aid: run the extra strong-scaling measurement with this many tiles per GPU whatever N is")
@@ -493,6 +513,10 @@ def main():
     step = m.DistillStep(opt, n_data, device=device, sync=sync)
     for crd in (step.criterion_kd, step.criterion_kd_path):
         crd.contrast.verbose = False
+    if sync is not None:
+        # phase markers inside the step (ph_prof_stamp, also inside the replayed graph): 5 = the trunk backward is done and
+        # the remaining gradient all-reduce is waited for, 10 = all gradients reduced (the `comm` object below)
+        step._stamps = torch.zeros(16, dtype=torch.int64, device=device)
     if args.no_fuse:
         step.ema_model._no_fuse = True
         step.fix_model.path_net._no_fuse = True
@@ -553,9 +577,28 @@ def main():
     loss = out["loss"].item()
     if not np.isfinite(loss):
         raise SystemExit("non-finite loss in benchmark: %r" % loss)
+    comm = None
+    if sync is not None:
+        # what the communicator saw (every rank takes part): ranks that joined an all-reduce, one PCI device per rank, and
+        # from the step's own markers the exposed part of the gradient all-reduce in the last timed step (max over ranks)
+        comm = m.dist.comm_report(sync, device, os.environ.get("PH_BENCH_BACKEND", "nccl"))
+        st_ = step._stamps.cpu().numpy() if step._stamps is not None else None
+        if st_ is not None and st_[10] > st_[5] > 0:
+            t = torch.tensor([(int(st_[10]) - int(st_[5])) * 1e-5, (int(st_[6]) - int(st_[0])) * 1e-5], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            comm["exposed_grad_allreduce_ms"] = round(t[0].item(), 4)      # 100 MHz device wall clock
+            comm["step_span_ms"] = round(t[1].item(), 3)
+        nparam = step.optimizer.flat.numel
+        comm["grad_allreduce_bytes"] = int(nparam) * 4
+        comm["exchanges_per_step"] = ("bucketed all-reduce of the flat gradient buffer in two phases (layers 3-4 + heads start "
+                                      "when the backward has passed layer 3), all-gather of (index, embed_s, embed_t) rows x 2 "
+                                      "criteria, all-reduce of the 5 x 5 GK-Refine Gram, one-off all-reduce of the CRD Z sums")
+        comm["launch"] = ("eager" if args.eager else "collectives captured inside the step's HIP graph") + \
+            ("; " + os.environ["PH_BENCH_LAUNCH"] if "PH_BENCH_LAUNCH" in os.environ else "")
 
-    def extra_run(batch, prec, steps):
-        """One more measurement on a fresh step object (another per-GPU batch or another arithmetic), same protocol."""
+    def extra_run(batch, prec, steps, profile=False):
+        """One more measurement on a fresh step object (another per-GPU batch or another arithmetic), same protocol.
+        profile: also 2 one-stream eager steps under the in-library kernel timer -> (seconds, loss, per-class summary)."""
         m.set_precision(prec)
         try:
             o2 = m.stage2_opt(dropout_rate=0.1, batch_size=batch)
@@ -569,11 +612,24 @@ def main():
             l2 = o["loss"].item()
             if not np.isfinite(l2):
                 raise SystemExit("non-finite loss in the extra benchmark run: %r" % l2)
+            prof = None
+            if profile:
+                st2._want_graph = False
+                st2._side_stream = None; st2._head_side = None
+                st2.model._no_bwd_overlap = True
+                st2.step(b2[0], epoch=1)
+                L.ph_prof_reset(); L.ph_prof_enable(1)
+                for i in range(2):
+                    st2.step(b2[i % 2], epoch=1)
+                torch.cuda.synchronize()
+                L.ph_prof_enable(0)
+                prof = (ctypes.c_double * (4 * NALL))()
+                L.ph_prof_summary4(prof, NALL)
             for mod in (st2.model, st2.ema_model, st2.fix_model.path_net):
                 mod.release_workspaces()
             del st2, b2
             torch.cuda.empty_cache()
-            return d2, l2
+            return (d2, l2, prof) if profile else (d2, l2)
         finally:
             m.set_precision("bf16")
 
@@ -588,6 +644,39 @@ def main():
                   "value": round(per * world * args.steps / d2, 2), "unit": "tiles/s",
                   "ms_per_step": round(1000.0 * d2 / args.steps, 3), "tiles_per_gpu": per, "global_batch": per * world,
                   "scaling": "strong", "final_loss": round(l2, 4)}
+    ns256 = None
+    if world == 1 and not args.no_north_star_block and not args.device_loader and (args.batch, args.size) == (64, 512):
+        # the north-star's own single-GPU point in the driver-timed line: batch 256 on one MI355X, 5 graph-replayed steps,
+        # the dominant kernel's roofline from this run's own launches and its own counter traffic (profiles/r04_b256_traffic.json)
+        for mod in (step.model, step.ema_model, step.fix_model.path_net):
+            mod.release_workspaces()
+        step._slots = None; step._static = None
+        torch.cuda.empty_cache()
+        nss = 5
+        d2, l2, pr = extra_run(256, "bf16", nss, profile=True)
+        ms256 = 1000.0 * d2 / nss
+        cls_ms = {c: pr[4 * c + 1] for c in range(NALL)}
+        domc = max(list(range(NCLS)) + [MASKED_CLS] + [c for c, _ in FUSED_CLS], key=lambda c: cls_ms[c])
+        n_, ms_, fl_ = pr[4 * domc], pr[4 * domc + 1], pr[4 * domc + 2]
+        ach_ = fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+        tr_ = None
+        tf = os.path.join(ROOT, "profiles", "r04_b256_traffic.json")
+        if os.path.exists(tf):
+            try:
+                tr_ = json.load(open(tf)).get(str(domc), {}).get("bytes_per_launch")
+            except Exception:
+                tr_ = None
+        ns256 = {"workload": "north-star single-GPU point: batch 256 on 1 MI355X, 512x512, bf16, same step (BASELINE.json north_star)",
+                 "steps": nss, "ms_per_step": round(ms256, 3), "value": round(256 * nss / d2, 2), "unit": "tiles/s",
+                 "final_loss": round(l2, 4),
+                 "step_frac": round(STEP_GFLOP_PER_TILE_512 * 256 / ms256 / MFMA_BF16_PEAK_TFLOPS, 4),
+                 "roofline": {"bound": "mfma", "kernel": dict([(c, n) for c, n in [(i, CLS_NAMES[i]) for i in range(NCLS)] + [(MASKED_CLS, MASKED_NAME)] + FUSED_CLS])[domc],
+                              "launches": int(n_), "avg_launch_ms": round(ms_ / max(n_, 1), 4),
+                              "algorithmic_gflop_per_launch": round(fl_ / max(n_, 1) / 1e9, 3), "achieved": round(ach_, 2),
+                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_ / MFMA_BF16_PEAK_TFLOPS, 4),
+                              "traffic": tr_,
+                              "traffic_note": "HBM bytes per launch at B = 256 from profiles/r04_b256_traffic.json (rocprofv3 --pmc, "
+                                              "separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --north-star --serial`)"}}
     parity = None
     if world == 1 and not args.no_parity_mode and not args.device_loader:
         # the arithmetics that meet the north-star's 1e-3 tolerance (tests/test_gpu_step.py::
@@ -718,6 +807,10 @@ def main():
             step_gflop = STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2 * args.batch * world
             res["roofline"] = {"bound": "mfma", "step_frac": round(step_gflop / (1000.0 * dt / args.steps) / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        if comm is not None:
+            res["comm"] = comm
+        if ns256 is not None:
+            res["north_star_b256"] = ns256
         if strong is not None:
             res["north_star_global_256"] = strong
         if parity is not None:

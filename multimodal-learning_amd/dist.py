@@ -100,3 +100,35 @@ def shard_batch(batch, rank, world_size):
     f = lambda t: t[s] if torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == B else t
     return ((f(x_path), f(ema_x_path)), f(x_grph), f(x_omic), f(censor), f(survtime), f(grade), f(index),
             f(sample_idx))
+
+
+def comm_report(sync, device=None, backend=None):
+    """What the communicator itself observed (bench.py's `comm` object; every rank must call it): the backend and its
+    library version, the number of ranks that joined an all-reduce of ones, the PCI bus id of every rank's device (N
+    distinct ones = one process per GPU) and the bucket plan of the gradient all-reduce.  Works under gloo on CPU
+    (tests/test_dist_gloo.py)."""
+    import os
+    backend = backend or dist.get_backend(sync.group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    one = torch.ones(1, device=dev if dev.type == "cuda" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM, group=sync.group)
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        bus = getattr(pr, "pci_bus_id", None)
+        ident = ("%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), bus, getattr(pr, "pci_device_id", 0))) if bus is not None \
+            else "%s#%d" % (pr.name, dev.index)
+        ident = "%s (%s)" % (ident, getattr(pr, "uuid", ""))
+    else:
+        ident = "cpu pid %d" % os.getpid()
+    ids = [None] * sync.world_size
+    dist.all_gather_object(ids, ident, group=sync.group)
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+    return {"backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else ""), "library_version": ver,
+            "world_size": sync.world_size, "ranks_joined_all_reduce": int(round(one.item())),
+            "device_ids": ids, "distinct_devices": len(set(ids)),
+            "grad_bucket_bytes": sync.bucket_elems * 4}

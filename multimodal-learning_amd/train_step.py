@@ -482,6 +482,7 @@ class DistillStep:
             self._stamp(5)
             if self.sync is not None:
                 self.sync.all_reduce_grads(self.optimizer.flat)
+                self._stamp(10)       # stamp 5 -> 10 = the part of the gradient all-reduce the backward did not hide
             self.optimizer.step()                                                                           # :328 (+ :329 fused)
             self._stamp(6)
             o = Hc.out

@@ -193,6 +193,12 @@ def test_bench_launches_its_own_replicas_without_torchrun():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["sum"] == 2 * 64.0 ** 3
     assert res["config"]["launch"] == "self-launched"
+    # the `comm` object (dist.comm_report): what the communicator itself observed - the JSON line alone answers "did the
+    # backend see N ranks, one device each" 
+    c = res["comm"]
+    assert c["backend"].startswith("gloo") and c["world_size"] == 2 and c["ranks_joined_all_reduce"] == 2
+    assert len(c["device_ids"]) == 2 and c["distinct_devices"] == 2 and c["launch"] == "self-launched"
+    assert c["grad_bucket_bytes"] == 32 << 20
 
 
 def test_bench_launcher_falls_back_to_eager_when_the_graph_attempt_fails():

@@ -518,6 +518,50 @@ def test_distill_step_at_benchmark_size(variant):
     assert runs[0][1].item() == runs[1][1].item(), "updated student differs between two runs from the same seeds"
 
 
+def test_half_pair_arithmetic_tracks_parity_mode_at_benchmark_size():
+    """The tolerance-compliant arithmetic of the bench's `parity_mode` (fp16x3: fp16-pair operands, 3 MFMA products) against
+    the fp32-equivalent parity mode (bf16x6) at BASELINE configs[1] (64 tiles of 512 x 512, where the 4 608-term sums, the
+    1 M-pixel BatchNorm statistics and the per-tensor dz scales are at their real sizes): two steps from the same seeds,
+    logits of all three networks and every loss term within the north-star's 1e-3, the updated student within Adam's step."""
+    import multimodal_learning_amd as m
+    B, H = 64, 512
+    res = {}
+    try:
+        for mode in ("bf16x6", "fp16x3"):
+            m.set_precision(mode)
+            step, n_data, K = _variant_step("miccai2022", B, seed=5)
+            outs = []
+            for it in range(2):
+                g = torch.Generator().manual_seed(70 + it)
+                x = _images(B, H, 70 + it)
+                x2 = (x + 0.01 * torch.randn(B, 3, H, H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(80 + it))).clamp_(-1, 1)
+                index = torch.randperm(n_data, generator=g)[:B]
+                sidx = torch.randint(0, n_data, (B, K + 1), generator=g); sidx[:, 0] = index
+                z = torch.zeros(B)
+                bt = ((x, x2), z.cuda(), torch.randn(B, 320, generator=g).cuda(), z.cuda(), z.cuda(), (index % 3).cuda(), index.cuda(), sidx.cuda())
+                out = step.step(bt, epoch=1)
+                outs.append({k: out[k].detach().float().clone() for k in
+                             ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2", "logit_path", "ema_logit", "fuse_logit")})
+            torch.cuda.synchronize()
+            res[mode] = (outs, torch.cat([p.detach().flatten() for p in step.model.parameters()]).clone())
+            for net in (step.model, step.ema_model, step.fix_model.path_net):
+                net.release_workspaces()
+            del step
+            torch.cuda.empty_cache()
+    finally:
+        m.set_precision("bf16")
+    for it in range(2):
+        a, b = res["bf16x6"][0][it], res["fp16x3"][0][it]
+        for k in a:
+            assert torch.isfinite(b[k]).all(), (it, k)
+            err = (a[k] - b[k]).abs().max().item()
+            print("step %d %-12s |fp16x3 - bf16x6| %.3e  (max|ref| %.3e)" % (it, k, err, a[k].abs().max().item()))
+            assert err <= 1e-3, (it, k, err)
+    dp = (res["bf16x6"][1] - res["fp16x3"][1]).abs().max().item()
+    print("updated student parameters: max|d| %.3e" % dp)
+    assert dp <= 2e-4      # (two Adam steps of lr 5e-4: a wrong update direction shows as ~1e-3)
+
+
 def test_tsvd_stage1_step_at_config3_size():
     """BASELINE configs[3] (MIA-2022 train_test_tSVD, batch 128) at the benchmark tile size: the stage-1 step (student +
     mean-teacher PathomicNet, t-SVD constraint with 4 views, one-sided Jacobi prox at B = 128) on 128 tiles of 512 x 512
