@@ -521,45 +521,66 @@ def test_distill_step_at_benchmark_size(variant):
 def test_half_pair_arithmetic_tracks_parity_mode_at_benchmark_size():
     """The tolerance-compliant arithmetic of the bench's `parity_mode` (fp16x3: fp16-pair operands, 3 MFMA products) against
     the fp32-equivalent parity mode (bf16x6) at BASELINE configs[1] (64 tiles of 512 x 512, where the 4 608-term sums, the
-    1 M-pixel BatchNorm statistics and the per-tensor dz scales are at their real sizes): two steps from the same seeds,
-    logits of all three networks and every loss term within the north-star's 1e-3, the updated student within Adam's step."""
+    1 M-pixel BatchNorm statistics and the per-tensor dz scales are at their real sizes): one step from the same seeds -
+    logits of all three networks and every loss term within the north-star's 1e-3, the student's gradients (first layer to
+    head, through 20 train-mode BatchNorms and every dz scale) within 1e-2 in relative L2: the GK-Refine weights that multiply
+    the four distillation losses are cosines of DIFFERENCES of student and teacher probabilities and turn the 1e-5 logit
+    difference of the two arithmetics into ~1e-3 of every gradient, head included (the kernels themselves are held to ~1e-6
+    by tests/test_gpu_conv.py and, stage by stage on the reference's golden, by tests/test_gpu_step.py).  (A second step is not compared:
+    from zero Adam moments the first update is lr * sign(g), which turns rounding differences of near-zero gradient entries
+    into +-lr parameter differences - the regime tests/test_gpu_step.py::test_two_steps_from_mid_training_state avoids.)"""
     import multimodal_learning_amd as m
     B, H = 64, 512
+    watch = ("conv1.weight", "layer1.1.conv2.weight", "layer2.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.bn1.weight",
+             "layer4.1.conv2.weight", "fc_new1.0.weight", "fc_new2.weight")
     res = {}
     try:
         for mode in ("bf16x6", "fp16x3"):
             m.set_precision(mode)
             step, n_data, K = _variant_step("miccai2022", B, seed=5)
-            outs = []
-            for it in range(2):
-                g = torch.Generator().manual_seed(70 + it)
-                x = _images(B, H, 70 + it)
-                x2 = (x + 0.01 * torch.randn(B, 3, H, H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(80 + it))).clamp_(-1, 1)
-                index = torch.randperm(n_data, generator=g)[:B]
-                sidx = torch.randint(0, n_data, (B, K + 1), generator=g); sidx[:, 0] = index
-                z = torch.zeros(B)
-                bt = ((x, x2), z.cuda(), torch.randn(B, 320, generator=g).cuda(), z.cuda(), z.cuda(), (index % 3).cuda(), index.cuda(), sidx.cuda())
-                out = step.step(bt, epoch=1)
-                outs.append({k: out[k].detach().float().clone() for k in
-                             ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2", "logit_path", "ema_logit", "fuse_logit")})
+            named = dict(step.model.named_parameters())
+            grads = {}
+            orig = step.optimizer.step
+
+            def spy(*a, **k):
+                if not grads:
+                    for kk in watch:
+                        grads[kk] = named[kk].grad.detach().clone()
+                return orig(*a, **k)
+            step.optimizer.step = spy
+            g = torch.Generator().manual_seed(70)
+            x = _images(B, H, 70)
+            x2 = (x + 0.01 * torch.randn(B, 3, H, H, device="cuda", generator=torch.Generator(device="cuda").manual_seed(80))).clamp_(-1, 1)
+            index = torch.randperm(n_data, generator=g)[:B]
+            sidx = torch.randint(0, n_data, (B, K + 1), generator=g); sidx[:, 0] = index
+            z = torch.zeros(B)
+            bt = ((x, x2), z.cuda(), torch.randn(B, 320, generator=g).cuda(), z.cuda(), z.cuda(), (index % 3).cuda(), index.cuda(), sidx.cuda())
+            out = step.step(bt, epoch=1)
             torch.cuda.synchronize()
-            res[mode] = (outs, torch.cat([p.detach().flatten() for p in step.model.parameters()]).clone())
+            res[mode] = ({k: out[k].detach().float().clone() for k in
+                          ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1", "loss_kd2", "logit_path", "ema_logit", "fuse_logit",
+                           "scale")}, grads)
             for net in (step.model, step.ema_model, step.fix_model.path_net):
                 net.release_workspaces()
-            del step
+            del step, named
             torch.cuda.empty_cache()
     finally:
         m.set_precision("bf16")
-    for it in range(2):
-        a, b = res["bf16x6"][0][it], res["fp16x3"][0][it]
-        for k in a:
-            assert torch.isfinite(b[k]).all(), (it, k)
-            err = (a[k] - b[k]).abs().max().item()
-            print("step %d %-12s |fp16x3 - bf16x6| %.3e  (max|ref| %.3e)" % (it, k, err, a[k].abs().max().item()))
-            assert err <= 1e-3, (it, k, err)
-    dp = (res["bf16x6"][1] - res["fp16x3"][1]).abs().max().item()
-    print("updated student parameters: max|d| %.3e" % dp)
-    assert dp <= 2e-4      # (two Adam steps of lr 5e-4: a wrong update direction shows as ~1e-3)
+    a, b = res["bf16x6"][0], res["fp16x3"][0]
+    for k in a:
+        assert torch.isfinite(b[k]).all(), k
+        err = (a[k] - b[k]).abs().max().item()
+        print("%-12s |fp16x3 - bf16x6| %.3e  (max|ref| %.3e)" % (k, err, a[k].abs().max().item()))
+        assert err <= (1e-2 if k == "scale" else 1e-3), (k, err)
+    bad = []
+    for k in watch:
+        ga, gb = res["bf16x6"][1][k], res["fp16x3"][1][k]
+        err, mx = (ga - gb).abs().max().item(), ga.abs().max().item()
+        l2 = ((ga - gb).double().norm() / ga.double().norm()).item()
+        print("grad %-30s |fp16x3 - bf16x6| %.3e  (max|ref| %.3e, rel %.1e, rel L2 %.1e)" % (k, err, mx, err / mx, l2))
+        if not (torch.isfinite(gb).all() and l2 <= 1e-2):
+            bad.append(k)
+    assert not bad, bad
 
 
 def test_tsvd_stage1_step_at_config3_size():
