@@ -23,6 +23,7 @@
 // Same GEMM view, LDS image and epilogue semantics as conv_tap.hip (PhTapConv; forward and stride-1 dgrad with the
 // fused residual mask; per-tile BatchNorm partial sums).  Workgroup tile: (8*WM) x 16 pixels x (64*WN) channels.
 #include "ph_common.h"
+#include <cstdlib>
 #include <type_traits>
 #include "ph_kernels.h"
 #include "tap_common.h"
@@ -1218,6 +1219,15 @@ int launch2(const PhTapConv& p, hipStream_t st) {
 
 }  // namespace
 
+// A/B and test switch between the second- and third-generation dense kernels: PH_TAP3=0 in the environment, or
+// ph_debug_set_tap3() at run time (not part of the public C-ABI).  set < 0: query.
+int ph_tap3_switch(int set) {
+  static int on = [] { const char* e = getenv("PH_TAP3"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (set >= 0) on = set ? 1 : 0;
+  return on;
+}
+extern "C" int ph_debug_set_tap3(int on) { return ph_tap3_switch(on ? 1 : 0); }
+
 // ---- stride-2 3x3 convolutions as MASKED stride-1 tap grids (PhTapConv::m_*).  Both fill the tap-grid part of a
 // descriptor whose tensors / batch / channel fields the caller has set (forward: in = x [B][IH][IW][Cin], Cin / Cout of
 // the convolution; dgrad: in = dy [B][OH][OW][Cout_fwd], t->Cin = Cout_fwd, t->Cout = Cin_fwd, OH / OW of dx) and
@@ -1277,7 +1287,10 @@ int ph_tapconv2_stat_parts(const PhTapConv* p) {
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
   if (p->in_scale && (!p->in_shift || p->Cin > 512)) return PH_EINVAL;
   if (p->m_groups) return (p->Cout % 128 == 0 && !p->in_scale) ? launch2<2, 2, 4, false, true>(*p, st) : PH_EINVAL;
-  if (p->Cout % 128 == 0) return launch2<2, 2, 4, false>(*p, st);
+  if (p->Cout % 128 == 0) {
+    if (ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv3_launch(p, st);
+    return launch2<2, 2, 4, false>(*p, st);
+  }
 #ifdef PH_L1_ONE_GROUP   // A/B build: the one-wave-per-SIMD resident-weights configuration
   return launch2<4, 1, 2, true>(*p, st);
 #else

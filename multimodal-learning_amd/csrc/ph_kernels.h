@@ -77,6 +77,11 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec);
 int ph_tapconv2_tile_h(const PhTapConv* p, int S, int prec);
 int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st);
 int ph_tapconv2_stat_parts(const PhTapConv* p);   // one BatchNorm partial row per persistent workgroup
+// third-generation dense 3x3 stride-1 kernel (conv_tap3.hip: 16x16x32 fragments, 8-byte stores); PH_TAP3=0 in the environment
+// keeps the second-generation kernel (same-box A/B)
+int ph_tap3_switch(int set);
+bool ph_tapconv3_eligible(const PhTapConv* p);
+int ph_tapconv3_launch(const PhTapConv* p, hipStream_t st);
 // stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
 bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 
