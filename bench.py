@@ -58,6 +58,84 @@ HBM_PEAK_GBS = 8000.0            # HBM3E peak (6290 GB/s measured with a float4 
 STEP_GFLOP_PER_TILE_512 = 93.52
 
 
+def hbm_ledger(B, H, es=2):
+    """Algorithmic HBM bytes of ONE distillation step in perf mode, tensor by tensor, as the data flow of csrc/resnet_plan.hip
+    defines it (every tensor a launch must read or write counted once per launch; weights, BatchNorm vectors and the heads /
+    losses / optimiser are listed separately).  `es` = bytes per activation element (2 in perf mode).  Train-mode BatchNorm
+    needs the batch statistics of a whole conv output before any consumer can normalise it, so every conv output is written
+    raw and read again - that, not the convolutions, is what makes the step HBM-heavy.  Returns {category: bytes}."""
+    led = {}
+
+    def add(k, v):
+        led[k] = led.get(k, 0.0) + float(v)
+    OH = H // 2
+    P = OH // 2
+    act = lambda c, h: B * c * h * h * es      # noqa: E731
+    layers = [(64, 64, P, 1), (64, 128, P // 2, 2), (128, 256, P // 4, 2), (256, 512, P // 8, 2)]      # Cin, Cout, OH, stride of block 0
+    wbytes = 0
+    for net in ("student", "ema", "teacher"):
+        train = net == "student"
+        if net != "teacher":
+            add("pack_input", B * 3 * H * H * 4 + B * H * H * 4 * es)      # the student and the teacher share one packed image
+        x4 = B * H * H * 4 * es
+        if train:
+            add("stem conv", x4 + act(64, OH))
+            add("stem bn+relu+maxpool", act(64, OH) + act(64, P) * 2 + B * 64 * P * P)      # + arg codes (1 B) + conv output at the arg-max
+        else:
+            add("stem conv with pooled epilogue", x4 + act(64, P))
+        for li, (cin, cout, oh, stride) in enumerate(layers):
+            ih = oh * stride
+            for bi in range(2):
+                c_in = cin if bi == 0 else cout
+                h_in = ih if bi == 0 else oh
+                add("conv forward (in + out)", act(c_in, h_in) + act(cout, oh))                    # conv1
+                fused_a1 = (not train) and cout <= 128
+                if not fused_a1:
+                    add("bn_apply a1", 2 * act(cout, oh))
+                add("conv forward (in + out)", 2 * act(cout, oh))                                 # conv2
+                if bi == 0 and stride == 2:
+                    add("conv forward (in + out)", act(c_in, h_in) / 4 + act(cout, oh))           # 1x1 / 2 downsample
+                add("bn_apply block output", 3 * act(cout, oh))                                   # y2 + shortcut -> out
+        add("avgpool", act(256, P // 4) + act(512, P // 8))
+    # student backward
+    for li, (cin, cout, oh, stride) in enumerate(layers):
+        ih = oh * stride
+        for bi in range(2):
+            c_in = cin if bi == 0 else cout
+            h_in = ih if bi == 0 else oh
+            a, ai = act(cout, oh), act(c_in, h_in)
+            add("bn backward (reduce + apply)", 3 * a + 4 * a)                                    # bn2: g, out, y2 | + dz
+            add("conv wgrad (x + dz + slab)", 2 * a + 2 * 37.7e6)
+            add("conv dgrad (dz + dx [+ residual])", 2 * a)
+            add("bn backward (reduce + apply)", 2 * a + 3 * a)                                    # bn1: mask re-derived from y1
+            add("conv wgrad (x + dz + slab)", ai + a + 2 * 37.7e6)
+            add("conv dgrad (dz + dx [+ residual])", a + ai + (2 * ai if not (bi == 0 and stride == 2) else 0))
+            if bi == 0 and stride == 2:
+                add("bn backward (reduce + apply)", 3 * a + 4 * a)
+                add("conv wgrad (x + dz + slab)", ai / 4 + a + 2 * 37.7e6 / 9)
+                add("conv dgrad (dz + dx [+ residual])", a + 2 * ai)
+    add("avgpool backward", act(512, P // 8) + 2 * act(256, P // 4))
+    add("stem backward (pool scatter + bn + wgrad)", 2 * act(64, P) * 2 + B * 64 * P * P * 4 + 2 * act(64, OH) + act(64, OH) + B * H * H * 4 * es + 2 * 29e6)
+    nparam = 11.18e6 + 0.05e6
+    add("weights: packing (3 networks x fwd + student dgrad layouts)", 3 * nparam * 4 + (3 + 1) * nparam * 2 + 4 * nparam * 2 * 2)
+    add("adam + ema (28 B + 8 B per parameter)", nparam * 36)
+    add("heads, fusion, losses, CRD bank rows (n_data 1024)", 2 * 2 * B * 1000 * 512 + 2 * 2 * B * 532 * 512 + 30e6)
+    return led
+
+
+def _counter_step_gb():
+    """HBM bytes of one whole step from the PMC counters (profiles/summarize.py writes `step_total_bytes` into the traffic file)."""
+    for tname in ("r04_traffic.json",):
+        tf = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(tf):
+            try:
+                v = json.load(open(tf)).get("step_total_bytes")
+                return None if v is None else round(v / 1e9, 2)
+            except Exception:
+                return None
+    return None
+
+
 def make_batch(B, H, n_data, opt, device, seed):
     import torch
     g = torch.Generator(device="cpu")
@@ -756,7 +834,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = None
             tname = None
-            for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            for tname in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 tf = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tf):
                     try:
@@ -794,6 +872,17 @@ def main():
                                "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                                "step_frac": round(step_tflops / world / MFMA_BF16_PEAK_TFLOPS, 4),
                                "step_tflops_per_gpu": round(step_tflops / world, 1),
+                               "step_hbm": (lambda led: {"algorithmic_gb_per_step": round(sum(led.values()) / 1e9, 2),
+                                                         "achieved_gbs": round(sum(led.values()) / (dt / args.steps) / 1e9, 1),
+                                                         "peak_gbs": HBM_PEAK_GBS,
+                                                         "frac": round(sum(led.values()) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                                         "counter_gb_per_step": _counter_step_gb(),
+                                                         "ledger_gb": {k: round(v / 1e9, 3) for k, v in sorted(led.items(), key=lambda kv: -kv[1])},
+                                                         "note": "per-tensor algorithmic HBM bytes of one step (bench.py: hbm_ledger) / ms_per_step / 8 TB/s - "
+                                                                 "the step's real bound: train-mode BatchNorm makes every conv output travel "
+                                                                 "to HBM and back; counter_gb_per_step: FETCH_SIZE x 2 + WRITE_SIZE over all "
+                                                                 "kernels of one step (profiles/r04_traffic.json, null until collected)"})(
+                                   hbm_ledger(args.batch, args.size)) if args.precision == "bf16" else None,
                                "step_note": "whole step: %.2f GFLOP per tile (3 ResNet-18 forwards + 1 backward, SURVEY 8-d) x tiles / "
                                             "ms_per_step / 2500 TFLOP/s; the reference executes 276.8 GFLOP per tile for the same "
                                             "numbers (6 backward passes)" % (STEP_GFLOP_PER_TILE_512 * (args.size / 512.0) ** 2),

@@ -25,6 +25,8 @@ def short(k):
 def cls_of(name):
     """kernel name -> class index of ph_prof_summary / bench.py CLS_NAMES"""
     n = name
+    if "tapconv3_kernel" in n:      # third-generation dense 3x3 kernel (conv_tap3.hip): the same launches as class 6
+        return 6
     if "tapconv2_l1_kernel" in n:   # layer 1 (Cin = Cout = 64): two wave groups, resident weights
         return 7
     if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel, Cout >= 128; <..., true>: masked stride-2 grid
@@ -133,6 +135,15 @@ def main():
             traffic[str(c)] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(ww),
                                "bytes_per_launch": round(rd + ww), "launches_sampled": nf}
             lines.append(f"class {c}: read {rd/1e6:9.2f} MB  write {ww/1e6:9.2f} MB  per launch ({nf} launches)")
+        # whole-step total over ALL kernels of the profiled run (bench.py --steps 3 --warmup 3 --eager: 6 steps; the few
+        # initialisation kernels in front of them are negligible beside 6 x ~35 GB)
+        nsteps = 6
+        tot_r = sum(2.0 * d.get("FETCH_SIZE", 0.0) * 1024 for d in fa.values())
+        tot_w = sum(d.get("WRITE_SIZE", 0.0) * 1024 for d in wa.values())
+        traffic["step_total_bytes"] = round((tot_r + tot_w) / nsteps)
+        traffic["step_read_bytes"] = round(tot_r / nsteps)
+        traffic["step_write_bytes"] = round(tot_w / nsteps)
+        lines.append(f"whole step (all kernels / {nsteps} steps): read {tot_r/nsteps/1e9:.2f} GB  write {tot_w/nsteps/1e9:.2f} GB")
         json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
         open(os.path.join(out, f"{tag}_traffic.txt"), "w").write(
             "# HBM traffic per launch (FETCH_SIZE x2 correction, WRITE_SIZE exact; separate --pmc passes)\n" + "\n".join(lines) + "\n")
