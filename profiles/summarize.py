@@ -74,7 +74,9 @@ def main():
     # ---- kernel stats: the one-stream run (per-kernel durations) and the product run (three forward streams, weight
     # gradients beside the BatchNorm-backward passes: a launch's wall duration includes time it shares the chip)
     for sub, suffix, cmd in (("stats", "", "python3 bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
-                             ("stats_concurrent", "_concurrent", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants")):
+                             ("stats_concurrent", "_concurrent", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
+                             ("stats_b256", "_b256", "python3 bench.py --north-star --serial --steps 5 --warmup 3 ... (batch 256 on one GPU)"),
+                             ("stats_fp16x3", "_fp16x3", "python3 bench.py --precision fp16x3 --serial --steps 5 --warmup 3 ... (the tolerance-compliant arithmetic)")):
         f = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
         if not f:
             continue
@@ -147,6 +149,28 @@ def main():
         json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
         open(os.path.join(out, f"{tag}_traffic.txt"), "w").write(
             "# HBM traffic per launch (FETCH_SIZE x2 correction, WRITE_SIZE exact; separate --pmc passes)\n" + "\n".join(lines) + "\n")
+    # ---- the same at batch 256 (the north-star's single-GPU point): profiles/<tag>_b256_traffic.json
+    ff = glob.glob(os.path.join(src, "fetch_b256", "*", "*counter_collection.csv"))
+    fw = glob.glob(os.path.join(src, "write_b256", "*", "*counter_collection.csv"))
+    if ff and fw:
+        fa, fc = load_pmc(ff[0])
+        wa, wc = load_pmc(fw[0])
+        traffic = {}
+        per = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
+        for k in fa:
+            c = cls_of(k)
+            if c is not None:
+                per[c][0] += fa[k].get("FETCH_SIZE", 0.0); per[c][2] += fc[k]
+        for k in wa:
+            c = cls_of(k)
+            if c is not None:
+                per[c][1] += wa[k].get("WRITE_SIZE", 0.0); per[c][3] += wc[k]
+        for c, (fe, wr, nf, nw) in sorted(per.items()):
+            rd = 2.0 * fe * 1024 / max(nf, 1)
+            ww = wr * 1024 / max(nw, 1)
+            traffic[str(c)] = {"read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(ww),
+                               "bytes_per_launch": round(rd + ww), "launches_sampled": nf}
+        json.dump(traffic, open(os.path.join(out, f"{tag}_b256_traffic.json"), "w"), indent=1)
     # ---- L2 (TCC) view per MFMA kernel class: hit rate and fabric read requests
     ft = glob.glob(os.path.join(src, "tcc", "*", "*counter_collection.csv"))
     if ft:
