@@ -512,6 +512,8 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_stat_parts(p);
+  // (half-pair mode on the third-generation kernel: one partial row per persistent workgroup, like the second generation)
+  if (prec == PH_PREC_FP16X3 && S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv2_stat_parts(p);
   const bool perf_cfg = prec == PH_PREC_BF16 || prec == PH_PREC_FP16X3;
   const int TH = (S == 1) ? ((p->Cout % 128 == 0 && !perf_cfg) ? 8 : 16) : (perf_cfg ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
@@ -522,7 +524,11 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
   if (p->in_scale || p->m_groups) return PH_EINVAL;   // in-LDS BatchNorm + ReLU / masked tap grids: second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
-  if (prec == PH_PREC_FP16X3) return launch_T<hp16>(*p, S, st);
+  if (prec == PH_PREC_FP16X3) {
+    // dense 3x3 stride-1, Cout % 128 == 0: the third-generation kernel's half-pair form (conv_tap3.hip)
+    if (S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv3_launch_hp(p, st);
+    return launch_T<hp16>(*p, S, st);
+  }
   if (PH_IS_SPLIT_PREC(prec)) {
     PhTapConv q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;

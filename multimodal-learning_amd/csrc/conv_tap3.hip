@@ -83,12 +83,19 @@ __device__ __forceinline__ int a3_off(int hr, int hc, int c) {
   return (Tap3Cfg::HPW / 2 * hr + (hc >> 1)) * 256 + ((hc & 1) << 7) + ((c ^ (((hc >> 1) & 3) << 1)) << 4);
 }
 
-template <bool FUSE_IN>
+// HPM: the half-pair arithmetic (PH_PREC_FP16X3, ph_common.h): `in` is an fp16-pair tensor (per 64-channel slice a 128-B line
+// of hi values and one of lo values: element strides x 2), the weights hold per slice the fp16 blocks [hi 2^11 | lo | hi], the K
+// loop walks 3 Cin / 64 (A block, W block) pairs (x hi, w hi 2^11), (x hi, w lo), (x lo, w hi) on v_mfma_f32_16x16x32_f16 and the
+// epilogue stores fp32: four consecutive channels of a lane = one 16-byte store, 256 contiguous bytes per pixel.
+template <bool FUSE_IN, bool HPM = false>
 __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
+  static_assert(!(FUSE_IN && HPM), "the in-LDS BatchNorm + ReLU is a perf-mode feature");
   using C = Tap3Cfg;
   constexpr int NM = C::NM, NN = C::NN, TH = C::TH, TW = C::TW, BNT = C::BNT, HPW = C::HPW, HP = C::HP, NTAPS = C::NTAPS;
   constexpr int WN = C::WN, WM = C::WM, NTH = C::NTH, B_BASE = C::B_BASE;
-  typedef __bf16 T;
+  typedef __bf16 T;                    // (2-byte operand element: bf16, or fp16 in the half-pair mode)
+  typedef typename std::conditional<HPM, float, __bf16>::type TO;      // output / residual element
+  constexpr int EW = HPM ? 2 : 1;      // operand elements per input element
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(lds_uchar*)smem;
 
@@ -100,10 +107,14 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
   const int tiles_sp = tiles_w * ((p.OHt + TH - 1) / TH);
   const int nblk = p.Cout / BNT;
   const int total = tiles_sp * nblk * p.B;
-  const long pix_st = p.in_pix_stride ? p.in_pix_stride : p.Cin;
-  const long row_st = p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin;
-  const long img_st = p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin;
+  const long pix_st = (p.in_pix_stride ? p.in_pix_stride : p.Cin) * EW;
+  const long row_st = (p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin) * EW;
+  const long img_st = (p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin) * EW;
   const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
+  const int wK = HPM ? 3 * p.Cin : p.Cin;      // K extent of a packed weight row
+  // slice -> element offset of its A block inside a pixel record (half-pair: slices 3c, 3c+1, 3c+2 read the blocks hi, hi, lo
+  // of 64-channel group c); its W block is columns 64 sl .. of the weight row
+  auto slice_a = [&](int sl) -> long { return HPM ? (long)((sl / 3) * 128 + ((sl % 3 == 2) ? 64 : 0)) : (long)(sl << 6); };
 
   // ---- tile list (as tapconv2_kernel): linear tile id -> (spatial tile fastest, Cout block, image), XCD-contiguous
   struct TileCtx { int r0, c0, n0, b, iy_base, ix_base; const T* in; };
@@ -147,10 +158,10 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     const int t = ((int)blockIdx.x & 7) * per_xcd + local;
     return (local < per_xcd && t < total) ? t : -1;
   };
-  const int nslices = p.Cin >> 6;      // even (the launcher checks): the A buffer index is compile-time inside a slice pair
+  const int nslices = (p.Cin >> 6) * (HPM ? 3 : 1);      // even (the launcher checks): the A buffer index is compile-time inside a slice pair
 
   // weight slab of tap t = wtap[0] + t * (wtap[1] - wtap[0]) (the launcher checks: forward 0, 1, .., 8; dgrad 8, 7, .., 0)
-  const long slab_bytes = (long)p.Cout * p.Cin * 2;
+  const long slab_bytes = (long)p.Cout * wK * 2;
   const long wtap0 = (long)p.wtap[0] * slab_bytes, wtap_step = (long)(p.wtap[1] - p.wtap[0]) * slab_bytes;
 
   // ---- per-lane DMA sources.  Weights: piece (wave * NBE + e) of a tap block covers LDS rows 8 q .. 8 q + 7; LDS row R of
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     const int rp = (wave * C::NBE + e) * 4 + (lane >> 4), u = (lane & 15) ^ (rp & PH_SWZ_MASK);
     const int R = 2 * rp + (u >> 3);
     const int ch = (R & 64) | ((R & 15) << 2) | ((R >> 4) & 3);
-    wb_off[e] = (ch * p.Cin + (u & 7) * 8) * 2;
+    wb_off[e] = (ch * wK + (u & 7) * 8) * 2;
   }
   // halo piece h = wave + 4 e covers row pairs 4 h .. 4 h + 3 of the image; lane l fills slot l & 15 of row pair rp = 4 h + (l >> 4):
   // halo row rp / 9, column 2 (rp % 9) + (slot >> 3), chunk (slot & 7) ^ T(column)
@@ -283,18 +294,50 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     constexpr int RM = decltype(rmc)::value;
     const size_t img = (size_t)tc.b * p.OH * p.OW * p.Cout;
     // per-image base pointers are wave-uniform; the per-lane part is a 32-bit element offset (one image < 2^31 elements)
-    T* out = reinterpret_cast<T*>(p.out) + img;
-    const T* resg = reinterpret_cast<const T*>(p.res_g) + img;
-    const T* resa = reinterpret_cast<const T*>(p.res_a) + img;
+    TO* out = reinterpret_cast<TO*>(p.out) + img;
+    const TO* resg = reinterpret_cast<const TO*>(p.res_g) + img;
+    const TO* resa = reinterpret_cast<const TO*>(p.res_a) + img;
     const unsigned chan = (unsigned)(tc.n0 + wn * 64 + 4 * li);
     const unsigned colstep = (unsigned)(p.os * p.Cout);
     // element offset of (tile row 0 of this wave, column 4 lg) - rows advance by rowstep, columns by colstep
     const unsigned o00 = (unsigned)(((tc.r0 + wm * NM) * p.os + p.oa_h) * p.OW + (tc.c0 + 4 * lg) * p.os + p.oa_w) * (unsigned)p.Cout + chan;
     const unsigned rowstep = (unsigned)(p.os * p.OW * p.Cout);
+    const float osc = HPM ? PH_HP_LO_INV * (p.in_unscale ? p.in_unscale[1] : 1.f) : 1.f;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       const int r = tc.r0 + wm * NM + m;
       const unsigned orow = o00 + (unsigned)m * rowstep;
+      if constexpr (HPM) {
+        // fp32 output: accumulators x 2^-11 (the W blocks' scaling) x the dz tensor's un-scale; residual / mask operands are fp32
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = tc.c0 + 4 * lg + q;
+          const bool mine = FULL || (r < p.OHt && c < p.OWt);
+          f32x4 v;
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            v[n] = acc[m][n][q] * osc;
+            if constexpr (!FULL) v[n] = mine ? v[n] : 0.f;
+            s1[n] += v[n];
+            s2[n] += v[n] * v[n];
+          }
+          if constexpr (RM > 0) {
+            if (mine) {
+              const f32x4 g = *reinterpret_cast<const f32x4*>(resg + (orow + (unsigned)q * colstep));
+              if constexpr (RM > 1) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(resa + (orow + (unsigned)q * colstep));
+#pragma unroll
+                for (int n = 0; n < NN; ++n) v[n] += a[n] > 0.f ? g[n] : 0.f;
+              } else {
+                v += g;
+              }
+            }
+          }
+          if (mine) *reinterpret_cast<f32x4*>(out + (orow + (unsigned)q * colstep)) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       u32x2 rg[4], ra[4];
       if constexpr (RM > 0) {
 #pragma unroll
@@ -303,8 +346,8 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
           rg[q] = u32x2{0u, 0u};
           ra[q] = u32x2{0x3f803f80u, 0x3f803f80u};
           if (FULL || (r < p.OHt && c < p.OWt)) {
-            rg[q] = *reinterpret_cast<const u32x2*>(resg + (orow + (unsigned)q * colstep));
-            if constexpr (RM > 1) ra[q] = *reinterpret_cast<const u32x2*>(resa + (orow + (unsigned)q * colstep));
+            rg[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(resg) + (orow + (unsigned)q * colstep));
+            if constexpr (RM > 1) ra[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(resa) + (orow + (unsigned)q * colstep));
           }
         }
       }
@@ -335,7 +378,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
           }
           w[h] = __builtin_bit_cast(unsigned, b);
         }
-        if (mine) *reinterpret_cast<u32x2*>(out + (orow + (unsigned)q * colstep)) = w;
+        if (mine) *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(out) + (orow + (unsigned)q * colstep)) = w;
       }
       __builtin_amdgcn_sched_barrier(0);      // one tile row at a time: hoisting all 64 residual loads in front spills
     }
@@ -365,7 +408,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     return reinterpret_cast<const unsigned char*>(tc.in) + ((long)tc.iy_base * row_st + (long)tc.ix_base * pix_st + off) * 2;
   };
   auto w_base = [&](int n0, int k0, int tap) {
-    return reinterpret_cast<const unsigned char*>(wbase) + wtap0 + (long)tap * wtap_step + ((long)n0 * p.Cin + k0) * 2;
+    return reinterpret_cast<const unsigned char*>(wbase) + wtap0 + (long)tap * wtap_step + ((long)n0 * wK + k0) * 2;
   };
 
   {  // prologue: first halo and the first RING-1 taps of weights
@@ -392,8 +435,11 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
   // read tiles 0 and 1 of the NEXT k-step), groups 0..3 also one B read of the next k-step.  The MFMAs are inline asm with
   // the accumulators pinned to AGPRs ("+a"), a sched_barrier after every slot keeps the order (see conv_tap2.hip).
   bf16x8 fa[4], fb[2][NN];
-#define PH3_MM(M, N, AI, BS) \
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[M][N]) : "v"(fa[AI]), "v"(fb[BS][N]))
+#define PH3_MM(M, N, AI, BS)                                                                                        \
+  do {                                                                                                              \
+    if constexpr (HPM) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[M][N]) : "v"(fa[AI]), "v"(fb[BS][N]));  \
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[M][N]) : "v"(fa[AI]), "v"(fb[BS][N]));  \
+  } while (0)
 #define PH3_LD(ADDR, IMM) (*reinterpret_cast<const bf16x8*>(smem + (ADDR) + (IMM)))
 #define PH3_SB() __builtin_amdgcn_sched_barrier(0)
   // A read of M tile MT (0..7) of the k-step whose bases are (AB0, AB1)[KS] with immediate offset AOFF (buffer + tap row)
@@ -424,7 +470,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
       const bool last_sl = sl + 1 == nslices;
       const bool h_next_tile = last_sl && nvalid;
       const int nsl = last_sl ? 0 : sl + 1;
-      const unsigned char* hb = h_next_tile ? halo_base(tnext, 0) : halo_base(tcur, (long)(nsl << 6));
+      const unsigned char* hb = h_next_tile ? halo_base(tnext, 0) : halo_base(tcur, slice_a(nsl));
       const int hm = h_next_tile ? hm_next : hm_cur;
       const int wn0 = (last_sl && nvalid) ? tnext.n0 : tcur.n0;
       const int wk0 = nsl << 6;
@@ -506,10 +552,10 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
   }
 }
 
-template <bool FUSE_IN>
+template <bool FUSE_IN, bool HPM = false>
 int launch3(const PhTapConv& p, hipStream_t st) {
   using C = Tap3Cfg;
-  auto kern = tapconv3_kernel<FUSE_IN>;
+  auto kern = tapconv3_kernel<FUSE_IN, HPM>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
@@ -522,7 +568,7 @@ int launch3(const PhTapConv& p, hipStream_t st) {
   void* tok = nullptr;
   if (ph_prof_on())
     ph_prof_begin2(p.in_scale ? PH_CLS_TAPCONV2_FUSEDIN : PH_CLS_TAPCONV2, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin,
-                   ph_tapconv_bytes(p, 1, 2), st, &tok);
+                   ph_tapconv_bytes(p, 1, HPM ? 4 : 2), st, &tok);
   hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
@@ -544,4 +590,10 @@ bool ph_tapconv3_eligible(const PhTapConv* p) {
 int ph_tapconv3_launch(const PhTapConv* p, hipStream_t st) {
   if (!ph_tapconv3_eligible(p)) return PH_EINVAL;
   return p->in_scale ? launch3<true>(*p, st) : launch3<false>(*p, st);
+}
+
+// the same kernel in the half-pair arithmetic (PH_PREC_FP16X3): 3 Cin / 64 slices (even for Cin = 128 / 256 / 512), no in-LDS BatchNorm
+int ph_tapconv3_launch_hp(const PhTapConv* p, hipStream_t st) {
+  if (!ph_tapconv3_eligible(p) || p->in_scale) return PH_EINVAL;
+  return launch3<false, true>(*p, st);
 }

@@ -82,6 +82,7 @@ int ph_tapconv2_stat_parts(const PhTapConv* p);   // one BatchNorm partial row p
 int ph_tap3_switch(int set);
 bool ph_tapconv3_eligible(const PhTapConv* p);
 int ph_tapconv3_launch(const PhTapConv* p, hipStream_t st);
+int ph_tapconv3_launch_hp(const PhTapConv* p, hipStream_t st);      // PH_PREC_FP16X3 form of the same kernel
 // stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
 bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 

@@ -7,6 +7,7 @@
 // combine) into scale/shift; the consumer-side elementwise kernel applies BN(+residual)+ReLU.
 // Saved for backward per BasicBlock: x_in, y1, a1, y2, (y_ds), out.
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -462,7 +463,8 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     if ((rc = raw_in ? conv_fwd(c, b.u1, ws + b.in_off, c.stat(u0, 2), c.stat(u0, 3)) : conv_fwd(c, b.u1, ws + b.in_off))) return rc;
     // (measured per launch, B = 64, 512^2: the in-LDS pass costs the conv +10 us in layer 1 and +13 us in layers 2-4 - it
     // runs with the matrix pipe idle - against bn_apply launches of 49 / 25 / 13 / 8 us: fused where it pays)
-    if (fuse_a1 && b.Cout <= 128) {
+    static const bool fuse_all = [] { const char* e = getenv("PH_FUSE_ALL"); return e && e[0] == '1'; }();      // A/B switch
+    if (fuse_a1 && (b.Cout <= 128 || fuse_all)) {
       if ((rc = conv_fwd(c, b.u2, ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3)))) return rc;
     } else {
       if ((rc = ph_bn_apply_launch(ws + u1.y_off, c.stat(u1, 2), c.stat(u1, 3), nullptr, nullptr, nullptr, nullptr,

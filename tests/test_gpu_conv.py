@@ -162,6 +162,40 @@ def test_tapconv2_multitile_stream(case):
     assert_close(dx_ref, nchw_cpu(dx), 1e-6, 1.0 / 128, "multi-tile conv dgrad")
 
 
+@pytest.mark.parametrize("case", [(128, 128, 64, 20), (256, 256, 24, 40), (512, 512, 16, 80)])
+def test_tapconv3_half_pair_multitile_stream(case):
+    """The third-generation dense kernel in the half-pair arithmetic (conv_tap3.hip, tapconv3_kernel<false, true>: 3 x Cin / 64
+    slices of fp16 operand blocks, fp32 16-byte stores): persistent workgroups walking several tiles / Cout blocks, ragged maps,
+    forward (+ BatchNorm partial sums) and dgrad against fp64 F.conv2d on the same fp32 operands; repeated launches bitwise."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close, hp_pack
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, B = case
+    g = torch.Generator().manual_seed(Cin + Cout + H + B + 1)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    torch.set_num_threads(8)
+    y_ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dx_ref = F.conv_transpose2d(dy.double(), w.double(), None, 1, 1)
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 1, 1), device="cuda", dtype=torch.uint8)
+    xd = hp_pack(nhwc(x, torch.float32)); wd = w.cuda(); dyd = hp_pack(nhwc(dy, torch.float32))
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    outs = []
+    for rep in range(4):
+        y = torch.full((B, H, H, Cout), float("nan"), device="cuda")
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 1, 1, 3, ptr(ws), stream()), "fwd")
+        outs.append((y.clone(), s1.clone(), s2.clone()))
+    assert_close(y_ref, nchw_cpu(outs[0][0]), 1e-6, 3e-6, "multi-tile half-pair conv fwd")
+    assert_close(y_ref.sum(dim=(0, 2, 3)), outs[0][1].cpu(), 1e-2, 1e-4, "channel sum")
+    assert_close((y_ref ** 2).sum(dim=(0, 2, 3)), outs[0][2].cpu(), 1e-2, 1e-4, "channel sumsq")
+    for rep in range(1, 4):
+        assert torch.equal(outs[0][0], outs[rep][0]), "fwd differs between launches"
+        assert torch.equal(outs[0][1], outs[rep][1]) and torch.equal(outs[0][2], outs[rep][2])
+    dx = torch.full((B, H, H, Cin), float("nan"), device="cuda")
+    check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx), B, Cin, H, H, Cout, 3, 1, 1, 3, ptr(ws), stream()), "dgrad")
+    assert_close(dx_ref, nchw_cpu(dx), 1e-6, 3e-6, "multi-tile half-pair conv dgrad")
+
+
 MASKED_S2 = [  # Cin, Cout, H (input), B
     (64, 128, 64, 40),      # 1 slice per plane, 32 x 32 maps: 160 tiles ... x 1 Cout block
     (64, 128, 128, 12),     # 64 x 64 maps: 192 tiles (the 512^2 layer-2 shape)
