@@ -63,12 +63,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   // SPLIT: the plane-staged path (three bf16 split planes of fp32 operands; T = hp16, PH_PREC_FP16X3: the two fp16 planes
   // of the half-pair input against the three weight planes (hi 2^11, lo, hi), fp32 output = accumulators * 2^-11)
   constexpr bool HPM = is_hp<T>::value;
-  constexpr bool SPLIT = is_f32<T>::value || HPM;
-  constexpr int NP = SPLIT ? PH_NPLANES : 1;
+  constexpr bool SPLIT = is_f32<T>::value;      // synchronous plane staging (fp32 operands split in the kernel)
+  constexpr int NP = (SPLIT || HPM) ? PH_NPLANES : 1;      // weight planes
+  constexpr int NPA = SPLIT ? PH_NPLANES : (HPM ? 2 : 1);   // activation planes of ONE halo buffer
   typedef typename std::conditional<HPM, float, T>::type TO;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // perf mode: two halo buffers (tile t+1 is written while nobody reads it: one barrier per tile); parity: NP planes
-  constexpr int XBUFS = SPLIT ? NP : 2;
+  // perf mode and half-pair mode: two halo buffers of NPA planes (tile t+1 is written while nobody reads it: one barrier per
+  // tile; the half-pair planes arrive as they lie in HBM, nothing is converted); split-plane modes: one buffer of 3 planes
+  constexpr int XBUFS = SPLIT ? NP : 2 * NPA;
   unsigned char* ldsX = smem;               // XBUFS x XB
   unsigned char* ldsW = smem + XB * XBUFS;  // NP planes of WB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,9 +95,24 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   // out-of-image pixel reads a zero page - and, for interior tiles, unconditional stores in the epilogue, so the
   // compiler can count the s_waitcnt instead of draining the queue) and written to the other LDS buffer after them.
   constexpr int HCH = (HP + 255) / 256;
-  u32x2 hreg[SPLIT ? 1 : HCH];
+  u32x2 hreg[SPLIT ? 1 : HCH], hregl[HPM ? HCH : 1];
   auto load_halo_regs = [&](int t) {
-    if constexpr (!SPLIT) {
+    if constexpr (HPM) {
+      const int b = t / tiles_img, tile = t - b * tiles_img;
+      const int iy_base = (tile / tiles_w) * TH * 2 - 3, ix_base = (tile % tiles_w) * TW * 2 - 3;
+      const f16* xp = reinterpret_cast<const f16*>(p.x4);
+      const size_t lo_plane = (size_t)p.B * p.IH * p.IW * 4;
+#pragma unroll
+      for (int e = 0; e < HCH; ++e) {
+        const int i = tid + e * 256;
+        const int hr = i / HPW, hc = i - hr * HPW;
+        const int iy = iy_base + hr, ix = ix_base + hc;
+        const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const f16* src = ok ? xp + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const f16*>(stem_zero8);
+        hreg[e] = *reinterpret_cast<const u32x2*>(src);
+        hregl[e] = *reinterpret_cast<const u32x2*>(ok ? src + lo_plane : src);
+      }
+    } else if constexpr (!SPLIT) {
       const int b = t / tiles_img, tile = t - b * tiles_img;
       const int iy_base = (tile / tiles_w) * TH * 2 - 3, ix_base = (tile % tiles_w) * TW * 2 - 3;
 #pragma unroll
@@ -114,7 +131,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
 #pragma unroll
       for (int e = 0; e < HCH; ++e) {
         const int i = tid + e * 256;
-        if (i < HP) *reinterpret_cast<u32x2*>(dst + i * 8) = hreg[e];
+        if (i < HP) {
+          *reinterpret_cast<u32x2*>(dst + i * 8) = hreg[e];
+          if constexpr (HPM) *reinterpret_cast<u32x2*>(dst + XB + i * 8) = hregl[e];
+        }
       }
     }
   };
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       stage_halo<T>(x4, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid, p.B);
       __syncthreads();
     } else {
-      ldsXc = ldsX + ((tt - t_begin) & 1) * XB;
+      ldsXc = ldsX + ((tt - t_begin) & 1) * NPA * XB;
       if (tt + 1 < t_end) load_halo_regs(tt + 1);
     }
 
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     // each stores one [even channel, odd channel] word (half the store instructions of 2-byte stores, which bound the
     // kernel: 537 MB of output left the CU in 128-B wave-instructions)
     TO* out = reinterpret_cast<TO*>(p.out) + (size_t)b * p.OH * p.OW * 64;
-    if constexpr (!SPLIT) {
+    if constexpr (!SPLIT && !HPM) {
       typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
       const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
       auto store_tile = [&](auto fullc) {
@@ -211,11 +231,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       };
       // the next tile's halo (requested before the MFMAs) goes to the buffer nobody reads BEFORE this tile's output
       // stores are issued: the wait in front of the LDS write then covers the loads only, not 16 stores in flight
-      if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * XB);
+      if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * NPA * XB);
       if (r0 + TH <= p.OH && c0 + TW <= p.OW) store_tile(std::true_type{});
       else store_tile(std::false_type{});
       __syncthreads();
     } else {
+      // fp32 outputs, one 4-byte store per value (a wave-instruction writes two 128-byte runs).  Half-pair mode: the next tile's
+      // halo planes (requested before the MFMAs) go to the other buffer first, one barrier per tile as in perf mode
+      if constexpr (HPM) { if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * NPA * XB); }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
@@ -228,6 +251,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
           if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
         }
       }
+      if constexpr (HPM) __syncthreads();
     }
   }
   if (p.stats) {   // one partial row per workgroup
@@ -738,7 +762,7 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, q);
   } else if (prec == PH_PREC_FP16X3) {
     static bool done = false;
-    const int lds = PH_NPLANES * (XB + WB);
+    const int lds = 4 * XB + PH_NPLANES * WB;      // two halo buffers of two planes + the three weight planes
     if (set_lds(stem_fwd_kernel<hp16>, lds, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_fwd_kernel<hp16>, grid, dim3(256), lds, st, *p);
   } else {
