@@ -370,3 +370,26 @@ def test_two_stage1_replicas_with_tsvd_orth_crd_equal_one_process():
             assert err <= 1e-3 * float(g1[h].abs().max()) + 1e-7, (h, err)
     finally:
         m.set_precision("bf16")
+
+
+def test_replica_sync_step_is_captured_in_one_graph_with_rccl_inside():
+    """with a ReplicaSync attached, the fused loss head must not wait on its side stream (it never
+    forks it then) - a wait on a stream outside the capture invalidates the capture.  One rank, RCCL: `bench.py --force-dist`
+    runs the data-parallel code path (bucketed gradient all-reduce in two phases, bank-row all-gathers, Gram all-reduce) INSIDE
+    the captured step; the line must say the step was replayed from a graph and carry the communicator's own observations."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--batch", "8", "--size", "128", "--steps", "3",
+                        "--no-parity-mode", "--no-variants", "--no-cpu-baseline", "--no-north-star-block"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["config"]["launch"].startswith("one captured HIP graph per step"), res["config"]["launch"]
+    c = res["comm"]
+    assert c["backend"].startswith("nccl") and c["ranks_joined_all_reduce"] == 1 and c["distinct_devices"] == 1
+    assert c["launch"].startswith("collectives captured inside the step's HIP graph")
+    assert c["grad_allreduce_bytes"] > 40e6 and 0.0 <= c["exposed_grad_allreduce_ms"] < 5.0
