@@ -376,14 +376,16 @@ def test_replica_sync_step_is_captured_in_one_graph_with_rccl_inside():
     """with a ReplicaSync attached, the fused loss head must not wait on its side stream (it never
     forks it then) - a wait on a stream outside the capture invalidates the capture.  One rank, RCCL: `bench.py --force-dist`
     runs the data-parallel code path (bucketed gradient all-reduce in two phases, bank-row all-gathers, Gram all-reduce) INSIDE
-    the captured step; the line must say the step was replayed from a graph and carry the communicator's own observations."""
+    the captured step, at the per-GPU shape of BASELINE configs[2] (32 tiles of 512 x 512 = global batch 256 over 8 GPUs); the line
+    must say the step was replayed from a graph and carry the communicator's own observations."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--batch", "8", "--size", "128", "--steps", "3",
+    # 32 tiles of 512 x 512 = the per-GPU leg of BASELINE configs[2] (global batch 256 over 8 GPUs) through the replica-sync path
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--batch", "32", "--size", "512", "--steps", "3",
                         "--no-parity-mode", "--no-variants", "--no-cpu-baseline", "--no-north-star-block"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
