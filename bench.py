@@ -41,12 +41,12 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
              "tapconv_kernel<bf16,S=1,BNT=128> (first generation: 1x1 and dgrad parity classes, Cout>=128)",
              "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
              "stem_wgrad_kernel<bf16>",
-             "tapconv2_kernel<2,2,4,false> (3x3 stride-1 fwd+dgrad, Cout>=128)",
+             "tapconv3_kernel (conv_tap3.hip: 3x3 stride-1 fwd+dgrad, Cout>=128, 16x16x32 fragments; PH_TAP3=0: tapconv2_kernel<2,2,4,false>)",
              "tapconv2_l1_kernel (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1, two wave groups)"]
 NCLS = len(CLS_NAMES)
 # ... + class 12 of ph_kernels.h (behind the four HBM-bound classes 8-11)
 MASKED_CLS, MASKED_NAME = 12, "tapconv2_kernel<2,2,4,false,masked> (3x3 stride-2 fwd as a masked grid over the 4 pixel-parity planes)"
-FUSED_CLS = [(13, "tapconv2_kernel<2,2,4,false> + input BatchNorm/ReLU applied in LDS (conv2 of layer 2, forward-only networks)"),
+FUSED_CLS = [(13, "tapconv3_kernel<fused input> + input BatchNorm/ReLU applied in LDS (conv2 of layer 2, forward-only networks)"),
              (14, "tapconv2_l1_kernel + input BatchNorm/ReLU applied in LDS (conv2 of layer 1, forward-only networks)")]
 HBM_NAMES = ["crd_score_kernel (2 banks x B x 1000 rows of 512 B)", "crd_loss_grad_kernel (2 banks x B x 532 rows of 512 B)",
              "adam_ema_dev_kernel (28 B / parameter + 8 B / EMA parameter)", "bn_apply_kernel (2-3 activation tensors)"]
