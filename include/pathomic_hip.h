@@ -31,6 +31,8 @@ typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
 #define PH_PREC_FP16X3 3 /* half-pair mode: tensors a convolution reads are fp16 pairs x = hi + lo * 2^-11 (4 B / element, 22
                             significant bits), conv outputs / gradients fp32, 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi) */
 
+#define PH_PREC_FP16X1 4 /* only as ph_resnet_plan_set_backward_prec() of a PH_PREC_FP16X3 plan: dgrad / wgrad on the hi planes alone */
+
 #define PH_ACT_NONE 0
 #define PH_ACT_RELU 1
 #define PH_ACT_ELU 2
@@ -74,7 +76,8 @@ int ph_resnet_pack_weights(const PhResnetPlan* plan, const void* const* params, 
  * is the NHWC4 tensor ph_pack_input made of the image (the student and the teacher read the same x_path,
  * train_test_path_multi_distill.py:249,256: packed once) - it must stay valid until the matching backward has run */
 /* Arithmetic of the backward's dgrad / wgrad launches where it differs from the plan's (PH_PREC_BF16X3 on a PH_PREC_BF16X6
- * plan: parity-mode forward, three-product backward; -1 = follow the plan) */
+ * plan: parity-mode forward, three-product backward; PH_PREC_FP16X1 on a PH_PREC_FP16X3 plan: three-product forward, the hi
+ * planes' product alone in the backward; -1 = follow the plan) */
 int ph_resnet_plan_set_backward_prec(const PhResnetPlan* plan, int prec);
 /* Scheduling of ph_resnet_backward / _part: 1 (default) = the weight-gradient launches run on a second, process-wide
  * stream of the library (created once per device, never destroyed) beside the BatchNorm-backward / dgrad chain and are

@@ -662,8 +662,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
             for (int j = 0; j < 2; ++j) {
               const f16x8 ah = __builtin_bit_cast(f16x8, a[0][j]), al = __builtin_bit_cast(f16x8, a[1][j]);
               const f16x8 bh = __builtin_bit_cast(f16x8, bq[0]), bl = __builtin_bit_cast(f16x8, bq[1]);
-              accx[HPM ? ai : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[HPM ? ai : 0][j], 0, 0, 0);
-              accx[HPM ? ai : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[HPM ? ai : 0][j], 0, 0, 0);
+              if (!p.hp_hi_only) {      // (PH_PREC_FP16X1: the leading product alone)
+                accx[HPM ? ai : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accx[HPM ? ai : 0][j], 0, 0, 0);
+                accx[HPM ? ai : 0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accx[HPM ? ai : 0][j], 0, 0, 0);
+              }
               acc[ai][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ai][j], 0, 0, 0);
             }
           } else if constexpr (SPLIT) {
@@ -819,10 +821,12 @@ int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st) {
     PhStemWgrad q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;
     hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), PH_NPLANES * base, st, q);
-  } else if (prec == PH_PREC_FP16X3) {
+  } else if (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) {
     static bool done = false;
     if (set_lds(stem_wgrad_kernel<hp16>, 2 * base, done)) return PH_ELAUNCH;
-    hipLaunchKernelGGL(stem_wgrad_kernel<hp16>, grid, dim3(256), 2 * base, st, *p);
+    PhStemWgrad q = *p;
+    q.hp_hi_only = prec == PH_PREC_FP16X1;
+    hipLaunchKernelGGL(stem_wgrad_kernel<hp16>, grid, dim3(256), 2 * base, st, q);
   } else {
     return PH_EINVAL;
   }

@@ -76,8 +76,10 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const int wK = HPM ? 3 * p.Cin : p.Cin;                       // K extent of a packed weight row
   // slice index -> element offset of its A block in a pixel's channel record / of its W block in a weight row.  Half-pair
   // mode: slices 3c, 3c+1, 3c+2 of 64-channel group c pair the A blocks (hi, hi, lo) with the W blocks (hi 2^11, lo, hi).
-  auto slice_a = [&](int sl) { return HPM ? ((sl / 3) * 128 + ((sl % 3 == 2) ? 64 : 0)) : (sl << 6); };
-  auto slice_w = [&](int sl) { return sl << 6; };
+  // (hi-only form, PH_PREC_FP16X1: one slice per group, A block hi x W block hi = the third block of the group's three)
+  const bool hi1 = HPM && p.hp_hi_only;
+  auto slice_a = [&](int sl) { return HPM ? (hi1 ? sl * 128 : ((sl / 3) * 128 + ((sl % 3 == 2) ? 64 : 0))) : (sl << 6); };
+  auto slice_w = [&](int sl) { return hi1 ? (3 * sl + 2) << 6 : sl << 6; };
   PH_TRACE(0);
   PH_TRACE_HWID();
   const int iy_base = r0 * S + p.iy0, ix_base = c0 * S + p.ix0;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   for (int j = 0; j < FN; ++j) nrow[j] = (wn * FN + j) * 32 + (lane & 31);
   const int khalf = lane >> 5;
 
-  const int nslices = (p.Cin >> 6) * (HPM ? 3 : 1);
+  const int nslices = (p.Cin >> 6) * ((HPM && !p.hp_hi_only) ? 3 : 1);
   const int ngroups = (p.ntaps + TG - 1) / TG;
   const int nstages = nslices * ngroups;
   // tap table in a VGPR (lane t holds tap t): the per-tap weight slab and halo offset are fetched with
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     int sl = 0, tg0 = 0, sl1 = 0, tg1 = 0;
     advance(sl1, tg1);
     load_halo_regs(slice_a(0));
-    load_w_regs(0, 0, gc(0));
+    load_w_regs(slice_w(0), 0, gc(0));
     store_halo_regs();
     store_w_regs(gc(0), ldsB);
     if (nstages > 1) load_w_regs(slice_w(sl1), tg1, gc(tg1));
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     // s+1 (weights, and the next slice's halo when the slice changes) are in flight into registers; they
     // are written to LDS after the barrier that ends stage s.
     load_halo_regs(slice_a(0));
-    load_w_regs(0, 0, p.ntaps < TG ? p.ntaps : TG);
+    load_w_regs(slice_w(0), 0, p.ntaps < TG ? p.ntaps : TG);
     store_halo_regs();
     store_w_regs(p.ntaps < TG ? p.ntaps : TG, ldsB);
     __syncthreads();
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const TO* resa = p.res_a ? reinterpret_cast<const TO*>(p.res_a) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
   // half-pair mode: the accumulators hold 2^11 x the sum (the W blocks' scaling) times the dz tensor's power-of-two scale
   float osc = 1.f;
-  if constexpr (HPM) osc = PH_HP_LO_INV * (p.in_unscale ? p.in_unscale[1] : 1.f);
+  if constexpr (HPM) osc = (p.hp_hi_only ? 1.f : PH_HP_LO_INV) * (p.in_unscale ? p.in_unscale[1] : 1.f);
   float s1[FN], s2[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -524,10 +526,12 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
   if (p->in_scale || p->m_groups) return PH_EINVAL;   // in-LDS BatchNorm + ReLU / masked tap grids: second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);
-  if (prec == PH_PREC_FP16X3) {
+  if (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) {
+    PhTapConv q = *p;
+    q.hp_hi_only = prec == PH_PREC_FP16X1;
     // dense 3x3 stride-1, Cout % 128 == 0: the third-generation kernel's half-pair form (conv_tap3.hip)
-    if (S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv3_launch_hp(p, st);
-    return launch_T<hp16>(*p, S, st);
+    if (S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(&q)) return ph_tapconv3_launch_hp(&q, st);
+    return launch_T<hp16>(q, S, st);
   }
   if (PH_IS_SPLIT_PREC(prec)) {
     PhTapConv q = *p;

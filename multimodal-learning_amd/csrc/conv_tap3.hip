@@ -114,7 +114,10 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
   const int wK = HPM ? 3 * p.Cin : p.Cin;      // K extent of a packed weight row
   // slice -> element offset of its A block inside a pixel record (half-pair: slices 3c, 3c+1, 3c+2 read the blocks hi, hi, lo
   // of 64-channel group c); its W block is columns 64 sl .. of the weight row
-  auto slice_a = [&](int sl) -> long { return HPM ? (long)((sl / 3) * 128 + ((sl % 3 == 2) ? 64 : 0)) : (long)(sl << 6); };
+  // (hi-only form, PH_PREC_FP16X1: one slice per 64-channel group: A block hi x W block hi, the third of the group's three)
+  const bool hi1 = HPM && p.hp_hi_only;
+  auto slice_a = [&](int sl) -> long { return HPM ? (hi1 ? (long)(sl * 128) : (long)((sl / 3) * 128 + ((sl % 3 == 2) ? 64 : 0))) : (long)(sl << 6); };
+  auto slice_w = [&](int sl) -> int { return hi1 ? (3 * sl + 2) << 6 : sl << 6; };
 
   // ---- tile list (as tapconv2_kernel): linear tile id -> (spatial tile fastest, Cout block, image), XCD-contiguous
   struct TileCtx { int r0, c0, n0, b, iy_base, ix_base; const T* in; };
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     const int t = ((int)blockIdx.x & 7) * per_xcd + local;
     return (local < per_xcd && t < total) ? t : -1;
   };
-  const int nslices = (p.Cin >> 6) * (HPM ? 3 : 1);      // even (the launcher checks): the A buffer index is compile-time inside a slice pair
+  const int nslices = (p.Cin >> 6) * ((HPM && !p.hp_hi_only) ? 3 : 1);      // even (the launcher checks): the A buffer index is compile-time inside a slice pair
 
   // weight slab of tap t = wtap[0] + t * (wtap[1] - wtap[0]) (the launcher checks: forward 0, 1, .., 8; dgrad 8, 7, .., 0)
   const long slab_bytes = (long)p.Cout * wK * 2;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     // element offset of (tile row 0 of this wave, column 4 lg) - rows advance by rowstep, columns by colstep
     const unsigned o00 = (unsigned)(((tc.r0 + wm * NM) * p.os + p.oa_h) * p.OW + (tc.c0 + 4 * lg) * p.os + p.oa_w) * (unsigned)p.Cout + chan;
     const unsigned rowstep = (unsigned)(p.os * p.OW * p.Cout);
-    const float osc = HPM ? PH_HP_LO_INV * (p.in_unscale ? p.in_unscale[1] : 1.f) : 1.f;
+    const float osc = HPM ? (p.hp_hi_only ? 1.f : PH_HP_LO_INV) * (p.in_unscale ? p.in_unscale[1] : 1.f) : 1.f;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       const int r = tc.r0 + wm * NM + m;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
         lds_dma16(((hm_cur >> e) & 1) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
 #pragma unroll
     for (int j = 0; j < C::RING - 1; ++j) {
-      const unsigned char* wb = w_base(tcur.n0, 0, j);
+      const unsigned char* wb = w_base(tcur.n0, slice_w(0), j);
 #pragma unroll
       for (int e = 0; e < C::NBE; ++e)
         lds_dma16_s(wb, wb_off[e], lds0 + B_BASE + j * C::TAPB + (wave * C::NBE + e) * 1024);
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
       const unsigned char* hb = h_next_tile ? halo_base(tnext, 0) : halo_base(tcur, slice_a(nsl));
       const int hm = h_next_tile ? hm_next : hm_cur;
       const int wn0 = (last_sl && nvalid) ? tnext.n0 : tcur.n0;
-      const int wk0 = nsl << 6;
-      const unsigned char* wcur = w_base(tcur.n0, sl << 6, 0);      // tap 0 of this slice's weight block / of the next one's
+      const int wk0 = slice_w(nsl);
+      const unsigned char* wcur = w_base(tcur.n0, slice_w(sl), 0);      // tap 0 of this slice's weight block / of the next one's
       const unsigned char* wnxt = w_base(wn0, wk0, 0);
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) {

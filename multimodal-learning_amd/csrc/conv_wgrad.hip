@@ -194,11 +194,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
     // then the accumulators are multiplied by 2^-11, then (dh, xh) - as ONE stream of 3 * ntiles items through the same
     // two LDS buffers; a 64-channel block of a pixel record is [hi 64 | lo 64] fp16 (ph_common.h).
     const int nt = t_end > t_begin ? t_end - t_begin : 0;
-    const int nitems = HPM ? 3 * nt : nt;
+    const bool hi1 = HPM && p.hp_hi_only;      // PH_PREC_FP16X1: ONE pass, (dz hi, x hi)
+    const int nitems = (HPM && !hi1) ? 3 * nt : nt;
     const int dblk = HPM ? (co0 >> 6) * 128 : co0, xblk = HPM ? (ci0 >> 6) * 128 : ci0;
     auto issue = [&](int item, int buf) {
       int pass = 0, tt = t_begin + item;
-      if constexpr (HPM) { pass = item / nt; tt = t_begin + (item - pass * nt); }
+      if constexpr (HPM) { if (!hi1) { pass = item / nt; tt = t_begin + (item - pass * nt); } else pass = 2; }
       const int dpl = (HPM && pass == 1) ? 64 : 0, xpl = (HPM && pass == 0) ? 64 : 0;     // lo plane of dz' / of x
       const int b = tt / tiles_img, ti = tt - b * tiles_img;
       const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
       if (it + 1 < nitems) issue(it + 1, buf ^ 1);
 #endif
       if constexpr (HPM) {
-        if (it == 2 * nt) {      // the cross terms are complete: weight them before the leading products accumulate
+        if (!hi1 && it == 2 * nt) {      // the cross terms are complete: weight them before the leading products accumulate
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -523,7 +524,11 @@ int ph_wgrad_tile_h(int S) { return S == 1 ? 8 : 4; }
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->nchunks < 1) return PH_EINVAL;
   if (prec == PH_PREC_BF16) return launch_wg_T<bf16>(*p, st);
-  if (prec == PH_PREC_FP16X3) return launch_wg_T<hp16>(*p, st);
+  if (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) {
+    PhWgrad q = *p;
+    q.hp_hi_only = prec == PH_PREC_FP16X1;
+    return launch_wg_T<hp16>(q, st);
+  }
   if (PH_IS_SPLIT_PREC(prec)) {
     PhWgrad q = *p;
     q.prod6 = prec == PH_PREC_BF16X6;

@@ -27,6 +27,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define PH_PREC_FP16X3 3  // "half-pair" mode: every tensor a convolution READS (activations, BatchNorm-backward dz) is stored as two fp16
                           // planes x = hi + lo * 2^-11 (4 B per element, layout below); conv outputs / gradients stay fp32; three
                           // fp16 MFMA products per k-step (hi*hi, hi*lo, lo*hi: 22-bit operands, ~2^-22 per product)
+#define PH_PREC_FP16X1 4  // BACKWARD arithmetic of a PH_PREC_FP16X3 plan only (ph_resnet_plan_set_backward_prec): dgrad / wgrad multiply the hi
+                          // planes alone (one fp16 product, 11-bit operands, fp32 accumulation) - the tensors are the half-pair ones
 #define PH_IS_F32_OUT_PREC(p) ((p) == PH_PREC_BF16X6 || (p) == PH_PREC_BF16X3 || (p) == PH_PREC_FP16X3)   // conv outputs are fp32
 
 #define PH_LAUNCH_CHECK()                                  \

@@ -69,6 +69,8 @@ struct PhTapConv {
   // (x hi, w hi 2^11), (x hi, w lo), (x lo, w hi) and the fp32 result is acc * 2^-11 * (in_unscale ? in_unscale[1] : 1):
   // in_unscale = the {2^s, 2^-s} record of a dz tensor (ph_bn_bwd_finalize_launch), null for activations
   const float* in_unscale;
+  int hp_hi_only;        // half-pair kernels: 1 = the hi planes' product alone (A block hi x W block hi: one slice per 64 channels,
+                         // result = acc * in_unscale[1]); set by the launcher for PH_PREC_FP16X1
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 double ph_tapconv_bytes(const PhTapConv& p, int S, int es);
@@ -96,6 +98,7 @@ struct PhWgrad {
   int nchunks, tiles_per_chunk;
   long x_pix_stride, x_row_stride, x_img_stride;   // element strides of the x view (0 = dense NHWC)
   int prod6;             // split-plane modes: 1 = all six products (bf16x6), 0 = the three leading ones (bf16x3); set by the launcher
+  int hp_hi_only;        // half-pair mode: 1 = one pass over the chunk on the hi planes (PH_PREC_FP16X1); set by the launcher
 };
 int ph_wgrad_launch(const PhWgrad* p, int prec, hipStream_t st);
 int ph_wgrad_tile_h(int S);
@@ -133,6 +136,7 @@ struct PhStemWgrad {
   int B, IH, IW, OH, OW;
   int nchunks, tiles_per_chunk;
   int prod6;
+  int hp_hi_only;        // half-pair mode: the hi planes' product alone (PH_PREC_FP16X1); set by the launcher
 };
 int ph_stem_wgrad_launch(const PhStemWgrad* p, int prec, hipStream_t st);
 // input gradient of the 7x7/2 stem conv: dy [B][H/2][W/2][64] (type of the mode) -> dx [B][3][H][W] f32 (stem_dgrad.hip)

@@ -238,7 +238,7 @@ struct Ctx {
   float* stat(const Unit& u, int which) const {
     return reinterpret_cast<float*>(ws + u.st_off) + (size_t)which * u.Cout;
   }
-  int bprec() const { return (P->bwd_prec >= 0 && PH_IS_SPLIT_PREC(P->prec)) ? P->bwd_prec : P->prec; }
+  int bprec() const { return (P->bwd_prec >= 0 && P->prec != PH_PREC_BF16) ? P->bwd_prec : P->prec; }
   // PH_PREC_FP16X3: scale record {2^s, 2^-s} of dz buffer k (null in the other modes), and the amax scratch
   float* dzs(int k) const { return P->prec == PH_PREC_FP16X3 ? reinterpret_cast<float*>(ws + P->dzs_off) + 2 * k : nullptr; }
   float* amax() const { return P->prec == PH_PREC_FP16X3 ? reinterpret_cast<float*>(ws + P->amax_off) : nullptr; }
@@ -723,7 +723,10 @@ extern "C" {
 // backward (gradients at ~1e-3 relative); -1 = follow the plan.  Both arithmetics read the same fp32 activations and the
 // same packed weight planes.
 int ph_resnet_plan_set_backward_prec(const PhResnetPlan* P, int prec) {
-  if (!P || (prec != -1 && !PH_IS_SPLIT_PREC(prec)) || (prec != -1 && P->prec == PH_PREC_BF16)) return PH_EINVAL;
+  // (a half-pair plan admits PH_PREC_FP16X1 - the hi planes' product alone in dgrad / wgrad - a split-plane plan the other
+  // split-plane arithmetic)
+  if (!P || (prec != -1 && P->prec == PH_PREC_BF16)) return PH_EINVAL;
+  if (prec != -1 && !(P->prec == PH_PREC_FP16X3 ? (prec == PH_PREC_FP16X1 || prec == PH_PREC_FP16X3) : PH_IS_SPLIT_PREC(prec))) return PH_EINVAL;
   P->bwd_prec = prec;
   return PH_OK;
 }

@@ -10,7 +10,7 @@ from ._lib import lib, check, ptr, stream, require_cuda
 
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EW_RELU, EW_GATE, EW_RELU_BWD, EW_ADD, EW_ELU_BWD, EW_MUL = 0, 1, 2, 3, 4, 5
-PREC_BF16, PREC_BF16X6, PREC_BF16X3, PREC_FP16X3 = 0, 1, 2, 3
+PREC_BF16, PREC_BF16X6, PREC_BF16X3, PREC_FP16X3, PREC_FP16X1 = 0, 1, 2, 3, 4
 
 _precision = PREC_BF16
 _fwd_only_precision = None      # optional other arithmetic for forward-only (no_grad) trunk forwards, see set_precision
@@ -38,6 +38,7 @@ def set_precision(mode):
                   power-of-two scale) is stored as two fp16 planes x = hi + lo * 2^-11 (22 significant bits, 4 B per element),
                   conv outputs and gradients stay fp32, three fp16 MFMA products per k-step (hi*hi, hi*lo, lo*hi: ~2^-22 per
                   product, fp32 accumulation) - the cheapest arithmetic that meets the 1e-3 parity tolerance everywhere;
+      'fp16x3/x1' 'fp16x3' for every forward, ONE fp16 product (the hi planes) in the backward's dgrad / wgrad kernels;
       'bf16x6/x3' parity mode for every forward, three products in the backward's dgrad / wgrad kernels;
       'bf16x6+x3' parity mode for every forward that is followed by a backward (the student), 'bf16x3' for the forward-only
                   networks (the no_grad EMA / teacher forwards of train_test_path_multi_distill.py:253-256)."""
@@ -47,6 +48,10 @@ def set_precision(mode):
              PREC_BF16X6: PREC_BF16X6, PREC_BF16X3: PREC_BF16X3, PREC_FP16X3: PREC_FP16X3}
     if mode == "bf16x6+x3":
         _precision, _fwd_only_precision = PREC_BF16X6, PREC_BF16X3
+    elif mode == "fp16x3/x1":
+        # half-pair forward (logits, losses, GK-Refine weights as in 'fp16x3'); the backward's dgrad / wgrad multiply the hi
+        # planes alone: one fp16 product on 11-bit operands with fp32 accumulation (gradients at ~1e-4 of their scale)
+        _precision, _fwd_only_precision, _backward_precision = PREC_FP16X3, None, PREC_FP16X1
     elif mode == "bf16x6/x3":
         # every FORWARD in parity arithmetic (logits, losses, GK-Refine weights as in 'bf16x6'), the backward's dgrad /
         # wgrad kernels with three products
