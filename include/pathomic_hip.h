@@ -31,7 +31,7 @@ typedef struct ihipStream_t* ph_stream_t; /* a hipStream_t */
 #define PH_PREC_FP16X3 3 /* half-pair mode: tensors a convolution reads are fp16 pairs x = hi + lo * 2^-11 (4 B / element, 22
                             significant bits), conv outputs / gradients fp32, 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi) */
 
-#define PH_PREC_FP16X1 4 /* only as ph_resnet_plan_set_backward_prec() of a PH_PREC_FP16X3 plan: dgrad / wgrad on the hi planes alone */
+#define PH_PREC_FP16X1 4 /* only as the backward arithmetic of a PH_PREC_FP16X3 plan (set_backward_prec below): dgrad / wgrad on the hi planes alone */
 
 #define PH_ACT_NONE 0
 #define PH_ACT_RELU 1

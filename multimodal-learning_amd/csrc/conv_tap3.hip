@@ -33,11 +33,16 @@ typedef __attribute__((address_space(3))) unsigned char lds_uchar;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds_addr), "v"(g) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(g) : "memory");
 }
 // the same with a wave-uniform base (scalar register pair) and a 32-bit per-lane byte offset: no 64-bit vector add per piece
 __device__ __forceinline__ void lds_dma16_s(const unsigned char* sbase, int voff, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+  // (both are wave-uniform by construction; readfirstlane states it for builds that do not prove it - it folds away at -O3)
+  const unsigned long long sb = reinterpret_cast<unsigned long long>(sbase);
+  const unsigned long long sbu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)sb);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               : : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(sbu) : "memory");
 }
 #define PH3_WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define PH3_BARRIER() asm volatile("s_barrier" ::: "memory")
