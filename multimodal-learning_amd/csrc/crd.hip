@@ -264,234 +264,365 @@ __global__ __launch_bounds__(256) void crd_update_kernel(float* __restrict__ mem
 // the query's class with the largest cosine similarity to the query's OWN bank row.  One block per (query, bank);
 // every thread scans a strided slice keeping a private top-NP list, the lists are merged through LDS.  The
 // reference copies the whole bank to the host and calls sklearn per step; here the bank is read once from L2/HBM.
-constexpr int TOPK_MAX = 8, TOPK_SPLIT = 8;     // (32 slices: 4096 selection workgroups of 8 arg-max rounds each, 83 us at B = 64)
+constexpr int TOPK_MAX = 8;
 
-// block-wide pick of the best (value desc, index asc) live candidate among n entries of (sv, si); every thread gets it
-__device__ __forceinline__ void block_argbest(const float* sv, const int* si, int n, float* rv, int* ri, int* rs, float& best,
-                                              int& besti, int& bestslot) {
-  const int tid = threadIdx.x;
-  float v = -INFINITY; int i = 0x7fffffff, sl = -1;
-  for (int e = tid; e < n; e += 256) {
-    const float ve = sv[e]; const int ie = si[e];
-    if (ie != 0x7fffffff && (ve > v || (ve == v && ie < i))) { v = ve; i = ie; sl = e; }
+// A similarity and its bank row as one unsigned key: larger key = earlier in torch.sort(descending) with ties broken by the
+// lower row (value bits made monotone, -0 folded onto +0; low word = ~row).  0 = an empty list slot.
+using u64 = unsigned long long;
+__device__ __forceinline__ u64 knn_key(float v, int row) {
+  unsigned u = __float_as_uint(v + 0.f);
+  u ^= (u & 0x80000000u) ? 0xffffffffu : 0x80000000u;
+  return ((u64)u << 32) | (unsigned)(~row);
+}
+__device__ __forceinline__ float knn_value(u64 key) {
+  const unsigned u = (unsigned)(key >> 32);
+  return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+// insert into a descending list of TOPK_MAX keys held in registers (the caller has checked c > L[TOPK_MAX - 1])
+__device__ __forceinline__ void knn_insert(u64 (&L)[TOPK_MAX], u64 c) {
+#pragma unroll
+  for (int k = 0; k < TOPK_MAX; ++k) {
+    const bool g = c > L[k];
+    const u64 hi = g ? c : L[k];
+    c = g ? L[k] : c;
+    L[k] = hi;
   }
-  rv[tid] = v; ri[tid] = i; rs[tid] = sl;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
-      const float v2 = rv[tid + o]; const int i2 = ri[tid + o];
-      if (i2 != 0x7fffffff && (v2 > rv[tid] || (v2 == rv[tid] && i2 < ri[tid]))) { rv[tid] = v2; ri[tid] = i2; rs[tid] = rs[tid + o]; }
-    }
-    __syncthreads();
-  }
-  best = rv[0]; besti = ri[0]; bestslot = rs[0];
-  __syncthreads();
 }
 
-// stage 0: the B query rows of each bank (the bank row of the sample itself, idx[b][0]) copied next to their norms
-__global__ __launch_bounds__(64) void crd_topk_queries_kernel(const float* __restrict__ mem1, const float* __restrict__ mem2,
-                                                              const int64_t* __restrict__ idx, int PK, float* __restrict__ qbuf,
-                                                              float* __restrict__ qnorm) {
-  const int b = blockIdx.x, bank = blockIdx.y, t = threadIdx.x;
-  const float* mem = bank ? mem2 : mem1;
-  const int64_t qrow = idx[(size_t)b * PK];
-  const float q0 = mem[qrow * D + t], q1 = mem[qrow * D + t + 64];
-  float* q = qbuf + ((size_t)bank * gridDim.x + b) * D;
-  q[t] = q0; q[t + 64] = q1;
-  const float s = wave_sum(q0 * q0 + q1 * q1);
-  if (t == 0) qnorm[bank * gridDim.x + b] = sqrtf(s);
+// stages 1-4: class-masked cosine similarity of EVERY bank row with EVERY query (CRD_criterion_v10.py:72-79: the reference's
+// cosine_similarity(bank[idx], bank) * class_mask) and the selection of the best rows without the similarity matrix ever
+// existing in memory.  The product is a [n_data x 128] x [128 x B] GEMM per bank on the EXACT fp32 matrix instruction
+// (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain).  A wave owns tiles of 32 bank rows; bank rows are the M side and
+// the queries the N side, so a lane's 16 accumulator registers are 16 bank rows of ONE query per 32-query block and the lane can
+// select for that query in registers.  The rows arrive by LDS-DMA, a quarter tile (32 rows x 32 features) per group, two groups
+// in flight behind the one being multiplied (three 4-KiB buffers per wave, hand-counted vmcnt); the 16-byte chunks are
+// XOR-swizzled on the source side; the row norms are accumulated from the matrix operands themselves; the queries (the bank
+// rows idx[b][0]) are gathered into LDS by every workgroup.  Eight waves of 147 registers, two per SIMD.
+//   Keeping a sorted list per lane costs ~500 cycles per (row, query-block) step whenever ANY of the 64 lanes inserts, and with
+// 2048 waves a list sees 32 rows - every step inserted (57 us for the pass, 4x its matrix time).  So the selection is seeded:
+//   1. SAMPLE pass: every 8th tile, one per wave, one 32-query block per workgroup; a lane only keeps the MAXIMUM key of its 16
+//      rows - one compare per element - and leaves it in gmax[bank][query][group].  The groups are disjoint row sets, so the
+//      TOPK_MAX-th largest of a query's group maxima (stage 2, `thr`) is a lower bound of its TOPK_MAX-th best similarity over
+//      the whole bank.
+//   3. FULL pass: an element enters a lane's list only if its key reaches thr - about TOPK_MAX x 8 elements per query in
+//      the whole bank, so the insertion path is skipped by almost every step: a step is one multiply-compare on the raw
+//      accumulator (conservative by 2^-20, the exact key is formed inside the rare path).  Each wave leaves one list per query.
+//   4. merge: the NP best keys of a query's lists (mostly empty: key plane 0 is read coalesced, plane k only behind a
+//      non-empty plane k - 1).
+// The result does not depend on the sample (any thr that is a true lower bound gives the same NP keys); a bank sorted by
+// class only makes the full pass slower.  Measured at 65 536 rows x 64 queries (rocprofv3, tests/bench_topk_gpu.py): sample 9.5 +
+// thr 5.1 + full 35 + merge 9.6 = 59 us.  The full pass runs at matrix time + selection time (3.9 + 2.3 us per tile and
+// SIMD): the VALU work of one wave does not hide under the other wave's fp32 MFMAs (delaying one wave of every SIMD by half a
+// matrix phase changed nothing), and the per-launch overhead of the four small launches is a third of the total.
+// History: one workgroup per (query, bank, slice) re-read the bank per query (1.4 GB through L2, 278 us); a thread per bank
+// row with the queries as scalar operands 120-132 us; similarity matrix [2][B][n_data] written by an MFMA kernel (59 us) and
+// re-read by a selection kernel (41 us) + merge (9 us): 136 MB of traffic for 67 MB of bank, 157-162 us per call (round 3);
+// one unseeded pass with lists 57 + 22 us; seeded, rows through registers and a half-tile LDS stage 16 + 5 + 38 + 10 us.
+constexpr int SIM_RS = 129;     // dwords per staged query row (odd: the 32 lanes of a ds_read_b32 group hit 32 different banks)
+constexpr int KNN_WAVES = 8, KNN_SAMPLE_WAVES = 4, KNN_NBUF = 3, KNN_MAX_GX = 128, KNN_SAMPLE_TILES = 256, KNN_MAX_B = 64;
+
+// DPP helpers (no LDS round trip, unlike __shfl): x of the lane N to the right inside the 16-lane row / lane 15 or 31 broadcast
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ u64 dpp_max_u64(u64 v) {
+  const u64 o = ((u64)dpp_u32<CTRL, ROW_MASK>((unsigned)(v >> 32)) << 32) | dpp_u32<CTRL, ROW_MASK>((unsigned)v);   // (0 where no source)
+  return o > v ? o : v;
+}
+// largest key of the wave, in every lane (uniform)
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+  v = dpp_max_u64<0x111>(v);           // row_shr:1
+  v = dpp_max_u64<0x112>(v);           // row_shr:2
+  v = dpp_max_u64<0x114>(v);           // row_shr:4
+  v = dpp_max_u64<0x118>(v);           // row_shr:8   -> lane 15 of every row holds the row's maximum
+  v = dpp_max_u64<0x142, 0xa>(v);      // row_bcast:15 into rows 1, 3
+  v = dpp_max_u64<0x143, 0xc>(v);      // row_bcast:31 into rows 2, 3 -> lane 63 holds the wave's maximum
+  return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// sum over the 16-lane row, valid in lane 15 of the row
+__device__ __forceinline__ float row16_sum_hi(float x) {
+  auto sh = [](float y, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, y), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  x += sh(x, std::integral_constant<int, 0x111>{});
+  x += sh(x, std::integral_constant<int, 0x112>{});
+  x += sh(x, std::integral_constant<int, 0x114>{});
+  x += sh(x, std::integral_constant<int, 0x118>{});
+  return x;
 }
 
-// stage 1: class-masked cosine similarity of EVERY bank row with EVERY query, S[bank][b][j] (CRD_criterion_v10.py:72-79: the
-// reference's cosine_similarity(bank[idx], bank) * class_mask) - a [B x 128] x [128 x n_data] product per bank on the EXACT
-// fp32 matrix instruction (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain, so every similarity is the
-// sequential dot product the scalar kernels computed).  A wave owns tiles of 32 bank rows: the rows arrive by coalesced
-// 16-byte loads (next tile prefetched into registers during the matrix loop) and sit in LDS with an odd row stride; the
-// queries sit in LDS once per workgroup; queries are the M side, bank rows the N side, so a lane's results are 32 consecutive
-// bank rows of one query: 128-byte stores.  History: one workgroup per (query, bank, slice) re-read the bank per query
-// (1.4 GB through L2, 278 us); a thread per bank row with the queries as scalar operands read the bank once but ran 120-132 us
-// (scalar-load latency per 128-feature query and one dependent fmac chain per pair; four interleaved chains and coalesced
-// row loads moved it by 10 %).
-constexpr int SIM_RS = 129;     // dwords per staged row (odd: the 32 lanes of a ds_read_b32 group hit 32 different banks)
+// one LDS-DMA wave-instruction: lane l copies 16 (4) bytes from its global address to LDS byte lds_addr + 16 (4) * l
+__device__ __forceinline__ void knn_dma16(const void* g, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(g) : "memory");
+}
+__device__ __forceinline__ void knn_dma4(const void* g, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(g) : "memory");
+}
 
-template <int NQ>
-__global__ __launch_bounds__(256) void crd_bank_sim_kernel(const float* __restrict__ mem1, const float* __restrict__ mem2,
-                                                           const int* __restrict__ labels, const float* __restrict__ qbuf,
-                                                           const float* __restrict__ qnorm,
-                                                           const int64_t* __restrict__ batch_label, int B, int n_data,
-                                                           float* __restrict__ S) {
+template <int NQ, bool SAMPLE>
+__global__ __launch_bounds__((SAMPLE ? KNN_SAMPLE_WAVES : KNN_WAVES) * 64) void crd_bank_knn_kernel(
+    const float* __restrict__ mem1, const float* __restrict__ mem2, const int* __restrict__ labels, const int64_t* __restrict__ idx,
+    int PK, const int64_t* __restrict__ batch_label, int B, int n_data, int stiles, int tstride, u64* __restrict__ gmax,
+    const u64* __restrict__ thr, u64* __restrict__ cand) {
+  constexpr int NW = SAMPLE ? KNN_SAMPLE_WAVES : KNN_WAVES;
+  typedef __attribute__((address_space(3))) unsigned char lds_uchar;
   extern __shared__ __attribute__((aligned(16))) float sim_lds[];
   float* Qs = sim_lds;                                   // [NQ * 32][SIM_RS]
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* Rs = sim_lds + NQ * 32 * SIM_RS + wv * 32 * SIM_RS;   // this wave's [32][SIM_RS]
+  constexpr int RQ0 = NQ * 32 * SIM_RS, RQW = KNN_NBUF * 1024, AUX0 = RQ0 + NW * RQW, AUXW = 32 + 2 * 64;
+  float* Rq = sim_lds + RQ0 + wv * RQW;                  // this wave's KNN_NBUF quarter tiles [32 rows][32 features], 16-B chunks swizzled
+  float* rnl = sim_lds + AUX0 + wv * AUXW;               // its 32 row norms | 2 x 64 row labels (tile parity; a 64-lane DMA each)
+  int* rli = reinterpret_cast<int*>(rnl) + 32;
+  float* qpart = sim_lds + AUX0 + NW * AUXW;             // [NQ * 32][2] halves of |q|^2
+  const unsigned lds0 = (unsigned)(size_t)(lds_uchar*)sim_lds;
+  const unsigned rq_lds = lds0 + (RQ0 + wv * RQW) * 4, rli_lds = lds0 + (AUX0 + wv * AUXW + 32) * 4;
   const int bank = blockIdx.y;
+  const int q0 = SAMPLE ? (int)blockIdx.z * 32 : 0;      // the sample pass: one 32-query block per workgroup (grid z)
   const float* mem = bank ? mem2 : mem1;
-  const float* q = qbuf + (size_t)bank * B * D;
-  float* Sb = S + (size_t)bank * B * n_data;
-  for (int e = threadIdx.x; e < NQ * 32 * D; e += 256) {
-    const int qi = e / D, d = e - qi * D;
-    Qs[qi * SIM_RS + d] = qi < B ? q[(size_t)qi * D + d] : 0.f;
-  }
-  // per lane: norm and label of the 16 * NQ queries its accumulator registers belong to
-  float qn[NQ][16];
-  int ql[NQ][16];
-#pragma unroll
-  for (int nq = 0; nq < NQ; ++nq)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      qn[nq][r] = qi < B ? qnorm[bank * B + qi] : 0.f;
-      ql[nq][r] = qi < B ? (int)batch_label[qi] : -2;
-    }
-  __syncthreads();
   const int ntiles = (n_data + 31) / 32;
-  const int stride = gridDim.x * 4;
-  f32x4 pre[16];
-  auto load_tile = [&](int t) {       // 32 rows x 512 B: instruction e covers rows 2e, 2e + 1
+  const int stride = SAMPLE ? ntiles : gridDim.x * NW;      // (a sample wave has one tile)
+  // Quarter group (tile, q) = 4 DMA instructions of 8 rows x 128 B (+ the 32 row labels in front of quarter 0): lane l carries
+  // chunk position l & 7 of row 8e + (l >> 3); the LDS image is linear, the XOR swizzle of the 16-byte chunks is applied to the
+  // SOURCE (chunk p of row r holds features 4 (p ^ ((r >> 1) & 7)) ..): the 32 lanes of a matrix operand read hit 16 banks
+  const int drow = lane >> 3, dchunk = ((lane & 7) ^ ((drow >> 1) & 3)) * 4;      // ((8e + drow) >> 1) & 7 = 4 (e & 1) + (drow >> 1)
+  auto issue = [&](int tile, int q, int buf, int par) {
+    tile = tile < ntiles ? tile : ntiles - 1;              // (past the end: harmless duplicates, the wait counts stay uniform)
+    if (q == 0) {
+      const int lrow = tile * 32 + (lane & 31);
+      knn_dma4(labels + (lrow < n_data ? lrow : 0), rli_lds + par * 256);
+    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = t * 32 + e * 2 + (lane >> 5);
-      pre[e] = *reinterpret_cast<const f32x4*>(mem + (size_t)(row < n_data ? row : 0) * D + (lane & 31) * 4);
+    for (int e = 0; e < 4; ++e) {
+      const int row = tile * 32 + e * 8 + drow;
+      knn_dma16(mem + (size_t)(row < n_data ? row : 0) * D + q * 32 + (dchunk ^ ((e & 1) << 4)), rq_lds + buf * 4096 + e * 1024);
     }
   };
-  auto stage_tile = [&]() {
+  const int slot = blockIdx.x * NW + wv;
+  int t = SAMPLE ? (slot < stiles ? slot * tstride : ntiles) : slot;
+  if (t < ntiles) {      // (in flight under the staging of the queries)
+    issue(t, 0, 0, 0);
+    issue(t, 1, 1, 0);
+  }
+  {   // the queries = the bank rows of the samples themselves, idx[b][0]: NQ * 32 rows of 32 16-byte pieces, all loads of a
+      // thread in flight together; a half-wave holds one row, its |q|^2 comes from the two 16-lane DPP rows
+    constexpr int NE = NQ * 32 * 32 / (NW * 64);
+    f32x4 qv[NE];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      float* dst = Rs + (e * 2 + (lane >> 5)) * SIM_RS + (lane & 31) * 4;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dst[k] = pre[e][k];
+    for (int e = 0; e < NE; ++e) {
+      const int pc = e * (NW * 64) + threadIdx.x, qi = q0 + (pc >> 5);
+      qv[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (qi < B) qv[e] = *reinterpret_cast<const f32x4*>(mem + idx[(size_t)qi * PK] * D + (pc & 31) * 4);
     }
-  };
-  int t = blockIdx.x * 4 + wv;
-  if (t < ntiles) load_tile(t);
-  for (; t < ntiles; t += stride) {
-    stage_tile();
-    if (t + stride < ntiles) load_tile(t + stride);
-    __builtin_amdgcn_wave_barrier();
-    const int j = lane & 31, kk = lane >> 5, row = t * 32 + j;
-    // norm of the lane's bank row, features in index order (bitwise the scalar kernels' value)
-    float nn = 0.f;
-#pragma unroll 16
-    for (int d = 0; d < D; ++d) { const float v = Rs[j * SIM_RS + d]; nn += v * v; }
-    const float rn = sqrtf(nn);
-    const int lab = row < n_data ? labels[row] : -1;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int pc = e * (NW * 64) + threadIdx.x, ql_ = pc >> 5;
+      float ps = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { Qs[ql_ * SIM_RS + (pc & 31) * 4 + k] = qv[e][k]; ps += qv[e][k] * qv[e][k]; }
+      ps = row16_sum_hi(ps);
+      if ((lane & 15) == 15) qpart[ql_ * 2 + ((lane >> 4) & 1)] = ps;
+    }
+  }
+  __syncthreads();
+  const int j = lane & 31, kk = lane >> 5;
+  float qn[NQ], tv[NQ];
+  int ql[NQ];
+  u64 L[NQ][SAMPLE ? 1 : TOPK_MAX], tk[NQ];
+#pragma unroll
+  for (int nq = 0; nq < NQ; ++nq) {
+    const int qi = q0 + nq * 32 + j;
+    qn[nq] = qi < B ? sqrtf(qpart[(nq * 32 + j) * 2] + qpart[(nq * 32 + j) * 2 + 1]) : 0.f;
+    ql[nq] = qi < B ? (int)batch_label[qi] : -2;
+    tk[nq] = (!SAMPLE && qi < B) ? thr[bank * B + qi] : 0;
+    tv[nq] = tk[nq] ? knn_value(tk[nq]) : -INFINITY;
+#pragma unroll
+    for (int k = 0; k < (SAMPLE ? 1 : TOPK_MAX); ++k) L[nq][k] = 0;
+  }
+  const int jrow = j * 32, gj = (j >> 1) & 7;
+  int par = 0, bufc = 0;      // parity of the wave's tile count (label buffer), buffer of the quarter being computed
+  for (; t < ntiles; t += stride, par ^= 1) {
     f32x16 acc[NQ];
 #pragma unroll
     for (int nq = 0; nq < NQ; ++nq)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nq][r] = 0.f;
-#pragma unroll 8
-    for (int k0 = 0; k0 < D; k0 += 2) {
-      const float bv = Rs[j * SIM_RS + k0 + kk];
+    float nn = 0.f;       // |row j|^2 over the features of parity kk: the matrix operands themselves
 #pragma unroll
-      for (int nq = 0; nq < NQ; ++nq)
-        acc[nq] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(nq * 32 + j) * SIM_RS + k0 + kk], bv, acc[nq], 0, 0, 0);
-    }
-#pragma unroll
-    for (int nq = 0; nq < NQ; ++nq)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const float den = rn * qn[nq][r];
-        float v = den > 0.f ? acc[nq][r] / den : 0.f;
-        if (lab != ql[nq][r]) v = 0.f;                       // other classes are masked to similarity 0 (class_mask *)
-        if (qi < B && row < n_data) Sb[(size_t)qi * n_data + row] = v;
+    for (int q = 0; q < 4; ++q) {
+      // quarter (t, q) has landed when only the group behind it is still in flight; then the group two ahead is issued into
+      // the buffer the previous quarter was read from
+      if (q == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      {
+        const int b2 = bufc + 2 >= KNN_NBUF ? bufc + 2 - KNN_NBUF : bufc + 2;
+        if (q < 2) issue(t, q + 2, b2, par);
+        else issue(t + stride, q - 2, b2, par ^ 1);
       }
+      const float* R = Rq + bufc * 1024 + jrow;
+      // operands of 4 k-steps (8 features = two 16-byte chunks) per batch, the next batch's LDS reads in flight under this
+      // batch's MFMAs
+      float av[2][4], qv[2][NQ][4];
+      auto ld = [&](int buf, int kb) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          av[buf][s4] = R[(((kb * 2 + (s4 >> 1)) ^ gj) << 2) + 2 * (s4 & 1) + kk];
+#pragma unroll
+          for (int nq = 0; nq < NQ; ++nq) qv[buf][nq][s4] = Qs[(nq * 32 + j) * SIM_RS + q * 32 + kb * 8 + 2 * s4 + kk];
+        }
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        if (kb + 1 < 4) ld((kb + 1) & 1, kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+          for (int nq = 0; nq < NQ; ++nq)
+            acc[nq] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][s4], qv[kb & 1][nq][s4], acc[nq], 0, 0, 0);
+          nn += av[kb & 1][s4] * av[kb & 1][s4];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bufc = bufc + 1 >= KNN_NBUF ? 0 : bufc + 1;
+    }
+    nn += __shfl_xor(nn, 32, 64);
+    if (kk == 0) rnl[j] = sqrtf(nn);
     __builtin_amdgcn_wave_barrier();
+    const int* rl = rli + par * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * kk, row = t * 32 + m;
+      const float rn = rnl[m];
+      const int lab = rl[m];
+#pragma unroll
+      for (int nq = 0; nq < NQ; ++nq) {
+        const float den = rn * qn[nq];
+        const bool masked = lab != ql[nq];                    // other classes are masked to similarity 0 (class_mask *)
+        const bool live = ql[nq] != -2 && row < n_data;
+        if constexpr (SAMPLE) {
+          float v = den > 0.f ? acc[nq][r] / den : 0.f;
+          if (masked) v = 0.f;
+          const u64 key = knn_key(v, row);
+          if (live && key > L[nq][0]) L[nq][0] = key;
+        } else {
+          // v >= tv can only hold if acc >= tv * den up to the rounding of the division (masked / zero-norm rows: v = 0)
+          const float bound = tv[nq] * den;
+          const bool maybe = masked ? tv[nq] <= 0.f : acc[nq][r] >= bound - fabsf(bound) * 9.5367431640625e-7f - 1e-37f;
+          if (live && maybe) {
+            float v = den > 0.f ? acc[nq][r] / den : 0.f;
+            if (masked) v = 0.f;
+            const u64 key = knn_key(v, row);
+            if (key >= tk[nq] && key > L[nq][TOPK_MAX - 1]) knn_insert(L[nq], key);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the groups issued past the end)
+  if constexpr (SAMPLE) {
+    // group maxima: two per (query, sample wave), the half-waves hold disjoint rows
+    if (slot < stiles)
+#pragma unroll
+      for (int nq = 0; nq < NQ; ++nq) {
+        const int qi = q0 + nq * 32 + j;
+        if (qi < B) gmax[((size_t)bank * B + qi) * (2 * stiles) + 2 * slot + kk] = L[nq][0];
+      }
+  } else {
+    // the two half-waves hold disjoint rows of the same queries: fold the upper half's lists into the lower's, one list per wave
+    const int nlists = gridDim.x * KNN_WAVES;
+#pragma unroll
+    for (int nq = 0; nq < NQ; ++nq) {
+      u64 other[TOPK_MAX];
+#pragma unroll
+      for (int k = 0; k < TOPK_MAX; ++k) other[k] = __shfl_xor(L[nq][k], 32, 64);
+      if (kk == 0) {
+#pragma unroll
+        for (int k = 0; k < TOPK_MAX; ++k)
+          if (other[k] > L[nq][TOPK_MAX - 1]) knn_insert(L[nq], other[k]);
+        const int qi = nq * 32 + j;
+        if (qi < B) {
+          u64* dst = cand + ((size_t)bank * B + qi) * TOPK_MAX * nlists + slot;     // [k][list]
+          dst[0] = L[nq][0];
+#pragma unroll
+          for (int k = 1; k < TOPK_MAX; ++k)
+            if (L[nq][k - 1]) dst[(size_t)k * nlists] = L[nq][k];
+        }
+      }
+    }
   }
 }
 
-// stage 2: block (query b, bank, slice z) scans its slice of the similarity row; every thread keeps a private top list over
-// its columns, the block picks its TOPK_MAX best by parallel arg-max rounds and leaves them in the workspace
-__global__ __launch_bounds__(256) void crd_bank_topk_kernel(const float* __restrict__ S, int B, int n_data,
-                                                            float* __restrict__ cand_v, int* __restrict__ cand_i) {
-  const int b = blockIdx.x, bank = blockIdx.y, z = blockIdx.z;
-  const float* row = S + ((size_t)bank * B + b) * n_data;
-  float bv[TOPK_MAX]; int bi[TOPK_MAX];
+// pop the largest key of the wave's sorted private lists (DPP max; keys are unique); the owner drops its head
+__device__ __forceinline__ u64 knn_wave_pop(u64 (&L)[TOPK_MAX]) {
+  const u64 v = wave_max_u64(L[0]);
+  if (L[0] == v && v != 0) {
 #pragma unroll
-  for (int k = 0; k < TOPK_MAX; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
-  const int chunk = (n_data + TOPK_SPLIT - 1) / TOPK_SPLIT, lo = z * chunk, hi = min(n_data, lo + chunk);
-  for (int j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    const float v = row[j];
-    // insert (v, j) into the descending private list (ties: lower index first)
-    if (v > bv[TOPK_MAX - 1] || (v == bv[TOPK_MAX - 1] && j < bi[TOPK_MAX - 1])) {
-      int pos = TOPK_MAX - 1;
-#pragma unroll
-      for (int k = TOPK_MAX - 1; k > 0; --k) {
-        const bool up = (v > bv[k - 1]) || (v == bv[k - 1] && j < bi[k - 1]);
-        if (up) { bv[k] = bv[k - 1]; bi[k] = bi[k - 1]; pos = k - 1; }
-      }
-      bv[pos] = v; bi[pos] = j;
-    }
+    for (int k = 0; k + 1 < TOPK_MAX; ++k) L[k] = L[k + 1];
+    L[TOPK_MAX - 1] = 0;
   }
-  // The block's TOPK_MAX best out of its 256 sorted private lists: every wave pops the best list head TOPK_MAX times
-  // (butterfly arg-max over the lanes: value descending, index ascending - a total order, so the result does not depend on
-  // how the elements are dealt to threads), the four waves' winners meet in LDS and wave 0 repeats the selection on those
-  // 32.  (The first version kept all 2048 candidates in LDS and ran TOPK_MAX block-wide arg-max rounds of nine barriers
-  // each: 62 us at 65 536 rows x 64 queries.)
-  auto better = [](float v, int i, float v2, int i2) { return v2 > v || (v2 == v && i2 < i); };
-  auto wave_pop_best = [&](float& ov, int& oi) {
-    float v = bv[0]; int i = bi[0];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float v2 = __shfl_xor(v, o, 64); const int i2 = __shfl_xor(i, o, 64);
-      if (better(v, i, v2, i2)) { v = v2; i = i2; }
-    }
-    ov = v; oi = i;
-    if (bi[0] == i && i != 0x7fffffff) {      // the owner drops its head (indices are unique within the block)
-#pragma unroll
-      for (int k = 0; k + 1 < TOPK_MAX; ++k) { bv[k] = bv[k + 1]; bi[k] = bi[k + 1]; }
-      bv[TOPK_MAX - 1] = -INFINITY; bi[TOPK_MAX - 1] = 0x7fffffff;
-    }
-  };
-  __shared__ float wv_[4 * TOPK_MAX];
-  __shared__ int wi_[4 * TOPK_MAX];
+  return v;
+}
+// the block's TOPK_MAX largest keys, in order, left in wave 0 (returned one per call of the functor `out(pick, key)` on lane 0)
+template <class F>
+__device__ __forceinline__ void knn_block_best(u64 (&L)[TOPK_MAX], int npick, F out) {
+  __shared__ u64 wk[4 * TOPK_MAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int pick = 0; pick < TOPK_MAX; ++pick) {
-    float v; int i;
-    wave_pop_best(v, i);
-    if (lane == 0) { wv_[wave * TOPK_MAX + pick] = v; wi_[wave * TOPK_MAX + pick] = i; }
+    const u64 v = knn_wave_pop(L);
+    if (lane == 0) wk[wave * TOPK_MAX + pick] = v;
   }
   __syncthreads();
   if (wave == 0) {
-    bv[0] = lane < 4 * TOPK_MAX ? wv_[lane] : -INFINITY;
-    bi[0] = lane < 4 * TOPK_MAX ? wi_[lane] : 0x7fffffff;
+    L[0] = lane < 4 * TOPK_MAX ? wk[lane] : 0;
 #pragma unroll
-    for (int k = 1; k < TOPK_MAX; ++k) { bv[k] = -INFINITY; bi[k] = 0x7fffffff; }
-    const size_t base = (((size_t)b * 2 + bank) * TOPK_SPLIT + z) * TOPK_MAX;
-#pragma unroll
-    for (int pick = 0; pick < TOPK_MAX; ++pick) {
-      float v; int i;
-      wave_pop_best(v, i);
-      if (lane == 0) { cand_v[base + pick] = v; cand_i[base + pick] = i; }
+    for (int k = 1; k < TOPK_MAX; ++k) L[k] = 0;
+    for (int pick = 0; pick < npick; ++pick) {
+      const u64 v = knn_wave_pop(L);
+      if (lane == 0) out(pick, v);
     }
   }
 }
 
-// stage 3: the NP best of the TOPK_SPLIT * TOPK_MAX candidates of a (query, bank)
-__global__ __launch_bounds__(256) void crd_bank_topk_merge_kernel(const float* __restrict__ cand_v, const int* __restrict__ cand_i,
-                                                                  int NP, int64_t* __restrict__ nb1, int64_t* __restrict__ nb2,
-                                                                  float* __restrict__ sim1, float* __restrict__ sim2) {
+// stage 2: thr[bank][query] = the TOPK_MAX-th largest of the query's group maxima (0 when there are fewer: everything passes)
+__global__ __launch_bounds__(256) void crd_knn_thr_kernel(const u64* __restrict__ gmax, int ng, u64* __restrict__ thr) {
   const int b = blockIdx.x, bank = blockIdx.y;
-  constexpr int NC = TOPK_SPLIT * TOPK_MAX;
-  __shared__ float sv[NC];
-  __shared__ int si[NC];
-  __shared__ float rv[256];
-  __shared__ int ri[256], rs[256];
-  const size_t base = ((size_t)b * 2 + bank) * NC;
-  for (int e = threadIdx.x; e < NC; e += 256) { sv[e] = cand_v[base + e]; si[e] = cand_i[base + e]; }
-  __syncthreads();
-  for (int pick = 0; pick < NP; ++pick) {
-    float best; int besti, slot;
-    block_argbest(sv, si, NC, rv, ri, rs, best, besti, slot);
-    if (threadIdx.x == 0) {
-      if (slot >= 0) si[slot] = 0x7fffffff;
-      (bank ? nb2 : nb1)[(size_t)b * NP + pick] = besti;
-      (bank ? sim2 : sim1)[(size_t)b * NP + pick] = best;
-    }
-    __syncthreads();
+  const u64* g = gmax + ((size_t)bank * gridDim.x + b) * ng;
+  u64 L[TOPK_MAX];
+#pragma unroll
+  for (int k = 0; k < TOPK_MAX; ++k) L[k] = 0;
+  for (int e = threadIdx.x; e < ng; e += 256) {
+    const u64 key = g[e];
+    if (key > L[TOPK_MAX - 1]) knn_insert(L, key);
   }
+  knn_block_best(L, TOPK_MAX, [&](int pick, u64 v) {
+    if (pick == TOPK_MAX - 1) thr[bank * gridDim.x + b] = v;
+  });
+}
+
+// stage 4: the NP best of the keys a (query, bank) was left with, planes [k][list]
+__global__ __launch_bounds__(256) void crd_knn_merge_kernel(const u64* __restrict__ cand, int nlists, int NP, int64_t* __restrict__ nb1,
+                                                            int64_t* __restrict__ nb2, float* __restrict__ sim1,
+                                                            float* __restrict__ sim2) {
+  const int b = blockIdx.x, bank = blockIdx.y;
+  const u64* c = cand + ((size_t)bank * gridDim.x + b) * TOPK_MAX * nlists;
+  u64 L[TOPK_MAX];
+#pragma unroll
+  for (int k = 0; k < TOPK_MAX; ++k) L[k] = 0;
+  for (int e = threadIdx.x; e < nlists; e += 256)
+    for (int k = 0; k < TOPK_MAX; ++k) {
+      const u64 key = c[(size_t)k * nlists + e];
+      if (!key) break;
+      if (key > L[TOPK_MAX - 1]) knn_insert(L, key);
+    }
+  knn_block_best(L, NP, [&](int pick, u64 v) {
+    (bank ? nb2 : nb1)[(size_t)b * NP + pick] = v ? (int64_t)(~(unsigned)v) : (int64_t)0x7fffffff;
+    (bank ? sim2 : sim1)[(size_t)b * NP + pick] = v ? knn_value(v) : -INFINITY;
+  });
 }
 
 
@@ -611,21 +742,30 @@ __global__ __launch_bounds__(256) void contrast_loss_v2_kernel(const float* __re
 
 }  // namespace
 
-// workspace: similarity rows S [2][B][n_data] f32 | candidates | query rows [2][B][128] + norms [2][B]
-static inline size_t topk_cand_bytes(int B) { return (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX * (sizeof(float) + sizeof(int)); }
+// workspace: list keys [2][B][TOPK_MAX][nlists] u64 | group maxima [2][B][2 * stiles] | thr [2][B]  (B <= 64 per pass)
+static inline int knn_gx(int n_data) {
+  const int g = cdiv(cdiv(n_data, 32), KNN_WAVES);
+  return g < KNN_MAX_GX ? g : KNN_MAX_GX;      // one workgroup per CU over the two banks; a wave walks its tiles
+}
+static inline int knn_stiles(int n_data) {
+  const int nt = cdiv(n_data, 32);
+  return nt < KNN_SAMPLE_TILES ? nt : KNN_SAMPLE_TILES;
+}
 size_t ph_crd_bank_topk_workspace_bytes(int B, int n_data) {
-  return (size_t)2 * B * n_data * sizeof(float) + topk_cand_bytes(B) + (size_t)2 * B * (D + 1) * sizeof(float) + 256;
+  const size_t bc = B < KNN_MAX_B ? B : KNN_MAX_B;
+  return 2 * bc * ((size_t)knn_gx(n_data) * KNN_WAVES * TOPK_MAX + 2 * knn_stiles(n_data) + 1) * sizeof(u64) + 256;
 }
 
 int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, const int64_t* idx, int PK,
                      const int64_t* batch_label, int B, int n_data, int num_pos, int feat_dim, int64_t* nb1,
                      int64_t* nb2, float* sim1, float* sim2, void* workspace, hipStream_t st) {
   if (feat_dim != D || num_pos < 1 || num_pos > TOPK_MAX || !workspace || B < 1 || n_data < 1) return PH_EINVAL;
-  if (B > 128) {
-    // the similarity kernel holds up to 128 normalised queries in LDS: larger batches (the reference has no limit; a replica
-    // batch of 256 is the north-star size) run in chunks of 128 queries through the same workspace, in stream order
-    for (int c0 = 0; c0 < B; c0 += 128) {
-      const int bc = B - c0 < 128 ? B - c0 : 128;
+  if (B > KNN_MAX_B) {
+    // a lane selects for one query per 32-query block and two blocks fill its registers (accumulators + lists): larger batches
+    // (the reference has no limit; a replica batch of 256 is the north-star size) run in chunks of 64 queries through the same
+    // workspace, in stream order - the matrix work is the same, only the 67 MB bank is read once per chunk
+    for (int c0 = 0; c0 < B; c0 += KNN_MAX_B) {
+      const int bc = B - c0 < KNN_MAX_B ? B - c0 : KNN_MAX_B;
       const int rc = ph_crd_bank_topk(mem1, mem2, labels, idx + (size_t)c0 * PK, PK, batch_label + c0, bc, n_data, num_pos, feat_dim,
                                       nb1 + (size_t)c0 * num_pos, nb2 + (size_t)c0 * num_pos, sim1 + (size_t)c0 * num_pos,
                                       sim2 + (size_t)c0 * num_pos, workspace, st);
@@ -633,41 +773,36 @@ int ph_crd_bank_topk(const float* mem1, const float* mem2, const int* labels, co
     }
     return PH_OK;
   }
-  float* S = reinterpret_cast<float*>(workspace);
-  float* cv = S + (size_t)2 * B * n_data;
-  int* ci = reinterpret_cast<int*>(cv + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
-  float* qbuf = reinterpret_cast<float*>(ci + (size_t)B * 2 * TOPK_SPLIT * TOPK_MAX);
-  float* qnorm = qbuf + (size_t)2 * B * D;
+  const int gx = knn_gx(n_data), nlists = gx * KNN_WAVES, stiles = knn_stiles(n_data), tstride = cdiv(n_data, 32) / stiles;
+  u64* cand = reinterpret_cast<u64*>(workspace);
+  u64* gmax = cand + (size_t)2 * B * TOPK_MAX * nlists;
+  u64* thr = gmax + (size_t)2 * B * 2 * stiles;
   void* tok = nullptr;
   if (ph_prof_on())   // algorithmic bytes: every row of both banks once + the row labels + the 2 x B x num_pos results
     ph_prof_begin(PH_CLS_CRD_TOPK, 2.0 * n_data * D * 4 + 4.0 * n_data + 2.0 * B * num_pos * 12, st, &tok);
-  hipLaunchKernelGGL(crd_topk_queries_kernel, dim3(B, 2), dim3(64), 0, st, mem1, mem2, idx, PK, qbuf, qnorm);
-  PH_LAUNCH_CHECK();
-  {
-    const int nq = cdiv(B, 32);      // <= 4 (chunked above)
-    const int ntiles = cdiv(n_data, 32);
-    int gx = cdiv(ntiles, 4);
-    const int cus = ph_num_cus();
-    if (gx > cus / 2) gx = cus / 2;     // one workgroup per CU over the two banks; a wave walks its tiles
-    const size_t lds = (size_t)(nq * 32 + 4 * 32) * SIM_RS * sizeof(float);
-#define PH_SIM_LAUNCH(N)                                                                                                    \
+  const int nq = cdiv(B, 32);      // <= 2 (chunked above)
+#define PH_KNN_LAUNCH(N, SAMPLE, GX, GZ)                                                                                        \
   do {                                                                                                                      \
+    constexpr int NW = SAMPLE ? KNN_SAMPLE_WAVES : KNN_WAVES;                                                               \
+    const size_t lds = (size_t)(N * 32 * SIM_RS + NW * (KNN_NBUF * 1024 + 32 + 128) + N * 64) * sizeof(float);              \
     static bool done = false;                                                                                               \
     if (!done) {                                                                                                            \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(crd_bank_sim_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds) != hipSuccess) return PH_ELAUNCH;                                                   \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(crd_bank_knn_kernel<N, SAMPLE>),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                          \
+        return PH_ELAUNCH;                                                                                                  \
       done = true;                                                                                                          \
     }                                                                                                                       \
-    hipLaunchKernelGGL(crd_bank_sim_kernel<N>, dim3(gx, 2), dim3(256), lds, st, mem1, mem2, labels, qbuf, qnorm, batch_label, B, \
-                       n_data, S);                                                                                          \
+    hipLaunchKernelGGL((crd_bank_knn_kernel<N, SAMPLE>), dim3(GX, 2, GZ), dim3(NW * 64), lds, st, mem1, mem2, labels, idx, PK, \
+                       batch_label, B, n_data, stiles, tstride, gmax, thr, cand);                                           \
   } while (0)
-    if (nq == 1) PH_SIM_LAUNCH(1); else if (nq == 2) PH_SIM_LAUNCH(2); else if (nq == 3) PH_SIM_LAUNCH(3); else PH_SIM_LAUNCH(4);
-#undef PH_SIM_LAUNCH
-  }
+  PH_KNN_LAUNCH(1, true, cdiv(stiles, KNN_SAMPLE_WAVES), nq);      // one 32-query block per workgroup (grid z)
   PH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(crd_bank_topk_kernel, dim3(B, 2, TOPK_SPLIT), dim3(256), 0, st, S, B, n_data, cv, ci);
+  hipLaunchKernelGGL(crd_knn_thr_kernel, dim3(B, 2), dim3(256), 0, st, gmax, 2 * stiles, thr);
   PH_LAUNCH_CHECK();
-  hipLaunchKernelGGL(crd_bank_topk_merge_kernel, dim3(B, 2), dim3(256), 0, st, cv, ci, num_pos, nb1, nb2, sim1, sim2);
+  if (nq == 1) PH_KNN_LAUNCH(1, false, gx, 1); else PH_KNN_LAUNCH(2, false, gx, 1);
+#undef PH_KNN_LAUNCH
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(crd_knn_merge_kernel, dim3(B, 2), dim3(256), 0, st, cand, nlists, num_pos, nb1, nb2, sim1, sim2);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;

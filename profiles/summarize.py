@@ -202,7 +202,7 @@ def main():
         fdur = dict(dur)
         wa, wc = load_pmc(fw[0])
         fam = {"crd_score": ("crd_score_kernel",), "crd_loss_grad": ("crd_loss_grad_kernel", "crd_loss_grad_reduce_kernel"),
-               "crd_bank_topk": ("crd_topk_queries_kernel", "crd_bank_sim_kernel", "crd_bank_topk_kernel", "crd_bank_topk_merge_kernel")}
+               "crd_bank_topk": ("crd_topk_queries_kernel", "crd_bank_knn_kernel", "crd_knn_merge_kernel")}
         crd[var] = {}
         for name, kerns in fam.items():
             rd = wr = t = 0.0

@@ -330,13 +330,14 @@ def test_mia2023_crd_v10_centers_golden(golden_dir):
         V10.CRDLoss(m.stage2_opt(nce_k=16, nce_p=3, pos_extra="prototypes"), n_data, class_idx)
 
 
-def test_mia2023_bank_topk_bit_exact():
-    """The KNN indices are integer work: identical to torch.sort of the class-masked cosine on the same bank."""
+@pytest.mark.parametrize("n,B,NP", [(65536, 8, 6), (65536, 64, 6), (5000, 100, 8), (77, 3, 2)])
+def test_mia2023_bank_topk_bit_exact(n, B, NP):
+    """The KNN indices are integer work: identical to torch.sort of the class-masked cosine on the same bank.  (65536 rows =
+    BASELINE config 5's bank; 64 queries = the benchmark batch; 100 queries = two passes of <= 64; ragged last tile.)"""
     from multimodal_learning_amd._lib import lib, ptr, stream, check
     import torch.nn.functional as F
     L = lib()
     g = torch.Generator().manual_seed(2)
-    n, B, NP = 65536, 8, 6          # BASELINE config 5 bank size
     mem1 = torch.rand(n, 128, generator=g) - 0.5; mem2 = torch.rand(n, 128, generator=g) - 0.5
     labels = torch.randint(0, 3, (n,), generator=g).int()
     idx = torch.randint(0, n, (B, 5), generator=g)
@@ -353,6 +354,40 @@ def test_mia2023_bank_topk_bit_exact():
         srt = torch.sort(sim, descending=True, dim=-1)
         assert torch.equal(nb.cpu(), srt[1][:, :NP])
         assert torch.allclose(s.cpu(), srt[0][:, :NP], atol=1e-6)
+
+
+def test_mia2023_bank_topk_rare_class_and_sorted_bank():
+    """Cases the seeded selection must survive unchanged: a class with fewer members than num_pos (the masked zeros fill the
+    list in row order - torch.sort(stable=True)), and a bank sorted by class (the sample sees the classes in blocks)."""
+    from multimodal_learning_amd._lib import lib, ptr, stream, check
+    import torch.nn.functional as F
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    n, B, NP = 20000, 16, 8
+    for case in ("rare", "sorted"):
+        mem1 = torch.rand(n, 128, generator=g) - 0.5; mem2 = torch.rand(n, 128, generator=g) - 0.5
+        if case == "rare":
+            labels = torch.randint(0, 2, (n,), generator=g).int()
+            rare = torch.tensor([17, 4000, 9999, 19998])
+            labels[rare] = 2
+            idx = torch.randint(0, n, (B, 5), generator=g)
+            idx[:4, 0] = rare
+        else:
+            labels = (torch.arange(n) * 3 // n).int()
+            idx = torch.randint(0, n, (B, 5), generator=g)
+        bl = labels[idx[:, 0]].long()
+        nb1 = torch.empty(B, NP, dtype=torch.int64, device="cuda"); nb2 = torch.empty_like(nb1)
+        s1 = torch.empty(B, NP, device="cuda"); s2 = torch.empty_like(s1)
+        m1, m2, lb, ix, blc = mem1.cuda(), mem2.cuda(), labels.cuda(), idx.cuda(), bl.cuda()
+        ws = torch.empty(L.ph_crd_bank_topk_workspace_bytes(B, n), dtype=torch.uint8, device="cuda")
+        check(L.ph_crd_bank_topk(ptr(m1), ptr(m2), ptr(lb), ptr(ix), 5, ptr(blc), B, n, NP, 128,
+                                 ptr(nb1), ptr(nb2), ptr(s1), ptr(s2), ptr(ws), stream()), "topk")
+        for mem, nb, s in ((mem1, nb1, s1), (mem2, nb2, s2)):
+            sim = (labels.view(1, -1) == bl.view(-1, 1)).float() * (F.normalize(mem[idx[:, 0]], dim=1) @ F.normalize(mem, dim=1).T)
+            sim = sim + 0.0      # (-0.0 of a masked negative similarity sorts like +0.0)
+            srt = torch.sort(sim, descending=True, dim=-1, stable=True)
+            assert torch.equal(nb.cpu(), srt[1][:, :NP]), case
+            assert torch.allclose(s.cpu(), srt[0][:, :NP], atol=1e-6), case
 
 
 def test_mia2023_rows_golden(golden_dir):
