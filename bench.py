@@ -194,7 +194,7 @@ def cpu_baseline(nsteps=10, faithful_steps=3, like_steps=2):
     return res
 
 
-def variant_setup(name, B, H, device, rank=0, sync=None):
+def variant_setup(name, B, H, device, rank=0, sync=None, generic_head=False):
     """The other stage-2 bodies / the stage-1 t-SVD trainer at BASELINE sizes (configs[3] / configs[4], single-GPU legs):
     "mia2022": MIA-2022 stage 2, vanilla K+1 CRD bank with nce_k 4096 (bank 16 384 rows), momentum GK-Refine;
     "mia2023": MIA-2023 stage 2 = configs[4]: n_data 65 536 bank rows, nce_k 4096, nce_p 6 class-aware KNN positives
@@ -218,6 +218,7 @@ def variant_setup(name, B, H, device, rank=0, sync=None):
     if name == "mia2022":
         opt = m.stage2_opt(dropout_rate=0.1, batch_size=B)
         opt.nce_k, opt.grads_m, opt.grads_thresh, opt.thresh = 4096, 0.9, "False", 0.1
+        opt.fused_loss_head = not generic_head
         n_data = 16384
         step = m.DistillStep(opt, n_data, device=device, variant="mia2022", sync=sync)
         desc = "MIA-2022 stage 2 (train_test_path_multi_distill_v2.py): CRD bank %d rows, nce_k 4096, momentum GK-Refine" % n_data
@@ -558,7 +559,7 @@ def main():
         np.random.seed(2019 + rank)
         L = m.lib()
         step, batches, desc = variant_setup(args.variant, 128 if (args.variant == "tsvd" and args.batch == 64) else args.batch,
-                                            args.size, device, rank, sync)
+                                            args.size, device, rank, sync, generic_head=args.generic_loss_head)
         graph = hasattr(step, "enable_graph") and not args.eager
         if graph:
             step.enable_graph()

@@ -258,6 +258,13 @@ int ph_gk_finish(const float* gram, const float* losses, const float* coef, cons
  * first call, set to 1 by the kernel) */
 int ph_gk_scale_momentum(const float* gram, int ng, int use_thresh, float thresh, float momentum, float* mo_scale,
                          int* mo_init, ph_stream_t stream);
+/* The closed-form loss head's finish for that trainer (loss_head.py, variant mia2022): gram / losses in the head's internal order
+ * [div1, div2, CE, kd1, kd2]; mo_scale (persistent, [5]) and scale_ext in the trainer's order [div1, div2, kd1, kd2, CE];
+ * w = gradient weights (lam for CE, mult * state_i * c_i for the distillation terms, c = (alpha, alpha, beta e, beta e) with
+ * e = *e_dev, the epoch weight of the CRD terms, :436-437), total = w . losses, scaled = losses * c (:452-455) */
+int ph_gk_finish_momentum(const float* gram, const float* losses, float alpha, float beta, const float* e_dev, float lam,
+                          float mult, int use_thresh, float thresh, float momentum, float* mo_scale, int* mo_init, float* w,
+                          float* total, float* scaled, float* scale_ext, ph_stream_t stream);
 /* GK_refine_thresh ("MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":81-128): per-sample cosine
  * matrix of the ng gradients G[ng][B][128] -> all_scale[B][ng] */
 int ph_gk_rows(const float* G, int ng, int B, int D, int use_thresh, float thresh, float* all_scale,

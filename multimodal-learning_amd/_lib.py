@@ -99,6 +99,7 @@ SIGNATURES = {
     "ph_gk_scale_momentum": (i32, [vp, i32, i32, f32, f32, vp, vp, vp]),
     "ph_logit_losses": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp]),
     "ph_gk_finish": (i32, [vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]),
+    "ph_gk_finish_momentum": (i32, [vp, vp, f32, f32, vp, f32, f32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "ph_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, f64, vp]),
     "ph_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, vp, vp]),
     "ph_ema_update": (i32, [vp, vp, sz, f32, vp]),

@@ -84,6 +84,44 @@ __global__ void gk_finish_kernel(const float* __restrict__ gram, const float* __
   scale_ext[0] = sc[0]; scale_ext[1] = sc[1]; scale_ext[2] = sc[3]; scale_ext[3] = sc[4]; scale_ext[4] = sc[2];
 }
 
+// The same for the MIA-2022 trainer's momentum GK-Refine ("MIA 2022/train_test_path_multi_distill_v2.py":89-132, 436-477): the
+// Gram arrives in the loss head's internal order [div1, div2, CE, kd1, kd2]; the weights are the row sums of the cosine matrix in
+// the trainer's order [div1, div2, kd1, kd2, CE] (optionally binarised with thresh), EMA-ed into the persistent state; the loss
+// is lam * CE + mult * sum_i state_i c_i L_i with c = (alpha, alpha, beta e, beta e) and e the epoch weight of the CRD terms
+// (a device scalar: a captured graph reads the current value).
+__global__ void gk_finish_momentum_kernel(const float* __restrict__ gram, const float* __restrict__ losses, float alpha,
+                                          float beta, const float* __restrict__ e_dev, float lam, float mult, int use_thresh,
+                                          float thresh, float momentum, float* __restrict__ mo_scale, int* __restrict__ mo_init,
+                                          float* __restrict__ w, float* __restrict__ total, float* __restrict__ scaled,
+                                          float* __restrict__ scale_ext) {
+  if (threadIdx.x != 0) return;
+  const int ng = 5;
+  const int ext2int[5] = {0, 1, 3, 4, 2};
+  const float e = e_dev ? e_dev[0] : 1.f;
+  const float c[5] = {alpha, alpha, 1.f, beta * e, beta * e};      // internal order; CE unscaled
+  const int first = mo_init ? (*mo_init == 0) : 1;
+  float t = 0.f;
+  for (int ie = 0; ie < ng; ++ie) {
+    const int i = ext2int[ie];
+    float s = 0.f;
+    for (int je = 0; je < ng; ++je) {
+      const int j = ext2int[je];
+      float r = gram[i * ng + j] / (sqrtf(gram[i * ng + i]) * sqrtf(gram[j * ng + j]));
+      if (use_thresh) r = r > thresh ? 1.f : 0.f;
+      s += r;
+    }
+    const float st = first ? s : momentum * mo_scale[ie] + (1.f - momentum) * s;
+    mo_scale[ie] = st;
+    scale_ext[ie] = st;
+    const float wi = i == 2 ? lam : mult * st * c[i];
+    w[i] = wi;
+    t += wi * losses[i];
+    scaled[i] = losses[i] * c[i];
+  }
+  if (mo_init) *mo_init = 1;
+  *total = t;
+}
+
 // Adam (torch.optim.Adam semantics) + optional EMA of the parameters, 4 elements per thread.
 //   g' = g + wd*p ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 //   ema = alpha*ema + (1-alpha)*p_new
@@ -303,6 +341,16 @@ int ph_gk_finish(const float* gram, const float* losses, const float* coef, cons
                  float* scale_int, float* w, float* total, float* scaled, float* scale_ext, hipStream_t st) {
   hipLaunchKernelGGL(gk_finish_kernel, dim3(1), dim3(64), 0, st, gram, losses, coef, add, logc, mult, scale_int, w, total,
                      scaled, scale_ext);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_gk_finish_momentum(const float* gram, const float* losses, float alpha, float beta, const float* e_dev, float lam,
+                          float mult, int use_thresh, float thresh, float momentum, float* mo_scale, int* mo_init, float* w,
+                          float* total, float* scaled, float* scale_ext, hipStream_t st) {
+  if (!gram || !losses || !mo_scale || !w || !total || !scaled || !scale_ext) return PH_EINVAL;
+  hipLaunchKernelGGL(gk_finish_momentum_kernel, dim3(1), dim3(64), 0, st, gram, losses, alpha, beta, e_dev, lam, mult,
+                     use_thresh, thresh, momentum, mo_scale, mo_init, w, total, scaled, scale_ext);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -12,7 +12,13 @@ student heads), so the per-loss gradients are computed once, in closed form, wit
 
 GK-Refine's weights are the row sums of the cosine Gram of these five vectors (scale-invariant, so the alpha / beta
 factors are applied afterwards); the gradient of the final loss is their weighted sum - no second pass through the
-losses.  Values equal the generic path's up to fp32 summation order (tests/test_gpu_step.py)."""
+losses.  Values equal the generic path's up to fp32 summation order (tests/test_gpu_step.py).
+
+The MIA-2022 stage-2 body ("MIA 2022/train_test_path_multi_distill_v2.py":419-483, `LossHeadCtx.variant == "mia2022"`) is the
+same function of the student feature with two differences: its CRD criterion is the plain v3 bank (one positive, no
+discrepancy selection) whose loss carries the epoch weight e (a device scalar), and GK-Refine keeps an exponential moving
+average of the weights across iterations (`step._mo_state`, the trainer's order [div1, div2, kd1, kd2, CE]) with an optional
+binarisation - ph_gk_finish_momentum."""
 import torch
 
 from . import ops
@@ -25,10 +31,12 @@ _ORDER_INT = (0, 1, 4, 2, 3)      # external [div1, div2, kd1, kd2, CE] -> inter
 class LossHeadCtx:
     """Non-differentiable inputs of one step (plain container)."""
 
-    def __init__(self, step, grade, t_logit, ema_logit, fuse_feat, ema_feat, index, sample_idx, r1, r2, bnorm):
+    def __init__(self, step, grade, t_logit, ema_logit, fuse_feat, ema_feat, index, sample_idx, r1, r2, bnorm,
+                 variant="miccai2022", e_dev=None):
         self.step, self.grade, self.t_logit, self.ema_logit = step, grade, t_logit, ema_logit
         self.fuse_feat, self.ema_feat, self.index, self.sample_idx = fuse_feat, ema_feat, index, sample_idx
         self.r1, self.r2, self.bnorm = r1, r2, bnorm
+        self.variant, self.e_dev = variant, e_dev
         self.out = None
 
 
@@ -115,10 +123,20 @@ class FusedDistillLossFn(torch.autograd.Function):
             step.sync.all_reduce_sum(gram)
         a, b, lam = float(opt.alpha), float(opt.beta), float(opt.lambda_nll)
         fin = torch.empty(21, device=dev, dtype=torch.float32)    # scale_int[5] | w[5] | total | scaled[5] | scale_ext[5]
-        check(L.ph_gk_finish(ptr(gram), ptr(Lb), ptr(_const(step, "coef", (a, a, 0, b, b))),
-                             ptr(_const(step, "lam", (0, 0, lam, 0, 0))), ptr(_const(step, "logc", (a, a, 1, b, b))), 4.0,
-                             ptr(fin[0:5]), ptr(fin[5:10]), ptr(fin[10:11]), ptr(fin[11:16]), ptr(fin[16:21]), st),
-              "ph_gk_finish")                                     # x len(KD list) = 4 (:61)
+        if H.variant == "mia2022":
+            if step._mo_state is None:       # persistent across iterations (and in the checkpoint): the trainer's mo_scale
+                step._mo_state = torch.zeros(5, device=dev, dtype=torch.float32)
+                step._mo_init = torch.zeros(1, device=dev, dtype=torch.int32)
+            thr_on = opt.grads_thresh == "True"
+            check(L.ph_gk_finish_momentum(ptr(gram), ptr(Lb), a, b, ptr(H.e_dev), lam, 1.0 if thr_on else 4.0,   # :474-477
+                                          1 if thr_on else 0, float(opt.thresh), float(opt.grads_m), ptr(step._mo_state),
+                                          ptr(step._mo_init), ptr(fin[5:10]), ptr(fin[10:11]), ptr(fin[11:16]),
+                                          ptr(fin[16:21]), st), "ph_gk_finish_momentum")
+        else:
+            check(L.ph_gk_finish(ptr(gram), ptr(Lb), ptr(_const(step, "coef", (a, a, 0, b, b))),
+                                 ptr(_const(step, "lam", (0, 0, lam, 0, 0))), ptr(_const(step, "logc", (a, a, 1, b, b))), 4.0,
+                                 ptr(fin[0:5]), ptr(fin[5:10]), ptr(fin[10:11]), ptr(fin[11:16]), ptr(fin[16:21]), st),
+                  "ph_gk_finish")                                     # x len(KD list) = 4 (:61)
         w, total, scaled = fin[5:10], fin[10], fin[11:16]
         H.out = dict(loss_cls=scaled[2], loss_div1=scaled[0], loss_div2=scaled[1], loss_kd1=scaled[3], loss_kd2=scaled[4],
                      scale=fin[16:21], logit_path=logits, pred_path=pred)

@@ -468,7 +468,8 @@ class DistillStep:
             # :262-313 as one function of the student feature (loss_head.py): same values, ~50 launches instead of ~125
             from .loss_head import FusedDistillLossFn, LossHeadCtx
             Hc = LossHeadCtx(self, grade, logits[-1].detach(), ema_logit_path.detach(), fuse_feat.detach(),
-                             ema_path_feat.detach(), index, sample_idx, r1, r2, bnorm)
+                             ema_path_feat.detach(), index, sample_idx, r1, r2, bnorm, variant=self.variant,
+                             e_dev=e if self.variant == "mia2022" else None)
             loss = FusedDistillLossFn.apply(path_feat, Hc)
             loss = self._add_reg(loss)                                                                      # :312-313
             self.optimizer.zero_grad()                                                                      # :326
@@ -587,14 +588,18 @@ class DistillStep:
         return loss + (self.opt.lambda_reg / w) * define_reg(self.opt, self.model)
 
     def _fused_head_ok(self):
-        """The closed-form loss head covers the shipped MICCAI stage-2 command: two teachers, CRD, GK-Refine with the CE
-        gradient, a log-softmax grading head.  `opt.fused_loss_head = False` selects the generic autograd path."""
+        """The closed-form loss head covers the shipped MICCAI and MIA-2022 stage-2 commands: two teachers, CRD, GK-Refine
+        (plain / momentum) with the CE gradient, a log-softmax grading head.  `opt.fused_loss_head = False` selects the
+        generic autograd path."""
         opt = self.opt
         if self._reg_on:
             # the fused head WRITES fc_new2's gradients (accumulate=False) after L1RegFn.backward has added
             # lambda_reg * sgn(W) into the same flat buffer: the L1 term on fc_new2 would be lost (ADVICE r02)
             return False
-        return (self.variant == "miccai2022" and getattr(opt, "fused_loss_head", True) and opt.assign_weights == "True"
+        if self.variant == "mia2022" and (self.zoo_kd is not None or not torch.is_tensor(getattr(self, "_e_dev", None))):
+            return False
+        return (self.variant in ("miccai2022", "mia2022") and getattr(opt, "fused_loss_head", True)
+                and opt.assign_weights == "True"
                 and bool(opt.CE_grads) and opt.num_teachers == 2 and opt.distill == "crd"
                 and isinstance(getattr(self.model, "fc_new2", None), nn.Linear)
                 and isinstance(getattr(self.model, "act", None), nn.LogSoftmax))

@@ -76,7 +76,8 @@ def main():
     for sub, suffix, cmd in (("stats", "", "python3 bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
                              ("stats_concurrent", "_concurrent", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
                              ("stats_b256", "_b256", "python3 bench.py --north-star --serial --steps 5 --warmup 3 ... (batch 256 on one GPU)"),
-                             ("stats_fp16x3", "_fp16x3", "python3 bench.py --precision fp16x3 --serial --steps 5 --warmup 3 ... (the tolerance-compliant arithmetic)")):
+                             ("stats_fp16x3", "_fp16x3", "python3 bench.py --precision fp16x3/x1 --serial --steps 5 --warmup 3 ... (the tolerance-compliant arithmetic)"),
+                             ("stats_mia2023", "_mia2023", "python3 bench.py --variant mia2023 --steps 5 --warmup 3 --eager (BASELINE configs[4] single-GPU leg: the full-bank KNN kernels)")):
         f = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
         if not f:
             continue
@@ -202,7 +203,7 @@ def main():
         fdur = dict(dur)
         wa, wc = load_pmc(fw[0])
         fam = {"crd_score": ("crd_score_kernel",), "crd_loss_grad": ("crd_loss_grad_kernel", "crd_loss_grad_reduce_kernel"),
-               "crd_bank_topk": ("crd_topk_queries_kernel", "crd_bank_knn_kernel", "crd_knn_merge_kernel")}
+               "crd_bank_topk": ("crd_bank_knn_kernel", "crd_knn_thr_kernel", "crd_knn_merge_kernel")}
         crd[var] = {}
         for name, kerns in fam.items():
             rd = wr = t = 0.0
@@ -211,7 +212,7 @@ def main():
                 if any(q in k for q in kerns):
                     rd += 2.0 * fa[k].get("FETCH_SIZE", 0.0) * 1024
                     t += fdur.get(k, 0)
-                    if kerns[0] in k:
+                    if kerns[-1] in k:       # (a kernel launched once per call of the family)
                         calls = fc[k]
             for k in wa:
                 if any(q in k for q in kerns):

@@ -650,6 +650,63 @@ def test_fused_loss_head_equals_generic_autograd_path():
         m.set_precision("bf16")
 
 
+@pytest.mark.parametrize("grads_thresh", ["False", "True"])
+def test_fused_loss_head_equals_generic_autograd_path_mia2022(grads_thresh):
+    """The same for the MIA-2022 body (loss_head.py, variant mia2022: v3 bank with the epoch weight on the device, momentum
+    GK-Refine through ph_gk_finish_momentum) against its generic autograd path (DistillStep._momentum_gk), two consecutive
+    steps so that the moving average of the weights is exercised, plain and binarised (`grads_thresh`) cosine sums."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    from oracle.variants import CRDv3State
+    n_data, K = 256, 64
+    m.set_precision("bf16x6")
+    try:
+        res = {}
+        for fused in (True, False):
+            opt = default_opt(nce_k=K, grads_m=0.9, grads_thresh=grads_thresh, thresh=0.1, niter_decay=10)
+            opt.fused_loss_head = fused
+            step = m.DistillStep(opt, n_data, device="cuda", variant="mia2022")
+            step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+            step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+            step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+            for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+                crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 10 + 2 * i))
+                crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 11 + 2 * i))
+                st = CRDv3State(n_data, K=K, seed=20 + i)
+                crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+                crd.contrast.verbose = False
+            rec = []
+            for it in range(2):
+                bt = synthetic_batch(8, 64, n_data=n_data, P=1, K=K, seed=400 + it)
+                out = step.step(_tuple(bt), epoch=3 + it)
+                if it == 0:
+                    assert step._fused_head_ok() == fused
+                P = dict(step.module_list.named_parameters())
+                rec.append(dict(out={k: out[k].detach().float().clone() for k in ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1",
+                                                                               "loss_kd2", "scale", "logit_path")},
+                                grads={k: p.grad.detach().clone() for k, p in P.items() if p.grad is not None},
+                                mo=step._mo_state.clone()))
+            res[fused] = rec
+        for it in range(2):
+            a, b = res[True][it], res[False][it]
+            # (step 1 starts from Adam's first, sign-like update of two gradient sets that differ in the last bits: +-lr on
+            # near-zero entries, 1e-3 on the logits - it checks the moving average of the weights, not rounding)
+            tol = 1e-5 if it == 0 else 1e-2
+            for k in a["out"]:
+                d = (a["out"][k] - b["out"][k]).abs().max().item()
+                assert d <= tol * max(1.0, b["out"][k].abs().max().item()), (it, k, d)
+            assert (a["mo"] - b["mo"]).abs().max().item() <= tol * max(1.0, b["mo"].abs().max().item()), (it, a["mo"], b["mo"])
+            if it == 0:
+                assert set(a["grads"]) == set(b["grads"])
+                for k in b["grads"]:
+                    ga, gb = a["grads"][k], b["grads"][k]
+                    d = max((ga - gb).abs().max().item() - 1e-6, 0.0) / (gb.abs().max().item() + 1e-12)
+                    assert d <= 2e-4, (k, d)
+    finally:
+        m.set_precision("bf16")
+
+
 def test_stage1_step_with_superpixel_masking_terms():
     """MIA-2023 stage-1 batch body (train_test_MT_SP_Masking.py:185-330): with opt.masking the step adds the two
     masked-view consistency terms.  Every component is pinned against the reference on its own (the attention masks
