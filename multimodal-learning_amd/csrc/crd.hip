@@ -300,11 +300,11 @@ __device__ __forceinline__ void knn_insert(u64 (&L)[TOPK_MAX], u64 c) {
 // rows idx[b][0]) are gathered into LDS by every workgroup.  Eight waves of 147 registers, two per SIMD.
 //   Keeping a sorted list per lane costs ~500 cycles per (row, query-block) step whenever ANY of the 64 lanes inserts, and with
 // 2048 waves a list sees 32 rows - every step inserted (57 us for the pass, 4x its matrix time).  So the selection is seeded:
-//   1. SAMPLE pass: every 8th tile, one per wave, one 32-query block per workgroup; a lane only keeps the MAXIMUM key of its 16
+//   1. SAMPLE pass: every 16th tile, one per wave, one 32-query block per workgroup; a lane only keeps the MAXIMUM key of its 16
 //      rows - one compare per element - and leaves it in gmax[bank][query][group].  The groups are disjoint row sets, so the
 //      TOPK_MAX-th largest of a query's group maxima (stage 2, `thr`) is a lower bound of its TOPK_MAX-th best similarity over
 //      the whole bank.
-//   3. FULL pass: an element enters a lane's list only if its key reaches thr - about TOPK_MAX x 8 elements per query in
+//   3. FULL pass: an element enters a lane's list only if its key reaches thr - about TOPK_MAX x 16 elements per query in
 //      the whole bank, so the insertion path is skipped by almost every step: a step is one multiply-compare on the raw
 //      accumulator (conservative by 2^-20, the exact key is formed inside the rare path).  Each wave leaves one list per query.
 //   4. merge: the NP best keys of a query's lists (mostly empty: key plane 0 is read coalesced, plane k only behind a
@@ -319,7 +319,7 @@ __device__ __forceinline__ void knn_insert(u64 (&L)[TOPK_MAX], u64 c) {
 // re-read by a selection kernel (41 us) + merge (9 us): 136 MB of traffic for 67 MB of bank, 157-162 us per call (round 3);
 // one unseeded pass with lists 57 + 22 us; seeded, rows through registers and a half-tile LDS stage 16 + 5 + 38 + 10 us.
 constexpr int SIM_RS = 129;     // dwords per staged query row (odd: the 32 lanes of a ds_read_b32 group hit 32 different banks)
-constexpr int KNN_WAVES = 8, KNN_SAMPLE_WAVES = 4, KNN_NBUF = 3, KNN_MAX_GX = 128, KNN_SAMPLE_TILES = 256, KNN_MAX_B = 64;
+constexpr int KNN_WAVES = 8, KNN_SAMPLE_WAVES = 4, KNN_NBUF = 3, KNN_MAX_GX = 128, KNN_SAMPLE_TILES = 128, KNN_MAX_B = 64;
 
 // DPP helpers (no LDS round trip, unlike __shfl): x of the lane N to the right inside the 16-lane row / lane 15 or 31 broadcast
 template <int CTRL, int ROW_MASK = 0xf>

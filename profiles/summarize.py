@@ -87,7 +87,7 @@ def main():
             o.write(f"# rocprofv3 --kernel-trace --stats -- {cmd}   (sum of kernel durations {tot/1e6:.1f} ms"
                     + (": kernels overlap, durations include shared time" if suffix else "") + ")\n")
             o.write(f"{'kernel':<100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}\n")
-            for r in rows[:45]:
+            for r in rows[:(70 if suffix == "_mia2023" else 45)]:
                 o.write(f"{short(r['Name'])[:100]:<100s} {r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} "
                         f"{float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}\n")
     # ---- SQ counters
