@@ -230,6 +230,7 @@ def variant_setup(name, B, H, device, rank=0, sync=None, generic_head=False):
         for k, v in dict(nce_k=4096, nce_p=6, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
                          max_discrep=2.0, use_grads_thresh="True", grads_thresh=0.0, loss_weighting="GK_refine").items():
             setattr(opt, k, v)
+        opt.fused_loss_head = not generic_head
         cls = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
         step = m.DistillStep(opt, n_data, device=device, variant="mia2023", train_class_idx=cls, sync=sync)
         desc = ("BASELINE configs[4] single-GPU leg: MIA-2023 stage 2, CRD bank %d rows (full-bank class-masked cosine KNN, "

@@ -110,11 +110,28 @@ class CRDLoss(nn.Module):
         batch_label = batch_label.to(dev).long().contiguous()
         if self.pos_extra == "centers":
             return self._forward_centers(sample_weights, v1, v2, batch_label, idx, contrast_idx)
+        idx1, knn = self.neighbor_columns(B, v1.shape[1], batch_label, contrast_idx)
+        rows = _CRDCoreFn.apply(v1, v2, mem, idx, idx1, None, True)          # [B]: (s + t) sample losses / bsz
+        mem.last.update(knn)
+        w = sample_weights.to(dev).reshape(-1) if torch.is_tensor(sample_weights) else float(sample_weights)
+        bn = float(mem.batch_norm_size or B)                                 # global batch under data parallelism
+        sample_loss = w * rows * bn                                          # the reference's per-sample values
+        return sample_loss.sum(0) / bn, sample_loss
+
+
+    def neighbor_columns(self, B, D, batch_label, contrast_idx):
+        """`pos_extra == "neighbors"` (:72-80, :110-117): the num_pos same-class nearest bank rows of every query in either
+        bank (ph_crd_bank_topk) in front of the K sampled negatives.  Sets the memory module up for the fused CRD kernels
+        (column list of bank 2, similarity weights of the positives) and returns (column list of bank 1, the KNN tensors);
+        shared by forward() and the closed-form loss head (loss_head.FusedMia2023LossFn)."""
+        mem = self.contrast
+        NP, K = self.num_pos, mem.K
+        dev = contrast_idx.device
         nb1 = torch.empty(B, NP, device=dev, dtype=torch.int64); nb2 = torch.empty_like(nb1)
         sim1 = torch.empty(B, NP, device=dev, dtype=torch.float32); sim2 = torch.empty_like(sim1)
         ws = torch.empty(lib().ph_crd_bank_topk_workspace_bytes(B, mem.nLem), device=dev, dtype=torch.uint8)
         check(lib().ph_crd_bank_topk(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(mem.all_sample_labels),
-                                     ptr(contrast_idx), K + 1, ptr(batch_label), B, mem.nLem, NP, v1.shape[1], ptr(nb1),
+                                     ptr(contrast_idx), K + 1, ptr(batch_label), B, mem.nLem, NP, D, ptr(nb1),
                                      ptr(nb2), ptr(sim1), ptr(sim2), ptr(ws), stream()), "ph_crd_bank_topk")
         # column lists: [num_pos KNN rows of that bank] + [the K sampled negatives]  (:80, :117)
         idx1 = torch.cat((nb1, contrast_idx[:, 1:]), 1).contiguous()
@@ -124,13 +141,7 @@ class CRDLoss(nn.Module):
         mem._idx_bank2 = idx2
         mem._posw_s = (sim2 / sim2.sum(1, keepdim=True)).contiguous()
         mem._posw_t = (sim1 / sim1.sum(1, keepdim=True)).contiguous()
-        rows = _CRDCoreFn.apply(v1, v2, mem, idx, idx1, None, True)          # [B]: (s + t) sample losses / bsz
-        mem.last.update(nb1=nb1, nb2=nb2, sim1=sim1, sim2=sim2)
-        w = sample_weights.to(dev).reshape(-1) if torch.is_tensor(sample_weights) else float(sample_weights)
-        bn = float(mem.batch_norm_size or B)                                 # global batch under data parallelism
-        sample_loss = w * rows * bn                                          # the reference's per-sample values
-        return sample_loss.sum(0) / bn, sample_loss
-
+        return idx1, dict(nb1=nb1, nb2=nb2, sim1=sim1, sim2=sim2, _ws=ws)
 
     def _forward_centers(self, sample_weights, v1, v2, batch_label, idx, contrast_idx):
         """:81-101 / :118-139 with num_pos == 2 and ContrastLoss (:241-277): columns = [class centre, the K + 1 sampled

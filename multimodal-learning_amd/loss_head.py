@@ -190,3 +190,148 @@ class FusedDistillLossFn(torch.autograd.Function):
                         t.record_stream(hs)
         ctx.crd_saved = None
         return dfeat, None
+
+
+class FusedMia2023LossFn(torch.autograd.Function):
+    """The MIA-2023 stage-2 body ("MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":348-448) as one function
+    of the student feature.  Everything there is per sample: KL rows, CRD rows of the v10 criterion (KNN positives) under the
+    discrepancy weights w = 1 + rw * discrepancy, and GK_refine_thresh's weights s[b, i] = sum_j f(cos(g_i[b], g_j[b])) over
+    the five per-sample gradient rows (:81-128).  With g_i[b] in closed form (as in FusedDistillLossFn) the loss is
+        lambda * CE + (1 / B) sum_b ( alpha s[b,0] KL1[b] + alpha s[b,1] KL2[b] + beta s[b,2] kd1[b] + beta s[b,3] kd2[b] )
+    and its gradient with respect to feature row b is the same combination of the rows g_i[b] (s is a constant, :120-126).
+    TERMINAL like FusedDistillLossFn: backward writes the heads' gradients into their .grad buffers."""
+
+    @staticmethod
+    def forward(ctx, feat, H):
+        from .mia2023 import assign_sample_weights
+        step = H.step
+        opt, model = step.opt, step.model
+        L = lib()
+        st = stream()
+        feat = ops._f32(feat).contiguous()
+        B, D = feat.shape
+        dev = feat.device
+        W2, b2 = model.fc_new2.weight, model.fc_new2.bias
+        Cc = W2.shape[0]
+        inv = 1.0 / H.bnorm
+        T = float(opt.kd_T)
+        a, b, lam = float(opt.alpha), float(opt.beta), float(opt.lambda_nll)
+        logits = ops.linear_fwd(feat, W2, b2)
+        pred = torch.empty_like(logits)
+        Lb = torch.empty(3, device=dev, dtype=torch.float32)           # batch means: KL to the fused teacher, to the EMA teacher, CE
+        dl = torch.empty(3, B, Cc, device=dev, dtype=torch.float32)    # d (those means) / d logits
+        yts = (ops._f32(H.t_logit).contiguous(), ops._f32(H.ema_logit).contiguous())
+        grade = H.grade.contiguous()
+        check(L.ph_logit_losses(ptr(logits), ptr(yts[0]), ptr(yts[1]), ptr(grade), ptr(pred), ptr(Lb), ptr(dl), B, Cc, T, inv, st),
+              "ph_logit_losses")
+        rows_div = torch.empty(2, B, device=dev, dtype=torch.float32)   # per-sample KL (:349-350)
+        for k in range(2):
+            check(L.ph_kl_rows_fwd(ptr(logits), ptr(yts[k]), ptr(rows_div[k]), B, Cc, T, st), "ph_kl_rows_fwd")
+        # :361-382 - discrepancy weights of the two CRD terms (constants of the graph); rw = H.e_dev: 0 before opt.start_reweight
+        ws = [1.0 + H.e_dev * assign_sample_weights(logits, yt, grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
+              for yt in yts]
+        G = torch.empty(5, B, D, device=dev, dtype=torch.float32)       # the trainer's order [div1, div2, kd1, kd2, CE]
+        ops.sgemm(dl[0:2], W2, None, G[0:2], 2 * B, D, Cc, Cc, 1, D, 1)
+        ops.sgemm(dl[2], W2, None, G[4], B, D, Cc, Cc, 1, D, 1)
+        lossp = [None, None]
+        crd_saved = [None, None]
+
+        def crd_chain(k, crd, tf):
+            stc = stream()
+            tf = ops._f32(tf).contiguous()
+            es, et = crd.embed_s.linear, crd.embed_t.linear
+            v1 = torch.empty(B, es.weight.shape[0], device=dev, dtype=torch.float32); n1 = torch.empty(B, device=dev)
+            v2 = torch.empty_like(v1); n2 = torch.empty_like(n1)
+            pre_s = ops.linear_fwd(feat, es.weight, es.bias)
+            check(L.ph_l2norm_fwd(ptr(pre_s), ptr(v1), ptr(n1), B, v1.shape[1], stc), "ph_l2norm_fwd")
+            pre_t = ops.linear_fwd(tf, et.weight, et.bias)
+            check(L.ph_l2norm_fwd(ptr(pre_t), ptr(v2), ptr(n2), B, v2.shape[1], stc), "ph_l2norm_fwd")
+            idx1, knn = crd.neighbor_columns(B, v1.shape[1], grade, H.sample_idx)
+            rows, dv1, dv2 = crd_core(v1, v2, crd.contrast, H.index, idx1, None, True)     # rows: (s + t) losses / bsz per sample
+            crd.contrast.last.update(knn)
+            dps = torch.empty_like(v1)
+            check(L.ph_l2norm_bwd(ptr(dv1), ptr(v1), ptr(n1), ptr(dps), B, v1.shape[1], stc), "ph_l2norm_bwd")
+            Do = es.weight.shape[0]
+            ops.sgemm(dps, es.weight, None, G[2 + k], B, D, Do, Do, 1, D, 1)              # d rows[b] / d feat[b]
+            lossp[k] = rows
+            crd_saved[k] = (dps, dv2, v2, n2, tf)
+            return (tf, v1, n1, v2, n2, pre_s, pre_t, dv1, dv2, dps, rows, idx1) + tuple(knn.values())
+
+        chains = ((step.criterion_kd, H.fuse_feat), (step.criterion_kd_path, H.ema_feat))
+        hs = step._head_stream() if step.sync is None and hasattr(step, "_head_stream") else None
+        if hs is not None:
+            main_s = torch.cuda.current_stream()
+            hs.wait_stream(main_s)
+            with torch.cuda.stream(hs):
+                made = crd_chain(1, *chains[1])
+                for t in made:
+                    if torch.is_tensor(t):
+                        t.record_stream(main_s)
+            crd_chain(0, *chains[0])
+            main_s.wait_stream(hs)
+        else:
+            for k, (crd, tf) in enumerate(chains):
+                crd_chain(k, crd, tf)
+        s = torch.empty(B, 5, device=dev, dtype=torch.float32)
+        check(L.ph_gk_rows(ptr(G), 5, B, D, 1 if opt.use_grads_thresh == "True" else 0, float(opt.grads_thresh), ptr(s), st),
+              "ph_gk_rows")
+        # coefficient of gradient row (i, b) in d loss / d feat[b]; G rows 0, 1, 4 are gradients of batch MEANS (x 1 / B already),
+        # rows 2, 3 of the per-sample CRD rows, which crd_core has divided by B
+        Cf = torch.empty(5, B, device=dev, dtype=torch.float32)
+        Cf[0] = a * s[:, 0]; Cf[1] = a * s[:, 1]
+        Cf[2] = b * s[:, 2] * ws[0]; Cf[3] = b * s[:, 3] * ws[1]
+        Cf[4] = lam
+        total = lam * Lb[2] + inv * (Cf[0] * rows_div[0] + Cf[1] * rows_div[1]).sum() + (Cf[2] * lossp[0] + Cf[3] * lossp[1]).sum()
+        mean_scale = s.mean(0)
+        if step.sync is not None:
+            mean_scale = step.sync.all_reduce_sum(mean_scale) / step.sync.world_size
+        H.out = dict(loss_cls=Lb[2], loss_div1=Lb[0], loss_div2=Lb[1],
+                     loss_kd1=(ws[0] * lossp[0]).sum(), loss_kd2=(ws[1] * lossp[1]).sum(),
+                     rows_div1=rows_div[0], rows_kd1=ws[0] * lossp[0] * H.bnorm, w1=ws[0].view(-1, 1), w2=ws[1].view(-1, 1),
+                     scale=mean_scale, logit_path=logits, pred_path=pred)
+        ctx.H, ctx.feat, ctx.dl, ctx.G, ctx.Cf, ctx.crd_saved = H, feat, dl, G, Cf, crd_saved
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        H, feat, dl, G, Cf = ctx.H, ctx.feat, ctx.dl, ctx.G, ctx.Cf
+        step = H.step
+        model = step.model
+        L = lib()
+        B, D = feat.shape
+        dev = feat.device
+        Cc = dl.shape[2]
+        dfeat = (Cf.unsqueeze(-1) * G).sum(0)
+        dlt = Cf[0].unsqueeze(-1) * dl[0] + Cf[1].unsqueeze(-1) * dl[1] + Cf[4].unsqueeze(-1) * dl[2]
+        hs = step._head_stream() if step.sync is None and hasattr(step, "_head_stream") else None
+        main_s = torch.cuda.current_stream()
+        if hs is not None:
+            hs.wait_stream(main_s)
+        with torch.cuda.stream(hs if hs is not None else main_s):
+            stb = stream()
+            ones = ops._ones(B, dev)
+            ops.sgemm(dlt, feat, None, _grad_dst(model.fc_new2.weight), Cc, D, B, 1, Cc, D, 1)      # dW2 = dlogit^T feat
+            ops.sgemm(ones, dlt, None, _grad_dst(model.fc_new2.bias), 1, Cc, B, 0, 1, Cc, 1)
+            made = [dlt]
+            for k, (crd, (dps, dv2, v2, n2, tf)) in enumerate(zip((step.criterion_kd, step.criterion_kd_path), ctx.crd_saved)):
+                wk = Cf[2 + k].unsqueeze(-1)
+                es, et = crd.embed_s.linear, crd.embed_t.linear
+                Do = es.weight.shape[0]
+                gs = dps * wk
+                ops.sgemm(gs, feat, None, _grad_dst(es.weight), Do, D, B, 1, Do, D, 1)
+                ops.sgemm(ones, gs, None, _grad_dst(es.bias), 1, Do, B, 0, 1, Do, 1)
+                dpt = torch.empty_like(v2)
+                check(L.ph_l2norm_bwd(ptr(dv2), ptr(v2), ptr(n2), ptr(dpt), B, v2.shape[1], stb), "ph_l2norm_bwd")
+                gt = dpt * wk
+                Dt = tf.shape[1]
+                ops.sgemm(gt, tf, None, _grad_dst(et.weight), Do, Dt, B, 1, Do, Dt, 1)
+                ops.sgemm(ones, gt, None, _grad_dst(et.bias), 1, Do, B, 0, 1, Do, 1)
+                made += [gs, dpt, gt]
+            if hs is not None:
+                for t in [feat, Cf, dl] + made:
+                    t.record_stream(hs)
+                for dps, dv2, v2, n2, tf in ctx.crd_saved:
+                    for t in (dps, dv2, v2, n2, tf):
+                        t.record_stream(hs)
+        ctx.crd_saved = None
+        return dfeat, None

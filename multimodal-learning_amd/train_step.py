@@ -466,11 +466,11 @@ class DistillStep:
         self._stamp(2)
         if self._fused_head_ok():
             # :262-313 as one function of the student feature (loss_head.py): same values, ~50 launches instead of ~125
-            from .loss_head import FusedDistillLossFn, LossHeadCtx
+            from .loss_head import FusedDistillLossFn, FusedMia2023LossFn, LossHeadCtx
             Hc = LossHeadCtx(self, grade, logits[-1].detach(), ema_logit_path.detach(), fuse_feat.detach(),
                              ema_path_feat.detach(), index, sample_idx, r1, r2, bnorm, variant=self.variant,
-                             e_dev=e if self.variant == "mia2022" else None)
-            loss = FusedDistillLossFn.apply(path_feat, Hc)
+                             e_dev=e if self.variant != "miccai2022" else None)
+            loss = (FusedMia2023LossFn if self.variant == "mia2023" else FusedDistillLossFn).apply(path_feat, Hc)
             loss = self._add_reg(loss)                                                                      # :312-313
             self.optimizer.zero_grad()                                                                      # :326
             self._stamp(3)
@@ -487,10 +487,11 @@ class DistillStep:
             self.optimizer.step()                                                                           # :328 (+ :329 fused)
             self._stamp(6)
             o = Hc.out
+            extra = {k: o[k] for k in ("rows_div1", "rows_kd1", "w1", "w2") if k in o}       # (the MIA-2023 body's per-sample values)
             return dict(loss=loss.detach(), loss_cls=o["loss_cls"], loss_div1=o["loss_div1"], loss_div2=o["loss_div2"],
                         loss_kd1=o["loss_kd1"], loss_kd2=o["loss_kd2"], scale=o["scale"], logit_path=o["logit_path"],
                         pred_path=o["pred_path"], path_feat=path_feat.detach(), ema_logit=ema_logit_path,
-                        fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+                        fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat, **extra)
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
         if self.variant == "mia2023":
             return self._mia2023_tail(e, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path,
@@ -596,9 +597,12 @@ class DistillStep:
             # the fused head WRITES fc_new2's gradients (accumulate=False) after L1RegFn.backward has added
             # lambda_reg * sgn(W) into the same flat buffer: the L1 term on fc_new2 would be lost
             return False
-        if self.variant == "mia2022" and (self.zoo_kd is not None or not torch.is_tensor(getattr(self, "_e_dev", None))):
+        if self.variant != "miccai2022" and (self.zoo_kd is not None or not torch.is_tensor(getattr(self, "_e_dev", None))):
             return False
-        return (self.variant in ("miccai2022", "mia2022") and getattr(opt, "fused_loss_head", True)
+        if self.variant == "mia2023" and (getattr(opt, "loss_weighting", "GK_refine") != "GK_refine"
+                                          or getattr(opt, "pos_extra", "neighbors") != "neighbors"):
+            return False
+        return (self.variant in ("miccai2022", "mia2022", "mia2023") and getattr(opt, "fused_loss_head", True)
                 and opt.assign_weights == "True"
                 and bool(opt.CE_grads) and opt.num_teachers == 2 and opt.distill == "crd"
                 and isinstance(getattr(self.model, "fc_new2", None), nn.Linear)

@@ -707,6 +707,61 @@ def test_fused_loss_head_equals_generic_autograd_path_mia2022(grads_thresh):
         m.set_precision("bf16")
 
 
+@pytest.mark.parametrize("use_thresh", ["True", "False"])
+def test_fused_loss_head_equals_generic_autograd_path_mia2023(use_thresh):
+    """The same for the MIA-2023 body (loss_head.FusedMia2023LossFn: per-sample KL / CRD rows under the discrepancy weights,
+    per-sample GK-Refine weights from the closed-form gradient rows) against its generic autograd path
+    (DistillStep._mia2023_tail), with the re-weighting switched on, binarised and ReLU-ed cosine sums."""
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    from oracle.variants import CRDv10State
+    n_data, K, B = 512, 64, 8
+    labels = torch.arange(n_data) % 3
+    class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+    m.set_precision("bf16x6")
+    try:
+        res = {}
+        for fused in (True, False):
+            opt = default_opt(nce_k=K, nce_p=4, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
+                              max_discrep=2.0, use_grads_thresh=use_thresh, grads_thresh=0.1, loss_weighting="GK_refine",
+                              batch_size=B)
+            opt.fused_loss_head = fused
+            step = m.DistillStep(opt, n_data, device="cuda", variant="mia2023", train_class_idx=class_idx)
+            step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+            step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+            step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+            for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+                crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 10 + 2 * i))
+                crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 11 + 2 * i))
+                st = CRDv10State(n_data, labels, K=K, seed=20 + i)
+                crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+                crd.contrast.verbose = False
+            bt = synthetic_batch(B, 64, n_data=n_data, P=1, K=K, seed=500)
+            bt["grade"] = labels[bt["index"]].long()
+            out = step.step(_tuple(bt), epoch=2)
+            assert step._fused_head_ok() == fused
+            P = dict(step.module_list.named_parameters())
+            res[fused] = dict(out={k: out[k].detach().float().clone() for k in ("loss", "loss_cls", "loss_div1", "loss_div2", "loss_kd1",
+                                                                             "loss_kd2", "scale", "logit_path", "rows_div1", "rows_kd1",
+                                                                             "w1", "w2")},
+                              grads={k: p.grad.detach().clone() for k, p in P.items() if p.grad is not None},
+                              bank=step.criterion_kd.contrast.memory_v1.clone())
+        a, b = res[True], res[False]
+        assert float(b["out"]["w1"].max()) > 1.0
+        for k in a["out"]:
+            d = (a["out"][k].reshape(-1) - b["out"][k].reshape(-1)).abs().max().item()
+            assert d <= 1e-5 * max(1.0, b["out"][k].abs().max().item()), (k, d)
+        assert set(a["grads"]) == set(b["grads"])
+        for k in b["grads"]:
+            ga, gb = a["grads"][k], b["grads"][k]
+            d = max((ga - gb).abs().max().item() - 1e-6, 0.0) / (gb.abs().max().item() + 1e-12)
+            assert d <= 2e-4, (k, d)
+        assert torch.equal(a["bank"], b["bank"])
+    finally:
+        m.set_precision("bf16")
+
+
 def test_stage1_step_with_superpixel_masking_terms():
     """MIA-2023 stage-1 batch body (train_test_MT_SP_Masking.py:185-330): with opt.masking the step adds the two
     masked-view consistency terms.  Every component is pinned against the reference on its own (the attention masks
