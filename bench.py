@@ -245,7 +245,7 @@ def variant_setup(name, B, H, device, rank=0, sync=None, generic_head=False):
         opt.Lambda_global, opt.aux_iter = 0.05, 1
         step = m.TeacherStage1Step(opt, device=device, sync=sync)
         desc = ("BASELINE configs[3] single-GPU leg: MIA-2022 stage-1 trainer with the t-SVD term (train_test_tSVD.py), %d tiles, "
-                "4 views, auxiliary update every batch; eager launches" % B)
+                "4 views, auxiliary update every batch" % B)
         bts = [make_batch(B, H, 1024, opt, device, seed=rank * 100 + 31 + i) for i in range(2)]
     else:
         raise SystemExit("unknown variant %r" % name)

@@ -384,6 +384,9 @@ int ph_maxnorm_mix(const float* a, const float* b, float* out, size_t n, float w
 size_t ph_tsvd_workspace_bytes(int V, int B);
 int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn /* may be NULL */, int V, int B, float tau,
                        void* workspace, ph_stream_t stream);
+/* the same with tau = tau_dev[0] read on the device (a HIP graph of the stage-1 step replays with the current mu) */
+int ph_tsvd_update_aux_dev(const float* adj, float* aux, float* tnn /* may be NULL */, int V, int B, const float* tau_dev,
+                           void* workspace, ph_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * In-library kernel timer for bench.py's `roofline` object: HIP events around every MFMA kernel launch on the

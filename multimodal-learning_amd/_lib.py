@@ -76,6 +76,7 @@ SIGNATURES = {
     "ph_maxnorm_mix": (i32, [vp, vp, vp, sz, f32, f32, vp]),
     "ph_tsvd_workspace_bytes": (sz, [i32, i32]),
     "ph_tsvd_update_aux": (i32, [vp, vp, vp, i32, i32, f32, vp, vp]),
+    "ph_tsvd_update_aux_dev": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
     "ph_crd_score": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp]),
     "ph_crd_select": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "ph_crd_bank_topk_workspace_bytes": (sz, [i32, i32]),

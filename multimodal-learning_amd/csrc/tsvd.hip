@@ -77,7 +77,8 @@ __device__ __forceinline__ void dft_elem(const float* __restrict__ adj, int V, s
 
 __global__ __launch_bounds__(256) void tsvd_slice_kernel(const float* __restrict__ adj, float* __restrict__ yre,
                                                          float* __restrict__ yim, float* __restrict__ tnn_k, int V,
-                                                         int B, float tau) {
+                                                         int B, float tau, const float* __restrict__ tau_dev) {
+  if (tau_dev) tau = tau_dev[0];      // (a captured graph reads the current threshold: mu grows every update)
   extern __shared__ float sm[];
   const int n = 2 * B, tid = threadIdx.x, k = blockIdx.x;
   float* S = sm;                         // [n][TS_LD]  symmetric matrix, later P
@@ -270,7 +271,8 @@ __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_el
 __global__ __launch_bounds__(1024) void tsvd_slice_big_kernel(const float* __restrict__ adj, float* __restrict__ yre,
                                                               float* __restrict__ yim, float* __restrict__ tre,
                                                               float* __restrict__ tim, float* __restrict__ tnn_k, int V,
-                                                              int B, float tau) {
+                                                              int B, float tau, const float* __restrict__ tau_dev) {
+  if (tau_dev) tau = tau_dev[0];
   extern __shared__ float sm[];
   float* A = sm;                         // [n][TB_CS]: column j at A + j * TB_CS, row r at floats 2r (re), 2r + 1 (im)
   float* dj = sm + TB_MAXB * TB_CS;      // [TB_MAXB]
@@ -512,7 +514,17 @@ int ph_scaled_diff(const float* a, const float* b, const float* gscalar, float a
   return PH_OK;
 }
 
+static int tsvd_update_aux_impl(const float* adj, float* aux, float* tnn, int V, int B, float tau, const float* tau_dev, void* ws_,
+                                hipStream_t st);
 int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn, int V, int B, float tau, void* ws_, hipStream_t st) {
+  return tsvd_update_aux_impl(adj, aux, tnn, V, B, tau, nullptr, ws_, st);
+}
+int ph_tsvd_update_aux_dev(const float* adj, float* aux, float* tnn, int V, int B, const float* tau_dev, void* ws_, hipStream_t st) {
+  if (!tau_dev) return PH_EINVAL;
+  return tsvd_update_aux_impl(adj, aux, tnn, V, B, 0.f, tau_dev, ws_, st);
+}
+static int tsvd_update_aux_impl(const float* adj, float* aux, float* tnn, int V, int B, float tau, const float* tau_dev, void* ws_,
+                                hipStream_t st) {
   if (!adj || !aux || !ws_ || V < 2 || V > TSVD_MAX_V || (V & 1) || B < 1 || B > TB_MAXB) return PH_EINVAL;
   float* ws = reinterpret_cast<float*>(ws_);
   const size_t bb = (size_t)B * B;
@@ -530,7 +542,7 @@ int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn, int V, int B, f
         return PH_ELAUNCH;
       attr_big = true;
     }
-    hipLaunchKernelGGL(tsvd_slice_big_kernel, dim3(V / 2 + 1), dim3(1024), ldsb, st, adj, yre, yim, tre, tim, tk, V, B, tau);
+    hipLaunchKernelGGL(tsvd_slice_big_kernel, dim3(V / 2 + 1), dim3(1024), ldsb, st, adj, yre, yim, tre, tim, tk, V, B, tau, tau_dev);
     PH_LAUNCH_CHECK();
     hipLaunchKernelGGL(tsvd_idft_kernel, dim3((unsigned)((bb * V + 255) / 256)), dim3(256), 0, st, yre, yim, tk, aux, tnn, V, B);
     PH_LAUNCH_CHECK();
@@ -544,7 +556,7 @@ int ph_tsvd_update_aux(const float* adj, float* aux, float* tnn, int V, int B, f
       return PH_ELAUNCH;
     attr_done = true;
   }
-  hipLaunchKernelGGL(tsvd_slice_kernel, dim3(V / 2 + 1), dim3(256), lds, st, adj, yre, yim, tk, V, B, tau);
+  hipLaunchKernelGGL(tsvd_slice_kernel, dim3(V / 2 + 1), dim3(256), lds, st, adj, yre, yim, tk, V, B, tau, tau_dev);
   PH_LAUNCH_CHECK();
   hipLaunchKernelGGL(tsvd_idft_kernel, dim3((unsigned)((bb * V + 255) / 256)), dim3(256), 0, st, yre, yim, tk, aux, tnn, V, B);
   PH_LAUNCH_CHECK();

@@ -1043,6 +1043,15 @@ class TeacherStage1Step:
         """The t-SVD auxiliary update runs every opt.aux_iter batches of an epoch (:375): reset the batch counter."""
         self._batch_idx = 0
 
+    def enable_graph(self):
+        """Replay the device part of the step from captured HIP graphs (one per resident input set and per kind of step -
+        with / without the t-SVD auxiliary update).  Call after at least two eager steps; shapes must stay fixed.  The
+        per-step scalars that the eager path bakes into its launches (the CRD weight that drops at epoch 15, the t-SVD
+        threshold Lambda / mu and the penalty's mu, Adam's bias corrections, the EMA rate) are read from device memory.
+        Steps with the superpixel-masking terms (MIA-2023 stage 1) stay eager: their attention masks are built with host
+        control flow."""
+        self._want_graph = True
+
     def step(self, batch, epoch=0, batch_idx=None):
         opt = self.opt
         self.model.train()              # train_test_MT.py:110 `module_list.train()` per epoch (its test() leaves eval mode)
@@ -1055,29 +1064,124 @@ class TeacherStage1Step:
         else:
             x_path, ema_x_path = views
         dev = self.device
-        x_path, ema_x_path = x_path.to(dev, non_blocking=True), ema_x_path.to(dev, non_blocking=True)
-        x_omic, grade = x_omic.to(dev, non_blocking=True), grade.to(dev, non_blocking=True)
         B = float(x_path.shape[0] * (self.sync.world_size if self.sync is not None else 1))   # global batch
         self.optimizer.ema_alpha = min(1 - 1 / (self.iter_num + 1), opt.ema_decay)
-        loss_masking = torch.zeros((), device=dev)
-        if getattr(opt, "masking", 0) and epoch > opt.start_epoch:                              # MIA-2023 :198-220
-            # superpixel attention: mask the Path_K superpixels / Omic_K genes the fused prediction is most sensitive to
-            # and ask the two masked views to agree with the mean teacher's predictions on the loader's masked views
-            from . import superpixel as SPX
-            if sp_mask is None:
-                raise ValueError("opt.masking needs the 6-view loader tuple (x_path, sp_mask, ema_x_path, ema_sp_mask, "
-                                 "x_path_m_v1, x_path_m_v2)")
-            for mod in self.model.modules():
-                if hasattr(mod, "_get_workspace"):
-                    mod._multi_forward = True     # three taped forwards of the same trunk before one backward
-            pm, om = SPX.superpixel_attention_mask(opt, self.optimizer, self.model, x_path, x_grph, x_omic, sp_mask, grade,
-                                                   dev, getattr(opt, "num_superpixels_max", None))
-            pred_m1 = self.model(x_path=SPX.apply_mask(x_path, pm), x_omic=x_omic)[5]            # :204-205
-            pred_m2 = self.model(x_path=x_path, x_omic=SPX.apply_mask(x_omic, om))[5]            # :207-208
-            with torch.no_grad():
-                ema_m1 = self.ema_model(x_path=x_path_m_v1.to(dev), x_omic=x_omic)[5]             # :211-215
-                ema_m2 = self.ema_model(x_path=x_path_m_v2.to(dev), x_omic=x_omic)[5]
-            loss_masking = self.pred_KD_loss(pred_m1, ema_m1, B) + self.pred_KD_loss(pred_m2, ema_m2, B)   # :217-220
+        masking_on = bool(getattr(opt, "masking", 0)) and epoch > opt.start_epoch
+        # t-SVD schedule on the host: whether this batch updates the auxiliary tensors (:375), the threshold it uses and the
+        # mu of the penalty, which is the value AFTER the update's `mu = min(mu * pho, max_mu)` (:413)
+        do_aux, tau, mu_pen, bidx = False, 0.0, 0.0, 0
+        if self.tsvd_on:
+            bidx = self._batch_idx if batch_idx is None else batch_idx
+            do_aux = bidx % opt.aux_iter == 0
+            tau = opt.Lambda_global / self.mu
+            mu_pen = min(self.mu * opt.pho, opt.max_mu) if do_aux else self.mu
+        given = dict(x_path=x_path, ema_x_path=ema_x_path, x_omic=x_omic, grade=grade, index=index, sample_idx=sample_idx)
+        use_graph = (getattr(self, "_want_graph", False) and not masking_on and self.iter_num - opt.global_step >= 2
+                     and all(torch.is_tensor(t) for t in given.values()))
+        out = None
+        if use_graph:
+            out = self._graph_step(given, B, do_aux, float(getattr(opt, "CRD_weight", 1.0)), tau, mu_pen)
+        if out is None:
+            loss_masking = None
+            x_path, ema_x_path = x_path.to(dev, non_blocking=True), ema_x_path.to(dev, non_blocking=True)
+            x_omic, grade = x_omic.to(dev, non_blocking=True), grade.to(dev, non_blocking=True)
+            if masking_on:                                                                       # MIA-2023 :198-220
+                # superpixel attention: mask the Path_K superpixels / Omic_K genes the fused prediction is most sensitive to
+                # and ask the two masked views to agree with the mean teacher's predictions on the loader's masked views
+                from . import superpixel as SPX
+                if sp_mask is None:
+                    raise ValueError("opt.masking needs the 6-view loader tuple (x_path, sp_mask, ema_x_path, ema_sp_mask, "
+                                     "x_path_m_v1, x_path_m_v2)")
+                for mod in self.model.modules():
+                    if hasattr(mod, "_get_workspace"):
+                        mod._multi_forward = True     # three taped forwards of the same trunk before one backward
+                pm, om = SPX.superpixel_attention_mask(opt, self.optimizer, self.model, x_path, x_grph, x_omic, sp_mask, grade,
+                                                       dev, getattr(opt, "num_superpixels_max", None))
+                pred_m1 = self.model(x_path=SPX.apply_mask(x_path, pm), x_omic=x_omic)[5]            # :204-205
+                pred_m2 = self.model(x_path=x_path, x_omic=SPX.apply_mask(x_omic, om))[5]            # :207-208
+                with torch.no_grad():
+                    ema_m1 = self.ema_model(x_path=x_path_m_v1.to(dev), x_omic=x_omic)[5]             # :211-215
+                    ema_m2 = self.ema_model(x_path=x_path_m_v2.to(dev), x_omic=x_omic)[5]
+                loss_masking = self.pred_KD_loss(pred_m1, ema_m1, B) + self.pred_KD_loss(pred_m2, ema_m2, B)   # :217-220
+            out = self._device_body(x_path, ema_x_path, x_omic, grade, index.to(dev) if self.crd_on else index,
+                                    sample_idx.to(dev) if self.crd_on else sample_idx, B, do_aux, getattr(opt, "CRD_weight", 1.0), tau, mu_pen,
+                                    loss_masking)
+        if self.tsvd_on:
+            if do_aux:
+                self.mu = mu_pen                                                                 # :413
+            self._batch_idx = bidx + 1
+        self.iter_num += 1
+        return out
+
+    _IN_NAMES = ("x_path", "ema_x_path", "x_omic", "grade", "index", "sample_idx")
+
+    def _graph_step(self, given, B, do_aux, crd_w, tau, mu_pen):
+        """One step from a captured graph; None if no graph can serve it (capture failed: eager from now on).  Device-resident,
+        contiguous inputs are adopted as they are (up to two input sets, one graph each per kind of step, sharing one memory
+        pool); anything else is copied into the first set's buffers."""
+        dev = self.device
+        names = self._IN_NAMES
+        if getattr(self, "_g_scal", None) is None:
+            self._g_scal = torch.zeros(3, device=dev, dtype=torch.float32)       # CRD weight | tau | mu of the penalty
+            self._g_sets = []
+        on_dev = all(t.is_cuda and t.is_contiguous() for t in given.values())
+        ptrs = tuple(given[k].data_ptr() for k in names) if on_dev else None
+        shapes = tuple(tuple(given[k].shape) for k in names)
+        if self._g_sets and self._g_sets[0]["shapes"] != shapes:
+            self._g_sets = []
+        st = next((q for q in self._g_sets if ptrs is not None and q["ptrs"] == ptrs), None)
+        if st is None and (not self._g_sets or (on_dev and len(self._g_sets) < 2)):
+            bufs = dict(given) if on_dev else {k: torch.empty(given[k].shape, device=dev, dtype=given[k].dtype) for k in names}
+            st = dict(shapes=shapes, ptrs=tuple(bufs[k].data_ptr() for k in names), bufs=bufs, graphs={})
+            self._g_sets.append(st)
+        if st is None:
+            st = self._g_sets[0]
+        for k in names:
+            if given[k].data_ptr() != st["bufs"][k].data_ptr():
+                st["bufs"][k].copy_(given[k], non_blocking=True)
+        self._g_scal.copy_(torch.tensor([crd_w, tau, mu_pen], dtype=torch.float32), non_blocking=False)
+        if do_aux not in st["graphs"]:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            pool = next((gr.pool() for q in self._g_sets for gr, _, _ in q["graphs"].values()), None)
+            was_prepared = self.optimizer._prepared
+            try:
+                bf = st["bufs"]
+                with torch.cuda.graph(g, pool=pool):
+                    self.optimizer._prepared = True       # the step scalars are read from device memory at replay
+                    out = self._device_body(bf["x_path"], bf["ema_x_path"], bf["x_omic"], bf["grade"], bf["index"],
+                                            bf["sample_idx"], B, do_aux, self._g_scal[0], self._g_scal[1], self._g_scal[2], None)
+                # the graph holds raw pointers into the trunk workspaces it was captured with: keep them alive with it
+                refs = [ws for net in (self.model, self.ema_model) for mod in net.modules() if hasattr(mod, "pinned_workspaces")
+                        for ws in mod.pinned_workspaces()]
+                st["graphs"][do_aux] = (g, out, refs)
+                self.optimizer._prepared = was_prepared
+            except Exception as exc:
+                import warnings
+                warnings.warn("HIP graph capture of the stage-1 step failed (%r); continuing with eager launches" % (exc,))
+                torch.cuda.synchronize()
+                try:      # on this HIP runtime a failed capture can leave its streams in capture state for good
+                    torch.ones(1).to(dev)
+                except Exception as exc2:
+                    raise RuntimeError("HIP graph capture of the stage-1 step failed (%r) and the runtime did not leave capture "
+                                       "mode (%r): restart the process without enable_graph()" % (exc, exc2)) from exc
+                self._want_graph = False
+                self._g_sets = []
+                self.optimizer._prepared = was_prepared
+                return None
+        g, out, _ = st["graphs"][do_aux]
+        self.optimizer.prepare_step()
+        self.optimizer._prepared = False
+        g.replay()
+        return out
+
+    def _device_body(self, x_path, ema_x_path, x_omic, grade, index, sample_idx, B, do_aux, crd_w, tau, mu_pen, loss_masking):
+        """Everything of the step that runs on the device (capturable in one HIP graph).  `crd_w`, `tau`, `mu_pen`: floats on
+        the eager path, 1-element device tensors under capture."""
+        opt = self.opt
+        dev = self.device
+        if loss_masking is None:
+            loss_masking = torch.zeros((), device=dev)
         # the mean teacher's forward (no_grad, :143-145) does not depend on the student's (:137): a second stream, joined
         # before the losses, as in DistillStep._device_body
         main = torch.cuda.current_stream()
@@ -1096,8 +1200,8 @@ class TeacherStage1Step:
         loss_CRD = torch.zeros((), device=dev)
         if self.crd_on:                                                                          # :157-165
             self.CRD_criterion_fuse.contrast.batch_norm_size = B
-            loss_CRD = opt.CRD_weight * self.CRD_criterion_fuse(
-                fuse_feat, ema_fuse_feat.detach(), index.to(dev), sample_idx.to(dev)).reshape(())
+            loss_CRD = crd_w * self.CRD_criterion_fuse(
+                fuse_feat, ema_fuse_feat.detach(), index, sample_idx).reshape(())
         kd = lambda p_s, p_t: self.pred_KD_loss(p_s, p_t, B)      # noqa: E731
         if getattr(opt, "pred_distill", 1) == 1:
             nt = opt.num_teachers
@@ -1149,41 +1253,46 @@ class TeacherStage1Step:
                     feats2.append(T.maxnorm_mix(ema_omic_feat, ema_path_feat, wa, 1.0 - wa))
             self.adj_tensor1 = T.update_adj_tensor(self.adj_tensor1, feats1)                    # :365-366
             self.adj_tensor2 = T.update_adj_tensor(self.adj_tensor2, feats2)
-            bidx = self._batch_idx if batch_idx is None else batch_idx
-            if bidx % opt.aux_iter == 0:
+            if do_aux:
                 # `if opt.tSVD_mode == "path" or "pathomic":` (:378, :398) is always true: both tensors are updated.  The two
                 # proximal updates are independent and each is a launch of only n_views / 2 + 1 workgroups (one per Fourier
-                # slice, ~5 ms at B = 128): the second runs on a side stream beside the first
+                # slice, ~5 ms at B = 128): the second runs on a side stream beside the first.  The results land in the
+                # PERSISTENT auxiliary tensors (captured graphs of other input sets / of the steps without an update read them)
                 main = torch.cuda.current_stream()
                 if getattr(self, "_tsvd_side", None) is None:
                     self._tsvd_side = torch.cuda.Stream(device=dev)
                 side = self._tsvd_side
                 side.wait_stream(main)
-                res = {}
-                for adj, name, strm in ((self.adj_tensor2, "2", side), (self.adj_tensor1, "1", main)):
+                tnns = {}
+                for adj, auxs, name, strm in ((self.adj_tensor2, self.aux_tensor2, "2", side),
+                                              (self.adj_tensor1, self.aux_tensor1, "1", main)):
                     with torch.cuda.stream(strm):
                         stack = torch.stack([a.detach() for a in adj], dim=2)
-                        aux, tnn = T.update_aux(stack, opt.Lambda_global / self.mu)             # :382, :402
-                        res[name] = ([aux[:, :, v].contiguous() for v in range(opt.n_views)], tnn)
+                        aux, tnns[name] = T.update_aux(stack, tau)                              # :382, :402
+                        for v in range(opt.n_views):
+                            auxs[v].copy_(aux[:, :, v])
+                        if strm is side:
+                            stack.record_stream(main); aux.record_stream(main)
                 main.wait_stream(side)
-                for t in res["2"][0] + [res["2"][1]]:
-                    if torch.is_tensor(t):
-                        t.record_stream(main)
-                self.aux_tensor1, self.path_TNN = res["1"]
-                self.aux_tensor2, self.omic_TNN = res["2"]
-                self.mu = min(self.mu * opt.pho, opt.max_mu)                                    # :413
-            self._batch_idx = bidx + 1
+                if torch.is_tensor(tnns["2"]):
+                    tnns["2"].record_stream(main)
+                self.path_TNN, self.omic_TNN = tnns["1"], tnns["2"]
             if opt.tSVD_mode in ("path", "pathomic"):                                           # :418-431
-                loss_tsvd = loss_tsvd + T.tsvd_penalty(self.adj_tensor1, self.aux_tensor1, self.mu)
+                loss_tsvd = loss_tsvd + T.tsvd_penalty(self.adj_tensor1, self.aux_tensor1, mu_pen)
             if opt.tSVD_mode in ("omic", "pathomic"):
-                loss_tsvd = loss_tsvd + T.tsvd_penalty(self.adj_tensor2, self.aux_tensor2, self.mu)
+                loss_tsvd = loss_tsvd + T.tsvd_penalty(self.adj_tensor2, self.aux_tensor2, mu_pen)
             loss = loss + loss_tsvd
         self.optimizer.zero_grad()
         loss.backward()
         if self.sync is not None:
             self.sync.all_reduce_grads(self.optimizer.flat)
         self.optimizer.step()                                                                   # + EMA (:229) fused
-        self.iter_num += 1
+        if self.tsvd_on:
+            # the adjacency tensors are kept as VALUES: with their grad_fn they would keep this step's autograd graph - and the
+            # AccumulateGrad nodes of every parameter, bound to the stream of this step - alive into the next one (a capture of
+            # the next step then runs them on the wrong stream: the runtime crashes in hipStreamEndCapture)
+            self.adj_tensor1 = [a.detach() for a in self.adj_tensor1]
+            self.adj_tensor2 = [a.detach() for a in self.adj_tensor2]
         return dict(loss=loss.detach(), loss_nll=loss_nll.detach(), loss_pred_KD=loss_pred_KD.detach(),
                     loss_CRD=loss_CRD.detach(), loss_orth=loss_orth.detach(), loss_tsvd=loss_tsvd.detach(),
                     loss_pred_KD_masking=loss_masking.detach(), loss_reg=loss_reg.detach(),

@@ -33,8 +33,9 @@ def maxnorm_mix(a, b, wa, wb):
 
 
 def update_aux(adj, tau, print_bool=False):
-    """adj: [B, B, n_views] detached adjacency stack, tau = Lambda_global / mu.  Returns (aux [B, B, n_views], TNN)
-    like the call at train_test_tSVD.py:382; TNN is a 0-d device tensor (no host sync)."""
+    """adj: [B, B, n_views] detached adjacency stack, tau = Lambda_global / mu (a float, or a 1-element device tensor that a
+    captured graph re-reads at every replay).  Returns (aux [B, B, n_views], TNN) like the call at train_test_tSVD.py:382;
+    TNN is a 0-d device tensor (no host sync)."""
     B, B2, V = adj.shape
     if B != B2:
         raise ValueError("adjacency stack must be [B, B, n_views]")
@@ -42,7 +43,11 @@ def update_aux(adj, tau, print_bool=False):
     aux = torch.empty_like(a)
     tnn = torch.empty(1, device=a.device, dtype=torch.float32)
     ws = torch.empty(lib().ph_tsvd_workspace_bytes(V, B), device=a.device, dtype=torch.uint8)
-    check(lib().ph_tsvd_update_aux(ptr(a), ptr(aux), ptr(tnn), V, B, float(tau), ptr(ws), stream()), "ph_tsvd_update_aux")
+    if torch.is_tensor(tau):
+        check(lib().ph_tsvd_update_aux_dev(ptr(a), ptr(aux), ptr(tnn), V, B, ptr(ops._f32(tau).reshape(1)), ptr(ws), stream()),
+              "ph_tsvd_update_aux_dev")
+    else:
+        check(lib().ph_tsvd_update_aux(ptr(a), ptr(aux), ptr(tnn), V, B, float(tau), ptr(ws), stream()), "ph_tsvd_update_aux")
     return aux.permute(1, 2, 0), tnn[0]
 
 
@@ -66,8 +71,13 @@ class _SqDiffFn(torch.autograd.Function):
 
 
 def tsvd_penalty(adj_tensor, aux_tensor, mu):
-    """sum_v mu/2 * ||adj_v - aux_v||_F^2  (train_test_tSVD.py:418-431, one modality)."""
+    """sum_v mu/2 * ||adj_v - aux_v||_F^2  (train_test_tSVD.py:418-431, one modality); mu: a float, or a 1-element device
+    tensor (captured graphs)."""
     loss = 0
+    if torch.is_tensor(mu):
+        for a, x in zip(adj_tensor, aux_tensor):
+            loss = loss + _SqDiffFn.apply(a, x, 1.0)
+        return loss * (mu.reshape(()) * 0.5)
     for a, x in zip(adj_tensor, aux_tensor):
         loss = loss + _SqDiffFn.apply(a, x, mu / 2.0)
     return loss

@@ -525,6 +525,54 @@ def test_stage1_step_with_crd_and_orth_terms_vs_reference_golden(golden_dir):
         m.set_precision("bf16")
 
 
+@pytest.mark.parametrize("aux_iter", [1, 2])
+def test_tsvd_stage1_step_graph_replay_equals_eager(aux_iter):
+    """TeacherStage1Step.enable_graph(): the stage-1 step with the t-SVD constraint replayed from captured HIP graphs (one per
+    kind of step: with / without the auxiliary update; the threshold Lambda / mu, the penalty's mu and the CRD weight read from
+    device memory) against the same steps launched eagerly - same weights, same batches, two resident input sets in turn.
+    Perf arithmetic on both sides (the graph changes launch mechanics, not kernels): losses and updated weights agree to
+    rounding of mu in fp32 (the eager path passes it as a double-precision host scalar)."""
+    import copy
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import synthetic_batch
+    B = 8
+    opt = m.stage2_opt(dropout_rate=0.0, batch_size=B, cut_fuse_grad=False, num_teachers=2)
+    opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, 1.0, 0, 0, "False"
+    opt.tSVD_loss, opt.tSVD_mode, opt.n_views, opt.aux_iter = "True", "pathomic", 4, aux_iter
+    opt.mu, opt.pho, opt.max_mu, opt.Lambda_global = 1e-3, 1.3, 10.0, 0.05
+    bts = []
+    for i in range(2):
+        bt = synthetic_batch(B, 64, seed=90 + i)
+        z = torch.zeros(B).cuda()
+        bts.append(((bt["x_path"].cuda(), bt["ema_x_path"].cuda()), z, bt["x_omic"].cuda(), z, z, bt["grade"].cuda(), bt["index"].cuda(),
+                    bt["sample_idx"].cuda()))
+    res = {}
+    for graph in (False, True):
+        model = m.define_net(opt, 1); ema = m.define_net(opt, 1)
+        model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3)); ema.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 4))
+        st = m.TeacherStage1Step(copy.copy(opt), device="cuda", models=(model.cuda(), ema.cuda()))
+        if graph:
+            st.enable_graph()
+        st.start_epoch()
+        losses = []
+        for it in range(8):
+            out = st.step(bts[(it // 2) % 2])      # (both kinds of step on both input sets)
+            losses.append({k: float(out[k]) for k in ("loss", "loss_nll", "loss_tsvd", "loss_pred_KD")})
+        if graph:
+            assert st._g_sets and len(st._g_sets) == 2 and all(len(q["graphs"]) == (1 if aux_iter == 1 else 2) for q in st._g_sets), \
+                "steps 2.. must have been replayed from graphs (two input sets)"
+        res[graph] = dict(losses=losses, w=st.model.state_dict()["path_net.fc_new2.weight"].clone() if "path_net.fc_new2.weight" in st.model.state_dict()
+                          else next(iter(st.model.parameters())).detach().clone(), mu=st.mu, aux=st.aux_tensor1[2].clone())
+    for it in range(8):
+        for k, v in res[False]["losses"][it].items():
+            g = res[True]["losses"][it][k]
+            assert abs(g - v) <= 2e-3 * max(1.0, abs(v)), (it, k, g, v)
+    assert res[True]["mu"] == res[False]["mu"]
+    assert (res[True]["aux"] - res[False]["aux"]).abs().max().item() <= 2e-3 * max(1.0, res[False]["aux"].abs().max().item())
+    assert (res[True]["w"] - res[False]["w"]).abs().max().item() <= 5e-3 * max(1e-3, res[False]["w"].abs().max().item())
+
+
 @pytest.mark.parametrize("fixture", ["tsvd_step_b8_h64.npz", "tsvd_step_b8_h64_v8.npz"])
 def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir, fixture):
     """Row a16 end to end (BASELINE cfg 4's computation at a small size): two stage-1 steps with the t-SVD constraint
