@@ -292,7 +292,7 @@ def run_variant(name, B, H, device, L, steps=5):
             traffic = json.load(open(tf)).get(name, {})
         rows = []
         for cls, key, nm in ((8, "crd_score", "crd_score_kernel: 2 banks x B x (P+K) rows of 512 B"),
-                             (TOPK_CLS, "crd_bank_topk", "crd_bank_knn_kernel (+ merge): 2 banks x n_data rows of 512 B, each once"),
+                             (TOPK_CLS, "crd_bank_topk", "ph_crd_bank_topk = 4 launches (sample pass, threshold, full pass, merge) under ONE event pair in eager steps, launch gaps included; kernel durations alone: profiles/r04_kernel_stats_mia2023.txt (11 + 6 + 35 + 11 us); 2 banks x n_data rows of 512 B, each once (+ 1/16 in the sample pass)"),
                              (9, "crd_loss_grad", "crd_loss_grad_kernel (+ reduce): 2 banks x B x (P2+K2) rows of 512 B")):
             n, ms, by = buf[4 * cls], buf[4 * cls + 1], buf[4 * cls + 2]
             if n == 0:
