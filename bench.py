@@ -548,6 +548,15 @@ def main():
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         backend = os.environ.get("PH_BENCH_BACKEND", "nccl")
+        # collectives inside captured graphs: the watchdog's asynchronous error handling must not touch the streams (torch's own
+        # recipe for whole-network capture with a process group)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        if world == 1 and "RANK" not in os.environ:      # --force-dist straight from a shell: a one-rank group of its own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:

@@ -811,7 +811,7 @@ class DistillStep:
             pool = next((q["graph"].pool() for q in slots if q["graph"] is not None), None)
             was_prepared = self.optimizer._prepared
             try:
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=_capture_mode(self.sync)):
                     self.optimizer._prepared = True       # the step scalars are read from device memory at replay
                     if getattr(self, "_capture_pre", None) is not None:
                         self._capture_pre()               # the on-device input pipeline fills this input set first
@@ -934,6 +934,15 @@ class DistillStep:
         """The graph path's resident input buffers (fill them in place to skip the device-to-device copy)."""
         st = getattr(self, "_static", None)
         return None if st is None else {k: st[k] for k in ("x_path", "ema_x_path", "x_omic", "grade", "index", "sample_idx")}
+
+
+def _capture_mode(sync):
+    """Stream-capture error mode of the step graphs.  Under data parallelism the process group's watchdog thread keeps polling
+    the completion events of earlier collectives (hipEventQuery); in the default "global" mode that call from ANOTHER thread is
+    illegal while a capture runs and takes the process down (seen intermittently with `bench.py --force-dist`): "thread_local"
+    restricts the check to the capturing thread.  Kernels enqueued on the capturing stream by other threads (autograd's
+    backward worker) are captured either way."""
+    return "thread_local" if sync is not None else "global"
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -1147,7 +1156,7 @@ class TeacherStage1Step:
             was_prepared = self.optimizer._prepared
             try:
                 bf = st["bufs"]
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=_capture_mode(self.sync)):
                     self.optimizer._prepared = True       # the step scalars are read from device memory at replay
                     out = self._device_body(bf["x_path"], bf["ema_x_path"], bf["x_omic"], bf["grade"], bf["index"],
                                             bf["sample_idx"], B, do_aux, self._g_scal[0], self._g_scal[1], self._g_scal[2], None)
