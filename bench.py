@@ -287,9 +287,11 @@ def run_variant(name, B, H, device, L, steps=5):
         buf = (ctypes.c_double * (4 * NALL))()
         L.ph_prof_summary4(buf, NALL)
         traffic = {}
-        tf = os.path.join(ROOT, "profiles", "r03_crd_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(name, {})
+        for tname in ("r04_crd_traffic.json", "r03_crd_traffic.json"):      # (the newest committed counter pass)
+            tf = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get(name, {})
+                break
         rows = []
         for cls, key, nm in ((8, "crd_score", "crd_score_kernel: 2 banks x B x (P+K) rows of 512 B"),
                              (TOPK_CLS, "crd_bank_topk", "ph_crd_bank_topk = 4 launches (sample pass, threshold, full pass, merge) under ONE event pair in eager steps, launch gaps included; kernel durations alone: profiles/r04_kernel_stats_mia2023.txt (11 + 6 + 35 + 11 us); 2 banks x n_data rows of 512 B, each once (+ 1/16 in the sample pass)"),
