@@ -272,6 +272,7 @@ def run_variant(name, B, H, device, L, steps=5):
         out = step.step(bts[i % 2], epoch=5)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    graph = graph and bool(getattr(step, "_want_graph", False))      # (a failed capture falls back to eager launches and says so)
     res = {"workload": desc, "tiles_per_gpu": B, "steps": steps, "ms_per_step": round(1000.0 * dt / steps, 3),
            "value": round(B * steps / dt, 2), "unit": "tiles/s", "final_loss": round(float(out["loss"]), 4),
            "launch": "one captured HIP graph per step" if graph else "eager"}
@@ -583,6 +584,7 @@ def main():
             out = step.step(batches[i % 2], epoch=5)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        graph = graph and bool(getattr(step, "_want_graph", False))      # (a failed capture falls back to eager launches)
         Bv = batches[0][0][0].shape[0]
         if rank == 0:
             print(json.dumps({"metric": "ROI-tiles/sec (variant step)", "value": round(Bv * world * args.steps / dt, 2), "unit": "tiles/s",

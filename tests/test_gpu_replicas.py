@@ -395,3 +395,20 @@ def test_replica_sync_step_is_captured_in_one_graph_with_rccl_inside():
     assert c["backend"].startswith("nccl") and c["ranks_joined_all_reduce"] == 1 and c["distinct_devices"] == 1
     assert c["launch"].startswith("collectives captured inside the step's HIP graph")
     assert c["grad_allreduce_bytes"] > 40e6 and 0.0 <= c["exposed_grad_allreduce_ms"] < 5.0
+
+
+def test_stage1_tsvd_step_is_captured_with_rccl_inside():
+    """The stage-1 trainer with the t-SVD term under a process group (one rank, RCCL): the feature all-gathers of the global
+    adjacency tensors and the gradient all-reduce are captured inside TeacherStage1Step's step graph; the variant line of
+    `bench.py --force-dist --variant tsvd` must come from graph replay (a failed capture would fall back to eager and say so)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--variant", "tsvd", "--batch", "16", "--size", "128",
+                        "--steps", "4", "--warmup", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["config"]["launch"] == "one captured HIP graph per step", res["config"]
+    assert np.isfinite(res["config"]["final_loss"])
