@@ -643,6 +643,7 @@ def main():
     if args.eager and not args.no_kernel_timer:
         L.ph_prof_reset(); L.ph_prof_enable(1)
     dt, out = timed(step, batches, args.steps, sync, device)
+    replayed = bool(getattr(step, "_want_graph", False))      # (False after a capture that failed and fell back to eager launches)
     L.ph_prof_enable(0)
     timer_region = "the timed region (eager)"
     if not args.eager and not args.no_kernel_timer:
@@ -834,7 +835,8 @@ def main():
                           "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(loss, 4),
                           "launch": (("eager (external launcher: a failed graph capture cannot be recovered in-process; "
                                       "PH_BENCH_DDP_GRAPH=1 opts in)" if ext_eager else "eager") if args.eager
-                                     else "one captured HIP graph per step")
+                                     else ("one captured HIP graph per step" if replayed
+                                           else "eager (the graph capture failed: see the warning on stderr)"))
                                     + ("; replicas: " + os.environ["PH_BENCH_LAUNCH"] if "PH_BENCH_LAUNCH" in os.environ else ""),
                           "input_pipeline": ("on-device from resident uint8 tiles, inside the timed region and the graph"
                                              if args.device_loader else "inputs resident in HBM when the timed region starts")}}
