@@ -390,6 +390,41 @@ def test_mia2023_bank_topk_rare_class_and_sorted_bank():
             assert torch.allclose(s.cpu(), srt[0][:, :NP], atol=1e-6), case
 
 
+def test_mia2023_bank_topk_is_independent_of_batching_and_repeatable():
+    """Size-independent properties at BASELINE config 5's bank (65 536 rows): a query's neighbours do not depend on which other
+    queries share the call (64 at once == 2 x 32 == 64 x 1 for a few of them: different 32-query blocks, different thresholds from
+    the sample pass, different list layouts - the same keys), and two calls give bitwise the same result."""
+    from multimodal_learning_amd._lib import lib, ptr, stream, check
+    L = lib()
+    g = torch.Generator().manual_seed(9)
+    n, B, NP = 65536, 64, 6
+    m1 = (torch.rand(n, 128, generator=g) - 0.5).cuda(); m2 = (torch.rand(n, 128, generator=g) - 0.5).cuda()
+    lb = torch.randint(0, 3, (n,), generator=g).int().cuda()
+    ix = torch.randint(0, n, (B, 5), generator=g).cuda()
+    bl = lb[ix[:, 0]].long()
+
+    def call(sl):
+        b = sl.stop - sl.start
+        nb1 = torch.empty(b, NP, dtype=torch.int64, device="cuda"); nb2 = torch.empty_like(nb1)
+        s1 = torch.empty(b, NP, device="cuda"); s2 = torch.empty_like(s1)
+        ws = torch.empty(L.ph_crd_bank_topk_workspace_bytes(b, n), dtype=torch.uint8, device="cuda")
+        ixs, bls = ix[sl].contiguous(), bl[sl].contiguous()
+        check(L.ph_crd_bank_topk(ptr(m1), ptr(m2), ptr(lb), ptr(ixs), 5, ptr(bls), b, n, NP, 128, ptr(nb1), ptr(nb2), ptr(s1), ptr(s2),
+                                 ptr(ws), stream()), "topk")
+        torch.cuda.synchronize()
+        return nb1, nb2, s1, s2
+    full = call(slice(0, B))
+    again = call(slice(0, B))
+    assert all(torch.equal(a, b) for a, b in zip(full, again))
+    halves = [call(slice(0, 32)), call(slice(32, 64))]
+    for k in range(4):
+        assert torch.equal(full[k], torch.cat([h[k] for h in halves], 0))
+    for q in (0, 31, 32, 63):
+        one = call(slice(q, q + 1))
+        for k in range(4):
+            assert torch.equal(full[k][q:q + 1], one[k])
+
+
 def test_mia2023_rows_golden(golden_dir):
     import multimodal_learning_amd as m
     from multimodal_learning_amd import mia2023
