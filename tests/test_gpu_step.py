@@ -203,7 +203,8 @@ def test_checkpoint_resume_is_bit_identical():
         assert torch.equal(ca.contrast.params, cb.contrast.params)
 
 
-def test_stage1_teacher_step_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("pmode", ["bf16x6", "fp16x3/x1"])
+def test_stage1_teacher_step_vs_reference_golden(golden_dir, pmode):
     """Row f-1: two stage-1 mean-teacher steps (train_test_MT.py:121-230, grading task, num_teachers 2) in parity mode
     against the fixture produced by the reference's modules.  Step 0 (identical weights on both sides) is asserted
     tightly; step 1 runs on Adam-updated weights and is asserted at the post-update noise floor."""
@@ -211,7 +212,7 @@ def test_stage1_teacher_step_vs_reference_golden(golden_dir):
     from oracle import weights as W
     from oracle.step import synthetic_batch
     g = np.load(os.path.join(golden_dir, "stage1_b4_h64.npz"))
-    m.set_precision("bf16x6")
+    m.set_precision(pmode)
     try:
         opt = m.stage2_opt(dropout_rate=0.0, batch_size=4, cut_fuse_grad=False, num_teachers=2)
         opt.pred_distill, opt.KD_weight = 1, float(g["KD_weight"])
@@ -577,8 +578,9 @@ def test_tsvd_stage1_step_graph_replay_equals_eager(aux_iter):
     assert (res[True]["w"] - res[False]["w"]).abs().max().item() <= 5e-3 * max(1e-3, res[False]["w"].abs().max().item())
 
 
+@pytest.mark.parametrize("pmode", ["bf16x6", "fp16x3/x1"])
 @pytest.mark.parametrize("fixture", ["tsvd_step_b8_h64.npz", "tsvd_step_b8_h64_v8.npz"])
-def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir, fixture):
+def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir, fixture, pmode):
     """Row a16 end to end (BASELINE cfg 4's computation at a small size): two stage-1 steps with the t-SVD constraint
     ("MIA 2022/train_test_tSVD.py":199-470: adjacency tensors over 4 views per modality, auxiliary update at every batch,
     mu schedule, Frobenius penalty) against the reference's modules driven in the trainer's order; the absent
@@ -590,7 +592,7 @@ def test_tsvd_stage1_step_vs_reference_trainer_logic(golden_dir, fixture):
     from tests.gpu_util import Report
     g = np.load(os.path.join(golden_dir, fixture))
     B = int(g["B"])
-    m.set_precision("bf16x6")
+    m.set_precision(pmode)
     try:
         opt = m.stage2_opt(dropout_rate=0.0, batch_size=B, cut_fuse_grad=bool(int(g["cut_fuse_grad"])), num_teachers=2)
         opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, float(g["KD_weight"]), 0, 0, "False"
