@@ -275,6 +275,12 @@ int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /*
 /* HIP-graph-replayable form: hyper = device float[5] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha} */
 int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1,
                          double beta2, double eps, double weight_decay, const float* hyper, ph_stream_t stream);
+/* torch.optim.Adagrad as define_optimizer builds it (reference MICCAI-2022/networks_new.py:86-87: lr, weight_decay,
+ * initial_accumulator_value = 0.1, lr_decay 0, eps 1e-10): g' = g + wd p, sum += g'^2, p -= lr g' / (sqrt(sum) + eps), with the
+ * mean-teacher EMA copy (train_test_path_multi_distill.py:34-38) fused as in ph_adam_ema_step_dev.  hyper: the same device
+ * float[5] record ([0] = lr, [3] / [4] = EMA rate and complement). */
+int ph_adagrad_ema_step_dev(float* p, const float* g, float* sum, float* ema /* may be NULL */, size_t n, double eps,
+                            double weight_decay, const float* hyper, ph_stream_t stream);
 int ph_ema_update(float* ema, const float* p, size_t n, float alpha, ph_stream_t stream);
 /* define_reg (MICCAI-2022/networks_new.py:93-108 -> utils.py:60-198, the `lambda_reg * loss_reg` term of
  * train_test_MT.py:209-217 and train_test_path_multi_distill.py:312-313): L1 norm of a contiguous run of fp32
@@ -371,6 +377,13 @@ int ph_augment_apply(const uint8_t* src, const int64_t* rows /* NULL - image b o
 int ph_contrast_sampler(const int64_t* index, const int64_t* grade, const int* cls_pos, const int* cls_pos_off,
                         const int* cls_neg, const int* cls_neg_off, int n_data, int B, int P, int K, int pos_mode,
                         int neg_mode, uint64_t seed, const uint64_t* step, int64_t* out, ph_stream_t stream);
+
+/* ContrastMemory_v3.forward called WITHOUT contrast indices (reference MICCAI-2022/CL_utils/memory_new.py:265-267:
+ * `idx = self.multinomial.draw(batchSize * (self.K + P)).view(batchSize, -1); idx.select(1, 0).copy_(y.data)`, AliasMethod
+ * :401-458 over uniform unigrams): out [B][S] int64, column 0 = y[b], every other entry uniform in [0, n_data) with
+ * replacement.  `seed` and the device counter `step` (may be NULL) select the draw; distributional parity. */
+int ph_alias_uniform_draw(const int64_t* y, int64_t* out, int n_data, int B, int S, uint64_t seed, const uint64_t* step,
+                          ph_stream_t stream);
 
 /* Orthogonality loss of the stage-1 trainer (reference MICCAI-2022/CL_utils/orthogonal_loss.py:18-32): rows scaled by
  * a DETACHED 1/(||x||+eps) (:24-28); the D x D cross-correlation and its mean square are ph_sgemm + ph_sqdiff_sum. */

@@ -10,8 +10,9 @@ eps = 1e-7
 
 
 class CRDLoss(nn.Module):
-    """CRD loss with DC-Distill pair selection.  forward(epoch, f_s, f_t, idx, contrast_idx) -> 0-d loss,
-    differentiable w.r.t. f_s and both Embed layers; mutates the banks and Z exactly like the reference."""
+    """CRD loss with DC-Distill pair selection.  forward(epoch, f_s, f_t, idx, contrast_idx) -> 0-d loss (the [B] per-sample
+    losses with opt.sample_KD == "True"), differentiable w.r.t. f_s and both Embed layers; mutates the banks and Z exactly
+    like the reference."""
 
     def __init__(self, opt, n_data):
         super().__init__()
@@ -21,16 +22,18 @@ class CRDLoss(nn.Module):
         self.embed_t = Embed(opt.t_dim, opt.feat_dim)
         self.contrast = ContrastMemory_v3(opt.feat_dim, n_data, opt.nce_p, opt.nce_k, opt.nce_t, opt.nce_m,
                                           opt.select_pos_pairs, opt.nce_p2, opt.select_neg_pairs, opt.nce_k2)
-        if getattr(opt, "sample_KD", "False") != "False":
-            raise NotImplementedError("sample_KD == 'True' is not used by the shipped stage-2 command")
+        # --sample_KD True (options.py:69): both criteria return the [B] per-sample losses of ContrastLoss_v2's second branch
+        # (:246-250) and forward() their sum s_loss + t_loss, shape [B] - the same fused kernel, rows left un-normalised
+        self.sample_KD = getattr(opt, "sample_KD", "False")
+        self.contrast.sample_KD = self.sample_KD == "True"
         self.criterion_t = ContrastLoss_v2(n_data, sample_KD=opt.sample_KD)
         self.criterion_s = ContrastLoss_v2(n_data, sample_KD=opt.sample_KD)
         self.select_pos_mode = opt.select_pos_mode
 
     def forward(self, epoch, f_s, f_t, idx, contrast_idx=None, ranks=None):
-        if contrast_idx is None:
-            raise NotImplementedError("contrast_idx=None (AliasMethod.draw) never happens on the hot path "
-                                      "(memory_new.py:265-267)")
+        # (contrast_idx=None: ContrastMemory_v3 draws the rows itself, memory_new.py:265-267)
+        if self.sample_KD not in ("False", "True"):
+            raise UnboundLocalError("local variable 'loss' referenced before assignment")   # what :252 raises there
         f_s = self.embed_s(f_s)
         f_t = self.embed_t(f_t)
         return self.contrast.loss(epoch, f_s, f_t, idx, contrast_idx, self.select_pos_mode, ranks)

@@ -72,6 +72,8 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None, output
     dv1 = torch.empty(B, D, device=dev, dtype=torch.float32)
     dv2 = torch.empty_like(dv1)
     bnorm = float(mem.batch_norm_size or B)
+    if getattr(mem, "sample_KD", False):
+        bnorm = 1.0      # ContrastLoss_v2's per-sample branch (CRD_loss.py:246-250) does not divide by the batch size
     # long column lists (nce_k = 4096 of the MIA trainers) are dealt to several workgroups per sample through a workspace
     lg_ws = (torch.empty(L.ph_crd_loss_grad_workspace_bytes(B), device=dev, dtype=torch.uint8) if P2 + K2 >= 1024 else None)
     check(L.ph_crd_loss_grad(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(posw_s), ptr(posw_t),
@@ -188,6 +190,22 @@ class ContrastMemory_v3(nn.Module):
             raise RuntimeError("select_pos_mode '%s' needs nce_p > %d" % (select_pos_mode, int(r.max())))
         return torch.as_tensor(np.asarray(r), dtype=torch.int32)
 
+    def draw_indices(self, y):
+        """idx == None (memory_new.py:265-267): the reference draws B * (K + P) rows from its AliasMethod table over uniform
+        unigrams (:229-231, :401-458) - with all-ones unigrams every table entry keeps probability 1, so the draw is the
+        uniform integer draw - and overwrites column 0 with y.  One launch; the device counter makes captured replays draw
+        afresh.  Distributional parity: the reference's stream is torch's CUDA generator."""
+        y = require_cuda(y).contiguous()
+        B = y.shape[0]
+        if getattr(self, "_draw_step", None) is None or self._draw_step.device != y.device:
+            self._draw_step = torch.zeros(1, device=y.device, dtype=torch.int64)
+            self._draw_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+        out = torch.empty(B, self.P + self.K, device=y.device, dtype=torch.int64)
+        check(lib().ph_alias_uniform_draw(ptr(y), ptr(out), int(self.nLem), B, self.P + self.K, self._draw_seed,
+                                          ptr(self._draw_step), stream()), "ph_alias_uniform_draw")
+        self._draw_step += 1
+        return out
+
     def _ranks(self, epoch, select_pos_mode, ranks, dev):
         if ranks is None:
             ranks = self.draw_ranks(epoch, select_pos_mode)
@@ -197,7 +215,10 @@ class ContrastMemory_v3(nn.Module):
 
     def loss(self, epoch, v1, v2, y, idx, select_pos_mode="mid", ranks=None):
         """s_loss + t_loss of CRDLoss.forward (CRD_loss.py:167-174) in one fused pass (what CRDLoss calls)."""
-        return _CRDCoreFn.apply(v1, v2, self, y, idx, self._ranks(epoch, select_pos_mode, ranks, v1.device))
+        if idx is None:
+            idx = self.draw_indices(y)
+        return _CRDCoreFn.apply(v1, v2, self, y, idx, self._ranks(epoch, select_pos_mode, ranks, v1.device),
+                                bool(getattr(self, "sample_KD", False)))
 
     def forward(self, epoch, v1, v2, y, idx=None, select_pos_mode="mid", ranks=None):
         """memory_new.py:249-397 as written: returns (out_v1, out_v2), each [B, P2+K2, 1] (selected positives first),
@@ -205,6 +226,5 @@ class ContrastMemory_v3(nn.Module):
         list of the `mid` / `random` / `curriculum` modes comes from numpy's global RNG exactly as in the reference
         (:311-322) unless `ranks` is given."""
         if idx is None:
-            raise NotImplementedError("idx=None (AliasMethod.draw, memory_new.py:265-267): the loaders always pass "
-                                      "contrast_idx")
+            idx = self.draw_indices(y)
         return _CRDOutputsFn.apply(v1, v2, self, y, idx, self._ranks(epoch, select_pos_mode, ranks, v1.device))

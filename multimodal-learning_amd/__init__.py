@@ -16,7 +16,7 @@ from .networks_new import (define_net, define_optimizer, define_reg, define_sche
                            define_bifusion, MaxNet, PathomicNet, get_resnet)
 from .kd_loss import DistillKL
 from .CL_utils import CRDLoss, ContrastLoss_v2, Embed, Normalize, ContrastMemory_v3
-from .train_step import (AEKD_loss, momentum_AEKD_loss, update_ema_variables, DistillStep, FusedAdam, FlatParams,
+from .train_step import (AEKD_loss, momentum_AEKD_loss, update_ema_variables, DistillStep, FusedAdam, FusedAdagrad, FlatParams,
                          TeacherStage1Step)
 from . import dist
 from . import mia2023
@@ -33,4 +33,4 @@ __all__ = ["build", "lib", "set_precision", "get_precision", "init_net", "init_m
            "ResNet", "ResNet18", "BasicBlock", "BilinearFusion", "define_net", "define_optimizer", "define_reg",
            "define_scheduler", "define_act_layer", "define_bifusion", "MaxNet", "PathomicNet", "get_resnet",
            "DistillKL", "CRDLoss", "ContrastLoss_v2", "Embed", "Normalize", "ContrastMemory_v3", "AEKD_loss", "momentum_AEKD_loss",
-           "update_ema_variables", "DistillStep", "FusedAdam", "FlatParams", "TeacherStage1Step", "dist", "stage2_opt"]
+           "update_ema_variables", "DistillStep", "FusedAdam", "FusedAdagrad", "FlatParams", "TeacherStage1Step", "dist", "stage2_opt"]

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ph_rkd_loss_grad": (i32, [vp, vp, vp, vp, i32, i32, f32, f32, vp, vp]),
     "ph_superpixel_mask": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "ph_shuffle_indices": (i32, [vp, i32, i32, u64, vp, vp]),
+    "ph_alias_uniform_draw": (i32, [vp, vp, i32, i32, i32, u64, vp, vp]),
     "ph_augment_params": (i32, [vp, i32, u64, vp, i32, i32, i32, f32, f32, f32, f32, vp]),
     "ph_augment_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_apply_mask": (i32, [vp, vp, vp, i32, i32, sz, vp]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "ph_gk_finish_momentum": (i32, [vp, vp, f32, f32, vp, f32, f32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "ph_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, f64, vp]),
     "ph_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, vp, vp]),
+    "ph_adagrad_ema_step_dev": (i32, [vp, vp, vp, vp, sz, f64, f64, vp, vp]),
     "ph_ema_update": (i32, [vp, vp, sz, f32, vp]),
     "ph_l1_sum": (i32, [vp, sz, vp, vp, i32, vp]),
     "ph_l1_sign_axpy": (i32, [vp, vp, sz, vp, f32, vp]),

@@ -519,7 +519,9 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_pooled_kernel(const T* __
     if ((threadIdx.x & 63) == 0) sha[threadIdx.x >> 6] = am;
   }
   __syncthreads();
-  if (amax && threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
+  // (x 4: up to four overlapping 3 x 3 / stride-2 windows scatter their gradients onto ONE stem pixel, so max |dz| of the apply
+  // pass can be four times the largest window gradient - the bound the dz scale is derived from must cover it)
+  if (amax && threadIdx.x == 0) amax[blockIdx.x] = 4.f * fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
     float t = 0.f;
@@ -573,7 +575,9 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_raw_kernel(const T* __res
     if ((threadIdx.x & 63) == 0) sha[threadIdx.x >> 6] = am;
   }
   __syncthreads();
-  if (amax && threadIdx.x == 0) amax[blockIdx.x] = fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
+  // (x 4: up to four overlapping 3 x 3 / stride-2 windows scatter their gradients onto ONE stem pixel, so max |dz| of the apply
+  // pass can be four times the largest window gradient - the bound the dz scale is derived from must cover it)
+  if (amax && threadIdx.x == 0) amax[blockIdx.x] = 4.f * fmaxf(fmaxf(sha[0], sha[1]), fmaxf(sha[2], sha[3]));
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, ch = threadIdx.x & 63;
     float t = 0.f;

@@ -202,6 +202,25 @@ __global__ void adam_ema_dev_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+// torch.optim.Adagrad (lr_decay = 0: networks_new.py:86-87 passes lr, weight_decay, initial_accumulator_value = 0.1) with the
+// EMA copy fused like the Adam kernel: g' = g + wd p; sum += g'^2; p -= lr g' / (sqrt(sum) + eps).  hyper as above ([0] = lr,
+// [3] / [4] = the EMA rate and its complement).
+__global__ void adagrad_ema_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sum,
+                                       float* __restrict__ ema, size_t n, float eps, float wd, const float* __restrict__ hyper) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float lr = hyper[0], ema_alpha = hyper[3], om_alpha = hyper[4];
+  const size_t e1 = i + 4 <= n ? i + 4 : n;
+  for (size_t e = i; e < e1; ++e) {
+    const float gg = g[e] + wd * p[e];
+    const float sacc = sum[e] + gg * gg;
+    sum[e] = sacc;
+    const float pn = p[e] - lr * gg / (sqrtf(sacc) + eps);
+    p[e] = pn;
+    if (ema) ema[e] = ema_alpha * ema[e] + om_alpha * pn;
+  }
+}
+
 __global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n, float alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ema[i] = alpha * ema[i] + (1.f - alpha) * p[i];
@@ -377,6 +396,17 @@ int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* em
                      (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay,
                      hyper);
   ph_prof_end(tok, st);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+int ph_adagrad_ema_step_dev(float* p, const float* g, float* sum, float* ema, size_t n, double eps, double weight_decay,
+                            const float* hyper, hipStream_t st) {
+  if (!p || !g || !sum || !hyper) return PH_EINVAL;
+  if (n == 0) return PH_OK;
+  const size_t nt = (n + 3) / 4;
+  hipLaunchKernelGGL(adagrad_ema_dev_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, p, g, sum, ema, n, (float)eps,
+                     (float)weight_decay, hyper);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

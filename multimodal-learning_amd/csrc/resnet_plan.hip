@@ -8,6 +8,7 @@
 // Saved for backward per BasicBlock: x_in, y1, a1, y2, (y_ds), out.
 #include <atomic>
 #include <cstdlib>
+#include <iterator>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -54,7 +55,9 @@ struct PhResnetPlan {
   // pre-packed inputs (forward flag bit6) by the WORKSPACE of the forward that read them: the backward on that workspace
   // reads the same tensor again (stem wgrad).  Keyed by workspace, not cached per plan: a no_grad / eval forward or another
   // taped forward of a `_multi_forward` net on the same plan must not redirect an earlier forward's backward.
-  mutable std::unordered_map<const void*, const void*> x4_by_ws;
+  struct X4Ent { const void* x4; unsigned long long seq; };
+  mutable std::unordered_map<const void*, X4Ent> x4_by_ws;
+  mutable unsigned long long x4_seq = 0;
   mutable std::mutex x4_mu;
   // Backward on two streams (backward_impl): the weight-gradient launches run on a side stream beside the BatchNorm-backward /
   // dgrad chain; `dy2_off` is the second dz buffer they need.
@@ -388,8 +391,13 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   int rc = PH_OK;
   {
     std::lock_guard<std::mutex> lk(P->x4_mu);
-    if ((flags & 64) && P->x4_by_ws.size() > 256) P->x4_by_ws.clear();      // (workspaces long gone: keep the table bounded)
-    if (flags & 64) P->x4_by_ws[ws_] = reinterpret_cast<const void*>(x_nchw);
+    if ((flags & 64) && P->x4_by_ws.size() > 256) {
+      // workspaces long gone (a backward erases its entry; these never had one): drop the OLDER half, never an entry a taped
+      // forward of this step may still need (clear() also dropped live entries of `_multi_forward` nets)
+      const unsigned long long cut = P->x4_seq - 128;
+      for (auto it = P->x4_by_ws.begin(); it != P->x4_by_ws.end();) it = it->second.seq < cut ? P->x4_by_ws.erase(it) : std::next(it);
+    }
+    if (flags & 64) P->x4_by_ws[ws_] = PhResnetPlan::X4Ent{reinterpret_cast<const void*>(x_nchw), P->x4_seq++};
     else P->x4_by_ws.erase(ws_);
   }
   const unsigned char* x4p = (flags & 64) ? reinterpret_cast<const unsigned char*>(x_nchw) : ws + P->x4_off;
@@ -576,7 +584,8 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   const hipStream_t side = ov ? sr->side : st;
   Ctx cs = c;                       // the weight-gradient launches' context
   if (ov) { cs.st = side; cs.wg_want = WG_WANT_BESIDE; }
-  // this call's block of events (see SideRes): -EBUSY when all 16 are held by backward passes still in flight
+  // this call's block of events (see SideRes): eager calls take one of 15 blocks (waiting for the oldest call in flight when
+  // all are held), captured calls the 16th
   size_t ev_base = 0;
   int ev_blk = -1;
   bool capturing = false;
@@ -584,19 +593,33 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
     capturing = hipStreamIsCapturing(st, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
     std::lock_guard<std::mutex> lk(sr->mu);
-    for (size_t i = 0; i < EV_BLOCKS && ev_blk < 0; ++i) {
-      const size_t b = (sr->cursor + i) % EV_BLOCKS;
-      if (!sr->busy[b]) ev_blk = (int)b;
+    if (capturing) {
+      // A captured call uses the block RESERVED for captures: the capture turns its event waits into graph edges and keeps no
+      // reference to the events, so the block is free again when the call returns, and no hipEventQuery ever runs inside a
+      // capture (in the default "global" capture mode a query from the capturing thread would invalidate it - ADVICE r04).
+      ev_blk = (int)EV_BLOCKS - 1;
+    } else {
+      constexpr size_t NE = EV_BLOCKS - 1;      // blocks of eager calls
+      for (size_t i = 0; i < NE && ev_blk < 0; ++i) {
+        const size_t b = (sr->cursor + i) % NE;
+        if (!sr->busy[b]) ev_blk = (int)b;
+      }
+      // none known free: ask the `done` events of the calls in flight
+      for (size_t i = 0; i < NE && ev_blk < 0; ++i) {
+        const size_t b = (sr->cursor + i) % NE;
+        if (hipEventQuery(sr->done[b]) == hipSuccess) { sr->busy[b] = false; ev_blk = (int)b; }
+      }
+      (void)hipGetLastError();      // (hipErrorNotReady of a pending block is not an error of this call)
+      if (ev_blk < 0) {
+        // the host runs NE backward passes ahead of the GPU (an eager loop without a sync per step): back-pressure - wait for
+        // the OLDEST call in flight (round-robin hand-out: the block at the cursor) instead of failing the step
+        const size_t b = sr->cursor % NE;
+        if (hipEventSynchronize(sr->done[b]) != hipSuccess) return PH_EBUSY;
+        ev_blk = (int)b;
+      }
+      sr->busy[ev_blk] = true;      // (claimed; released below)
+      sr->cursor = ((size_t)ev_blk + 1) % NE;
     }
-    // none known free: ask the `done` events (recorded outside any capture, so the query is legal while `st` captures)
-    for (size_t i = 0; i < EV_BLOCKS && ev_blk < 0; ++i) {
-      const size_t b = (sr->cursor + i) % EV_BLOCKS;
-      if (hipEventQuery(sr->done[b]) == hipSuccess) { sr->busy[b] = false; ev_blk = (int)b; }
-    }
-    (void)hipGetLastError();      // (hipErrorNotReady of a pending block is not an error of this call)
-    if (ev_blk < 0) return PH_EBUSY;
-    sr->busy[ev_blk] = true;      // (claimed; released below)
-    sr->cursor = (size_t)ev_blk + 1;
     ev_base = (size_t)ev_blk * EV_BLOCK;
   }
   struct BlockGuard {      // every exit path: a captured call frees the block, an eager one marks it with `done` on the stream
@@ -604,7 +627,8 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     ~BlockGuard() {
       if (!r || b < 0) return;
       std::lock_guard<std::mutex> lk(r->mu);
-      if (cap || hipEventRecord(r->done[b], s) != hipSuccess) r->busy[b] = false;
+      if (cap) return;      // (the capture block is never marked busy)
+      if (hipEventRecord(r->done[b], s) != hipSuccess) r->busy[b] = false;
     }
   } guard{ov ? sr : nullptr, ev_blk, capturing, st};
   size_t ev_used = 0;
@@ -698,7 +722,10 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     {
       std::lock_guard<std::mutex> lk(P->x4_mu);
       auto it = P->x4_by_ws.find(ws_);
-      if (it != P->x4_by_ws.end()) x4_ext = it->second;
+      if (it != P->x4_by_ws.end()) {
+        x4_ext = it->second.x4;
+        if (stop == 0) P->x4_by_ws.erase(it);      // consumed (the debug harness re-runs the backward on one forward: kept there)
+      }
     }
     w.x4 = x4_ext ? x4_ext : ws + P->x4_off; w.dy = dzb[0]; w.slab = reinterpret_cast<float*>(ws + P->slab_off);
     w.B = P->B; w.IH = P->H; w.IW = P->W; w.OH = u.OH; w.OW = u.OW;

@@ -93,7 +93,31 @@ __global__ void shuffle_indices_kernel(int64_t* __restrict__ out, int n, int B, 
   out[j] = (int64_t)perm_at((unsigned)q, (unsigned)n, mix64(seed ^ mix64(epoch + 0x5bd1e995ull)));
 }
 
+// ContrastMemory_v3.forward with idx == None (memory_new.py:265-267): AliasMethod(torch.ones(n_data)).draw(B * (K + P)) viewed
+// [B, K + P], column 0 := y.  With uniform unigrams every alias-table entry has probability 1 (:418-440), torch.bernoulli(1) is 1
+// and the draw IS the uniform integer draw kk (:450-458): one hash per slot, with replacement.  Distributional parity (the
+// reference draws from torch's CUDA generator); bit-reproducible for a given (seed, step).
+__global__ void alias_uniform_draw_kernel(const int64_t* __restrict__ y, int64_t* __restrict__ out, int n_data, int B, int S,
+                                          uint64_t seed, const uint64_t* __restrict__ step) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * S) return;
+  const int b = (int)(i / S), j = (int)(i - (size_t)b * S);
+  const uint64_t stp = step ? *step : 0;
+  const uint64_t h = mix64(mix64(seed ^ (stp * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull)) + i * 0xD1B54A32D192ED03ull);
+  // (multiply-shift instead of %: unbiased to 2^-32 for n_data < 2^32)
+  out[i] = j == 0 ? y[b] : (int64_t)(((h >> 32) * (uint64_t)(unsigned)n_data) >> 32);
+}
+
 }  // namespace
+
+extern "C" int ph_alias_uniform_draw(const int64_t* y, int64_t* out, int n_data, int B, int S, uint64_t seed, const uint64_t* step,
+                                     hipStream_t st) {
+  if (!y || !out || n_data < 1 || B < 1 || S < 1) return PH_EINVAL;
+  const size_t n = (size_t)B * S;
+  hipLaunchKernelGGL(alias_uniform_draw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, out, n_data, B, S, seed, step);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
 
 extern "C" int ph_shuffle_indices(int64_t* out, int n, int B, uint64_t seed, const uint64_t* batch_no, hipStream_t st) {
   if (!out || n < 1 || B < 1 || B > n) return PH_EINVAL;

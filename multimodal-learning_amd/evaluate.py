@@ -1,5 +1,5 @@
 """Evaluation loop of the stage-2 trainer, reference MICCAI-2022/train_test_path_multi_distill.py:
-`test()` (:409-501), `compute_accuracy` (:504-513), `grading_metrics` (:516-526).
+`test()` (:409-501), `grading_metrics` (:516-526).
 
 Both networks run their eval-mode forward through the C-ABI (running-statistics BatchNorm, dropout off, no tape).  The
 reference copies logits, features and a loss scalar to the host after EVERY batch (three `.cpu()` / `.item()` syncs per
@@ -12,23 +12,16 @@ from . import ops
 from .networks_new import define_reg
 
 
-def compute_accuracy(preds, labels, probs_all, grad_acc_test):
-    """:504-513 - number of correct grades in the batch and the running matrix of predicted log-probabilities."""
-    grade_pred = preds.argmax(dim=1, keepdim=True)
-    grad_acc_test += grade_pred.eq(labels.view_as(grade_pred)).sum().item()
-    probs_np = preds.detach().cpu().numpy()
-    probs_all = probs_np if probs_all is None else np.concatenate((probs_all, probs_np), axis=0)
-    return grad_acc_test, probs_all
-
-
 def grading_metrics(y_label, y_pred, avg="micro"):
-    """:516-526 - (ROC-AUC, average precision, micro F1, F1 of grade IV)."""
-    from sklearn.metrics import roc_auc_score, average_precision_score, f1_score
-    rocauc = roc_auc_score(y_label, y_pred, average=avg)
-    ap = average_precision_score(y_label, y_pred, average=avg)
-    f1_micro = f1_score(np.argmax(y_label, axis=1), y_pred.argmax(axis=1), average=avg)
-    f1_gradeIV = f1_score(np.argmax(y_label, axis=1), y_pred.argmax(axis=1), average=None)[2]
-    return rocauc, ap, f1_micro, f1_gradeIV
+    """The reference's four ranking numbers of the grading task (train_test_path_multi_distill.py:516-526): ROC-AUC and
+    average precision of the one-hot labels against the predicted scores, the F1 of the arg-max grades, and the F1 of the
+    third class (grade IV) alone.  (Its per-batch `compute_accuracy` helper, :504-513, has no counterpart: `test()` below keeps
+    the per-batch predictions on the device and counts once.)"""
+    from sklearn import metrics as skm
+    true_grade, pred_grade = np.argmax(y_label, axis=1), np.argmax(y_pred, axis=1)
+    per_class_f1 = skm.f1_score(true_grade, pred_grade, average=None)
+    return (skm.roc_auc_score(y_label, y_pred, average=avg), skm.average_precision_score(y_label, y_pred, average=avg),
+            skm.f1_score(true_grade, pred_grade, average=avg), per_class_f1[2])
 
 
 def test_model(opt, model, test_loader, device):

@@ -41,10 +41,13 @@ def define_net(opt, k, path_only=False, omic_only=False):
 def define_optimizer(opt, model):
     """networks_new.py:80-90.  'adam' returns the fused multi-tensor HIP Adam (same update rule and
     state_dict surface as torch.optim.Adam with L2-in-grad weight decay)."""
-    from .train_step import FusedAdam
+    from .train_step import FusedAdam, FusedAdagrad
     if opt.optimizer_type == "adam":
         return FusedAdam(model.parameters(), lr=opt.lr, betas=(opt.beta1, opt.beta2), weight_decay=opt.weight_decay)
-    raise NotImplementedError("optimizer [%s]: the shipped commands use adam (options.py:126)" % opt.optimizer_type)
+    if opt.optimizer_type == "adagrad":                                                    # :86-87
+        return FusedAdagrad(model.parameters(), lr=opt.lr, weight_decay=opt.weight_decay, initial_accumulator_value=0.1)
+    # ('adabound', :82-83, needs the third-party `adabound` package the reference imports; absent here and out of scope)
+    raise NotImplementedError("initialization method [%s] is not implemented" % opt.optimizer_type)
 
 
 def define_reg(opt, model):

@@ -78,10 +78,20 @@ class _TrunkFn(torch.autograd.Function):
         # (`needs_input_grad` mirrors requires_grad even under torch.no_grad(), and grad mode is always off inside
         # Function.forward: the caller's grad mode is recorded by _forward_impl - a forward under no_grad is forward-only)
         fwd_only = not (getattr(net, "_caller_grad_mode", True) and any(ctx.needs_input_grad))
-        plan = net._get_plan(B, H, W, ops.get_precision(fwd_only))
+        want_dx = ctx.needs_input_grad[0]
+        prec = ops.get_precision(fwd_only)
+        if prec == ops.PREC_FP16X3 and (want_dx or ((H | W) & 3)):
+            # the half-pair arithmetic is built for image sizes that are multiples of 4 (the pooled form of the stem's
+            # BatchNorm-backward sums) and has no image gradient: such forwards (odd evaluation sizes; the MIA-2023 superpixel
+            # attention, train_test_MT_SP_Masking.py:62-75) run in the fp32-equivalent split-plane arithmetic instead, which
+            # meets the same tolerance (they used to fail inside ph_resnet_plan_create / ph_resnet_backward_input)
+            if net.training and any(ctx.needs_input_grad) and not fwd_only:
+                raise NotImplementedError("precision 'fp16x3': a TRAINING forward needs H and W to be multiples of 4 (got %dx%d); "
+                                          "use set_precision('bf16x6') for this size" % (H, W))
+            prec = ops.PREC_BF16X6
+        plan = net._get_plan(B, H, W, prec)
         packed = net._get_packed(plan)
         table = net._param_table()
-        want_dx = ctx.needs_input_grad[0]
         if want_dx and net.training:
             raise NotImplementedError("gradient with respect to the image in train mode (the reference only takes it "
                                       "through an eval-mode net: train_test_MT_SP_Masking.py:62-75)")
@@ -280,7 +290,7 @@ class ResNet(nn.Module):
         follow = getattr(self, "_follow_epoch", None)
         if follow is None:
             follow = any(c.weight.requires_grad for c, _ in self._units())
-        vers = (ops.weight_epoch() if follow else -1,) + tuple((c.weight._version, c.weight.data_ptr())
+        vers = (ops.weight_epoch() if follow else -1, plan.key[3]) + tuple((c.weight._version, c.weight.data_ptr())
                                                                 for c, _ in self._units())
         if self._packed is None or self._packed_versions != vers or self._packed.numel() != plan.packed_bytes:
             dev = self.conv1.weight.device

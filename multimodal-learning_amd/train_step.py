@@ -203,6 +203,87 @@ class FusedAdam(torch.optim.Optimizer):
             self._step = steps.pop()
 
 
+class FusedAdagrad(FusedAdam):
+    """torch.optim.Adagrad as the reference builds it (networks_new.py:86-87: lr, weight_decay, initial_accumulator_value = 0.1;
+    lr_decay 0, eps 1e-10) over the same flat buffers as FusedAdam, EMA copy fused (ph_adagrad_ema_step_dev).  `_v` holds the
+    accumulator `sum`; there is no first moment."""
+
+    def __init__(self, params, lr=1e-2, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10):
+        torch.optim.Optimizer.__init__(self, list(params), dict(lr=lr, lr_decay=0, eps=eps, weight_decay=weight_decay,
+                                                                  initial_accumulator_value=initial_accumulator_value))
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("one parameter group (the reference passes model.parameters())")
+        self._flat = None
+        self._step = 0
+        self.ema_flat = self.ema_alpha = self.ema_range = None
+        self._hyper = self._hyper_host = None
+        self._prepared = False
+
+    def _ensure_flat(self):
+        if self._flat is None:
+            super()._ensure_flat()
+            self._m = None
+            self._v.fill_(float(self.param_groups[0]["initial_accumulator_value"]))
+        return self._flat
+
+    def prepare_step(self):
+        self._ensure_flat()
+        self._step += 1
+        a = self.ema_alpha if self.ema_alpha is not None else 0.0
+        self._hyper_host.upload(self._hyper, [self.param_groups[0]["lr"], 1.0, 1.0, a, 1.0 - a, 0.0, 0.0, 0.0])
+        self._prepared = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        f = self._ensure_flat()
+        for t, o in zip(f.tensors, f.offsets):
+            if t.requires_grad and t.grad is not None and t.grad.data_ptr() != f.grad.data_ptr() + 4 * o:
+                f.grad[o:o + t.numel()].copy_(t.grad.reshape(-1))
+                t.grad = f.grad[o:o + t.numel()].view(t.shape)
+        g = self.param_groups[0]
+        if not self._prepared:
+            self.prepare_step()
+        self._prepared = False
+        for (s, e) in self._segs:
+            cuts = [s, e]
+            if self.ema_flat is not None and self.ema_range is not None and s < self.ema_range[1] < e:
+                cuts = [s, self.ema_range[1], e]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                ema = None
+                if self.ema_flat is not None and self.ema_range is not None and a >= self.ema_range[0] and b <= self.ema_range[1]:
+                    ema = self.ema_flat.flat[a:b]
+                check(lib().ph_adagrad_ema_step_dev(ptr(f.flat[a:b]), ptr(f.grad[a:b]), ptr(self._v[a:b]), ptr(ema), b - a,
+                                                    g["eps"], g["weight_decay"], ptr(self._hyper), stream()),
+                      "ph_adagrad_ema_step_dev")
+        ops.bump_weight_epoch()
+
+    def state_dict(self):
+        """torch.optim.Adagrad's layout (state[i] = {step, sum}) plus the flat accumulator under "fused"."""
+        sd = torch.optim.Optimizer.state_dict(self)
+        if self._flat is not None:
+            f = self._flat
+            sd["state"] = {i: dict(step=torch.tensor(float(self._step)), sum=self._v[o:o + t.numel()].view(t.shape).clone())
+                           for i, (t, o) in enumerate(zip(f.tensors, f.offsets)) if t.requires_grad}
+        sd["fused"] = dict(step=self._step, sum=None if self._flat is None else self._v.clone())
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        fused = sd.pop("fused", None)
+        per_param = sd.get("state") or {}
+        sd["state"] = {}
+        torch.optim.Optimizer.load_state_dict(self, sd)
+        f = self._ensure_flat()
+        if fused is not None and fused.get("sum") is not None:
+            self._step = fused["step"]
+            self._v.copy_(fused["sum"])
+        elif per_param:
+            for i, st in per_param.items():
+                t, o = f.tensors[int(i)], f.offsets[int(i)]
+                self._v[o:o + t.numel()].copy_(st["sum"].reshape(-1))
+                self._step = int(float(st["step"]))
+
+
 def update_ema_variables(model, ema_model, alpha, global_step):
     """train_test_path_multi_distill.py:34-38 - parameters only, BN buffers untouched."""
     alpha = min(1 - 1 / (global_step + 1), alpha)
@@ -272,9 +353,9 @@ def _validate_opt(opt, who):
     if getattr(opt, "mode", "pathomic") != "pathomic":
         raise NotImplementedError("%s: mode %r (the distillation trainers build the pathomic teacher and a path student)"
                                   % (who, opt.mode))
-    if getattr(opt, "optimizer_type", "adam") != "adam":
-        raise NotImplementedError("%s: optimizer_type %r (the shipped commands use adam, options.py:126)"
-                                  % (who, opt.optimizer_type))
+    if getattr(opt, "optimizer_type", "adam") not in ("adam", "adagrad"):
+        raise NotImplementedError("%s: optimizer_type %r (adam and adagrad are built; adabound needs the absent `adabound` "
+                                  "package, networks_new.py:82-83)" % (who, opt.optimizer_type))
     if getattr(opt, "act_type", "LSM") != "LSM":
         raise NotImplementedError("%s: act_type %r (the grading task uses the log-softmax head)" % (who, opt.act_type))
     if getattr(opt, "fusion_type", "pofusion") != "pofusion":
@@ -593,6 +674,11 @@ class DistillStep:
         (plain / momentum) with the CE gradient, a log-softmax grading head.  `opt.fused_loss_head = False` selects the
         generic autograd path."""
         opt = self.opt
+        if getattr(opt, "sample_KD", "False") != "False":
+            # per-sample CRD rows ([B]-shaped loss_kd): the reference's body then fails inside AEKD_loss's `loss_t.backward()`
+            # ("grad can be implicitly created only for scalar outputs") - the generic path fails the same way, the closed
+            # form would silently compute something else
+            return False
         if self._reg_on:
             # the fused head WRITES fc_new2's gradients (accumulate=False) after L1RegFn.backward has added
             # lambda_reg * sgn(W) into the same flat buffer: the L1 term on fc_new2 would be lost (ADVICE r02)
@@ -1132,23 +1218,29 @@ class TeacherStage1Step:
         names = self._IN_NAMES
         if getattr(self, "_g_scal", None) is None:
             self._g_scal = torch.zeros(3, device=dev, dtype=torch.float32)       # CRD weight | tau | mu of the penalty
+            self._g_ring = PinnedRing((3,), torch.float32)
             self._g_sets = []
         on_dev = all(t.is_cuda and t.is_contiguous() for t in given.values())
         ptrs = tuple(given[k].data_ptr() for k in names) if on_dev else None
         shapes = tuple(tuple(given[k].shape) for k in names)
         if self._g_sets and self._g_sets[0]["shapes"] != shapes:
             self._g_sets = []
-        st = next((q for q in self._g_sets if ptrs is not None and q["ptrs"] == ptrs), None)
-        if st is None and (not self._g_sets or (on_dev and len(self._g_sets) < 2)):
-            bufs = dict(given) if on_dev else {k: torch.empty(given[k].shape, device=dev, dtype=given[k].dtype) for k in names}
-            st = dict(shapes=shapes, ptrs=tuple(bufs[k].data_ptr() for k in names), bufs=bufs, graphs={})
+        st = next((q for q in self._g_sets if q["adopted"] and ptrs is not None and q["ptrs"] == ptrs), None)
+        if st is None and on_dev and sum(q["adopted"] for q in self._g_sets) < 2:
+            bufs = dict(given)
+            st = dict(shapes=shapes, ptrs=ptrs, bufs=bufs, graphs={}, adopted=True)
             self._g_sets.append(st)
         if st is None:
-            st = self._g_sets[0]
-        for k in names:
-            if given[k].data_ptr() != st["bufs"][k].data_ptr():
+            # host tensors, or a third resident set: staged into PRIVATE buffers - never into an adopted set, whose tensors
+            # belong to the caller (a loader's ring buffer must not be overwritten behind its back)
+            st = next((q for q in self._g_sets if not q["adopted"]), None)
+            if st is None:
+                bufs = {k: torch.empty(given[k].shape, device=dev, dtype=given[k].dtype) for k in names}
+                st = dict(shapes=shapes, ptrs=tuple(bufs[k].data_ptr() for k in names), bufs=bufs, graphs={}, adopted=False)
+                self._g_sets.append(st)
+            for k in names:
                 st["bufs"][k].copy_(given[k], non_blocking=True)
-        self._g_scal.copy_(torch.tensor([crd_w, tau, mu_pen], dtype=torch.float32), non_blocking=False)
+        self._g_ring.upload(self._g_scal, [crd_w, tau, mu_pen])      # (pinned rows: no host sync per replayed step)
         if do_aux not in st["graphs"]:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()

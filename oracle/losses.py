@@ -117,8 +117,9 @@ def contrast_memory_v3(st, v1, v2, y, idx, P2, K2, select_pos_mode="mid", mid_ra
     return out_v1, out_v2, aux
 
 
-def contrast_loss_v2(x, P, n_data):
-    """ContrastLoss_v2.forward, sample_KD == "False" branch (CRD_loss.py:221-244)."""
+def contrast_loss_v2(x, P, n_data, sample_KD="False"):
+    """ContrastLoss_v2.forward (CRD_loss.py:221-252): the 0-d batch mean of sample_KD == "False" (:240-244) or the [B]
+    per-sample losses of sample_KD == "True" (:246-250)."""
     bsz = x.shape[0]
     N = x.size(1) - P
     m = N
@@ -127,18 +128,20 @@ def contrast_loss_v2(x, P, n_data):
     log_D1 = torch.div(P_pos, P_pos.add(m * Pn + EPS)).log()
     P_neg = x.narrow(1, P, N)
     log_D0 = torch.div(torch.full_like(P_neg, m * Pn), P_neg.add(m * Pn + EPS)).log()
+    if sample_KD == "True":
+        return -(log_D1.squeeze(-1) + log_D0.repeat(1, 1, P).sum(1)).sum(1) / P
     loss = -((log_D1.squeeze(-1).sum(0) + log_D0.reshape(-1, 1).repeat(1, P).sum(0)) / bsz).sum(0) / P
     return loss
 
 
 def crd_loss(st, f_s, f_t, idx, contrast_idx, P2, K2, select_pos_mode="mid", mid_ranks=None,
-             return_aux=False):
-    """CRDLoss.forward (CRD_loss.py:153-175)."""
+             return_aux=False, sample_KD="False"):
+    """CRDLoss.forward (CRD_loss.py:153-175); sample_KD == "True": the [B] per-sample losses (:148-149 -> :246-250)."""
     v_s = embed_forward(f_s, st.embed_s["linear.weight"], st.embed_s["linear.bias"])
     v_t = embed_forward(f_t, st.embed_t["linear.weight"], st.embed_t["linear.bias"])
     out_s, out_t, aux = contrast_memory_v3(st, v_s, v_t, idx, contrast_idx, P2, K2,
                                            select_pos_mode, mid_ranks)
-    loss = contrast_loss_v2(out_s, P2, st.n_data) + contrast_loss_v2(out_t, P2, st.n_data)
+    loss = contrast_loss_v2(out_s, P2, st.n_data, sample_KD) + contrast_loss_v2(out_t, P2, st.n_data, sample_KD)
     if return_aux:
         aux.update(v_s=v_s, v_t=v_t, out_s=out_s, out_t=out_t)
         return loss, aux

@@ -1,8 +1,10 @@
 """CPU restatement (test infrastructure only) of the reference's contrast-index sampling rule, numpy RNG as in the
 reference: MICCAI-2022/data_loaders_MT.py:187-203 (class lists) and :229-249 (per-item draw); MIA-2023 `neg_mode`
-("MIA 2023/stage2_unimodal_student/data_loaders_MT.py":218-238).  The reference's dataset class itself cannot be
-instantiated here (it imports torchvision / PIL transforms), so this is pinned by reading, not by a golden vector:
-"parity unpinned" for the random stream; the GPU sampler is compared with it distributionally."""
+("MIA 2023/stage2_unimodal_student/data_loaders_MT.py":218-238).  PINNED: tests/golden/make_golden_sampler.py imports the
+reference's dataset class (stub `torchvision`: its transforms never touch numpy's stream), calls `__getitem__` for a fixed
+index sequence under a fixed `np.random.seed`, and tests/test_oracle_golden.py::test_sampler_draws_equal_the_reference holds
+this file to those rows draw for draw (11 cases: both trainers, every pos_mode / neg_mode, K below and above the candidate
+list).  The GPU sampler (csrc/sampler.hip) uses its own counter-based stream and is compared with this rule distributionally."""
 import numpy as np
 
 

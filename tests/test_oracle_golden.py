@@ -104,6 +104,32 @@ def test_crd_loss(golden_dir, mode):
         _close(g[f"bank_v1_rows{it}"], st.memory_v1[idx], 1e-6); _close(g[f"bank_v2_rows{it}"], st.memory_v2[idx], 1e-6)
 
 
+@pytest.mark.parametrize("mode", ["mid", "hard"])
+def test_crd_loss_sample_kd(golden_dir, mode):
+    """`--sample_KD True` inside CRDLoss (CRD_loss.py:148-149 -> :246-250): the [B] per-sample losses, two calls."""
+    g = _ld(golden_dir, "crd_samplekd.npz")
+    st = CRDState(int(g["n_data"]), seed=int(g["bank_seed"]), embed_s=W.make_state_dict(W.embed_shapes(), 10),
+                  embed_t=W.make_state_dict(W.embed_shapes(), 11))
+    for d in (st.embed_s, st.embed_t):
+        for v in d.values():
+            v.requires_grad_(True)
+    for it in range(2):
+        t = f"{mode}{it}"
+        f_s = torch.as_tensor(g[f"f_s_{t}"]).requires_grad_(True)
+        ranks = g[f"ranks_{mode}"][it] if mode == "mid" else None
+        rows = crd_loss(st, f_s, torch.as_tensor(g[f"f_t_{t}"]), torch.as_tensor(g[f"index_{t}"]), torch.as_tensor(g[f"sidx_{t}"]),
+                        int(g["nce_p2"]), int(g["nce_k2"]), mode, ranks, sample_KD="True")
+        assert rows.shape == (f_s.shape[0],)
+        gs = torch.autograd.grad((rows * torch.as_tensor(g[f"w_{t}"])).sum(),
+                                 [f_s, st.embed_s["linear.weight"], st.embed_t["linear.weight"], st.embed_s["linear.bias"]])
+        _close(g[f"rows_{t}"], rows, 1e-4, 1e-5)
+        _close(g[f"g_fs_{t}"], gs[0], 1e-5, 1e-3); _close(g[f"g_ws_{t}"], gs[1], 1e-5, 1e-3)
+        _close(g[f"g_wt_{t}"], gs[2], 1e-5, 1e-3); _close(g[f"g_bs_{t}"], gs[3], 1e-5, 1e-3)
+        _close(g[f"params_{t}"], st.params, 1e-2, 1e-5)
+        idx = torch.as_tensor(g[f"index_{t}"])
+        _close(g[f"bank_v1_rows_{t}"], st.memory_v1[idx], 1e-6); _close(g[f"bank_v2_rows_{t}"], st.memory_v2[idx], 1e-6)
+
+
 @pytest.mark.parametrize("faithful", [False, True])
 def test_full_step_b16_h224(golden_dir, faithful):
     """Three consecutive steps of train_test_path_multi_distill.py:249-330 vs the reference."""
@@ -281,3 +307,21 @@ def test_contrast_loss_v2_standalone(golden_dir):
     (gx,) = torch.autograd.grad(loss, [x])
     np.testing.assert_allclose(loss.item(), float(g["cl_loss_False"]), rtol=1e-6)
     np.testing.assert_allclose(gx.numpy(), g["cl_gx_False"], rtol=1e-5, atol=1e-7)
+
+
+def test_sampler_draws_equal_the_reference(golden_dir):
+    """oracle/sampler.py against the reference's `Pathomic_InstanceSample.__getitem__` run in the build container
+    (tests/golden/make_golden_sampler.py; MICCAI-2022/data_loaders_MT.py:229-249 and the MIA-2023 neg_mode variants): the same
+    seed gives the same `sample_idx` rows, draw for draw, over a sequence of items (the stream position carries over)."""
+    from oracle.sampler import class_lists, sample_item
+    g = _ld(golden_dir, "sampler_draws.npz")
+    labels, order, n = g["labels"], g["order"], int(g["n"])
+    cls_pos, cls_neg = class_lists(labels, 3)
+    assert len(g["cases"]) == 11
+    for name in g["cases"]:
+        rng = np.random.RandomState(int(g[f"{name}_seed"]))
+        want = g[f"{name}_rows"]
+        for r, index in enumerate(order):
+            got = sample_item(rng, int(index), int(labels[index]), cls_pos, cls_neg, n, int(g[f"{name}_P"]), int(g[f"{name}_K"]),
+                              str(g[f"{name}_pos_mode"]), str(g[f"{name}_neg_mode"]))
+            assert got.shape == want[r].shape and (got == want[r]).all(), (str(name), r, str(g[f"{name}_ref"]))
