@@ -56,6 +56,64 @@ HBM_PEAK_GBS = 8000.0            # HBM3E peak (6290 GB/s measured with a float4 
 # algorithmic FLOPs of the step per 512x512 tile: 3 ResNet-18 forwards + 1 backward without the image gradient
 # (SURVEY 8-d layer table: 93.52 GFLOP); convolutions scale with the tile area
 STEP_GFLOP_PER_TILE_512 = 93.52
+# one network's ResNet(+heads) forward + backward alone - the denominator of the north-star's ">= 70 % bf16 MFMA roofline on the
+# ResNet+fusion forward/backward at batch 256" (27.81 GMAC = 55.62 GFLOP per 512x512 tile, 14.24 TFLOP at B = 256)
+TRUNK_FWD_BWD_GFLOP_PER_TILE_512 = 55.62
+
+
+def trunk_fwd_bwd(m, B, H, device, steps=5):
+    """The literal north-star quantity: the student's ResNet-18 + heads forward and backward ALONE at batch
+    B, graph-replayed (two eager passes, one capture, `steps` timed replays), bf16.  Returns a dict for the bench line."""
+    import torch
+    m.set_precision("bf16")
+    opt = m.stage2_opt(dropout_rate=0.0, batch_size=B)
+    torch.manual_seed(1)
+    net = m.define_net(opt, 1, path_only=True).to(device)
+    net.train()
+    x = torch.randn(B, 3, H, H, device=device).clamp_(-1, 1)
+    w = torch.linspace(0.5, 1.5, 128, device=device)
+
+    def body():
+        _, feat, hazard, pred, _ = net(x_path=x)
+        loss = (feat * w).sum() + hazard.sum()
+        loss.backward()
+        return loss
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            for p_ in net.parameters():
+                p_.grad = None
+            body()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p_ in net.parameters():
+        p_.grad = None
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = body()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lv = float(loss)
+    gn = float(sum(p_.grad.float().abs().sum() for p_ in net.parameters() if p_.grad is not None))
+    if not (lv == lv and gn == gn and gn > 0):
+        raise RuntimeError("trunk_fwd_bwd: non-finite loss / gradients (%r, %r)" % (lv, gn))
+    tfl = TRUNK_FWD_BWD_GFLOP_PER_TILE_512 * (H / 512.0) ** 2 * B / 1e3
+    net.release_workspaces()
+    del g, net, x
+    torch.cuda.empty_cache()
+    return {"workload": "student ResNet-18 + heads forward + backward alone, batch %d, %dx%d, bf16, one captured HIP graph "
+                        "(BASELINE.json north_star: 'ResNet+fusion forward/backward at batch 256 on 1 MI355X')" % (B, H, H),
+            "steps": steps, "ms": round(1000.0 * dt, 3), "tiles_per_s": round(B / dt, 1),
+            "algorithmic_tflop": round(tfl, 3), "achieved": round(tfl / dt, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tfl / dt / MFMA_BF16_PEAK_TFLOPS, 4), "target_frac": 0.70,
+            "profile": "profiles/r05_kernel_stats_trunk_b256.txt (rocprofv3 --kernel-trace --stats -- python3 bench.py --trunk-only)"}
 
 
 def hbm_ledger(B, H, es=2):
@@ -276,6 +334,10 @@ def run_variant(name, B, H, device, L, steps=5):
     res = {"workload": desc, "tiles_per_gpu": B, "steps": steps, "ms_per_step": round(1000.0 * dt / steps, 3),
            "value": round(B * steps / dt, 2), "unit": "tiles/s", "final_loss": round(float(out["loss"]), 4),
            "launch": "one captured HIP graph per step" if graph else "eager"}
+    if name == "tsvd":
+        res["parity"] = ("adjacency / penalty / mu-schedule and the proximal operator pinned (reference goldens, float64 SVD at 2e-5); "
+                         "`update_aux` itself UNPINNED: the reference imports it from my_utils/, which is absent from the repository "
+                         "(MIA 2022/train_test_tSVD.py:31) - restated from its call site :382-391")
     if graph:
         step._want_graph = False
         step._side_stream = None
@@ -518,6 +580,9 @@ def main():
                          "5-step figures of all three in `variants`)")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (configs[3] / configs[4] legs)")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--trunk-only", action="store_true",
+                    help="only the north-star's literal quantity: student ResNet forward + backward alone at batch 256 (profiling aid)")
+    ap.add_argument("--no-trunk-block", action="store_true", help="skip `north_star_b256.trunk_fwd_bwd`")
     args = ap.parse_args()
     if args.north_star:
         args.batch = 256
@@ -565,6 +630,14 @@ def main():
         else:
             dist.init_process_group(backend=backend)
         sync = m.dist.ReplicaSync()
+    if args.trunk_only:
+        r = trunk_fwd_bwd(m, 256 if args.batch == 64 else args.batch, args.size, device, steps=max(args.steps, 5))
+        print(json.dumps({"metric": "student ResNet forward+backward alone", "value": r["tiles_per_s"], "unit": "tiles/s", "n_gpus": 1,
+                          "steps": r["steps"], "warmup": 3, "ms_per_step": r["ms"], "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "config": {"workload": r["workload"]},
+                          "roofline": {"bound": "mfma", "achieved": r["achieved"], "peak": r["peak"], "unit": "TFLOP/s", "frac": r["frac"],
+                                       "traffic": None}}), flush=True)
+        return
     m.set_precision(args.precision)
     if args.variant != "miccai2022":
         # profiling aid: another batch body through the same timing protocol (rocprofv3 -- python3 bench.py --variant ...)
@@ -813,6 +886,18 @@ def main():
                     "mia2023": run_variant("mia2023", 64, args.size, device, L),
                     "tsvd_stage1": run_variant("tsvd", 128, args.size, device, L)}
 
+    trunk = None
+    if ns256 is not None and not args.no_trunk_block:
+        # the literal north-star quantity, measured last (a capture that fails cannot disturb the numbers above)
+        for mod in (step.model, step.ema_model, step.fix_model.path_net):
+            mod.release_workspaces()
+        step._slots = None; step._static = None
+        torch.cuda.empty_cache()
+        try:
+            trunk = trunk_fwd_bwd(m, 256, args.size, device)
+        except Exception as exc:      # noqa: BLE001
+            trunk = {"error": repr(exc)}
+        ns256["trunk_fwd_bwd"] = trunk
     _flush_c_stdio()
     if sync is not None:
         torch.distributed.barrier()      # every rank's native output is out before rank 0 prints the line
@@ -924,6 +1009,13 @@ def main():
             res["north_star_global_256"] = strong
         if parity is not None:
             res["parity_mode"] = parity
+            # the headline `value` is the bf16 arithmetic of BASELINE configs[1] (logits at the bf16 noise floor, ~5e-2); the
+            # cheapest arithmetic that meets the north-star's 1e-3 on logits AND loss is quoted beside it
+            tc = parity[parity["tolerance_compliant"]]
+            res["value_tolerance_compliant"] = {"value": tc["value"], "unit": "tiles/s", "ms_per_step": tc["ms_per_step"],
+                                                "dtype": parity["tolerance_compliant"],
+                                                "note": "same step, same sizes, in the cheapest arithmetic whose logits / losses are within "
+                                                        "1e-3 of the fp32 reference (parity_mode block)"}
         if variants is not None:
             res["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:

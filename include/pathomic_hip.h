@@ -311,6 +311,15 @@ int ph_conv2d_dgrad(const void* dy, const float* w_oihw, void* dx, int B, int Ci
  * dx = round(dgrad) + (res_a == NULL || res_a > 0 ? res_g : 0); res_g / res_a: [B][IH][IW][Cin] in the activation type. */
 int ph_conv2d_dgrad_res(const void* dy, const float* w_oihw, void* dx, const void* res_g, const void* res_a, int B, int Cin,
                         int IH, int IW, int Cout, int KS, int stride, int pad, int prec, void* ws, ph_stream_t stream);
+/* Test access: the same stride-1 3x3 perf-mode dgrad with the BatchNorm-backward sums of its OUTPUT taken in the epilogue
+ * (the backward of `relu(bn(y))`: reference MICCAI-2022/resnets.py:58-74 through autograd - dgamma = sum dz xhat, dbeta = sum dz
+ * with dz = dx * relu'), as ph_resnet_backward uses it for layer 1.  bst_y [B][IH][IW][Cin] = the BatchNorm's input y; mask =
+ * (bst_a > 0) if bst_a else (bst_y * bst_scale + bst_shift > 0); sums [3][Cin] fp32 = sum dz | sum dz (bst_y - bst_mean) |
+ * sum dz (bst_y2 - bst_mean2) (row 2 zero without bst_y2).  ws: ph_conv2d_workspace_bytes() + 3 * 4 * Cin * 1024 bytes. */
+int ph_conv2d_dgrad_bnstat(const void* dy, const float* w_oihw, void* dx, const void* res_g, const void* res_a, const void* bst_y,
+                           const void* bst_a, const void* bst_y2, const float* bst_scale, const float* bst_shift,
+                           const float* bst_mean, const float* bst_mean2, float* sums, int B, int Cin, int IH, int IW, int Cout,
+                           void* ws, ph_stream_t stream);
 int ph_conv2d_wgrad(const void* x, const void* dy, float* dw_oihw, int B, int Cin, int IH, int IW, int Cout, int KS,
                     int stride, int pad, int prec, void* ws, ph_stream_t stream);
 

@@ -310,11 +310,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float
 // un-scale).  |dz'| = |gamma invstd (dz - c1 - xhat c2)| <= G A (2 + |xhat|) with A = max |dz|, G = max |gamma invstd| (|c1|,
 // |c2| <= A: means of dz and of dz xhat with E|xhat| <= 1); s puts G A at 2^9, so fp16 (max 65504) holds |xhat| up to 125 and
 // elements down to 2^-23 of the bound keep 11 + 11 significant bits.
+// Rows written by a convolution's fused sums (PhTapConv::bst_y): nrow = 3 per part, the second sum taken from row `row2` (1: this
+// BatchNorm, 2: the downsample branch reduced beside it) as sum dz (y - mean) and scaled here by s2_scale[c] = invstd[c] (in
+// double) to sum dz xhat.  The separate reduce pass writes nrow = 2 rows with xhat already applied (s2_scale = null).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C,
                                                               double count, float* dgamma, float* dbeta, float* c1,
                                                               float* c2, const float* __restrict__ amax, int namax,
                                                               const float* __restrict__ gamma,
-                                                              const float* __restrict__ invstd, float* dzs) {
+                                                              const float* __restrict__ invstd, float* dzs, int nrow, int row2,
+                                                              const float* __restrict__ s2_scale) {
   const int c = blockIdx.x, tid = threadIdx.x;
   if (dzs && c == 0) {
     float a = 0.f, g = 0.f;
@@ -338,8 +342,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
   double s1 = 0.0, s2 = 0.0;
   for (int p = tid; p < nparts; p += 256) {
-    s1 += (double)parts[((size_t)p * 2 + 0) * C + c];
-    s2 += (double)parts[((size_t)p * 2 + 1) * C + c];
+    s1 += (double)parts[((size_t)p * nrow + 0) * C + c];
+    s2 += (double)parts[((size_t)p * nrow + row2) * C + c];
   }
   __shared__ double sh[2][4];
   s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (tid == 0) {
     s1 = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
     s2 = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    if (s2_scale) s2 *= (double)s2_scale[c];
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     c1[c] = (float)(s1 / count);
@@ -701,7 +706,17 @@ int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double coun
                               float* c1, float* c2, const float* amax, int namax, const float* gamma, const float* invstd,
                               float* dzs, hipStream_t st) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, dgamma, dbeta, c1, c2,
-                     amax, namax, gamma, invstd, dzs);
+                     amax, namax, gamma, invstd, dzs, 2, 1, (const float*)nullptr);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+// the rows a convolution's fused sums left (PhTapConv::bst_y): [nparts][3][C]; row2 = 1 (the BatchNorm of bst_y) or 2 (of bst_y2)
+int ph_bn_bwd_finalize_fused_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
+                                    float* c1, float* c2, const float* invstd, int row2, hipStream_t st) {
+  if (row2 != 1 && row2 != 2) return PH_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, parts, nparts, C, count, dgamma, dbeta, c1, c2,
+                     (const float*)nullptr, 0, (const float*)nullptr, invstd, (float*)nullptr, 3, row2, invstd);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -17,6 +17,15 @@ __global__ void parts_sum_kernel(const float* __restrict__ parts, int nparts, in
   if (s2) s2[c] = (float)b;
 }
 
+__global__ void parts3_sum_kernel(const float* __restrict__ parts, int nparts, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a[3] = {0.0, 0.0, 0.0};
+  for (int p = 0; p < nparts; ++p)
+    for (int k = 0; k < 3; ++k) a[k] += parts[((size_t)p * 3 + k) * C + c];
+  for (int k = 0; k < 3; ++k) sums[(size_t)k * C + c] = (float)a[k];
+}
+
 // fp32 <-> half-pair tensors (ph_common.h), 8 channels per thread
 __global__ void hp_pack_kernel(const float* __restrict__ src, hp16* __restrict__ dst, size_t n8, float scale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,6 +135,34 @@ int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* re
         }
       if ((rc = ph_tapconv_launch(&t, 1, prec, st))) return rc;
     }
+  return PH_OK;
+}
+
+// test access to the fused BatchNorm-backward sums of a 3x3 stride-1 perf-mode dgrad launch (PhTapConv::bst_y, conv_tap4.hip):
+// dx = dgrad(dy, w) (+ res_g * (res_a > 0 | 1)) and sums[3][Cin] = sum dz | sum dz (bst_y - bst_mean) | sum dz (bst_y2 - bst_mean2)
+// with dz = dx * (bst_a ? bst_a > 0 : bst_y * bst_scale + bst_shift > 0), combined in double from the per-workgroup rows
+int ph_conv2d_dgrad_bnstat(const void* dy, const float* w, void* dx, const void* res_g, const void* res_a, const void* bst_y,
+                           const void* bst_a, const void* bst_y2, const float* bst_scale, const float* bst_shift,
+                           const float* bst_mean, const float* bst_mean2, float* sums, int B, int Cin, int IH, int IW, int Cout,
+                           void* ws_, hipStream_t st) {
+  if (Cin % 64 || Cout % 64 || !bst_y || !bst_mean || !sums) return PH_EINVAL;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(ws_);
+  const size_t plane = (size_t)9 * Cin * Cout;
+  bf16* hi = reinterpret_cast<bf16*>(ws);
+  int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, 3, st);
+  if (rc) return rc;
+  PhTapConv t{};
+  t.in = dy; t.w = hi; t.wplane = plane; t.out = dx; t.res_g = res_g; t.res_a = res_a;
+  t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cout; t.Cout = Cin; t.OH = IH; t.OW = IW;
+  t.OHt = IH; t.OWt = IW; t.os = 1; t.iy0 = -1; t.ix0 = -1; t.ntaps = 9;
+  for (int k = 0; k < 9; ++k) { t.dy[k] = k / 3; t.dx[k] = k % 3; t.wtap[k] = 8 - k; }
+  t.bst_y = bst_y; t.bst_a = bst_a; t.bst_y2 = bst_y2; t.bst_scale = bst_scale; t.bst_shift = bst_shift;
+  t.bst_mean = bst_mean; t.bst_mean2 = bst_mean2;
+  t.stats = reinterpret_cast<float*>(ws + up(PH_NPLANES * plane * sizeof(bf16)));
+  if ((rc = ph_tapconv_launch(&t, 1, PH_PREC_BF16, st))) return rc;
+  const int nparts = ph_tapconv2_stat_parts(&t);
+  hipLaunchKernelGGL(parts3_sum_kernel, dim3(cdiv(Cin, 64)), dim3(64), 0, st, t.stats, nparts, Cin, sums);
+  PH_LAUNCH_CHECK();
   return PH_OK;
 }
 

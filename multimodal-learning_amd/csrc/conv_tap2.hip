@@ -1227,6 +1227,13 @@ int ph_tap3_switch(int set) {
   return on;
 }
 extern "C" int ph_debug_set_tap3(int on) { return ph_tap3_switch(on ? 1 : 0); }
+// ... and between tapconv2_l1_kernel and the fourth-generation layer-1 kernel (conv_tap4.hip): PH_TAP4=0 / ph_debug_set_tap4()
+int ph_tap4_switch(int set) {
+  static int on = [] { const char* e = getenv("PH_TAP4"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (set >= 0) on = set ? 1 : 0;
+  return on;
+}
+extern "C" int ph_debug_set_tap4(int on) { return ph_tap4_switch(on ? 1 : 0); }
 
 // ---- stride-2 3x3 convolutions as MASKED stride-1 tap grids (PhTapConv::m_*).  Both fill the tap-grid part of a
 // descriptor whose tensors / batch / channel fields the caller has set (forward: in = x [B][IH][IW][Cin], Cin / Cout of
@@ -1291,6 +1298,8 @@ int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
     if (ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv3_launch(p, st);
     return launch2<2, 2, 4, false>(*p, st);
   }
+  if (ph_tap4_switch(-1) && ph_tapconv4_eligible(p)) return ph_tapconv4_launch(p, st);
+  if (p->bst_y) return PH_EINVAL;      // (the fused BatchNorm-backward sums exist in conv_tap4.hip only)
 #ifdef PH_L1_ONE_GROUP   // A/B build: the one-wave-per-SIMD resident-weights configuration
   return launch2<4, 1, 2, true>(*p, st);
 #else

@@ -71,6 +71,14 @@ struct PhTapConv {
   const float* in_unscale;
   int hp_hi_only;        // half-pair kernels: 1 = the hi planes' product alone (A block hi x W block hi: one slice per 64 channels,
                          // result = acc * in_unscale[1]); set by the launcher for PH_PREC_FP16X1
+  // optional (perf-mode stride-1 dgrad launches of conv_tap4.hip / conv_tap3.hip): the BatchNorm-backward sums of the tensor this
+  // launch WRITES, taken in its epilogue instead of by a separate bn_bwd_reduce pass.  bst_y: the raw output y of that BatchNorm's
+  // convolution (same shape as `out`); the ReLU mask is (bst_a > 0) when bst_a is given (a block output: bn2 / downsample) and
+  // (bst_y * bst_scale + bst_shift > 0) otherwise (the BatchNorm's own ReLU: bn1); dz = out * mask.  `stats` then receives per
+  // workgroup [3][Cout]: sum dz, sum dz (bst_y - bst_mean), sum dz (bst_y2 - bst_mean2) - bst_y2 (optional) = the downsample
+  // branch's raw output, whose BatchNorm backward reduces the same dz.  ph_bn_bwd_finalize_launch combines the rows.
+  const void* bst_y; const void* bst_a; const void* bst_y2;
+  const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_mean2;
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 double ph_tapconv_bytes(const PhTapConv& p, int S, int es);
@@ -85,6 +93,11 @@ int ph_tap3_switch(int set);
 bool ph_tapconv3_eligible(const PhTapConv* p);
 int ph_tapconv3_launch(const PhTapConv* p, hipStream_t st);
 int ph_tapconv3_launch_hp(const PhTapConv* p, hipStream_t st);      // PH_PREC_FP16X3 form of the same kernel
+// fourth-generation kernel for Cin = Cout = 64 (conv_tap4.hip: ResNet layer 1; one wave per SIMD, 16x16x32 fragments, resident
+// weights, one barrier per tile, optional fused BatchNorm-backward sums); PH_TAP4=0 keeps tapconv2_l1_kernel (same-box A/B)
+int ph_tap4_switch(int set);
+bool ph_tapconv4_eligible(const PhTapConv* p);
+int ph_tapconv4_launch(const PhTapConv* p, hipStream_t st);
 // stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
 bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 
@@ -201,6 +214,9 @@ int ph_bn_bwd_reduce_launch(const void* g, const void* a, const void* y, const f
 int ph_bn_bwd_finalize_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
                               float* c1, float* c2, const float* amax, int namax, const float* gamma, const float* invstd,
                               float* dzs, hipStream_t st);
+// the same from the [nparts][3][C] rows of a convolution's fused sums (PhTapConv::bst_y): sum dz | sum dz (y - mean) | sum dz (y2 - mean2)
+int ph_bn_bwd_finalize_fused_launch(const float* parts, int nparts, int C, double count, float* dgamma, float* dbeta,
+                                    float* c1, float* c2, const float* invstd, int row2, hipStream_t st);
 int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* c1, const float* c2, void* dy, size_t npix, int C,
                            int prec, const float* mscale, const float* mshift, const float* dzs, hipStream_t st);

@@ -65,6 +65,9 @@ struct PhResnetPlan {
   mutable int bwd_overlap = 1;
   // PH_PREC_FP16X3: per-block max |dz| of a BatchNorm-backward reduction, and the {2^s, 2^-s} scale records of the two dz buffers
   size_t amax_off = 0, dzs_off = 0;
+  // rows of a dgrad launch's fused BatchNorm-backward sums (PhTapConv::bst_y), [<= 1024][3][<= 512] floats, and the second
+  // BatchNorm's (downsample branch) c1 / c2 when one launch reduced for two
+  size_t fparts_off = 0, cc2_off = 0;
 };
 
 namespace {
@@ -184,6 +187,8 @@ PhResnetPlan* ph_resnet_plan_create(int B, int H, int W, int prec) {
     P->amax_off = take(rows * sizeof(float));
     P->dzs_off = take(256);
   }
+  P->fparts_off = take((size_t)1024 * 3 * 512 * sizeof(float));
+  P->cc2_off = take(2 * 512 * sizeof(float));
   P->ws_bytes = off;
   P->packed_bytes = woff * sizeof(bf16);
   return P;
@@ -275,8 +280,22 @@ int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullp
                                (int64_t*)c.params[ui * 6 + 5], c.st);
 }
 
-// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual); dzs: dY's scale record (half-pair mode)
-int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a, const float* dzs = nullptr) {
+// BatchNorm-backward sums a dgrad launch takes over the gradient it writes (PhTapConv::bst_y): of unit `u` (mask: its own ReLU
+// when a == null, else a > 0) and optionally of unit `u2` (the downsample branch reading the same dz)
+struct Bst { int u = -1, u2 = -1; const void* a = nullptr; };
+
+// A/B and test switch: PH_BST=0 in the environment / ph_debug_set_bst(0) keeps every BatchNorm-backward reduction a pass of its own
+int bst_switch(int set) {
+  static int on = [] { const char* e = getenv("PH_BST"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (set >= 0) on = set ? 1 : 0;
+  return on;
+}
+
+// dgrad of unit ui: in = dY [B][OH][OW][Cout] -> out = dX [B][IH][IW][Cin] (+ residual); dzs: dY's scale record (half-pair mode).
+// bst (optional) + fused_parts: when the launch can take the sums, *fused_parts = the number of [3][C] rows it left in the plan's
+// fparts buffer (0 = not fused: the caller runs the separate reduction)
+int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g, const void* res_a, const float* dzs = nullptr,
+               const Bst* bst = nullptr, int* fused_parts = nullptr) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   PhTapConv t{};
@@ -284,12 +303,28 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
   t.out = dx; t.stats = nullptr; t.res_g = res_g; t.res_a = res_a;
   t.B = P->B; t.IH = u.OH; t.IW = u.OW; t.Cin = u.Cout; t.Cout = u.Cin;
   t.OH = u.IH; t.OW = u.IW;
+  if (fused_parts) *fused_parts = 0;
   if (u.S == 1) {
     t.OHt = u.IH; t.OWt = u.IW; t.os = 1; t.oa_h = 0; t.oa_w = 0;
     t.iy0 = -(u.KS - 1 - u.pad); t.ix0 = t.iy0; t.ntaps = u.KS * u.KS;
     for (int k = 0; k < t.ntaps; ++k) {
       const int dyy = k / u.KS, dxx = k % u.KS;
       t.dy[k] = dyy; t.dx[k] = dxx; t.wtap[k] = (u.KS - 1 - dyy) * u.KS + (u.KS - 1 - dxx);
+    }
+    if (bst && fused_parts && bst->u >= 0 && P->prec == PH_PREC_BF16 && bst_switch(-1)) {
+      const Unit& bu = P->units[bst->u];
+      PhTapConv f = t;
+      f.bst_y = c.ws + bu.y_off; f.bst_mean = c.stat(bu, 0);
+      f.bst_a = bst->a;
+      if (!bst->a) { f.bst_scale = c.stat(bu, 2); f.bst_shift = c.stat(bu, 3); }
+      if (bst->u2 >= 0) { f.bst_y2 = c.ws + P->units[bst->u2].y_off; f.bst_mean2 = c.stat(P->units[bst->u2], 0); }
+      f.stats = reinterpret_cast<float*>(c.ws + P->fparts_off);
+      const bool ok = ph_tap4_switch(-1) && ph_tapconv4_eligible(&f) && bu.Cout == t.Cout && bu.OH == t.OH && bu.OW == t.OW;
+      if (ok) {
+        const int rc = ph_tapconv_launch(&f, 1, c.bprec(), c.st);
+        if (rc == PH_OK) *fused_parts = ph_tapconv2_stat_parts(&f);
+        return rc;
+      }
     }
     return ph_tapconv_launch(&t, 1, c.bprec(), c.st);
   }
@@ -342,25 +377,37 @@ int conv_wgrad(const Ctx& c, int ui, const void* x, const void* dy, float* dw, c
 
 // BN backward of unit ui: dz = g * (a > 0) -> dgamma/dbeta, dy (into ws dy buffer).  self_mask: `a` is this unit's own
 // relu(bn(y)) (bn1 of a block) - the mask is recomputed from y and `a` is not read.
+// fused_parts > 0: the sums were taken by the dgrad launch that wrote `g` (conv_dgrad: [fused_parts][3][C] rows in the plan's
+// fparts buffer, this unit's second sum in row `row2`) - no reduction pass.  cc2: the c1 / c2 pair lives in the plan's second
+// buffer (a downsample BatchNorm finalised together with bn2, applied later).  apply = false: finalise only.
 int bn_bwd(const Ctx& c, int ui, const void* g, const void* a, void* dy, float* dgamma, float* dbeta, bool self_mask = false,
-           float* dzs = nullptr) {
+           float* dzs = nullptr, int fused_parts = 0, int row2 = 1, bool cc2 = false, bool finalize = true, bool apply = true) {
   const PhResnetPlan* P = c.P;
   const Unit& u = P->units[ui];
   const size_t npix = (size_t)P->B * u.OH * u.OW;
   float* parts = reinterpret_cast<float*>(c.ws + P->bparts_off);
-  float* c1 = reinterpret_cast<float*>(c.ws + P->cc_off);
+  float* c1 = reinterpret_cast<float*>(c.ws + (cc2 ? P->cc2_off : P->cc_off));
   float* c2 = c1 + 512;
   const void* y = c.ws + u.y_off;
   const float* ms = self_mask ? c.stat(u, 2) : nullptr;
   const float* mh = self_mask ? c.stat(u, 3) : nullptr;
   if (self_mask) a = nullptr;
   float* amax = dzs ? c.amax() : nullptr;
-  const int nparts = ph_bn_bwd_parts(npix, u.Cout);
-  int rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, ms, mh, amax, c.st);
-  if (rc) return rc;
-  rc = ph_bn_bwd_finalize_launch(parts, nparts, u.Cout, (double)npix, dgamma, dbeta, c1, c2, amax, nparts,
-                                 (const float*)c.params[ui * 6 + 1], c.stat(u, 1), dzs, c.st);
-  if (rc) return rc;
+  int rc = PH_OK;
+  if (finalize) {
+    if (fused_parts > 0) {
+      rc = ph_bn_bwd_finalize_fused_launch(reinterpret_cast<const float*>(c.ws + P->fparts_off), fused_parts, u.Cout, (double)npix,
+                                           dgamma, dbeta, c1, c2, c.stat(u, 1), row2, c.st);
+    } else {
+      const int nparts = ph_bn_bwd_parts(npix, u.Cout);
+      rc = ph_bn_bwd_reduce_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), parts, npix, u.Cout, P->prec, ms, mh, amax, c.st);
+      if (rc) return rc;
+      rc = ph_bn_bwd_finalize_launch(parts, nparts, u.Cout, (double)npix, dgamma, dbeta, c1, c2, amax, nparts,
+                                     (const float*)c.params[ui * 6 + 1], c.stat(u, 1), dzs, c.st);
+    }
+    if (rc) return rc;
+  }
+  if (!apply) return PH_OK;
   return ph_bn_bwd_apply_launch(g, a, y, c.stat(u, 0), c.stat(u, 1), (const float*)c.params[ui * 6 + 1], c1, c2, dy, npix,
                                 u.Cout, P->prec, ms, mh, dzs, c.st);
 }
@@ -660,6 +707,7 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
     return PH_OK;
   };
   int rc, nst = 0;
+  int fused_out = 0;      // rows of fused bn2 (+ downsample) sums the last dgrad left for the block about to be processed
   if (part != 1) {
     if (hipMemsetAsync(ws + P->zero_off, 0, 256, st) != hipSuccess) return PH_ELAUNCH;
     const Block& b = P->blocks[7];
@@ -667,24 +715,46 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   }
   for (int bi = bi_hi; bi >= bi_lo; --bi) {
     const Block& b = P->blocks[bi];
-    if (bi == 5 && g_f3) PH_STAGE(ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st));
+    if (bi == 5 && g_f3) {
+      PH_STAGE(ph_avgpool_bwd_launch(g_f3, gcur, P->B, b.OH * b.OW, b.Cout, 1, P->prec, st));
+      fused_out = 0;      // (sums taken before this addition would be stale: the separate reduction runs)
+    }
     const void* out = ws + b.out32_off;      // (ReLU masks: the tensor as the elementwise passes read it)
     const void* a1 = ws + b.a1_off;
     const void* xin = ws + b.in_off;
-    // bn2 <- d_out * (out > 0)
+    const void* xin32 = ws + b.in32_off;     // (the block input as the elementwise passes read it: the previous block's ReLU mask)
+    // bn2 <- d_out * (out > 0); fused_out: the dgrad that wrote gcur (the next block's conv1 + residual) took bn2's sums - and
+    // the downsample BatchNorm's, which reduces the same dz: both are finalised here, the downsample pair into the second buffer
     if ((rc = claim(k))) return rc;
-    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dzb[k], (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2], false, c.dzs(k)));
+    if (fused_out > 0 && b.uds >= 0 &&
+        (rc = bn_bwd(c, b.uds, gcur, out, nullptr, (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2], false, nullptr,
+                     fused_out, 2, true, true, false)))
+      return rc;
+    const bool ds_done = fused_out > 0 && b.uds >= 0;
+    PH_STAGE(bn_bwd(c, b.u2, gcur, out, dzb[k], (float*)grads[b.u2 * 3 + 1], (float*)grads[b.u2 * 3 + 2], false, c.dzs(k), fused_out));
+    fused_out = 0;
     if (!ov) PH_STAGE(wgrad_of(b.u2, a1, k));
-    PH_STAGE(conv_dgrad(c, b.u2, dzb[k], dab, nullptr, nullptr, c.dzs(k)));
+    int fused_a1 = 0;      // conv2's dgrad writes d_a1 and takes bn1's sums over it (mask: bn1's own ReLU, re-derived from y1)
+    {
+      Bst bs; bs.u = b.u1;
+      PH_STAGE(conv_dgrad(c, b.u2, dzb[k], dab, nullptr, nullptr, c.dzs(k), &bs, &fused_a1));
+    }
     if (ov) PH_STAGE(wgrad_of(b.u2, a1, k));
     k ^= 1;
     // bn1 <- d_a1 * (a1 > 0)
     if ((rc = claim(k))) return rc;
-    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dzb[k], (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true, c.dzs(k)));
+    PH_STAGE(bn_bwd(c, b.u1, dab, a1, dzb[k], (float*)grads[b.u1 * 3 + 1], (float*)grads[b.u1 * 3 + 2], true, c.dzs(k), fused_a1));
     if (!ov) PH_STAGE(wgrad_of(b.u1, xin, k));
     if (b.uds < 0) {
-      // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue
-        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, gcur, out, c.dzs(k)));
+      // identity shortcut: d_xin = dgrad(conv1) + d_out * (out > 0), fused in the dgrad epilogue - which also takes the sums of
+      // the PREVIOUS block's bn2 (and downsample BatchNorm) over d_xin * (xin > 0).  Not where f3's gradient is added to
+      // d_xin afterwards (block 5 with g_f3: its producer is a downsample block anyway).
+      Bst bs;
+      if (bi > bi_lo) {
+        const Block& pb = P->blocks[bi - 1];
+        bs.u = pb.u2; bs.u2 = pb.uds; bs.a = xin32;
+      }
+        PH_STAGE(conv_dgrad(c, b.u1, dzb[k], gnext, gcur, out, c.dzs(k), &bs, &fused_out));
       if (ov) PH_STAGE(wgrad_of(b.u1, xin, k));
       k ^= 1;
     } else {
@@ -692,7 +762,8 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
       if (ov) PH_STAGE(wgrad_of(b.u1, xin, k));
       k ^= 1;
       if ((rc = claim(k))) return rc;
-      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dzb[k], (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2], false, c.dzs(k)));
+      PH_STAGE(bn_bwd(c, b.uds, gcur, out, dzb[k], (float*)grads[b.uds * 3 + 1], (float*)grads[b.uds * 3 + 2], false, c.dzs(k),
+                      0, 1, ds_done, !ds_done));
       if (!ov) PH_STAGE(wgrad_of(b.uds, xin, k));
         PH_STAGE(conv_dgrad(c, b.uds, dzb[k], gnext, gnext, nullptr, c.dzs(k)));   // in-place accumulate
       if (ov) PH_STAGE(wgrad_of(b.uds, xin, k));
@@ -760,6 +831,9 @@ int ph_resnet_plan_set_backward_prec(const PhResnetPlan* P, int prec) {
 
 // A/B and test switch: 0 = the whole backward on the caller's stream (the round-2 sequence), 1 (default) = weight
 // gradients on the side stream
+// A/B and test switch (not part of the public C-ABI): 0 = every BatchNorm-backward reduction as a pass of its own
+int ph_debug_set_bst(int on) { return bst_switch(on ? 1 : 0); }
+
 int ph_resnet_plan_set_backward_overlap(const PhResnetPlan* P, int on) {
   if (!P) return PH_EINVAL;
   P->bwd_overlap = on ? 1 : 0;

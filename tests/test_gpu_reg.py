@@ -183,7 +183,7 @@ def test_distill_step_all_regulariser_adds_sign_gradient():
 
 def test_steps_reject_options_they_do_not_implement():
     import multimodal_learning_amd as m
-    for bad in (dict(task="surv"), dict(reg_type="l2"), dict(optimizer_type="adagrad"), dict(act_type="Sigmoid"),
+    for bad in (dict(task="surv"), dict(reg_type="l2"), dict(optimizer_type="adabound"), dict(act_type="Sigmoid"),
                 dict(fusion_type="concat"), dict(return_grad="True")):
         opt = m.stage2_opt(**bad)
         with pytest.raises(NotImplementedError):
@@ -194,3 +194,28 @@ def test_steps_reject_options_they_do_not_implement():
     for rt in ("path", "mm", "omic"):
         with pytest.raises(AttributeError):
             m.DistillStep(m.stage2_opt(reg_type=rt), 64, device="cuda")
+
+
+def test_distill_step_with_the_adagrad_optimizer_runs_and_updates():
+    """`--optimizer_type adagrad` (networks_new.py:86-87) through the whole distillation step: FusedAdagrad drives the student
+    and the EMA copy (the update rule itself is pinned against torch.optim.Adagrad in tests/test_gpu_optim.py)."""
+    import numpy as np
+    import multimodal_learning_amd as m
+    from oracle.step import synthetic_batch
+    torch.manual_seed(0); np.random.seed(2019)
+    opt = m.stage2_opt(optimizer_type="adagrad", dropout_rate=0.0, batch_size=4, nce_p=120, nce_k=200, nce_p2=20, nce_k2=128)
+    step = m.DistillStep(opt, 256, device="cuda")
+    assert type(step.optimizer).__name__ == "FusedAdagrad"
+    for c in (step.criterion_kd, step.criterion_kd_path):
+        c.contrast.verbose = False
+    before = step.model.fc_new2.weight.detach().clone()
+    ema_before = step.ema_model.fc_new2.weight.detach().clone()
+    for it in range(2):
+        bt = synthetic_batch(4, 64, n_data=256, P=opt.nce_p, K=opt.nce_k, seed=it)
+        out = step.step(((bt["x_path"], bt["ema_x_path"]), torch.zeros(4), bt["x_omic"], torch.zeros(4), torch.zeros(4), bt["grade"],
+                         bt["index"], bt["sample_idx"]))
+        assert torch.isfinite(out["loss"]).item()
+    assert (step.model.fc_new2.weight - before).abs().max().item() > 0
+    assert (step.ema_model.fc_new2.weight - ema_before).abs().max().item() > 0
+    sd = step.optimizer.state_dict()
+    assert "sum" in sd["state"][0] and int(sd["state"][0]["step"]) == 2
