@@ -311,6 +311,11 @@ int ph_conv2d_dgrad(const void* dy, const float* w_oihw, void* dx, int B, int Ci
  * dx = round(dgrad) + (res_a == NULL || res_a > 0 ? res_g : 0); res_g / res_a: [B][IH][IW][Cin] in the activation type. */
 int ph_conv2d_dgrad_res(const void* dy, const float* w_oihw, void* dx, const void* res_g, const void* res_a, int B, int Cin,
                         int IH, int IW, int Cout, int KS, int stride, int pad, int prec, void* ws, ph_stream_t stream);
+/* Test access: 3x3 stride-1 pad-1 perf-mode forward whose INPUT is the raw output of a convolution: relu(x * in_scale[c] +
+ * in_shift[c]) (the BatchNorm + ReLU of reference resnets.py:58-66, rounded to bf16 as the stand-alone pass stores it) is applied to
+ * every halo tile in LDS, as the forward-only networks of the distillation step run conv2 of layers 1-2. */
+int ph_conv2d_fwd_fused_in(const void* x, const float* in_scale, const float* in_shift, const float* w_oihw, void* y,
+                           float* ch_sum, float* ch_sumsq, int B, int Cin, int IH, int IW, int Cout, void* ws, ph_stream_t stream);
 /* Test access: the same stride-1 3x3 perf-mode dgrad with the BatchNorm-backward sums of its OUTPUT taken in the epilogue
  * (the backward of `relu(bn(y))`: reference MICCAI-2022/resnets.py:58-74 through autograd - dgamma = sum dz xhat, dbeta = sum dz
  * with dz = dx * relu'), as ph_resnet_backward uses it for layer 1.  bst_y [B][IH][IW][Cin] = the BatchNorm's input y; mask =

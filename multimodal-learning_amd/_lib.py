@@ -119,6 +119,7 @@ SIGNATURES = {
     "ph_conv2d_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ph_conv2d_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "ph_conv2d_dgrad_res": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "ph_conv2d_fwd_fused_in": (i32, [vp] * 7 + [i32] * 5 + [vp, vp]),
     "ph_conv2d_dgrad_bnstat": (i32, [vp] * 13 + [i32] * 5 + [vp, vp]),
     "ph_conv2d_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
 }

@@ -138,6 +138,31 @@ int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* re
   return PH_OK;
 }
 
+// test access to the in-LDS BatchNorm + ReLU of a 3x3 stride-1 perf-mode forward launch (PhTapConv::in_scale): y = conv(relu(x *
+// in_scale[c] + in_shift[c]) rounded to bf16, w), bitwise what ph_bn_apply_launch + ph_conv2d_fwd give
+int ph_conv2d_fwd_fused_in(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y, float* ch_sum,
+                           float* ch_sumsq, int B, int Cin, int IH, int IW, int Cout, void* ws_, hipStream_t st) {
+  if (Cin % 64 || Cout % 64 || !in_scale || !in_shift) return PH_EINVAL;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(ws_);
+  const size_t plane = (size_t)9 * Cin * Cout;
+  bf16* hi = reinterpret_cast<bf16*>(ws);
+  int rc = ph_pack_w_fwd_launch(w, hi, Cout, Cin, 3, st);
+  if (rc) return rc;
+  PhTapConv t{};
+  t.in = x; t.w = hi; t.wplane = plane; t.out = y; t.in_scale = in_scale; t.in_shift = in_shift;
+  t.stats = reinterpret_cast<float*>(ws + up(PH_NPLANES * plane * sizeof(bf16)));
+  t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cin; t.Cout = Cout; t.OHt = IH; t.OWt = IW; t.OH = IH; t.OW = IW;
+  t.os = 1; t.iy0 = -1; t.ix0 = -1; t.ntaps = 9;
+  for (int k = 0; k < 9; ++k) { t.dy[k] = k / 3; t.dx[k] = k % 3; t.wtap[k] = k; }
+  if ((rc = ph_tapconv_launch(&t, 1, PH_PREC_BF16, st))) return rc;
+  if (ch_sum || ch_sumsq) {
+    hipLaunchKernelGGL(parts_sum_kernel, dim3(cdiv(Cout, 64)), dim3(64), 0, st, t.stats, ph_tapconv_stat_parts(&t, 1, PH_PREC_BF16), Cout,
+                       ch_sum, ch_sumsq);
+    PH_LAUNCH_CHECK();
+  }
+  return PH_OK;
+}
+
 // test access to the fused BatchNorm-backward sums of a 3x3 stride-1 perf-mode dgrad launch (PhTapConv::bst_y, conv_tap4.hip):
 // dx = dgrad(dy, w) (+ res_g * (res_a > 0 | 1)) and sums[3][Cin] = sum dz | sum dz (bst_y - bst_mean) | sum dz (bst_y2 - bst_mean2)
 // with dz = dx * (bst_a ? bst_a > 0 : bst_y * bst_scale + bst_shift > 0), combined in double from the per-workgroup rows

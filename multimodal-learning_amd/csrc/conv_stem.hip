@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
           for (int j = 0; j < 2; ++j) {
             const float v0 = v0ok ? acc[j][2 * q2] : 0.f, v1 = v1ok ? acc[j][2 * q2 + 1] : 0.f;
             s1[j] += v0 + v1;
-            s2[j] += v0 * v0 + v1 * v1;
+            s2[j] = __builtin_fmaf(v1, v1, __builtin_fmaf(v0, v0, s2[j]));
             bf16x2 own;
             own[0] = (bf16)v0;
             own[1] = (bf16)v1;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v = valid ? (HPM ? acc[j][q] * PH_HP_LO_INV : acc[j][q]) : 0.f;
-          s1[j] += v; s2[j] += v * v;
+          s1[j] += v; s2[j] = __builtin_fmaf(v, v, s2[j]);
           if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
         }
       }

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         float v = valid ? acc[i][j][q] : 0.f;
         if constexpr (HPM) v *= osc;
         s1[j] += v;
-        s2[j] += v * v;
+        s2[j] = __builtin_fmaf(v, v, s2[j]);      // (explicit: the compiler's contraction choice must not move the statistics)
         if constexpr (SPLIT || HPM) {
           if (valid) {
             if (resg) {

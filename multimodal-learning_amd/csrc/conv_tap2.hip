@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void tapconv2_kernel(PhTapConv p) {
               v[1] = (r < p.OHt && c0 + 2 * m + 1 < p.OWt) ? v[1] : 0.f;
             }
             s1[j] += v;
-            s2[j] += v * v;
+            s2[j] = __builtin_elementwise_fma(v, v, s2[j]);      // (explicit fused multiply-add: see conv_tap.hip)
             bf16x2 own;
             own[0] = (bf16)v[0];
             own[1] = (bf16)v[1];
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(512) void tapconv2_l1_kernel(PhTapConv p) {
               v[1] = mine ? v[1] : 0.f;
             }
             s1[j][2 * g + h2] += v;
-            s2[j][2 * g + h2] += v * v;
+            s2[j][2 * g + h2] = __builtin_elementwise_fma(v, v, s2[j][2 * g + h2]);
             bf16x2 b;
             b[0] = (bf16)v[0];
             b[1] = (bf16)v[1];
@@ -1296,6 +1296,7 @@ int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
   if (p->m_groups) return (p->Cout % 128 == 0 && !p->in_scale) ? launch2<2, 2, 4, false, true>(*p, st) : PH_EINVAL;
   if (p->Cout % 128 == 0) {
     if (ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv3_launch(p, st);
+    if (p->bst_y) return PH_EINVAL;      // (the fused BatchNorm-backward sums exist in conv_tap3.hip / conv_tap4.hip only)
     return launch2<2, 2, 4, false>(*p, st);
   }
   if (ph_tap4_switch(-1) && ph_tapconv4_eligible(p)) return ph_tapconv4_launch(p, st);

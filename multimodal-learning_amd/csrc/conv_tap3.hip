@@ -92,9 +92,13 @@ __device__ __forceinline__ int a3_off(int hr, int hc, int c) {
 // of hi values and one of lo values: element strides x 2), the weights hold per slice the fp16 blocks [hi 2^11 | lo | hi], the K
 // loop walks 3 Cin / 64 (A block, W block) pairs (x hi, w hi 2^11), (x hi, w lo), (x lo, w hi) on v_mfma_f32_16x16x32_f16 and the
 // epilogue stores fp32: four consecutive channels of a lane = one 16-byte store, 256 contiguous bytes per pixel.
-template <bool FUSE_IN, bool HPM = false>
+// BST: fused BatchNorm-backward sums over the tensor this (dgrad) launch writes, as in conv_tap4.hip (PhTapConv::bst_y): 0 = none,
+// 1 = mask from the BatchNorm's own ReLU (bst_y * bst_scale + bst_shift > 0), 2 = mask (bst_a > 0), 3 = 2 + a second BatchNorm
+// (bst_y2) over the same dz; rows [3][Cout] per workgroup.
+template <bool FUSE_IN, bool HPM = false, int BST = 0>
 __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
   static_assert(!(FUSE_IN && HPM), "the in-LDS BatchNorm + ReLU is a perf-mode feature");
+  static_assert(!(BST && (FUSE_IN || HPM)), "the fused BatchNorm-backward sums are a perf-mode dgrad feature");
   using C = Tap3Cfg;
   constexpr int NM = C::NM, NN = C::NN, TH = C::TH, TW = C::TW, BNT = C::BNT, HPW = C::HPW, HP = C::HP, NTAPS = C::NTAPS;
   constexpr int WN = C::WN, WM = C::WM, NTH = C::NTH, B_BASE = C::B_BASE;
@@ -261,35 +265,50 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
 
   // ---- BatchNorm partial sums in registers across the tiles of this workgroup (as tapconv2_kernel): a lane owns channels
   // n0 + 64 wn + 4 li + n (n = 0..3)
-  float* stat_acc = reinterpret_cast<float*>(smem + C::LDS_MAIN);
-  for (int i = tid; i < 2 * p.Cout; i += NTH) stat_acc[i] = 0.f;
+  constexpr bool Y2 = BST == 3;
+  constexpr int NS = BST ? 3 : 2;      // rows per channel block: sum y | sum y^2, or sum dz | sum dz (y - mean) | sum dz (y2 - mean2)
+  float* stat_acc = reinterpret_cast<float*>(smem + C::LDS_MAIN);      // [Cout / BNT][NS][BNT]
+  for (int i = tid; i < NS * p.Cout; i += NTH) stat_acc[i] = 0.f;
   if (FUSE_IN) {
     for (int i = tid; i < p.Cin; i += NTH) { ss[i] = p.in_scale[i]; ss[512 + i] = p.in_shift[i]; }
     __syncthreads();
   }
-  float s1[NN], s2[NN];
-#pragma unroll
-  for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; }
-  auto flush_stats = [&](int n0, unsigned char* scratch) {   // all threads; `scratch`: an A buffer nobody reads
-    float* red = reinterpret_cast<float*>(scratch);          // [WM][2][BNT]
-#pragma unroll
-    for (int n = 0; n < NN; ++n) {
-      float a1 = s1[n], a2 = s2[n];
-      a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
-      a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
-      if (lg == 0) {
-        red[(wm * 2 + 0) * BNT + wn * 64 + 4 * li + n] = a1;
-        red[(wm * 2 + 1) * BNT + wn * 64 + 4 * li + n] = a2;
-      }
-      s1[n] = 0.f; s2[n] = 0.f;
+  // BST: per-channel constants [mask scale | mask shift | mean | mean2] x 512 behind the three sum rows
+  float* bss = reinterpret_cast<float*>(smem + C::LDS_MAIN + 6144);
+  if (BST) {
+    for (int i = tid; i < p.Cout; i += NTH) {
+      bss[i] = (BST == 1) ? p.bst_scale[i] : 0.f;
+      bss[512 + i] = (BST == 1) ? p.bst_shift[i] : 0.f;
+      bss[1024 + i] = p.bst_mean[i];
+      bss[1536 + i] = Y2 ? p.bst_mean2[i] : 0.f;
     }
     __syncthreads();
-    if (tid < 2 * BNT) {
-      const int which = tid / BNT, n = tid % BNT;
+  }
+  float s1[NN], s2[NN], s3[Y2 ? NN : 1];
+#pragma unroll
+  for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; s3[Y2 ? n : 0] = 0.f; }
+  auto flush_stats = [&](int n0, unsigned char* scratch) {   // all threads; `scratch`: an A buffer nobody reads
+    float* red = reinterpret_cast<float*>(scratch);          // [WM][NS][BNT]
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      float a1 = s1[n], a2 = s2[n], a3 = s3[Y2 ? n : 0];
+      a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64);
+      a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+      if (Y2) { a3 += __shfl_xor(a3, 16, 64); a3 += __shfl_xor(a3, 32, 64); } else a3 = 0.f;
+      if (lg == 0) {
+        red[(wm * NS + 0) * BNT + wn * 64 + 4 * li + n] = a1;
+        red[(wm * NS + 1) * BNT + wn * 64 + 4 * li + n] = a2;
+        if (NS == 3) red[(wm * NS + 2) * BNT + wn * 64 + 4 * li + n] = a3;
+      }
+      s1[n] = 0.f; s2[n] = 0.f; s3[Y2 ? n : 0] = 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < NS * BNT; i += NTH) {
+      const int which = i / BNT, n = i % BNT;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BNT + n];
-      stat_acc[((n0 / BNT) * 2 + which) * BNT + n] += v;
+      for (int w = 0; w < WM; ++w) v += red[(w * NS + which) * BNT + n];
+      stat_acc[((n0 / BNT) * NS + which) * BNT + n] += v;
     }
     __syncthreads();
   };
@@ -311,6 +330,16 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
     const unsigned o00 = (unsigned)(((tc.r0 + wm * NM) * p.os + p.oa_h) * p.OW + (tc.c0 + 4 * lg) * p.os + p.oa_w) * (unsigned)p.Cout + chan;
     const unsigned rowstep = (unsigned)(p.os * p.OW * p.Cout);
     const float osc = HPM ? (p.hp_hi_only ? 1.f : PH_HP_LO_INV) * (p.in_unscale ? p.in_unscale[1] : 1.f) : 1.f;
+    const T* bsty = reinterpret_cast<const T*>(p.bst_y) + img;
+    const T* bsta = reinterpret_cast<const T*>(p.bst_a) + img;
+    const T* bsty2 = reinterpret_cast<const T*>(p.bst_y2) + img;
+    constexpr bool has_y2 = Y2;
+    f32x4 cms = {0.f, 0.f, 0.f, 0.f}, cmh = cms, cmu = cms, cmu2 = cms;
+    if constexpr (BST != 0) {
+      if constexpr (BST == 1) { cms = *reinterpret_cast<const f32x4*>(bss + chan); cmh = *reinterpret_cast<const f32x4*>(bss + 512 + chan); }
+      cmu = *reinterpret_cast<const f32x4*>(bss + 1024 + chan);
+      cmu2 = *reinterpret_cast<const f32x4*>(bss + 1536 + chan);
+    }
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       const int r = tc.r0 + wm * NM + m;
@@ -327,7 +356,7 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
             v[n] = acc[m][n][q] * osc;
             if constexpr (!FULL) v[n] = mine ? v[n] : 0.f;
             s1[n] += v[n];
-            s2[n] += v[n] * v[n];
+            s2[n] = __builtin_fmaf(v[n], v[n], s2[n]);
           }
           if constexpr (RM > 0) {
             if (mine) {
@@ -346,21 +375,32 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
         __builtin_amdgcn_sched_barrier(0);
         continue;
       }
-      u32x2 rg[4], ra[4];
-      if constexpr (RM > 0) {
+      // (with the fused sums a row's loads are taken two pixels at a time: five 8-byte operands per pixel and lane)
+      constexpr int QB = BST ? 2 : 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+      for (int q0 = 0; q0 < 4; q0 += QB) {
+      u32x2 rg[4], ra[4], ry[4], rb[4], ry2[4];
+      if constexpr (RM > 0 || BST != 0) {
+#pragma unroll
+        for (int q = q0; q < q0 + QB; ++q) {
           const int c = tc.c0 + 4 * lg + q;
           rg[q] = u32x2{0u, 0u};
           ra[q] = u32x2{0x3f803f80u, 0x3f803f80u};
+          ry[q] = u32x2{0u, 0u}; rb[q] = u32x2{0u, 0u}; ry2[q] = u32x2{0u, 0u};
           if (FULL || (r < p.OHt && c < p.OWt)) {
-            rg[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(resg) + (orow + (unsigned)q * colstep));
-            if constexpr (RM > 1) ra[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(resa) + (orow + (unsigned)q * colstep));
+            const unsigned o = orow + (unsigned)q * colstep;
+            if constexpr (RM > 0) rg[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(resg) + o);
+            if constexpr (RM > 1) ra[q] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const T*>(resa) + o);
+            if constexpr (BST != 0) {
+              ry[q] = *reinterpret_cast<const u32x2*>(bsty + o);
+              if constexpr (BST >= 2) rb[q] = *reinterpret_cast<const u32x2*>(bsta + o);
+              if constexpr (has_y2) ry2[q] = *reinterpret_cast<const u32x2*>(bsty2 + o);
+            }
           }
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = q0; q < q0 + QB; ++q) {
         const int c = tc.c0 + 4 * lg + q;
         const bool mine = FULL || (r < p.OHt && c < p.OWt);
         float v[4];
@@ -368,8 +408,10 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
         for (int n = 0; n < NN; ++n) {
           v[n] = acc[m][n][q];
           if constexpr (!FULL) v[n] = mine ? v[n] : 0.f;
-          s1[n] += v[n];
-          s2[n] += v[n] * v[n];
+          if constexpr (BST == 0) {
+            s1[n] += v[n];
+            s2[n] = __builtin_fmaf(v[n], v[n], s2[n]);
+          }
         }
         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
         u32x2 w;
@@ -385,8 +427,29 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
             b[1] = (bf16)((float)b[1] + ((RM < 2 || a1 > 0.f) ? g1 : 0.f));
           }
           w[h] = __builtin_bit_cast(unsigned, b);
+          if constexpr (BST != 0) {
+            // the sums are taken over the STORED gradient (bf16), exactly what the separate reduction pass reads back
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int n = 2 * h + e;
+              const float y = __builtin_bit_cast(float, e ? (ry[q][h] & 0xffff0000u) : (ry[q][h] << 16));
+              bool on;
+              if constexpr (BST == 1) on = __builtin_fmaf(y, cms[n], cmh[n]) > 0.f;
+              else on = __builtin_bit_cast(float, e ? (rb[q][h] & 0xffff0000u) : (rb[q][h] << 16)) > 0.f;
+              float dz = (float)b[e];
+              dz = (on && mine) ? dz : 0.f;
+              s1[n] += dz;
+              s2[n] = __builtin_fmaf(dz, y - cmu[n], s2[n]);
+              if constexpr (has_y2) {
+                const float y2 = __builtin_bit_cast(float, e ? (ry2[q][h] & 0xffff0000u) : (ry2[q][h] << 16));
+                s3[has_y2 ? n : 0] = __builtin_fmaf(dz, y2 - cmu2[n], s3[has_y2 ? n : 0]);
+              }
+            }
+          }
         }
         if (mine) *reinterpret_cast<u32x2*>(reinterpret_cast<T*>(out) + (orow + (unsigned)q * colstep)) = w;
+      }
+      if constexpr (BST != 0) __builtin_amdgcn_sched_barrier(0);
       }
       __builtin_amdgcn_sched_barrier(0);      // one tile row at a time: hoisting all 64 residual loads in front spills
     }
@@ -553,20 +616,23 @@ __global__ __launch_bounds__(256) void tapconv3_kernel(PhTapConv p) {
   }
   PH3_WAIT_VMCNT(0);   // the refills issued past the end of the stream must not outlive the workgroup's LDS
   if (p.stats) {
-    for (int i = tid; i < 2 * p.Cout; i += NTH) {
+    for (int i = tid; i < NS * p.Cout; i += NTH) {
       const int which = i / p.Cout, ch = i - which * p.Cout;
-      p.stats[((size_t)blockIdx.x * 2 + which) * p.Cout + ch] = stat_acc[((ch / BNT) * 2 + which) * BNT + ch % BNT];
+      p.stats[((size_t)blockIdx.x * NS + which) * p.Cout + ch] = stat_acc[((ch / BNT) * NS + which) * BNT + ch % BNT];
     }
   }
 }
 
-template <bool FUSE_IN, bool HPM = false>
+template <bool FUSE_IN, bool HPM = false, int BST = 0>
 int launch3(const PhTapConv& p, hipStream_t st) {
   using C = Tap3Cfg;
-  auto kern = tapconv3_kernel<FUSE_IN, HPM>;
+  auto kern = tapconv3_kernel<FUSE_IN, HPM, BST>;
+  // (the fused sums keep three rows of sums and four rows of per-channel constants behind the operand buffers: all 160 KiB)
+  constexpr int LDS_BYTES = BST ? C::LDS_MAIN + 6144 + 8192 : C::LDS_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
       return PH_ELAUNCH;
     attr_done = true;
   }
@@ -577,7 +643,7 @@ int launch3(const PhTapConv& p, hipStream_t st) {
   if (ph_prof_on())
     ph_prof_begin2(p.in_scale ? PH_CLS_TAPCONV2_FUSEDIN : PH_CLS_TAPCONV2, 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin,
                    ph_tapconv_bytes(p, 1, HPM ? 4 : 2), st, &tok);
-  hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NTH), LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
@@ -597,6 +663,12 @@ bool ph_tapconv3_eligible(const PhTapConv* p) {
 
 int ph_tapconv3_launch(const PhTapConv* p, hipStream_t st) {
   if (!ph_tapconv3_eligible(p)) return PH_EINVAL;
+  if (p->bst_y) {      // fused BatchNorm-backward sums (dgrad launches)
+    if (p->in_scale || !p->stats || !p->bst_mean || (p->bst_y2 && !p->bst_mean2) || (!p->bst_a && (!p->bst_scale || !p->bst_shift)))
+      return PH_EINVAL;
+    if (!p->bst_a) return p->bst_y2 ? PH_EINVAL : launch3<false, false, 1>(*p, st);
+    return p->bst_y2 ? launch3<false, false, 3>(*p, st) : launch3<false, false, 2>(*p, st);
+  }
   return p->in_scale ? launch3<true>(*p, st) : launch3<false>(*p, st);
 }
 

@@ -18,14 +18,17 @@
 //     whole 128-byte pixel records (conv_tap3.hip's epilogue);
 //   * 64 accumulator registers per wave: the kernel needs < 256 registers, so BatchNorm / elementwise waves of the other streams
 //     of the step can be resident beside it (the 512-register tap-conv kernels own their CUs).
+//   * the epilogue of tile k rides in the MFMA gaps of tile k + 1 (two accumulator sets, OVL below); the tile switch is scalar
+//     arithmetic; the end-of-tile wait counts the halo pieces only, not the stores' acknowledgements.
 // Optional fused BatchNorm-backward sums (PhTapConv::bst_y): a dgrad launch that produces the gradient a
 // BatchNorm backward reduces over can take the per-channel sums sum dz and sum dz (y - mean) in its epilogue - the ReLU mask and
-// y arrive as 8-byte loads in the accumulator layout, prefetched a tile row ahead - and the separate bn_bwd_reduce pass (a full
-// read of the gradient, y and the mask tensor) disappears from the dgrad chain.
+// y arrive as 8-byte loads in the accumulator layout, requested while the tile's last taps run - and the separate
+// bn_bwd_reduce pass (a full read of the gradient, y and the mask tensor) disappears from the dgrad chain.
 //
 // Same GEMM view, descriptor (PhTapConv) and semantics as conv_tap2.hip / conv_tap3.hip; outputs BITWISE those of
 // tapconv2_l1_kernel (same products, same fp32 accumulation order per output: slices of 32 channels, taps in order).
 #include "ph_common.h"
+#include <cstdlib>
 #include <type_traits>
 #include "ph_kernels.h"
 #include "tap_common.h"
@@ -37,6 +40,15 @@ __device__ const u32x4 ph4_nan16[4] = {{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0
                                        {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u}, {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u}};
 
 typedef __attribute__((address_space(3))) unsigned char lds_uchar4;
+
+#ifdef PH_TAP_TRACE      // debug build only (make trace): per-workgroup cycle accounts, read back by tests/trace_tapconv4_gpu.py
+__device__ unsigned long long ph_tap4_trace[1024 * 8];
+#define PH4_CLK() clock64()
+#define PH4_TR(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 1024) ph_tap4_trace[blockIdx.x * 8 + (k)] = (v); } while (0)
+#else
+#define PH4_CLK() 0ull
+#define PH4_TR(k, v)
+#endif
 
 __device__ __forceinline__ void lds_dma16_4(const void* g, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(g) : "memory");
@@ -90,20 +102,28 @@ __device__ __forceinline__ int a4_off(int hr, int hc, int c) {
 // BST: fused BatchNorm-backward sums over the tensor this launch writes (0 = none: forward launches take sum y / sum y^2 when
 // p.stats is set).  1: dz = out * (bst_y * bst_scale + bst_shift > 0), the BatchNorm's own ReLU (bn1 of a BasicBlock, reduced
 // over the output of conv2's dgrad); 2: dz = out * (bst_a > 0) (bn2, reduced over the block-input gradient that conv1's dgrad +
-// residual writes).  Row [3][64] per workgroup: sum dz, sum dz (bst_y - bst_mean), sum dz (bst_y2 - bst_mean2) (0 without bst_y2).
-template <bool FUSE_IN, int BST>
+// residual writes); 3: as 2 plus the second BatchNorm (bst_y2: a downsample branch reducing the same dz).  Row [3][64] per
+// workgroup: sum dz, sum dz (bst_y - bst_mean), sum dz (bst_y2 - bst_mean2) (0 without bst_y2).
+//
+// OVL: the epilogue of tile k runs INSIDE the tap stream of tile k + 1 (two accumulator sets): one 8-byte store and its ~17
+// vector instructions per k-step, cut into 8 micro-steps that sit in the MFMA gaps.  One after the other, the stores of a tile
+// and its 288 MFMAs per wave made the first version of this kernel 91 us, no faster than the kernel it replaces.  OVL launches
+// read nothing in their epilogue (forward: no residual, no fused sums); launches that do (dgrad) run the epilogue after the
+// tile (OVL = false), their operands requested two taps earlier.
+template <bool FUSE_IN, int BST, bool OVL>
 __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   static_assert(!(FUSE_IN && BST), "forward-only feature vs backward feature");
+  static_assert(!(OVL && BST), "the overlapped epilogue reads nothing");
   using C = Tap4Cfg;
   constexpr int NM = C::NM, NN = C::NN, TH = C::TH, TW = C::TW, BNT = C::BNT, HPW = C::HPW, NTAPS = C::NTAPS;
-  constexpr int NTH = C::NTH, B_BASE = C::B_BASE;
+  constexpr int B_BASE = C::B_BASE;
   typedef __bf16 T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds0 = (unsigned)(size_t)(lds_uchar4*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the wave's band of four tile rows
-  const int li = lane & 15, lg = lane >> 4;                       // MFMA 16x16x32: row / column index, k group (A, B) or pixel group (C)
+  const int li = lane & 15, lg = lane >> 4;                       // MFMA 16x16x32: row / column index, k group (A, B) or row group (C)
   const int tiles_w = (p.OWt + TW - 1) / TW;
   const int tiles_sp = tiles_w * ((p.OHt + TH - 1) / TH);
   const int total = tiles_sp * p.B;
@@ -113,25 +133,21 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   const bf16* wbase = reinterpret_cast<const bf16*>(p.w);
 
   // ---- tile list: linear tile id -> (spatial tile fastest, image), XCD-contiguous (as conv_tap3.hip)
+  // A tile switch used to cost ~2400 cycles per tile behind the barrier (float-reciprocal divisions, a bit mask of the halo
+  // pieces built from recomputed coordinates - cheap against the dense kernel's 23 k-cycle tiles, a quarter of this kernel's):
+  // the decode is wave-uniform integer arithmetic (multiply-high by a precomputed reciprocal: scalar instructions, which issue
+  // beside the MFMAs), and a halo piece's validity is tested from its packed coordinates when it is issued.
   struct TileCtx { int r0, c0, b, iy_base, ix_base; const T* in; };
-  const float rcp_sp = 1.0f / (float)tiles_sp, rcp_tw = 1.0f / (float)tiles_w;
-  auto fdiv = [](int a, int d, float rcp) {
-    int q = (int)((float)a * rcp);
-    int r = a - q * d;
-    if (r >= d) ++q;
-    if (r < 0) --q;
-    return q;
-  };
+  const unsigned m_sp = (unsigned)((0x100000000ull + (unsigned)tiles_sp - 1) / (unsigned)tiles_sp);      // t / d = (t * ceil(2^32 / d)) >> 32
+  const unsigned m_tw = (unsigned)((0x100000000ull + (unsigned)tiles_w - 1) / (unsigned)tiles_w);       // (exact for t, d < 2^16)
+  auto udiv = [](unsigned a, unsigned d, unsigned m) -> int { return d == 1 ? (int)a : (int)__umulhi(a, m); };
   auto decode = [&](int t) -> TileCtx {
     TileCtx c;
-    c.b = fdiv(t, tiles_sp, rcp_sp);
+    c.b = udiv((unsigned)t, (unsigned)tiles_sp, m_sp);
     const int tile = t - c.b * tiles_sp;
-    const int trow = fdiv(tile, tiles_w, rcp_tw);
+    const int trow = udiv((unsigned)tile, (unsigned)tiles_w, m_tw);
     c.r0 = trow * TH;
     c.c0 = (tile - trow * tiles_w) * TW;
-    c.b = __builtin_amdgcn_readfirstlane(c.b);
-    c.r0 = __builtin_amdgcn_readfirstlane(c.r0);
-    c.c0 = __builtin_amdgcn_readfirstlane(c.c0);
     c.iy_base = c.r0 + p.iy0;
     c.ix_base = c.c0 + p.ix0;
     c.in = reinterpret_cast<const T*>(p.in) + (size_t)c.b * img_st;
@@ -160,30 +176,17 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
     const int hc = 2 * q + (s >> 3), ch = (s & 7) ^ ((q & 3) << 1);
     h_off[e] = (int)(((long)hr * row_st + (long)hc * pix_st + ch * 8) * 2);
   }
-  auto piece_rc = [&](int e, int& hr, int& hc) {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int rp = (wave + 4 * e) * 4 + (ln >> 4), s = ln & 15;
-    hr = (rp * 7282) >> 16;                            // rp / 9 for rp < 1024
-    const int q = rp - hr * (HPW / 2);
-    hc = 2 * q + (s >> 3);
-  };
-  auto halo_mask = [&](int iy_base, int ix_base) {
-    auto range_bits = [](int lo, int hi) -> unsigned {
-      return hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
-    };
-    const int r_lo = iy_base < 0 ? -iy_base : 0, r_hi = (p.IH - iy_base) < C::HPH ? (p.IH - iy_base) : C::HPH;
-    const int c_lo = ix_base < 0 ? -ix_base : 0, c_hi = (p.IW - ix_base) < HPW ? (p.IW - ix_base) : HPW;
-    const unsigned rowok = range_bits(r_lo, r_hi < 0 ? 0 : r_hi), colok = range_bits(c_lo, c_hi < 0 ? 0 : c_hi);
-    int m = 0;
+  // packed halo coordinates of the element this lane fills in piece wave + 4 e: row | column << 8 (row >= HPH: past the image)
+  int h_rc[C::NHE];
 #pragma unroll
-    for (int e = 0; e < C::NHE; ++e) {
-      int hr, hc;
-      piece_rc(e, hr, hc);
-      const unsigned ok = (rowok >> (hr & 31)) & (colok >> (hc & 31)) & (hr < C::HPH ? 1u : 0u);
-      m |= (int)(ok & 1u) << e;
-    }
-    return m;
+  for (int e = 0; e < C::NHE; ++e) {
+    const int rp = (wave + 4 * e) * 4 + (lane >> 4), s_ = lane & 15;
+    const int hr = rp / (HPW / 2), q = rp - hr * (HPW / 2);
+    h_rc[e] = hr | ((2 * q + (s_ >> 3)) << 8);
+  }
+  auto piece_ok = [&](int e, int iy_base, int ix_base) -> bool {
+    const int hr = h_rc[e] & 0xff, hc = h_rc[e] >> 8;
+    return hr < C::HPH && (unsigned)(iy_base + hr) < (unsigned)p.IH && (unsigned)(ix_base + hc) < (unsigned)p.IW;
   };
   const unsigned char* zero_src = reinterpret_cast<const unsigned char*>(FUSE_IN ? ph4_nan16 : ph4_zero16);
   float* ss = reinterpret_cast<float*>(smem + C::SS_OFF);
@@ -202,9 +205,10 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
       }
   };
 
-  // ---- per-lane fragment addressing.  A: base of (halo row 4 wave, column li + dx, chunk lg) for dx = 0, 1, 2 and its k-step-1
-  // twin (chunk lg + 4 = address ^ 64); tile row m, tap row dy and the A buffer are immediate offsets.  B: row 16 n + li of the
-  // tap's 64 rows, chunk lg; the tap is an immediate (tap 8 = 7 taps past a second base: 8 * TAPB exceeds the 16-bit offset).
+  // ---- per-lane fragment addressing.  Pixels: base of (halo row 4 wave, column li + dx, chunk lg) for dx = 0, 1, 2 and its
+  // k-step-1 twin (chunk lg + 4 = address ^ 64); tile row, tap row dy and the halo buffer are immediate offsets.  Weights: LDS row
+  // 16 t + li of the tap's 64 rows, chunk lg; the tap is an immediate (tap 8 = 7 taps past a second base: 8 * TAPB exceeds the
+  // 16-bit offset field).
   int abase0[3], abase1[3];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx) {
@@ -218,10 +222,14 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
     bx1[n] = bx0[n] ^ 64;
   }
 
-  // ---- sums over all tiles of this workgroup: a lane owns channels 4 li + n (n = 0..3)
-  float s1[NN], s2[NN], s3[NN];
+  // ---- sums over all tiles of this workgroup.  Accumulator register r of (pixel tile row m, channel tile n) is pixel (row
+  // 4 wave + m, column 4 lg + r), LDS weight row 16 n + li; the DMA source mapping puts channel 4 i + n in LDS row 16 n + i, so a
+  // lane owns the four consecutive channels 4 li .. 4 li + 3: one 8-byte store per (m, r), and the 16 lanes of a quarter wave
+  // write one whole 128-byte pixel record (a 16-byte-per-lane layout - lane = pixel - was tried: every wave instruction then
+  // touches 16 cache lines in 16-byte pieces and costs ~450 cycles to issue, loads and stores alike).
+  float s1[NN], s2[NN], s3[BST == 3 ? NN : 1];
 #pragma unroll
-  for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; s3[n] = 0.f; }
+  for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; s3[BST == 3 ? n : 0] = 0.f; }
 
   // ---- prologue: per-channel constants, all nine taps of weights, the first halo
   if (FUSE_IN) {
@@ -232,13 +240,12 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
       ss[tid] = (BST == 1) ? p.bst_scale[tid] : 0.f;
       ss[BNT + tid] = (BST == 1) ? p.bst_shift[tid] : 0.f;
       ss[2 * BNT + tid] = p.bst_mean[tid];
-      ss[3 * BNT + tid] = p.bst_y2 ? p.bst_mean2[tid] : 0.f;
+      ss[3 * BNT + tid] = (BST == 3) ? p.bst_mean2[tid] : 0.f;
     }
   }
   if (FUSE_IN || BST) __syncthreads();
   {
-    // weight piece q = wave * NWP + j of the 72: tap q / 8, LDS rows 8 (q % 8) .. + 7 of the tap block; LDS row R holds channel
-    // 4 (R & 15) + (R >> 4) (N tile R >> 4, MFMA row R & 15), so that a lane of the MFMA owns four consecutive channels
+    // weight piece q = wave * NWP + j of the 72: tap q / 8, LDS rows 8 (q % 8) .. + 7 of the tap block
 #pragma unroll
     for (int j = 0; j < C::NWP; ++j) {
       const int q = wave * C::NWP + j, tap = q >> 3;
@@ -255,97 +262,138 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   bool nvalid = tn >= 0;
   TileCtx tnext = tcur;
   if (nvalid) tnext = decode(tn);
-  int hm_next = nvalid ? halo_mask(tnext.iy_base, tnext.ix_base) : 0;
   auto halo_base = [&](const TileCtx& tc) {
     return reinterpret_cast<const unsigned char*>(tc.in) + ((long)tc.iy_base * row_st + (long)tc.ix_base * pix_st) * 2;
   };
   {
-    const int hm = halo_mask(tcur.iy_base, tcur.ix_base);
     const unsigned char* hb = halo_base(tcur);
 #pragma unroll
     for (int e = 0; e < C::NHE; ++e)
       if (wave + 4 * e < C::NHD)
-        lds_dma16_4(((hm >> e) & 1) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
+        lds_dma16_4(piece_ok(e, tcur.iy_base, tcur.ix_base) ? hb + h_off[e] : zero_src, lds0 + (wave + 4 * e) * 1024);
   }
   PH4_WAIT_VMCNT(0);
-  if (FUSE_IN) xform_halo(0);
+  if (FUSE_IN) { xform_halo(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   PH4_BARRIER();
 
-  f32x4 acc[NM][NN];
+  // two accumulator sets (OVL: the tile in the MFMAs and the tile being stored), pinned to AGPRs; acc[set][pixel row m][channel tile n]
+  f32x4 acc[OVL ? 2 : 1][NM][NN];
   bf16x8 fa[2][NM], fb[2][NN];
-#define PH4_MM(M, N, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[M][N]) : "v"(fa[S][M]), "v"(fb[S][N]))
-#define PH4_MM0(M, N, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[M][N]) : "v"(fa[S][M]), "v"(fb[S][N]))
+#define PH4_MM(AS, M, N, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[AS][M][N]) : "v"(fa[S][M]), "v"(fb[S][N]))
+#define PH4_MM0(AS, M, N, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc[AS][M][N]) : "v"(fa[S][M]), "v"(fb[S][N]))
 #define PH4_LD(ADDR, IMM) (*reinterpret_cast<const bf16x8*>(smem + (ADDR) + (IMM)))
 #define PH4_SB() __builtin_amdgcn_sched_barrier(0)
 #define PH4_NOP ((void)0)
-  // one M group of a k-step on fragment set S: RA / RB = the reads of the NEXT k-step's A tile M / B tile M into set S ^ 1
-#define PH4_GROUP(MMAC, M, S, RA, RB, F0, F1)   \
-  MMAC(M, 0, S); RA; PH4_SB();                  \
-  MMAC(M, 1, S); RB; PH4_SB();                  \
-  MMAC(M, 2, S); F0; PH4_SB();                  \
-  MMAC(M, 3, S); F1; PH4_SB()
+  // one pixel-row group of a k-step on fragment set S: four MFMAs (channel tiles 0..3); RA / RB = the reads of the NEXT k-step's
+  // pixel fragment / weight fragment of the same index into set S ^ 1; F0 / F1 = filler slots
+#define PH4_GROUP(MMAC, AS, M, S, RA, RB, F0, F1)   \
+  MMAC(AS, M, 0, S); RA; PH4_SB();                  \
+  MMAC(AS, M, 1, S); RB; PH4_SB();                  \
+  MMAC(AS, M, 2, S); F0; PH4_SB();                  \
+  MMAC(AS, M, 3, S); F1; PH4_SB()
 
-  // ---- epilogue of one tile.  Accumulator register r of tile (m, n) is pixel (row 4 wave + m, column 4 lg + r), channel
-  // 4 li + n: the four N tiles give four consecutive channels = one 8-byte store per (m, r); a wave-instruction writes 128
-  // contiguous bytes for each of four pixels.
-  auto epilogue = [&](const TileCtx& tc, auto fullc, auto rmc) {
-    constexpr bool FULL = decltype(fullc)::value;
-    constexpr int RM = decltype(rmc)::value;
+  // ---- the epilogue in 8-byte pieces: piece (m, r) = pixel (row 4 wave + m, column 4 lg + r), channels 4 li .. + 3.
+  // Stores and operand loads go through buffer resources of the tile's IMAGE (base + size in scalar registers): a lane outside
+  // the output gets an offset past the resource and the hardware drops its store / returns 0 for its load - no exec masking, no
+  // branch around the instruction, and every piece issues exactly one store whatever the tile's shape, which is what lets
+  // the end-of-tile wait COUNT them.
+  constexpr unsigned OOB = 0x7ffffff0u;
+  constexpr int RSRC_FLAGS = 0x00020000;      // raw buffer, 32-bit offsets (gfx90a / gfx94x / gfx950 data format word)
+  struct EpiCtx { __amdgpu_buffer_rsrc_t out; unsigned o00, rowstep, colstep; int rlim, clim; };
+  const int img_bytes = p.OH * p.OW * p.Cout * 2;
+  auto epi_ctx = [&](const TileCtx& tc) -> EpiCtx {
+    EpiCtx e;
     const size_t img = (size_t)tc.b * p.OH * p.OW * p.Cout;
-    T* out = reinterpret_cast<T*>(p.out) + img;
-    const T* resg = reinterpret_cast<const T*>(p.res_g) + img;
-    const T* resa = reinterpret_cast<const T*>(p.res_a) + img;
-    const T* bsty = reinterpret_cast<const T*>(p.bst_y) + img;
-    const T* bsta = reinterpret_cast<const T*>(p.bst_a) + img;
-    const T* bsty2 = reinterpret_cast<const T*>(p.bst_y2) + img;
-    const bool has_y2 = BST && p.bst_y2 != nullptr;
-    const unsigned colstep = (unsigned)(p.os * p.Cout);
-    const unsigned o00 = (unsigned)(((tc.r0 + wave * NM) * p.os + p.oa_h) * p.OW + (tc.c0 + 4 * lg) * p.os + p.oa_w) * (unsigned)p.Cout + 4u * (unsigned)li;
-    const unsigned rowstep = (unsigned)(p.os * p.OW * p.Cout);
+    e.out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(p.out) + img, 0, img_bytes, RSRC_FLAGS);
+    // BYTE offset of this lane's piece (0, 0) inside the image; pixel rows advance by rowstep, columns by colstep
+    e.o00 = 2u * ((unsigned)(((tc.r0 + wave * NM) * p.os + p.oa_h) * p.OW + (tc.c0 + 4 * lg) * p.os + p.oa_w) * (unsigned)p.Cout + 4u * (unsigned)li);
+    e.rowstep = 2u * (unsigned)(p.os * p.OW * p.Cout);
+    e.colstep = 2u * (unsigned)(p.os * p.Cout);
+    e.rlim = p.OHt - (tc.r0 + wave * NM);      // piece row m lies inside the output iff m < rlim,
+    e.clim = p.OWt - tc.c0 - 4 * lg;           // its column r iff r < clim
+    return e;
+  };
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  // (OVL) the 8 micro-steps of one piece, spread over the filler slots of one k-step; state between the steps:
+  float ev[4];
+  u32x2 ew;
+  bool emine = true;
+  unsigned eoff = 0;
+  // step K (0..7) of piece (M, R) of the tile in accumulator set AS with context EC
+#define PH4_EPI_STEP(K, AS, M, R, EC)                                                                                        \
+  do {                                                                                                                       \
+    if ((K) == 0) { ev[0] = acc[AS][M][0][R]; ev[1] = acc[AS][M][1][R]; }                                                    \
+    else if ((K) == 1) { ev[2] = acc[AS][M][2][R]; ev[3] = acc[AS][M][3][R]; }                                               \
+    else if ((K) == 2) {                                                                                                     \
+      emine = (M) < (EC).rlim && (R) < (EC).clim;                                                                            \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) ev[j_] = emine ? ev[j_] : 0.f;                                        \
+    }                                                                                                                        \
+    else if ((K) == 3) { s1[0] += ev[0]; s1[1] += ev[1]; s1[2] += ev[2]; s1[3] += ev[3]; }                                   \
+    else if ((K) == 4) { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) s2[j_] = __builtin_fmaf(ev[j_], ev[j_], s2[j_]); }  \
+    else if ((K) == 5) {                                                                                                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { bf16x2 b_; b_[0] = (bf16)ev[2 * j_]; b_[1] = (bf16)ev[2 * j_ + 1]; ew[j_] = __builtin_bit_cast(unsigned, b_); } \
+    }                                                                                                                        \
+    else if ((K) == 6) { eoff = emine ? (EC).o00 + (unsigned)(M) * (EC).rowstep + (unsigned)(R) * (EC).colstep : OOB; }      \
+    else __builtin_amdgcn_raw_buffer_store_b64(ew, (EC).out, (int)eoff, 0, 0);                                               \
+  } while (0)
+
+  // The epilogue's operands (residual + mask, the fused sums' y / mask / second y; launches with OVL = false) are requested
+  // while the tile's last taps still run - taps 6 and 7 carry eight pieces each: a load issued where it is consumed exposes a
+  // full memory round trip per pixel row (17.6 k cycles per tile against 5.5 k of taps).  (One piece per k-step from tap 0 on
+  // was slower still: a one-wave-per-SIMD kernel has nowhere near the memory parallelism of a streaming pass - 120 to 400
+  // cycles of issue stall per load, growing with the loads in flight; the four-operand form is therefore off by default.)
+  // 8-byte loads, coalesced like the stores,
+  // unconditional (out-of-image lanes read 0 through the buffer resource: with "if (inside) load" on top of a default value the
+  // compiler's hazard tracking put an s_waitcnt vmcnt(0) in front of every piece - each load waited for the one before it).
+  constexpr bool EPI_LOADS = !OVL;
+  u32x2 e_rg[EPI_LOADS ? 16 : 1], e_ra[EPI_LOADS ? 16 : 1], e_ry[(EPI_LOADS && BST) ? 16 : 1], e_rb[(EPI_LOADS && BST >= 2) ? 16 : 1],
+      e_ry2[(EPI_LOADS && BST == 3) ? 16 : 1];
+  const int rmode = p.res_g ? (p.res_a ? 2 : 1) : 0;
+  auto in_rsrc = [&](const void* base, const TileCtx& tc) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(base)) + (size_t)tc.b * p.OH * p.OW * p.Cout, 0,
+                                             base ? img_bytes : 0, RSRC_FLAGS);
+  };
+  auto epi_load_piece = [&](const TileCtx& tc, const EpiCtx& ec, const int pc) {      // piece pc = (pixel row pc >> 2, column pc & 3)
+    if constexpr (EPI_LOADS) {
+      const int m = pc >> 2, r = pc & 3;
+      const bool mine = m < ec.rlim && r < ec.clim;
+      const int off = (int)(mine ? ec.o00 + (unsigned)m * ec.rowstep + (unsigned)r * ec.colstep : OOB);
+      if (rmode >= 1) e_rg[pc] = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc(p.res_g, tc), off, 0, 0);
+      if (rmode == 2) e_ra[pc] = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc(p.res_a, tc), off, 0, 0);
+      if constexpr (BST != 0) e_ry[pc] = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc(p.bst_y, tc), off, 0, 0);
+      if constexpr (BST >= 2) e_rb[pc] = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc(p.bst_a, tc), off, 0, 0);
+      if constexpr (BST == 3) e_ry2[pc] = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc(p.bst_y2, tc), off, 0, 0);
+    }
+  };
+
+  // ---- the sequential epilogue (OVL = false, and the last tile of an OVL workgroup): all sixteen pieces of a tile
+  auto epilogue_seq = [&](const TileCtx& tc, const int AS, auto rmc) {
+    constexpr int RM = decltype(rmc)::value;
+    const EpiCtx ec = epi_ctx(tc);
+    constexpr bool has_y2 = BST == 3;
     f32x4 cms = {0.f, 0.f, 0.f, 0.f}, cmh = cms, cmu = cms, cmu2 = cms;
     if constexpr (BST != 0) {
       if constexpr (BST == 1) { cms = *reinterpret_cast<const f32x4*>(ss + 4 * li); cmh = *reinterpret_cast<const f32x4*>(ss + BNT + 4 * li); }
       cmu = *reinterpret_cast<const f32x4*>(ss + 2 * BNT + 4 * li);
-      cmu2 = *reinterpret_cast<const f32x4*>(ss + 3 * BNT + 4 * li);
+      if constexpr (has_y2) cmu2 = *reinterpret_cast<const f32x4*>(ss + 3 * BNT + 4 * li);
     }
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-      const int r = tc.r0 + wave * NM + m;
-      const unsigned orow = o00 + (unsigned)m * rowstep;
-      u32x2 rg[4], ra[4], ry[4], rb[4], ry2[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int c = tc.c0 + 4 * lg + q;
-        const bool mine = FULL || (r < p.OHt && c < p.OWt);
-        const unsigned o = orow + (unsigned)q * colstep;
-        rg[q] = u32x2{0u, 0u};
-        ra[q] = u32x2{0x3f803f80u, 0x3f803f80u};
-        ry[q] = u32x2{0u, 0u}; rb[q] = u32x2{0u, 0u}; ry2[q] = u32x2{0u, 0u};
-        if (mine) {
-          if constexpr (RM > 0) rg[q] = *reinterpret_cast<const u32x2*>(resg + o);
-          if constexpr (RM > 1) ra[q] = *reinterpret_cast<const u32x2*>(resa + o);
-          if constexpr (BST != 0) {
-            ry[q] = *reinterpret_cast<const u32x2*>(bsty + o);
-            if constexpr (BST == 2) rb[q] = *reinterpret_cast<const u32x2*>(bsta + o);
-            if (has_y2) ry2[q] = *reinterpret_cast<const u32x2*>(bsty2 + o);
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = tc.c0 + 4 * lg + q;
-        const bool mine = FULL || (r < p.OHt && c < p.OWt);
+        const int pc = 4 * m + q;
+        const bool mine = m < ec.rlim && q < ec.clim;
+        const u32x2 rg = e_rg[EPI_LOADS ? pc : 0], ra = e_ra[EPI_LOADS ? pc : 0], ry = e_ry[(EPI_LOADS && BST) ? pc : 0],
+                    rb = e_rb[(EPI_LOADS && BST >= 2) ? pc : 0], ry2 = e_ry2[(EPI_LOADS && BST == 3) ? pc : 0];
         float v[4];
 #pragma unroll
         for (int n = 0; n < NN; ++n) {
-          v[n] = acc[m][n][q];
-          if constexpr (!FULL) v[n] = mine ? v[n] : 0.f;
+          v[n] = mine ? acc[AS][m][n][q] : 0.f;
           if constexpr (BST == 0) {
             s1[n] += v[n];
-            s2[n] += v[n] * v[n];
+            s2[n] = __builtin_fmaf(v[n], v[n], s2[n]);      // (explicit: every instantiation must round the sums alike)
           }
         }
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
         u32x2 w;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -353,8 +401,8 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
           b[0] = (bf16)v[2 * h];
           b[1] = (bf16)v[2 * h + 1];
           if constexpr (RM > 0) {
-            const float g0 = __builtin_bit_cast(float, rg[q][h] << 16), g1 = __builtin_bit_cast(float, rg[q][h] & 0xffff0000u);
-            const float a0 = __builtin_bit_cast(float, ra[q][h] << 16), a1 = __builtin_bit_cast(float, ra[q][h] & 0xffff0000u);
+            const float g0 = __builtin_bit_cast(float, rg[h] << 16), g1 = __builtin_bit_cast(float, rg[h] & 0xffff0000u);
+            const float a0 = __builtin_bit_cast(float, ra[h] << 16), a1 = __builtin_bit_cast(float, ra[h] & 0xffff0000u);
             b[0] = (bf16)((float)b[0] + ((RM < 2 || a0 > 0.f) ? g0 : 0.f));
             b[1] = (bf16)((float)b[1] + ((RM < 2 || a1 > 0.f) ? g1 : 0.f));
           }
@@ -364,50 +412,59 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
               const int n = 2 * h + e;
-              const float y = __builtin_bit_cast(float, e ? (ry[q][h] & 0xffff0000u) : (ry[q][h] << 16));
+              const float y = __builtin_bit_cast(float, e ? (ry[h] & 0xffff0000u) : (ry[h] << 16));
               bool on;
-              if constexpr (BST == 1) on = (y * cms[n] + cmh[n]) > 0.f;
-              else on = __builtin_bit_cast(float, e ? (rb[q][h] & 0xffff0000u) : (rb[q][h] << 16)) > 0.f;
+              if constexpr (BST == 1) on = __builtin_fmaf(y, cms[n], cmh[n]) > 0.f;
+              else on = __builtin_bit_cast(float, e ? (rb[h] & 0xffff0000u) : (rb[h] << 16)) > 0.f;
               float dz = (float)b[e];
               dz = (on && mine) ? dz : 0.f;
               s1[n] += dz;
-              s2[n] += dz * (y - cmu[n]);
-              if (has_y2) {
-                const float y2 = __builtin_bit_cast(float, e ? (ry2[q][h] & 0xffff0000u) : (ry2[q][h] << 16));
-                s3[n] += dz * (y2 - cmu2[n]);
+              s2[n] = __builtin_fmaf(dz, y - cmu[n], s2[n]);
+              if constexpr (has_y2) {
+                const float y2 = __builtin_bit_cast(float, e ? (ry2[h] & 0xffff0000u) : (ry2[h] << 16));
+                s3[has_y2 ? n : 0] = __builtin_fmaf(dz, y2 - cmu2[n], s3[has_y2 ? n : 0]);
               }
             }
           }
         }
-        if (mine) *reinterpret_cast<u32x2*>(out + (orow + (unsigned)q * colstep)) = w;
+        __builtin_amdgcn_raw_buffer_store_b64(w, ec.out, (int)(mine ? ec.o00 + (unsigned)m * ec.rowstep + (unsigned)q * ec.colstep : OOB), 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);      // one tile row at a time: hoisting every load of the tile in front spills
     }
   };
-  const int rmode = p.res_g ? (p.res_a ? 2 : 1) : 0;
-  auto epilogue_any = [&](const TileCtx& tc) {
-    const bool full = (tc.r0 + TH <= p.OHt) && (tc.c0 + TW <= p.OWt);
-    auto with_full = [&](auto fullc) {
-      if (rmode == 0) epilogue(tc, fullc, std::integral_constant<int, 0>{});
-      else if (rmode == 1) epilogue(tc, fullc, std::integral_constant<int, 1>{});
-      else epilogue(tc, fullc, std::integral_constant<int, 2>{});
-    };
-    if (full) with_full(std::true_type{});
-    else with_full(std::false_type{});
+  auto epilogue_any = [&](const TileCtx& tc, const int AS) {
+    if (rmode == 0) epilogue_seq(tc, AS, std::integral_constant<int, 0>{});
+    else if (rmode == 1) epilogue_seq(tc, AS, std::integral_constant<int, 1>{});
+    else epilogue_seq(tc, AS, std::integral_constant<int, 2>{});
   };
 
-  // ---- the tile stream.  ABUF (the halo buffer of this tile) is a literal at both call sites, so that after inlining every
-  // fragment address is a base register + an immediate.  Fragment set 0 / 1 = k-step 0 / 1 of a tap; each M group's four MFMAs
-  // carry the read of the next k-step's A tile and B tile of the same index.  Taps 0..5 also issue, two pieces per wave, the
-  // LDS-DMA of the NEXT tile's halo into the other buffer (nobody reads it before the barrier at the end of this tile).
+  // ---- the tile stream.  ABUF (the halo buffer of this tile = its accumulator set under OVL) is a literal at both call sites,
+  // so that after inlining every fragment address is a base register + an immediate.  Fragment set 0 / 1 = k-step 0 / 1 of a tap;
+  // each pixel-row group's four MFMAs carry the read of the next k-step's pixel and weight fragment of the same index.  Taps
+  // 0..5 also issue, two pieces per wave, the LDS-DMA of the NEXT tile's halo into the other buffer (nobody reads it before the
+  // barrier at the end of this tile); under OVL every k-step of taps 0..7 carries one 8-byte piece of the PREVIOUS tile's
+  // epilogue, otherwise taps 6 and 7 carry the loads of this tile's epilogue operands.
+  // (OVL) the first tile's "previous tile" is a dummy whose pieces all lie outside the output: its stores are issued and
+  // dropped, its accumulator garbage is masked out of the sums - no first-tile special case inside the stream
+  EpiCtx eprev = epi_ctx(tcur);
+  eprev.rlim = 0;
+  EpiCtx ecur = eprev;
   auto tile_body = [&](const int ABUF) __attribute__((always_inline)) {
     const int AOFF = ABUF * C::A_BYTES;
+    const int AS = OVL ? ABUF : 0, PS = OVL ? (ABUF ^ 1) : 0;
+    const bool need_loads = !OVL && (BST != 0 || rmode != 0);
     const unsigned char* hb = halo_base(tnext);
     const unsigned hdst = lds0 + (ABUF ^ 1) * C::A_BYTES + wave * 1024;
 #define PH4_DMA_H(E)                                                                                           \
   do {                                                                                                         \
     if (nvalid && (E) < C::NHE && wave + 4 * (E) < C::NHD)                                                     \
-      lds_dma16_4(((hm_next >> (E)) & 1) ? hb + h_off[(E) < C::NHE ? (E) : 0] : zero_src, hdst + (E) * 4096); \
+      lds_dma16_4(piece_ok((E) < C::NHE ? (E) : 0, tnext.iy_base, tnext.ix_base) ? hb + h_off[(E) < C::NHE ? (E) : 0] : zero_src, hdst + (E) * 4096); \
+  } while (0)
+    // slot J (0..7) of k-step KS of tap t: micro-step J of the previous tile's piece 2 t + KS = (m, r) = ((2 t + KS) >> 2, .. & 3),
+    // or (launches that read in their epilogue) one piece's loads
+#define PH4_EPI(KS, J)                                                                                                 \
+  do {                                                                                                                 \
+    if constexpr (OVL) { if (t < 8) PH4_EPI_STEP(J, PS, (2 * t + (KS)) >> 2, (2 * t + (KS)) & 3, eprev); }              \
+    else if (need_loads && (t == 6 || t == 7) && ((J) & 1) == 0) epi_load_piece(tcur, ecur, (t - 6) * 8 + (KS) * 4 + ((J) >> 1)); \
   } while (0)
     // first fragments of the tile: tap 0, k-step 0
 #pragma unroll
@@ -424,67 +481,96 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
       const int boffn = (tn_ == 8 ? 7 : tn_) * C::TAPB, bextn = tn_ == 8 ? C::TAPB : 0;
       // ---- k-step 0 (chunks lg) on set 0; reads of k-step 1 (chunks lg + 4) into set 1
       if (t == 0) {
-        PH4_GROUP(PH4_MM0, 0, 0, fa[1][0] = PH4_LD(abase1[dx], aoff + 0 * C::ROW_BYTES), fb[1][0] = PH4_LD(bx1[0] + bext, boff), PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM0, 1, 0, fa[1][1] = PH4_LD(abase1[dx], aoff + 1 * C::ROW_BYTES), fb[1][1] = PH4_LD(bx1[1] + bext, boff), PH4_NOP, PH4_DMA_H(0));
-        PH4_GROUP(PH4_MM0, 2, 0, fa[1][2] = PH4_LD(abase1[dx], aoff + 2 * C::ROW_BYTES), fb[1][2] = PH4_LD(bx1[2] + bext, boff), PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM0, 3, 0, fa[1][3] = PH4_LD(abase1[dx], aoff + 3 * C::ROW_BYTES), fb[1][3] = PH4_LD(bx1[3] + bext, boff), PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM0, AS, 0, 0, fa[1][0] = PH4_LD(abase1[dx], aoff + 0 * C::ROW_BYTES), fb[1][0] = PH4_LD(bx1[0] + bext, boff), PH4_EPI(0, 0), PH4_EPI(0, 1));
+        PH4_GROUP(PH4_MM0, AS, 1, 0, fa[1][1] = PH4_LD(abase1[dx], aoff + 1 * C::ROW_BYTES), fb[1][1] = PH4_LD(bx1[1] + bext, boff), PH4_EPI(0, 2), PH4_EPI(0, 3); PH4_DMA_H(0));
+        PH4_GROUP(PH4_MM0, AS, 2, 0, fa[1][2] = PH4_LD(abase1[dx], aoff + 2 * C::ROW_BYTES), fb[1][2] = PH4_LD(bx1[2] + bext, boff), PH4_EPI(0, 4), PH4_EPI(0, 5));
+        PH4_GROUP(PH4_MM0, AS, 3, 0, fa[1][3] = PH4_LD(abase1[dx], aoff + 3 * C::ROW_BYTES), fb[1][3] = PH4_LD(bx1[3] + bext, boff), PH4_EPI(0, 6), PH4_EPI(0, 7));
       } else {
-        PH4_GROUP(PH4_MM, 0, 0, fa[1][0] = PH4_LD(abase1[dx], aoff + 0 * C::ROW_BYTES), fb[1][0] = PH4_LD(bx1[0] + bext, boff), PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 1, 0, fa[1][1] = PH4_LD(abase1[dx], aoff + 1 * C::ROW_BYTES), fb[1][1] = PH4_LD(bx1[1] + bext, boff), PH4_NOP,
-                  if (t < C::HALO_TAPS) PH4_DMA_H(2 * t));
-        PH4_GROUP(PH4_MM, 2, 0, fa[1][2] = PH4_LD(abase1[dx], aoff + 2 * C::ROW_BYTES), fb[1][2] = PH4_LD(bx1[2] + bext, boff), PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 3, 0, fa[1][3] = PH4_LD(abase1[dx], aoff + 3 * C::ROW_BYTES), fb[1][3] = PH4_LD(bx1[3] + bext, boff), PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM, AS, 0, 0, fa[1][0] = PH4_LD(abase1[dx], aoff + 0 * C::ROW_BYTES), fb[1][0] = PH4_LD(bx1[0] + bext, boff), PH4_EPI(0, 0), PH4_EPI(0, 1));
+        PH4_GROUP(PH4_MM, AS, 1, 0, fa[1][1] = PH4_LD(abase1[dx], aoff + 1 * C::ROW_BYTES), fb[1][1] = PH4_LD(bx1[1] + bext, boff), PH4_EPI(0, 2),
+                  PH4_EPI(0, 3); if (t < C::HALO_TAPS) PH4_DMA_H(2 * t));
+        PH4_GROUP(PH4_MM, AS, 2, 0, fa[1][2] = PH4_LD(abase1[dx], aoff + 2 * C::ROW_BYTES), fb[1][2] = PH4_LD(bx1[2] + bext, boff), PH4_EPI(0, 4), PH4_EPI(0, 5));
+        PH4_GROUP(PH4_MM, AS, 3, 0, fa[1][3] = PH4_LD(abase1[dx], aoff + 3 * C::ROW_BYTES), fb[1][3] = PH4_LD(bx1[3] + bext, boff), PH4_EPI(0, 6), PH4_EPI(0, 7));
       }
       // ---- k-step 1 on set 1; reads of the next tap's k-step 0 into set 0 (the last tap has none: the next tile's halo is
       // published by the barrier that follows)
       if (t + 1 < NTAPS) {
-        PH4_GROUP(PH4_MM, 0, 1, fa[0][0] = PH4_LD(abase0[dxn], aoffn + 0 * C::ROW_BYTES), fb[0][0] = PH4_LD(bx0[0] + bextn, boffn), PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 1, 1, fa[0][1] = PH4_LD(abase0[dxn], aoffn + 1 * C::ROW_BYTES), fb[0][1] = PH4_LD(bx0[1] + bextn, boffn), PH4_NOP,
-                  if (t < C::HALO_TAPS) PH4_DMA_H(2 * t + 1));
-        PH4_GROUP(PH4_MM, 2, 1, fa[0][2] = PH4_LD(abase0[dxn], aoffn + 2 * C::ROW_BYTES), fb[0][2] = PH4_LD(bx0[2] + bextn, boffn), PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 3, 1, fa[0][3] = PH4_LD(abase0[dxn], aoffn + 3 * C::ROW_BYTES), fb[0][3] = PH4_LD(bx0[3] + bextn, boffn), PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM, AS, 0, 1, fa[0][0] = PH4_LD(abase0[dxn], aoffn + 0 * C::ROW_BYTES), fb[0][0] = PH4_LD(bx0[0] + bextn, boffn), PH4_EPI(1, 0), PH4_EPI(1, 1));
+        PH4_GROUP(PH4_MM, AS, 1, 1, fa[0][1] = PH4_LD(abase0[dxn], aoffn + 1 * C::ROW_BYTES), fb[0][1] = PH4_LD(bx0[1] + bextn, boffn), PH4_EPI(1, 2),
+                  PH4_EPI(1, 3); if (t < C::HALO_TAPS) PH4_DMA_H(2 * t + 1));
+        PH4_GROUP(PH4_MM, AS, 2, 1, fa[0][2] = PH4_LD(abase0[dxn], aoffn + 2 * C::ROW_BYTES), fb[0][2] = PH4_LD(bx0[2] + bextn, boffn), PH4_EPI(1, 4), PH4_EPI(1, 5));
+        PH4_GROUP(PH4_MM, AS, 3, 1, fa[0][3] = PH4_LD(abase0[dxn], aoffn + 3 * C::ROW_BYTES), fb[0][3] = PH4_LD(bx0[3] + bextn, boffn), PH4_EPI(1, 6), PH4_EPI(1, 7));
       } else {
-        PH4_GROUP(PH4_MM, 0, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 1, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 2, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
-        PH4_GROUP(PH4_MM, 3, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM, AS, 0, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM, AS, 1, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM, AS, 2, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
+        PH4_GROUP(PH4_MM, AS, 3, 1, PH4_NOP, PH4_NOP, PH4_NOP, PH4_NOP);
       }
     }
 #undef PH4_DMA_H
+#undef PH4_EPI
   };
 
+  int last_as = 0;
+  unsigned long long cy_main = 0, cy_epi = 0, cy_wait = 0, ntile = 0;
+  const unsigned long long cy_t0 = PH4_CLK();
+#ifdef PH_TAP_TRACE
+  const unsigned long long wall_t0 = wall_clock64();
+#endif
   for (int k = 0;; k += 2) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      // End of tile: the next halo (this wave's pieces, issued in taps 0..5) must have LANDED before the barrier publishes it.
+      // vmcnt(0) also covers the stores issued meanwhile - under OVL the previous tile's pieces (taps 0..7: the youngest is a
+      // tap old and acknowledged; a counted wait that leaves them in flight measured ~80 cycles per tile less and is not worth
+      // an ordering assumption), otherwise none: the sequential epilogue runs AFTER the barrier, so that its stores drain beside
+      // the next tile's first taps instead of being waited for.
+      const unsigned long long q0_ = PH4_CLK();
+      if constexpr (!OVL) ecur = epi_ctx(tcur);
       if (half == 0) tile_body(0); else tile_body(1);
-      epilogue_any(tcur);
-      // the next halo (this wave's pieces) has landed, the stores are out: transform, publish, release this tile's buffer
+      const unsigned long long q1_ = PH4_CLK();
+      if constexpr (OVL) { eprev = epi_ctx(tcur); last_as = half; }
+      const unsigned long long q2_ = PH4_CLK();
       PH4_WAIT_VMCNT(0);
-      if (FUSE_IN && nvalid) xform_halo(half ^ 1);
+      if (FUSE_IN && nvalid) {
+        xform_halo(half ^ 1);
+        // the transform's ds_writes must have completed before the barrier lets the other waves read them (an inline-asm
+        // s_barrier is invisible to the compiler's wait insertion; the first fragment reads follow the barrier at once)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       PH4_BARRIER();
+      const unsigned long long q3_ = PH4_CLK();
+      if constexpr (!OVL) epilogue_any(tcur, 0);
+      cy_main += q1_ - q0_; cy_wait += q3_ - q2_; cy_epi += (q2_ - q1_) + (PH4_CLK() - q3_); ++ntile;
       if (!nvalid) goto done;
       tcur = tnext;
       tn = tile_id(k + half + 2);
       nvalid = tn >= 0;
-      if (nvalid) {
-        tnext = decode(tn);
-        hm_next = halo_mask(tnext.iy_base, tnext.ix_base);
-      }
+      if (nvalid) tnext = decode(tn);
     }
   }
 done:
+  if constexpr (OVL) {      // the last tile's epilogue has no tap stream to ride in
+    if (last_as == 0) epilogue_seq(tcur, 0, std::integral_constant<int, 0>{});
+    else epilogue_seq(tcur, OVL ? 1 : 0, std::integral_constant<int, 0>{});
+  }
+  PH4_TR(0, cy_main); PH4_TR(1, cy_epi); PH4_TR(2, cy_wait); PH4_TR(3, ntile); PH4_TR(4, PH4_CLK() - cy_t0);
+#ifdef PH_TAP_TRACE
+  PH4_TR(5, wall_clock64() - wall_t0);
+#endif
+  (void)cy_main; (void)cy_epi; (void)cy_wait; (void)ntile; (void)cy_t0;
   if (p.stats) {   // one partial row per workgroup: [2][64] (forward) or [3][64] (fused BatchNorm-backward sums)
     constexpr int NS = BST ? 3 : 2;
     float* red = reinterpret_cast<float*>(smem + C::RED_OFF);   // [4 waves][NS][BNT]
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
-      float a1 = s1[n], a2 = s2[n], a3 = s3[n];
+      float a1 = s1[n], a2 = s2[n], a3 = s3[BST == 3 ? n : 0];
       a1 += __shfl_xor(a1, 16, 64); a2 += __shfl_xor(a2, 16, 64); a3 += __shfl_xor(a3, 16, 64);
       a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64); a3 += __shfl_xor(a3, 32, 64);
       if (lg == 0) {
         red[(wave * NS + 0) * BNT + 4 * li + n] = a1;
         red[(wave * NS + 1) * BNT + 4 * li + n] = a2;
-        if (NS == 3) red[(wave * NS + 2) * BNT + 4 * li + n] = a3;
+        if (NS == 3) red[(wave * NS + 2) * BNT + 4 * li + n] = BST == 3 ? a3 : 0.f;
       }
     }
     __syncthreads();
@@ -498,10 +584,10 @@ done:
   }
 }
 
-template <bool FUSE_IN, int BST>
+template <bool FUSE_IN, int BST, bool OVL>
 int launch4(const PhTapConv& p, hipStream_t st) {
   using C = Tap4Cfg;
-  auto kern = tapconv4_kernel<FUSE_IN, BST>;
+  auto kern = tapconv4_kernel<FUSE_IN, BST, OVL>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
@@ -523,6 +609,14 @@ int launch4(const PhTapConv& p, hipStream_t st) {
 
 }  // namespace
 
+// A/B and test switch: PH_TAP4_OVL=0 / ph_debug_set_tap4_ovl(0) = every launch with the epilogue after the tile
+static int ph_tap4_ovl_switch(int set) {
+  static int on = [] { const char* e = getenv("PH_TAP4_OVL"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (set >= 0) on = set ? 1 : 0;
+  return on;
+}
+extern "C" int ph_debug_set_tap4_ovl(int on) { return ph_tap4_ovl_switch(on ? 1 : 0); }
+
 // eligible: 3x3 stride-1 perf-mode configuration with Cin = Cout = 64 and the hard-coded 3x3 tap geometry (every ResNet-18 shape
 // that reached tapconv2_l1_kernel)
 bool ph_tapconv4_eligible(const PhTapConv* p) {
@@ -536,6 +630,20 @@ bool ph_tapconv4_eligible(const PhTapConv* p) {
 
 int ph_tapconv4_launch(const PhTapConv* p, hipStream_t st) {
   if (!ph_tapconv4_eligible(p)) return PH_EINVAL;
-  if (p->bst_y) return p->bst_a ? launch4<false, 2>(*p, st) : launch4<false, 1>(*p, st);
-  return p->in_scale ? launch4<true, 0>(*p, st) : launch4<false, 0>(*p, st);
+  if (p->bst_y) {
+    if (!p->bst_a) return p->bst_y2 ? PH_EINVAL : launch4<false, 1, false>(*p, st);
+    return p->bst_y2 ? launch4<false, 3, false>(*p, st) : launch4<false, 2, false>(*p, st);
+  }
+  // launches whose epilogue reads nothing (forward; dgrad without a residual) store the previous tile inside the next tile's taps
+  if (p->res_g || !ph_tap4_ovl_switch(-1)) return p->in_scale ? launch4<true, 0, false>(*p, st) : launch4<false, 0, false>(*p, st);
+  return p->in_scale ? launch4<true, 0, true>(*p, st) : launch4<false, 0, true>(*p, st);
 }
+
+#ifdef PH_TAP_TRACE
+extern "C" int ph_debug_tap4_trace(unsigned long long* host_out, int nwg) {
+  if (nwg > 1024) nwg = 1024;
+  if (hipDeviceSynchronize() != hipSuccess) return PH_ELAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(ph_tap4_trace), (size_t)nwg * 8 * sizeof(unsigned long long)) == hipSuccess
+             ? PH_OK : PH_ELAUNCH;
+}
+#endif

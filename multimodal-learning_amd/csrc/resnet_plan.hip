@@ -319,7 +319,15 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
       if (!bst->a) { f.bst_scale = c.stat(bu, 2); f.bst_shift = c.stat(bu, 3); }
       if (bst->u2 >= 0) { f.bst_y2 = c.ws + P->units[bst->u2].y_off; f.bst_mean2 = c.stat(P->units[bst->u2], 0); }
       f.stats = reinterpret_cast<float*>(c.ws + P->fparts_off);
-      const bool ok = ph_tap4_switch(-1) && ph_tapconv4_eligible(&f) && bu.Cout == t.Cout && bu.OH == t.OH && bu.OW == t.OW;
+      // Where it pays (same-box A/B, profiles/EXPERIMENTS.md round 5): layer 1's bn1 (conv_tap4.hip, the mask re-derived from
+      // y: one extra 8-byte load per piece; 114 us against 76 + a 65 us reduction pass).  Built, tested and OFF by default:
+      // the mask-tensor form behind conv1's dgrad + residual (four epilogue operands per piece: PH_BST2=1) and the dense
+      // kernel of layers 2-4 (conv_tap3.hip at 512 registers: 93 against 64 us per launch, more than the pass it replaces: PH_BST3=1)
+      static const bool bst3 = [] { const char* e = getenv("PH_BST3"); return e && e[0] == '1'; }();
+      static const bool bst2 = [] { const char* e = getenv("PH_BST2"); return e && e[0] == '1'; }();
+      const bool ok = bu.Cout == t.Cout && bu.OH == t.OH && bu.OW == t.OW && (bst2 || !bst->a) &&
+                      ((ph_tap4_switch(-1) && ph_tapconv4_eligible(&f)) ||
+                       (bst3 && ph_tap3_switch(-1) && ph_tapconv2_tile_h(&f, 1, P->prec) && ph_tapconv3_eligible(&f)));
       if (ok) {
         const int rc = ph_tapconv_launch(&f, 1, c.bprec(), c.st);
         if (rc == PH_OK) *fused_parts = ph_tapconv2_stat_parts(&f);

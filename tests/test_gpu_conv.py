@@ -333,6 +333,9 @@ def test_stem_dgrad_vs_conv_transpose(B, H, W):
 
 
 TAP4_CASES = [  # H, B  (Cin = Cout = 64)
+    (128, 64),      # the benchmark's layer-1 shape: 4096 tiles, 16 per workgroup
+    (128, 32),      # 2048 tiles: 8 per workgroup - the steady state of the tile stream (both halo buffers and both accumulator
+                    # sets several times over, the previous tile's epilogue riding in the next tile's taps)
     (32, 8),        # full tiles, one tile per workgroup
     (40, 12),       # partial tiles (40 = 16 + 16 + 8)
     (64, 24),       # 384 tiles: several tiles per workgroup, both halo buffers, XCD-contiguous lists
@@ -394,8 +397,8 @@ def test_tapconv4_bitwise_equals_the_two_group_layer1_kernel(case):
 
 
 @pytest.mark.parametrize("mode", ["self_mask", "act_mask", "act_mask_two"])
-@pytest.mark.parametrize("case", [(32, 8), (40, 12), (64, 24)])
-def test_tapconv4_fused_batchnorm_backward_sums(case, mode):
+@pytest.mark.parametrize("case", [(32, 8, 64), (40, 12, 64), (64, 24, 64), (24, 6, 128), (64, 20, 128), (16, 20, 256), (16, 40, 512)])
+def test_fused_batchnorm_backward_sums_of_the_dgrad_kernels(case, mode):
     """VERDICT r04 next 1: the BatchNorm-backward sums taken in the dgrad epilogue (PhTapConv::bst_y) against the definition,
     evaluated in float64 from the kernel's OWN stored gradient (so that the comparison sees the reduction alone): dbeta = sum dz,
     the centred second sum = sum dz (y - mean), with dz = dx * mask; mask = the BatchNorm's own ReLU re-derived from y
@@ -404,9 +407,8 @@ def test_tapconv4_fused_batchnorm_backward_sums(case, mode):
     un-fused launch's."""
     from tests.gpu_util import nhwc
     m, L, ptr, stream, check = _setup()
-    H, B = case
-    C = 64
-    g = torch.Generator().manual_seed(H * 7 + B + len(mode))
+    H, B, C = case      # C = 64: conv_tap4.hip (layer 1); C >= 128: conv_tap3.hip (layers 2-4, several Cout blocks per workgroup)
+    g = torch.Generator().manual_seed(H * 7 + B + len(mode) + C)
     dy = nhwc(torch.randn(B, C, H, H, generator=g), torch.bfloat16)
     wd = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5).cuda()
     y = nhwc(torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3, torch.bfloat16)
@@ -448,3 +450,38 @@ def test_tapconv4_fused_batchnorm_backward_sums(case, mode):
     err = ((sums.double() - want).abs() / mag.max(dim=1, keepdim=True).values).max().item()
     print(f"\nfused BatchNorm-backward sums {mode} H={H} B={B}: max error {err:.2e} of sum |terms|")
     assert err <= 3e-6, err
+
+
+@pytest.mark.parametrize("case", [(128, 64, 64), (128, 32, 64), (40, 12, 64), (64, 24, 64), (64, 20, 128), (24, 40, 256)])
+def test_input_batchnorm_applied_in_lds_equals_the_separate_pass(case):
+    """PhTapConv::in_scale at the kernel level (the trunk-level test_fused_input_batchnorm_equals_separate_pass sees it through
+    a whole network): conv(relu(x * s + h) -> bf16) with the map applied to each halo tile in LDS must be BITWISE the
+    convolution of the tensor the stand-alone pass writes, deep in the tile stream (8 tiles per workgroup), on partial
+    tiles, in repeated launches - outputs and BatchNorm partial sums."""
+    from tests.gpu_util import nhwc
+    m, L, ptr, stream, check = _setup()
+    H, B, C = case
+    g = torch.Generator().manual_seed(H + 3 * B + C)
+    xr = torch.randn(B, C, H, H, generator=g) * 1.3
+    x = nhwc(xr, torch.bfloat16)
+    sc = (torch.rand(C, generator=g) + 0.5).cuda(); sh = (torch.randn(C, generator=g) * 0.4).cuda()
+    wd = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5).cuda()
+    # what the stand-alone pass stores: one fused multiply-add in fp32 (evaluated here in float64 and rounded once), ReLU, bf16
+    a = torch.relu((x.double() * sc.double() + sh.double()).float()).bfloat16()
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, C, H, H, C, 3, 1, 1), device="cuda", dtype=torch.uint8)
+    y0 = torch.full((B, H, H, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+    s1 = torch.empty(C, device="cuda"); s2 = torch.empty(C, device="cuda")
+    check(L.ph_conv2d_fwd(ptr(a), ptr(wd), ptr(y0), ptr(s1), ptr(s2), B, C, H, H, C, 3, 1, 1, 0, ptr(ws), stream()), "fwd")
+    ref = (y0.clone(), s1.clone(), s2.clone())
+    for rep in range(3):
+        y1 = torch.full((B, H, H, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+        t1 = torch.empty(C, device="cuda"); t2 = torch.empty(C, device="cuda")
+        check(L.ph_conv2d_fwd_fused_in(ptr(x), ptr(sc), ptr(sh), ptr(wd), ptr(y1), ptr(t1), ptr(t2), B, C, H, H, C, ptr(ws), stream()), "fused in")
+        bad = (ref[0].view(torch.int16) != y1.view(torch.int16))
+        nbad = int(bad.sum().item())
+        if nbad:
+            idx = bad.nonzero()
+            print("mismatch rep", rep, "count", nbad, "of", y1.numel(), "first", idx[:6].tolist(), "last", idx[-3:].tolist(),
+                  "images", sorted(set(idx[:, 0].tolist()))[:10], "rows", sorted(set(idx[:, 1].tolist()))[:20], "cols", sorted(set(idx[:, 2].tolist()))[:20])
+        assert nbad == 0, (rep, nbad, y1.numel())
+        assert torch.equal(ref[1], t1) and torch.equal(ref[2], t2), rep

@@ -453,7 +453,7 @@ def test_image_gradient_perf_mode_tracks_parity_mode():
     assert 0.8 < float(b.norm() / a.norm()) < 1.25
 
 
-@pytest.mark.parametrize("B,H", [(6, 160), (3, 96), (20, 224), (64, 512)])
+@pytest.mark.parametrize("B,H", [(6, 160), (3, 96), (20, 224), (64, 512), (32, 512), (64, 256), (16, 512)])
 def test_fused_input_batchnorm_equals_separate_pass(B, H):
     """Forward-only networks (the EMA student and the teacher) run conv2 of every block on the RAW conv1 output and apply
     bn1 + ReLU to each halo tile in LDS (conv_tap2.hip, PhTapConv::in_scale; padding enters as NaN and leaves the ReLU
