@@ -29,6 +29,8 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats_b256" -- python3 bench.py --north-star --serial --steps 5 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --no-north-star-block > "$T/bench_stats_b256.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$T/fetch_b256" -- python3 bench.py --north-star --steps 2 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --no-north-star-block --eager --no-kernel-timer > "$T/bench_fetch_b256.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$T/write_b256" -- python3 bench.py --north-star --steps 2 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --no-north-star-block --eager --no-kernel-timer > "$T/bench_write_b256.log" 2>&1
+# the north-star's literal quantity: the student's ResNet forward + backward alone at batch 256 (bench.py --trunk-only)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats_trunk_b256" -- python3 bench.py --trunk-only --steps 5 > "$T/bench_stats_trunk_b256.log" 2>&1
 # the tolerance-compliant arithmetic (fp16x3/x1): where its step spends the time; the MIA-2023 leg with its full-bank KNN kernels
 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats_fp16x3" -- python3 bench.py --precision fp16x3/x1 --serial --steps 5 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants --no-north-star-block > "$T/bench_stats_fp16x3.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats_mia2023" -- python3 bench.py --variant mia2023 --steps 5 --warmup 3 --eager > "$T/bench_stats_mia2023.log" 2>&1

@@ -76,6 +76,7 @@ def main():
     for sub, suffix, cmd in (("stats", "", "python3 bench.py --serial --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
                              ("stats_concurrent", "_concurrent", "python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode --no-variants"),
                              ("stats_b256", "_b256", "python3 bench.py --north-star --serial --steps 5 --warmup 3 ... (batch 256 on one GPU)"),
+                             ("stats_trunk_b256", "_trunk_b256", "python3 bench.py --trunk-only --steps 5 (the north-star's literal quantity: the student's ResNet forward + backward alone at batch 256, one captured HIP graph)"),
                              ("stats_fp16x3", "_fp16x3", "python3 bench.py --precision fp16x3/x1 --serial --steps 5 --warmup 3 ... (the tolerance-compliant arithmetic)"),
                              ("stats_mia2023", "_mia2023", "python3 bench.py --variant mia2023 --steps 5 --warmup 3 --eager (BASELINE configs[4] single-GPU leg: the full-bank KNN kernels)")):
         f = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
