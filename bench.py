@@ -42,12 +42,12 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
              "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
              "stem_wgrad_kernel<bf16>",
              "tapconv3_kernel (conv_tap3.hip: 3x3 stride-1 fwd+dgrad, Cout>=128, 16x16x32 fragments; PH_TAP3=0: tapconv2_kernel<2,2,4,false>)",
-             "tapconv2_l1_kernel (3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1, two wave groups)"]
+             "tapconv4_kernel (conv_tap4.hip: 3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1; one wave per SIMD, 16x16x32 fragments, resident weights, epilogue inside the next tile; PH_TAP4=0: tapconv2_l1_kernel)"]
 NCLS = len(CLS_NAMES)
 # ... + class 12 of ph_kernels.h (behind the four HBM-bound classes 8-11)
 MASKED_CLS, MASKED_NAME = 12, "tapconv2_kernel<2,2,4,false,masked> (3x3 stride-2 fwd as a masked grid over the 4 pixel-parity planes)"
 FUSED_CLS = [(13, "tapconv3_kernel<fused input> + input BatchNorm/ReLU applied in LDS (conv2 of layer 2, forward-only networks)"),
-             (14, "tapconv2_l1_kernel + input BatchNorm/ReLU applied in LDS (conv2 of layer 1, forward-only networks)")]
+             (14, "tapconv4_kernel<fused input> + input BatchNorm/ReLU applied in LDS (layer 1, forward-only networks)")]
 HBM_NAMES = ["crd_score_kernel (2 banks x B x 1000 rows of 512 B)", "crd_loss_grad_kernel (2 banks x B x 532 rows of 512 B)",
              "adam_ema_dev_kernel (28 B / parameter + 8 B / EMA parameter)", "bn_apply_kernel (2-3 activation tensors)"]
 TOPK_CLS = 15                    # ph_kernels.h PH_CLS_CRD_TOPK
@@ -580,6 +580,8 @@ def main():
                          "5-step figures of all three in `variants`)")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (configs[3] / configs[4] legs)")
     ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--grad-exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="N > 1: the gradient sum as bucketed all-reduce (default) or reduce-scatter + all-gather per bucket (A/B)")
     ap.add_argument("--trunk-only", action="store_true",
                     help="only the north-star's literal quantity: student ResNet forward + backward alone at batch 256 (profiling aid)")
     ap.add_argument("--no-trunk-block", action="store_true", help="skip `north_star_b256.trunk_fwd_bwd`")
@@ -629,7 +631,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
-        sync = m.dist.ReplicaSync()
+        sync = m.dist.ReplicaSync(grad_exchange=args.grad_exchange)
     if args.trunk_only:
         r = trunk_fwd_bwd(m, 256 if args.batch == 64 else args.batch, args.size, device, steps=max(args.steps, 5))
         print(json.dumps({"metric": "student ResNet forward+backward alone", "value": r["tiles_per_s"], "unit": "tiles/s", "n_gpus": 1,
@@ -755,6 +757,12 @@ def main():
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             comm["exposed_grad_allreduce_ms"] = round(t[0].item(), 4)      # 100 MHz device wall clock
             comm["step_span_ms"] = round(t[1].item(), 3)
+            if st_[11] > 0 and st_[5] > st_[11]:
+                # phase 1 (layers 3-4 + heads, 93 % of the bytes) starts at stamp 11 and has until the end of the trunk backward
+                # (stamp 5) to hide; phase 2 (the rest) and whatever of phase 1 is left are the exposed part above
+                t2 = torch.tensor([(int(st_[5]) - int(st_[11])) * 1e-5], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(t2, op=torch.distributed.ReduceOp.MIN)
+                comm["phase1_overlap_window_ms"] = round(t2[0].item(), 4)
         nparam = step.optimizer.flat.numel
         comm["grad_allreduce_bytes"] = int(nparam) * 4
         comm["exchanges_per_step"] = ("bucketed all-reduce of the flat gradient buffer in two phases (layers 3-4 + heads start "

@@ -98,7 +98,7 @@ __global__ void bn_apply_kernel(const TY* __restrict__ y, const float* __restric
                                 const float* __restrict__ shift, const TY* __restrict__ res,
                                 const TY* __restrict__ y_r, const float* __restrict__ scale_r,
                                 const float* __restrict__ shift_r, T* __restrict__ out, TY* __restrict__ out32, size_t n8,
-                                int C8, int relu) {
+                                int C8, int relu, int res_as_t) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   const int c = (int)(i % C8) * 8;
@@ -107,7 +107,10 @@ __global__ void bn_apply_kernel(const TY* __restrict__ y, const float* __restric
 #pragma unroll
   for (int k = 0; k < 8; ++k) v[k] = v[k] * scale[c + k] + shift[c + k];
   if (res) {
-    load8(res + i * 8, r);
+    // res_as_t (PH_PREC_FP16X3, forward-only networks): the shortcut term is read from the half-pair operand image of the
+    // block input (hi + lo 2^-11: 22-23 significant bits) - those networks then keep no fp32 copy of their block outputs
+    if (!std::is_same<T, TY>::value && res_as_t) load8(reinterpret_cast<const T*>(res) + i * 8, r);
+    else load8(res + i * 8, r);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] += r[k];
   } else if (y_r) {
@@ -630,13 +633,19 @@ int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st) 
 int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
                        const float* scale_r, const float* shift_r, void* out, void* out32, size_t npix, int C, int relu, int prec,
                        hipStream_t st) {
+  return ph_bn_apply_launch2(y, scale, shift, res, y_r, scale_r, shift_r, out, out32, npix, C, relu, prec, 0, st);
+}
+
+int ph_bn_apply_launch2(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
+                        const float* scale_r, const float* shift_r, void* out, void* out32, size_t npix, int C, int relu, int prec,
+                        int res_as_t, hipStream_t st) {
   const size_t n8 = npix * (C / 8);
   void* tok = nullptr;
   if (ph_prof_on())
     ph_prof_begin(PH_CLS_BN_APPLY, (double)npix * C * (prec == PH_PREC_BF16 ? 2.0 : 4.0) * ((res || y_r) ? 3.0 : 2.0), st, &tok);
 #define PH_CALL(T, TY)                                                                                              \
   hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(nblk(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const TY*)res, \
-                     (const TY*)y_r, scale_r, shift_r, (T*)out, (TY*)out32, n8, C / 8, relu)
+                     (const TY*)y_r, scale_r, shift_r, (T*)out, (TY*)out32, n8, C / 8, relu, res_as_t)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
   ph_prof_end(tok, st);
@@ -664,6 +673,16 @@ int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* sh
 int ph_avgpool_launch(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st) {
   dim3 grid(C / 64, B);
 #define PH_CALL(T, TY) hipLaunchKernelGGL(avgpool_kernel<TY>, grid, dim3(256), 0, st, (const TY*)x, out, HW, C)
+  PH_DISPATCH(prec, PH_CALL);
+#undef PH_CALL
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+
+// the same over an activation in the form the convolutions read it (PH_PREC_FP16X3: the half-pair image; other modes: as above)
+int ph_avgpool_launch_t(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st) {
+  dim3 grid(C / 64, B);
+#define PH_CALL(T, TY) hipLaunchKernelGGL(avgpool_kernel<T>, grid, dim3(256), 0, st, (const T*)x, out, HW, C)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
   PH_LAUNCH_CHECK();

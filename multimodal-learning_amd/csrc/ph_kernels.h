@@ -194,6 +194,11 @@ int ph_bn_eval_params_launch(const PhBnEvalTable* t, float eps, hipStream_t st);
 int ph_bn_apply_launch(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
                        const float* scale_r, const float* shift_r, void* out, void* out32, size_t npix, int C, int relu, int prec,
                        hipStream_t st);
+// res_as_t: `res` is an activation as the convolutions read it (PH_PREC_FP16X3: the half-pair image instead of the fp32 copy)
+int ph_bn_apply_launch2(const void* y, const float* scale, const float* shift, const void* res, const void* y_r,
+                        const float* scale_r, const float* shift_r, void* out, void* out32, size_t npix, int C, int relu, int prec,
+                        int res_as_t, hipStream_t st);
+int ph_avgpool_launch_t(const void* x, float* out, int B, int HW, int C, int prec, hipStream_t st);
 // raw (optional, with idx): the conv output at every window's arg-max, [B][OH/2][OW/2][C] of the mode's type
 int ph_bn_relu_maxpool_launch(const void* y, const float* scale, const float* shift, void* out, uint8_t* idx, void* raw,
                               void* out32, int B, int H, int W, int C, int prec, hipStream_t st);

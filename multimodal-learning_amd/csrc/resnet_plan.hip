@@ -441,6 +441,11 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
   c.no_masked = P->no_masked;
   unsigned char* ws = c.ws;
   const bool hp = P->prec == PH_PREC_FP16X3;
+  // half-pair mode, forward-only network (flag bit 2): nobody reads ReLU masks later, so the fp32 copies of the block outputs are
+  // not written - the next block's shortcut term and the average pools read the half-pair operand images (22-23 significant
+  // bits): 1.0 GB of writes per network and forward at B = 64 / 512 x 512.  PH_HP_OUT32=1 keeps the copies (A/B and test switch).
+  static const bool keep32 = [] { const char* e = getenv("PH_HP_OUT32"); return e && e[0] == '1'; }();
+  const bool fo_hp = hp && (flags & 4) && !keep32;
   // bit6: `x_nchw` is not the image but an NHWC4 tensor of the mode's activation type that ph_pack_input produced from it
   // (the student and the teacher of the distillation step read the same x_path: packed once, train_test_path_multi_distill.py:249,256)
   int rc = PH_OK;
@@ -511,7 +516,7 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
     // (forward only: nobody scatters a gradient through the pooling windows - the argmax codes are not produced)
     if ((rc = ph_bn_relu_maxpool_launch(ws + u.y_off, c.stat(u, 2), c.stat(u, 3), ws + P->p0_off,
                                         (flags & 4) ? nullptr : ws + P->idx_off, (flags & 4) ? nullptr : ws + P->p0raw_off,
-                                        hp ? ws + P->blocks[0].in32_off : nullptr, P->B, u.OH, u.OW, 64, P->prec, st)))
+                                        (hp && !fo_hp) ? ws + P->blocks[0].in32_off : nullptr, P->B, u.OH, u.OW, 64, P->prec, st)))
       return rc;
   }
   // conv2 of every block is 3x3 / stride 1 with Cin = Cout in {64, 128, 256, 512}: always a second-generation kernel in perf mode
@@ -539,16 +544,21 @@ int ph_resnet_forward(const PhResnetPlan* P, const void* const* params, const vo
       const Unit& ud = P->units[b.uds];
       if ((rc = conv_fwd(c, b.uds, ws + b.in_off))) return rc;
       rc = ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + ud.y_off, c.stat(ud, 2),
-                              c.stat(ud, 3), ws + b.out_off, hp ? ws + b.out32_off : nullptr, npix, b.Cout, 1, P->prec, st);
+                              c.stat(ud, 3), ws + b.out_off, (hp && !fo_hp) ? ws + b.out32_off : nullptr, npix, b.Cout, 1, P->prec, st);
     } else {
       rc = raw_in ? ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), nullptr, ws + b.in_off, c.stat(u0, 2),
                                        c.stat(u0, 3), ws + b.out_off, nullptr, npix, b.Cout, 3, P->prec, st)
-                  : ph_bn_apply_launch(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), ws + b.in32_off, nullptr, nullptr, nullptr,
-                                       ws + b.out_off, hp ? ws + b.out32_off : nullptr, npix, b.Cout, 1, P->prec, st);
+                  : ph_bn_apply_launch2(ws + u2.y_off, c.stat(u2, 2), c.stat(u2, 3), fo_hp ? ws + b.in_off : ws + b.in32_off, nullptr,
+                                        nullptr, nullptr, ws + b.out_off, (hp && !fo_hp) ? ws + b.out32_off : nullptr, npix, b.Cout, 1,
+                                        P->prec, fo_hp ? 1 : 0, st);
     }
     if (rc) return rc;
-    if (bi == 5 && f3) { if ((rc = ph_avgpool_launch(ws + b.out32_off, f3, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
-    if (bi == 7 && f4) { if ((rc = ph_avgpool_launch(ws + b.out32_off, f4, P->B, b.OH * b.OW, b.Cout, P->prec, st))) return rc; }
+    if ((bi == 5 && f3) || (bi == 7 && f4)) {
+      float* dst = bi == 5 ? f3 : f4;
+      if ((rc = fo_hp ? ph_avgpool_launch_t(ws + b.out_off, dst, P->B, b.OH * b.OW, b.Cout, P->prec, st)
+                      : ph_avgpool_launch(ws + b.out32_off, dst, P->B, b.OH * b.OW, b.Cout, P->prec, st)))
+        return rc;
+    }
   }
   return PH_OK;
 }

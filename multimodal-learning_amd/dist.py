@@ -14,18 +14,50 @@ import torch.distributed as dist
 
 
 class ReplicaSync:
-    def __init__(self, group=None, bucket_bytes=32 << 20):
+    def __init__(self, group=None, bucket_bytes=32 << 20, grad_exchange="all_reduce"):
+        """grad_exchange: how the flat gradient buffer is summed over the replicas -
+          "all_reduce"      bucketed all-reduce (default);
+          "reduce_scatter"  every bucket as reduce-scatter (each rank receives the sum of its 1/W shard) + all-gather of the
+                            shards: the two halves of a ring all-reduce as separate collectives, so that on a point-to-point
+                            xGMI fabric the first 8-GPU run can A/B the two schedules (`bench.py --grad-exchange`).  Same sums
+                            up to the reduction order inside the library; a bucket's tail that does not divide by the world
+                            size (< W elements) goes through a small all-reduce."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if grad_exchange not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("grad_exchange must be 'all_reduce' or 'reduce_scatter', got %r" % (grad_exchange,))
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.grad_exchange = grad_exchange
+        self._shards = {}
+        # gloo runs asynchronous collectives on a thread pool: a dependent pair must be chained on the host there; NCCL / RCCL
+        # executes a group's collectives in issue order on its own stream
+        self._ordered = dist.get_backend(group) != "gloo"
 
     # 1 -------------------------------------------------------------------------------------------------
     def _buckets(self, g, lo, hi):
-        return [dist.all_reduce(g[s:min(hi, s + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group,
-                                async_op=True) for s in range(lo, hi, self.bucket_elems)]
+        if self.grad_exchange == "all_reduce" or self.world_size == 1:
+            return [dist.all_reduce(g[s:min(hi, s + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group,
+                                    async_op=True) for s in range(lo, hi, self.bucket_elems)]
+        W = self.world_size
+        step = max(W, self.bucket_elems // W * W)
+        works = []
+        for s in range(lo, hi, step):
+            e = min(hi, s + step)
+            main = (e - s) // W * W
+            if main:
+                shard = self._shards.get((s, main))
+                if shard is None:      # (one persistent shard buffer per bucket: a captured graph keeps its address)
+                    shard = self._shards[(s, main)] = torch.empty(main // W, device=g.device, dtype=g.dtype)
+                w1 = dist.reduce_scatter_tensor(shard, g[s:s + main], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if not self._ordered:
+                    w1.wait()
+                works.append(dist.all_gather_into_tensor(g[s:s + main], shard, group=self.group, async_op=True))
+            if main < e - s:
+                works.append(dist.all_reduce(g[s + main:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return works
 
     def begin_grad_slice(self, flat, lo):
         """Start the all-reduce of flat.grad[lo:] and return at once.  Called from the trunk backward when the
@@ -131,4 +163,4 @@ def comm_report(sync, device=None, backend=None):
     return {"backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else ""), "library_version": ver,
             "world_size": sync.world_size, "ranks_joined_all_reduce": int(round(one.item())),
             "device_ids": ids, "distinct_devices": len(set(ids)),
-            "grad_bucket_bytes": sync.bucket_elems * 4}
+            "grad_bucket_bytes": sync.bucket_elems * 4, "grad_exchange": sync.grad_exchange}

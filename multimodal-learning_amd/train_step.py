@@ -478,7 +478,8 @@ class DistillStep:
                 # is final once the trunk backward has passed layer 3: its all-reduce starts there (dist.begin_grad_slice)
                 first = self.model.layer3[0].conv1.weight
                 lo = next(o for t, o in zip(flat.tensors, flat.offsets) if t is first)
-                self.model._grad_ready_hook = lambda: self.sync.begin_grad_slice(self.optimizer.flat, lo)
+                # (stamp 11: the moment the first phase starts - bench.py's `comm` reports the window it has to hide in)
+                self.model._grad_ready_hook = lambda: (self._stamp(11), self.sync.begin_grad_slice(self.optimizer.flat, lo))[1]
 
     def _head_stream(self):
         return self._head_side

@@ -27,7 +27,7 @@ def cls_of(name):
     n = name
     if "tapconv3_kernel" in n:      # third-generation dense 3x3 kernel (conv_tap3.hip): the same launches as class 6
         return 6
-    if "tapconv2_l1_kernel" in n:   # layer 1 (Cin = Cout = 64): two wave groups, resident weights
+    if "tapconv2_l1_kernel" in n or "tapconv4_kernel" in n:   # layer 1 (Cin = Cout = 64): conv_tap4.hip (round 5), before it the two-group kernel
         return 7
     if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel, Cout >= 128; <..., true>: masked stride-2 grid
         if "false, true" in n or "Lb0ELb1E" in n:

@@ -54,6 +54,37 @@ def test_bucketed_grad_allreduce():
         assert s == expect.sum().item() and e == expect[1234].item()
 
 
+def _grads_reduce_scatter(rank, world):
+    from multimodal_learning_amd.dist import ReplicaSync
+    out = []
+    for n, bucket_bytes in ((5000, 4096), (5001, 4096), (37, 1 << 20), (4096, 4096)):      # tails that do not divide by the world size
+        ref = ReplicaSync(bucket_bytes=bucket_bytes)
+        rs = ReplicaSync(bucket_bytes=bucket_bytes, grad_exchange="reduce_scatter")
+        torch.manual_seed(100 * rank + n)
+        g0 = torch.randn(n)
+        a, b = g0.clone(), g0.clone()
+        ref.all_reduce_grads(a)
+        # two phases, as the step uses it: the tail slice starts while the head is not final
+        b[:n // 3] = -7.0
+        rs.begin_grad_slice(b, n // 3)
+        b[:n // 3] = g0[:n // 3]
+        rs.all_reduce_grads(b)
+        out.append((a, b))
+    return out
+
+
+def test_reduce_scatter_gradient_exchange_equals_all_reduce():
+    """`grad_exchange="reduce_scatter"` (reduce-scatter + all-gather per bucket, tails through a small
+    all-reduce, two phases) gives the sums of the bucketed all-reduce on every rank - with two ranks a sum of two numbers,
+    so bitwise."""
+    res = _run(_grads_reduce_scatter)
+    for case in range(4):
+        a0, b0 = res[0][case]
+        a1, b1 = res[1][case]
+        assert torch.equal(a0, a1) and torch.equal(b0, b1), case      # identical on both ranks
+        assert torch.equal(a0, b0), (case, (a0 - b0).abs().max().item())
+
+
 def _grads_two_phase(rank, world):
     from multimodal_learning_amd.dist import ReplicaSync
     sync = ReplicaSync(bucket_bytes=4096)
