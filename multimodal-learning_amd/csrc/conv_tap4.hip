@@ -110,10 +110,24 @@ __device__ __forceinline__ int a4_off(int hr, int hc, int c) {
 // and its 288 MFMAs per wave made the first version of this kernel 91 us, no faster than the kernel it replaces.  OVL launches
 // read nothing in their epilogue (forward: no residual, no fused sums); launches that do (dgrad) run the epilogue after the
 // tile (OVL = false), their operands requested two taps earlier.
-template <bool FUSE_IN, int BST, bool OVL>
+//
+// OVL with operands (ORM = 2: dgrad + masked residual; BST = 1: own-ReLU fused sums): the operands of a piece are 8-byte loads
+// issued PD k-steps ahead of the micro-steps that consume them - pieces PD .. 15 from inside the stream that stores them (a
+// rotating window of PD + 1 register slots), pieces 0 .. PD - 1 ("head") from taps 6-7 of the tile's OWN stream, so that they
+// have landed before the tile-end wait and nothing is in flight at the barrier.  The loads are compiler-visible builtins: its
+// wait in front of a consumer counts only the operations it knows (later loads and stores), so the inline-asm LDS-DMAs issued
+// since make that wait stricter by at most the few DMAs of PD k-steps - bounded, unlike the all-sixteen-pieces-after-the-tile
+// form, whose first consumer waited for everything.
+template <bool FUSE_IN, int BST, bool OVL, int ORM = 0>
 __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   static_assert(!(FUSE_IN && BST), "forward-only feature vs backward feature");
-  static_assert(!(OVL && BST), "the overlapped epilogue reads nothing");
+  static_assert(!(OVL && BST > 1), "the overlapped epilogue carries at most one operand pair");
+  static_assert(ORM == 0 || (ORM == 2 && OVL && !BST && !FUSE_IN), "ORM: overlapped dgrad + masked residual");
+  constexpr bool OPS = OVL && (ORM != 0 || BST == 1);      // overlapped epilogue WITH operands
+  #ifndef PH4_PD
+#define PH4_PD 4
+#endif
+  constexpr int PD = PH4_PD, NWIN = PD + 1, NSL = PD + NWIN;
   using C = Tap4Cfg;
   constexpr int NM = C::NM, NN = C::NN, TH = C::TH, TW = C::TW, BNT = C::BNT, HPW = C::HPW, NTAPS = C::NTAPS;
   constexpr int B_BASE = C::B_BASE;
@@ -299,12 +313,20 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   // the end-of-tile wait COUNT them.
   constexpr unsigned OOB = 0x7ffffff0u;
   constexpr int RSRC_FLAGS = 0x00020000;      // raw buffer, 32-bit offsets (gfx90a / gfx94x / gfx950 data format word)
-  struct EpiCtx { __amdgpu_buffer_rsrc_t out; unsigned o00, rowstep, colstep; int rlim, clim; };
+  struct EpiCtx { __amdgpu_buffer_rsrc_t out, q0, q1; unsigned o00, rowstep, colstep; int rlim, clim; };
   const int img_bytes = p.OH * p.OW * p.Cout * 2;
+  auto in_rsrc = [&](const void* base, const TileCtx& tc) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(base)) + (size_t)tc.b * p.OH * p.OW * p.Cout, 0,
+                                             base ? img_bytes : 0, RSRC_FLAGS);
+  };
   auto epi_ctx = [&](const TileCtx& tc) -> EpiCtx {
     EpiCtx e;
     const size_t img = (size_t)tc.b * p.OH * p.OW * p.Cout;
     e.out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(p.out) + img, 0, img_bytes, RSRC_FLAGS);
+    if constexpr (OPS) {      // operand 0 = residual gradient / the BatchNorm's y; operand 1 = the residual's mask tensor
+      e.q0 = in_rsrc(ORM ? p.res_g : p.bst_y, tc);
+      e.q1 = in_rsrc(ORM ? p.res_a : p.bst_y, tc);
+    } else { e.q0 = e.out; e.q1 = e.out; }
     // BYTE offset of this lane's piece (0, 0) inside the image; pixel rows advance by rowstep, columns by colstep
     e.o00 = 2u * ((unsigned)(((tc.r0 + wave * NM) * p.os + p.oa_h) * p.OW + (tc.c0 + 4 * lg) * p.os + p.oa_w) * (unsigned)p.Cout + 4u * (unsigned)li);
     e.rowstep = 2u * (unsigned)(p.os * p.OW * p.Cout);
@@ -315,10 +337,32 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   };
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
   // (OVL) the 8 micro-steps of one piece, spread over the filler slots of one k-step; state between the steps:
-  float ev[4];
+  float ev[4], ey[4];
   u32x2 ew;
   bool emine = true;
   unsigned eoff = 0;
+  // (OPS) operand registers: head slots 0 .. PD - 1 = pieces 0 .. PD - 1, then the rotating window
+  u32x2 o_r0[OPS ? NSL : 1], o_r1[(OPS && ORM) ? NSL : 1];
+  auto slot_of = [](const int pc) -> int { return pc < PD ? pc : PD + (pc - PD) % NWIN; };
+  // (the first stream of a workgroup consumes head slots nobody loaded: its dummy previous tile contributes 0 x (y - mean) to
+  // the fused sums, which must not be 0 x Inf)
+#pragma unroll
+  for (int i = 0; i < (OPS ? NSL : 1); ++i) { o_r0[i] = u32x2{0u, 0u}; o_r1[(OPS && ORM) ? i : 0] = u32x2{0u, 0u}; }
+  f32x4 ocms = {0.f, 0.f, 0.f, 0.f}, ocmh = ocms, ocmu = ocms;      // (OPS, BST = 1) mask scale / shift, mean of this lane's 4 channels
+  if constexpr (OPS && BST == 1) {
+    ocms = *reinterpret_cast<const f32x4*>(ss + 4 * li);
+    ocmh = *reinterpret_cast<const f32x4*>(ss + BNT + 4 * li);
+    ocmu = *reinterpret_cast<const f32x4*>(ss + 2 * BNT + 4 * li);
+  }
+  auto ovl_load = [&](const EpiCtx& ec, const int pc) {
+    if constexpr (OPS) {
+      const int m = pc >> 2, r = pc & 3, sl = slot_of(pc);
+      const bool mine = m < ec.rlim && r < ec.clim;
+      const int off = (int)(mine ? ec.o00 + (unsigned)m * ec.rowstep + (unsigned)r * ec.colstep : OOB);
+      o_r0[sl] = __builtin_amdgcn_raw_buffer_load_b64(ec.q0, off, 0, 0);
+      if constexpr (ORM != 0) o_r1[sl] = __builtin_amdgcn_raw_buffer_load_b64(ec.q1, off, 0, 0);
+    }
+  };
   // step K (0..7) of piece (M, R) of the tile in accumulator set AS with context EC
 #define PH4_EPI_STEP(K, AS, M, R, EC)                                                                                        \
   do {                                                                                                                       \
@@ -328,10 +372,35 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
       emine = (M) < (EC).rlim && (R) < (EC).clim;                                                                            \
       _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) ev[j_] = emine ? ev[j_] : 0.f;                                        \
     }                                                                                                                        \
-    else if ((K) == 3) { s1[0] += ev[0]; s1[1] += ev[1]; s1[2] += ev[2]; s1[3] += ev[3]; }                                   \
-    else if ((K) == 4) { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) s2[j_] = __builtin_fmaf(ev[j_], ev[j_], s2[j_]); }  \
+    else if ((K) == 3) {                                                                                                     \
+      if constexpr (OPS) {      /* the stored bf16 gradient: the residual is added to it, the fused sums are taken over it */  \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { bf16x2 b_; b_[0] = (bf16)ev[2 * j_]; b_[1] = (bf16)ev[2 * j_ + 1]; ew[j_] = __builtin_bit_cast(unsigned, b_); } \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { ev[2 * j_] = __builtin_bit_cast(float, ew[j_] << 16); ev[2 * j_ + 1] = __builtin_bit_cast(float, ew[j_] & 0xffff0000u); } \
+      } else { s1[0] += ev[0]; s1[1] += ev[1]; s1[2] += ev[2]; s1[3] += ev[3]; }                                             \
+    }                                                                                                                        \
+    else if ((K) == 4) {                                                                                                     \
+      if constexpr (OPS && ORM != 0) {                                                                                       \
+        const u32x2 g_ = o_r0[slot_of(4 * (M) + (R))], a_ = o_r1[(OPS && ORM) ? slot_of(4 * (M) + (R)) : 0];                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                                   \
+          const float g0_ = __builtin_bit_cast(float, g_[j_] << 16), g1_ = __builtin_bit_cast(float, g_[j_] & 0xffff0000u);   \
+          const float a0_ = __builtin_bit_cast(float, a_[j_] << 16), a1_ = __builtin_bit_cast(float, a_[j_] & 0xffff0000u);   \
+          ev[2 * j_] = ev[2 * j_] + (a0_ > 0.f ? g0_ : 0.f);                                                                 \
+          ev[2 * j_ + 1] = ev[2 * j_ + 1] + (a1_ > 0.f ? g1_ : 0.f);                                                         \
+        }                                                                                                                    \
+      } else if constexpr (OPS) {      /* BST = 1: dz = gradient under the BatchNorm's own ReLU */                           \
+        const u32x2 y_ = o_r0[slot_of(4 * (M) + (R))];                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                                   \
+          ey[j_] = __builtin_bit_cast(float, (j_ & 1) ? (y_[j_ >> 1] & 0xffff0000u) : (y_[j_ >> 1] << 16));                  \
+          ev[j_] = __builtin_fmaf(ey[j_], ocms[j_], ocmh[j_]) > 0.f ? ev[j_] : 0.f;                                          \
+        }                                                                                                                    \
+      } else { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) s2[j_] = __builtin_fmaf(ev[j_], ev[j_], s2[j_]); }           \
+    }                                                                                                                        \
     else if ((K) == 5) {                                                                                                     \
-      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { bf16x2 b_; b_[0] = (bf16)ev[2 * j_]; b_[1] = (bf16)ev[2 * j_ + 1]; ew[j_] = __builtin_bit_cast(unsigned, b_); } \
+      if constexpr (OPS && ORM == 0) {                                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) { s1[j_] += ev[j_]; s2[j_] = __builtin_fmaf(ev[j_], ey[j_] - ocmu[j_], s2[j_]); } \
+      } else {                                                                                                               \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { bf16x2 b_; b_[0] = (bf16)ev[2 * j_]; b_[1] = (bf16)ev[2 * j_ + 1]; ew[j_] = __builtin_bit_cast(unsigned, b_); } \
+      }                                                                                                                      \
     }                                                                                                                        \
     else if ((K) == 6) { eoff = emine ? (EC).o00 + (unsigned)(M) * (EC).rowstep + (unsigned)(R) * (EC).colstep : OOB; }      \
     else __builtin_amdgcn_raw_buffer_store_b64(ew, (EC).out, (int)eoff, 0, 0);                                               \
@@ -345,14 +414,10 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   // 8-byte loads, coalesced like the stores,
   // unconditional (out-of-image lanes read 0 through the buffer resource: with "if (inside) load" on top of a default value the
   // compiler's hazard tracking put an s_waitcnt vmcnt(0) in front of every piece - each load waited for the one before it).
-  constexpr bool EPI_LOADS = !OVL;
+  constexpr bool EPI_LOADS = !OVL || OPS;      // (OPS: the last tile of a workgroup only)
   u32x2 e_rg[EPI_LOADS ? 16 : 1], e_ra[EPI_LOADS ? 16 : 1], e_ry[(EPI_LOADS && BST) ? 16 : 1], e_rb[(EPI_LOADS && BST >= 2) ? 16 : 1],
       e_ry2[(EPI_LOADS && BST == 3) ? 16 : 1];
   const int rmode = p.res_g ? (p.res_a ? 2 : 1) : 0;
-  auto in_rsrc = [&](const void* base, const TileCtx& tc) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(reinterpret_cast<const T*>(base)) + (size_t)tc.b * p.OH * p.OW * p.Cout, 0,
-                                             base ? img_bytes : 0, RSRC_FLAGS);
-  };
   auto epi_load_piece = [&](const TileCtx& tc, const EpiCtx& ec, const int pc) {      // piece pc = (pixel row pc >> 2, column pc & 3)
     if constexpr (EPI_LOADS) {
       const int m = pc >> 2, r = pc & 3;
@@ -463,7 +528,14 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
     // or (launches that read in their epilogue) one piece's loads
 #define PH4_EPI(KS, J)                                                                                                 \
   do {                                                                                                                 \
-    if constexpr (OVL) { if (t < 8) PH4_EPI_STEP(J, PS, (2 * t + (KS)) >> 2, (2 * t + (KS)) & 3, eprev); }              \
+    if constexpr (OVL) {                                                                                               \
+      if (t < 8) PH4_EPI_STEP(J, PS, (2 * t + (KS)) >> 2, (2 * t + (KS)) & 3, eprev);                                    \
+      if constexpr (OPS) {                                                                                             \
+        if (t < 8 && (J) == 1 && 2 * t + (KS) + PD < 16) ovl_load(eprev, (2 * t + (KS) + PD) & 15);                      \
+        if ((t == 6 || t == 7) && ((J) == 3 || (J) == 6) && (2 * t + (KS) - 12) * 2 + ((J) == 6) < PD)                   \
+          ovl_load(ecur, ((2 * t + (KS) - 12) * 2 + ((J) == 6)) & 15);                                                   \
+      }                                                                                                                \
+    }                                                                                                                  \
     else if (need_loads && (t == 6 || t == 7) && ((J) & 1) == 0) epi_load_piece(tcur, ecur, (t - 6) * 8 + (KS) * 4 + ((J) >> 1)); \
   } while (0)
     // first fragments of the tile: tap 0, k-step 0
@@ -526,10 +598,10 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
       // an ordering assumption), otherwise none: the sequential epilogue runs AFTER the barrier, so that its stores drain beside
       // the next tile's first taps instead of being waited for.
       const unsigned long long q0_ = PH4_CLK();
-      if constexpr (!OVL) ecur = epi_ctx(tcur);
+      ecur = epi_ctx(tcur);
       if (half == 0) tile_body(0); else tile_body(1);
       const unsigned long long q1_ = PH4_CLK();
-      if constexpr (OVL) { eprev = epi_ctx(tcur); last_as = half; }
+      if constexpr (OVL) { eprev = ecur; last_as = half; }
       const unsigned long long q2_ = PH4_CLK();
       PH4_WAIT_VMCNT(0);
       if (FUSE_IN && nvalid) {
@@ -551,8 +623,22 @@ __global__ __launch_bounds__(256) void tapconv4_kernel(PhTapConv p) {
   }
 done:
   if constexpr (OVL) {      // the last tile's epilogue has no tap stream to ride in
-    if (last_as == 0) epilogue_seq(tcur, 0, std::integral_constant<int, 0>{});
-    else epilogue_seq(tcur, OVL ? 1 : 0, std::integral_constant<int, 0>{});
+    if constexpr (OPS) {
+      const EpiCtx ec = epi_ctx(tcur);
+#pragma unroll
+      for (int pc = 0; pc < 16; ++pc) epi_load_piece(tcur, ec, pc);
+    }
+    // (distinct markers at both ends of both arms: merged into one body by the optimizer, the two accumulator sets become one
+    // phi of 64 values, which the register coalescer resolves by giving both sets the SAME registers and copying at every tile)
+    if (last_as == 0) {
+      asm volatile("; tail of accumulator set 0" ::: "memory");
+      epilogue_seq(tcur, 0, std::integral_constant<int, ORM>{});
+      asm volatile("; end of tail 0" ::: "memory");
+    } else {
+      asm volatile("; tail of accumulator set 1" ::: "memory");
+      epilogue_seq(tcur, OVL ? 1 : 0, std::integral_constant<int, ORM>{});
+      asm volatile("; end of tail 1" ::: "memory");
+    }
   }
   PH4_TR(0, cy_main); PH4_TR(1, cy_epi); PH4_TR(2, cy_wait); PH4_TR(3, ntile); PH4_TR(4, PH4_CLK() - cy_t0);
 #ifdef PH_TAP_TRACE
@@ -584,10 +670,10 @@ done:
   }
 }
 
-template <bool FUSE_IN, int BST, bool OVL>
+template <bool FUSE_IN, int BST, bool OVL, int ORM = 0>
 int launch4(const PhTapConv& p, hipStream_t st) {
   using C = Tap4Cfg;
-  auto kern = tapconv4_kernel<FUSE_IN, BST, OVL>;
+  auto kern = tapconv4_kernel<FUSE_IN, BST, OVL, ORM>;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
@@ -616,6 +702,11 @@ static int ph_tap4_ovl_switch(int set) {
   return on;
 }
 extern "C" int ph_debug_set_tap4_ovl(int on) { return ph_tap4_ovl_switch(on ? 1 : 0); }
+// A/B switch: PH_TAP4_OVL_OPS=0 = launches whose epilogue reads operands keep it after the tile (the round-5 first form)
+static bool ph_tap4_ovl_ops() {
+  static const bool on = [] { const char* e = getenv("PH_TAP4_OVL_OPS"); return !(e && e[0] == '0'); }();
+  return on && ph_tap4_ovl_switch(-1);
+}
 
 // eligible: 3x3 stride-1 perf-mode configuration with Cin = Cout = 64 and the hard-coded 3x3 tap geometry (every ResNet-18 shape
 // that reached tapconv2_l1_kernel)
@@ -631,10 +722,14 @@ bool ph_tapconv4_eligible(const PhTapConv* p) {
 int ph_tapconv4_launch(const PhTapConv* p, hipStream_t st) {
   if (!ph_tapconv4_eligible(p)) return PH_EINVAL;
   if (p->bst_y) {
-    if (!p->bst_a) return p->bst_y2 ? PH_EINVAL : launch4<false, 1, false>(*p, st);
+    if (!p->bst_a) {
+      if (p->bst_y2) return PH_EINVAL;
+      return (ph_tap4_ovl_ops() && !p->res_g) ? launch4<false, 1, true>(*p, st) : launch4<false, 1, false>(*p, st);
+    }
     return p->bst_y2 ? launch4<false, 3, false>(*p, st) : launch4<false, 2, false>(*p, st);
   }
   // launches whose epilogue reads nothing (forward; dgrad without a residual) store the previous tile inside the next tile's taps
+  if (p->res_g && p->res_a && !p->in_scale && ph_tap4_ovl_ops()) return launch4<false, 0, true, 2>(*p, st);
   if (p->res_g || !ph_tap4_ovl_switch(-1)) return p->in_scale ? launch4<true, 0, false>(*p, st) : launch4<false, 0, false>(*p, st);
   return p->in_scale ? launch4<true, 0, true>(*p, st) : launch4<false, 0, true>(*p, st);
 }

@@ -452,6 +452,53 @@ def test_fused_batchnorm_backward_sums_of_the_dgrad_kernels(case, mode):
     assert err <= 3e-6, err
 
 
+@pytest.mark.parametrize("case", [(128, 64), (128, 20), (40, 12), (24, 40), (16, 3)])
+def test_tapconv4_epilogue_with_operands_inside_the_tile_stream(case):
+    """Round 5: dgrad launches whose epilogue READS (masked residual; fused BatchNorm-backward sums with the own-ReLU mask) also
+    run it inside the next tile's taps, their operands prefetched a few k-steps ahead through a rotating register window (head
+    pieces from the tile's own stream).  Against the same kernel with the epilogue after the tile (ph_debug_set_tap4_ovl(0)):
+    gradients AND sums bitwise (same per-lane accumulation order), on full / partial / ragged tile lists, 1 to 16 tiles per
+    workgroup (the last tile of a workgroup takes the sequential path in both), repeated launches."""
+    from tests.gpu_util import nhwc
+    m, L, ptr, stream, check = _setup()
+    H, B = case
+    C = 64
+    g = torch.Generator().manual_seed(H * 17 + B)
+    dy = nhwc(torch.randn(B, C, H, H, generator=g), torch.bfloat16)
+    wd = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5).cuda()
+    y = nhwc(torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3, torch.bfloat16)
+    res_g = nhwc(torch.randn(B, C, H, H, generator=g), torch.bfloat16)
+    res_a = nhwc(torch.randn(B, C, H, H, generator=g).relu_(), torch.bfloat16)
+    scale = (torch.rand(C, generator=g) + 0.5).cuda(); shift = (torch.randn(C, generator=g) * 0.5).cuda()
+    mean = (torch.randn(C, generator=g) * 0.3 + 0.3).cuda()
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, C, H, H, C, 3, 1, 1) + 3 * 4 * C * 1024, device="cuda", dtype=torch.uint8)
+
+    def run():
+        d_res = torch.full((B, H, H, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+        check(L.ph_conv2d_dgrad_res(ptr(dy), ptr(wd), ptr(d_res), ptr(res_g), ptr(res_a), B, C, H, H, C, 3, 1, 1, 0, ptr(ws), stream()), "dgrad_res")
+        d_bst = torch.full((B, H, H, C), float("nan"), device="cuda", dtype=torch.bfloat16)
+        sums = torch.full((3, C), float("nan"), device="cuda")
+        check(L.ph_conv2d_dgrad_bnstat(ptr(dy), ptr(wd), ptr(d_bst), None, None, ptr(y), None, None, ptr(scale), ptr(shift), ptr(mean),
+                                       None, ptr(sums), B, C, H, H, C, ptr(ws), stream()), "dgrad_bnstat")
+        torch.cuda.synchronize()
+        return d_res, d_bst, sums
+    try:
+        L.ph_debug_set_tap4_ovl(0)
+        seq = run()
+        L.ph_debug_set_tap4_ovl(1)
+        ovl = run()
+        again = run()
+    finally:
+        L.ph_debug_set_tap4_ovl(1)
+    for k, name in enumerate(("dgrad + masked residual", "dgrad under fused sums")):
+        assert torch.isfinite(ovl[k].float()).all(), name
+        assert torch.equal(seq[k].view(torch.int16), ovl[k].view(torch.int16)), name + ": differs from the epilogue after the tile"
+        assert torch.equal(ovl[k].view(torch.int16), again[k].view(torch.int16)), name + ": differs between launches"
+    assert torch.isfinite(ovl[2]).all()
+    assert torch.equal(seq[2], ovl[2]), "fused sums differ from the epilogue after the tile: max |d| = %g" % float((seq[2] - ovl[2]).abs().max())
+    assert torch.equal(ovl[2], again[2])
+
+
 @pytest.mark.parametrize("case", [(128, 64, 64), (128, 32, 64), (40, 12, 64), (64, 24, 64), (64, 20, 128), (24, 40, 256)])
 def test_input_batchnorm_applied_in_lds_equals_the_separate_pass(case):
     """PhTapConv::in_scale at the kernel level (the trunk-level test_fused_input_batchnorm_equals_separate_pass sees it through
