@@ -283,17 +283,18 @@ def variant_setup(name, B, H, device, rank=0, sync=None, generic_head=False):
         bts = [batch(n_data, 4096) for _ in range(2)]
     elif name == "mia2023":
         n_data = 65536
+        nce_k = int(os.environ.get("PH_BENCH_NCE_K", "4096"))      # 65536 = the other reading of configs[4] (SURVEY 8-e assumption (i))
         labels = torch.arange(n_data) % 3
         opt = m.stage2_opt(dropout_rate=0.1, batch_size=B)
-        for k, v in dict(nce_k=4096, nce_p=6, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
+        for k, v in dict(nce_k=nce_k, nce_p=6, pos_extra="neighbors", neg_mode="all_others", start_reweight=0, discrep_scale=1,
                          max_discrep=2.0, use_grads_thresh="True", grads_thresh=0.0, loss_weighting="GK_refine").items():
             setattr(opt, k, v)
         opt.fused_loss_head = not generic_head
         cls = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
         step = m.DistillStep(opt, n_data, device=device, variant="mia2023", train_class_idx=cls, sync=sync)
         desc = ("BASELINE configs[4] single-GPU leg: MIA-2023 stage 2, CRD bank %d rows (full-bank class-masked cosine KNN, "
-                "nce_p 6), nce_k 4096, per-sample GK-Refine" % n_data)
-        bts = [batch(n_data, 4096, labels) for _ in range(2)]
+                "nce_p 6), nce_k %d, per-sample GK-Refine" % (n_data, nce_k))
+        bts = [batch(n_data, nce_k, labels) for _ in range(2)]
     elif name == "tsvd":
         opt = m.stage2_opt(dropout_rate=0.1, batch_size=B, cut_fuse_grad=True, num_teachers=2)
         opt.pred_distill, opt.KD_weight, opt.CRD_distill, opt.SP_distill, opt.orth_loss = 1, 1.0, 0, 0, "False"
@@ -313,12 +314,24 @@ def variant_setup(name, B, H, device, rank=0, sync=None, generic_head=False):
     return step, bts, desc
 
 
-def run_variant(name, B, H, device, L, steps=5):
+def run_variant(name, B, H, device, L, steps=5, nce_k=None):
     """5 steps of one variant with resident inputs (graph replay for the stage-2 bodies), then 2 eager steps under the
-    in-library event timer for the CRD kernels' achieved GB/s.  Returns the `variants[name]` object of the JSON line."""
+    in-library event timer for the CRD kernels' achieved GB/s.  Returns the `variants[name]` object of the JSON line.
+    nce_k (mia2023): the other reading of configs[4] - 65 536 NEGATIVES per query over the 65 536-row bank (SURVEY 8-e
+    assumption (i)); CRDLoss then takes the negatives' terms in bank-scan form (CL_utils/memory_new.py: _crd_core_scan)."""
     import torch
     import multimodal_learning_amd as m
-    step, bts, desc = variant_setup(name, B, H, device)
+    saved = os.environ.get("PH_BENCH_NCE_K")
+    if nce_k is not None:
+        os.environ["PH_BENCH_NCE_K"] = str(nce_k)
+    try:
+        step, bts, desc = variant_setup(name, B, H, device)
+    finally:
+        if nce_k is not None:
+            if saved is None:
+                del os.environ["PH_BENCH_NCE_K"]
+            else:
+                os.environ["PH_BENCH_NCE_K"] = saved
     graph = hasattr(step, "enable_graph")
     if graph:
         step.enable_graph()
@@ -338,6 +351,13 @@ def run_variant(name, B, H, device, L, steps=5):
         res["parity"] = ("adjacency / penalty / mu-schedule and the proximal operator pinned (reference goldens, float64 SVD at 2e-5); "
                          "`update_aux` itself UNPINNED: the reference imports it from my_utils/, which is absent from the repository "
                          "(MIA 2022/train_test_tSVD.py:31) - restated from its call site :382-391")
+    if nce_k is not None:
+        n_rows = 65536
+        res["crd_form"] = ("bank-scan: scores = [B,128] x [128,%d] per bank (2 x %.1f MB of bank rows read once per GEMM), multiplicity "
+                           "weights [B,%d] int32; the gathered kernels would read 2 banks x B x %d rows x 512 B = %.2f GB per pass (same-box "
+                           "A/B PH_CRD_SCAN=0: 14.5 against 12.0 ms per step, profiles/EXPERIMENTS.md round 5)"
+                           % (n_rows, n_rows * 512 / 1e6, n_rows, nce_k, 2.0 * B * nce_k * 512 / 1e9))
+        graph = False      # (no per-kernel table for this leg)
     if graph:
         step._want_graph = False
         step._side_stream = None
@@ -893,6 +913,7 @@ def main():
         torch.cuda.empty_cache()
         variants = {"mia2022": run_variant("mia2022", 64, args.size, device, L),
                     "mia2023": run_variant("mia2023", 64, args.size, device, L),
+                    "mia2023_nce_k_65536": run_variant("mia2023", 64, args.size, device, L, nce_k=65536),
                     "tsvd_stage1": run_variant("tsvd", 128, args.size, device, L)}
 
     trunk = None

@@ -208,6 +208,25 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
                      const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
                      int feat_dim, float n_data, float inv_bnorm, void* workspace /* may be NULL */, ph_stream_t stream);
 size_t ph_crd_loss_grad_workspace_bytes(int B);
+/* Bank-scan form of the CRD negatives: BASELINE configs[4] read as nce_k = 65536 negatives per query (SURVEY 8-e assumption (i);
+ * the reference gathers them: "MIA 2023/stage2_unimodal_student/CL_utils/CRD_criterion_v10.py":68-70,106-107,140-141 index_select +
+ * bmm over [B][K+1][128], and sums their terms in ContrastLoss_v2 :300-306).  With K at or above the number of bank rows the same
+ * sums are taken over ALL rows weighted by multiplicity:
+ *   ph_crd_neg_hist:  mult[b][r] = #{k : idx[b * row_stride + col0 + k] == r}, k < K  (mult [B][n_data] int32, zeroed inside);
+ *   scores S1 = v1 . bank2^T, S2 = v2 . bank1^T ([B][n_data], ph_sgemm);
+ *   ph_crd_scan_neg with zsum_only = 1 (first call of a bank: zsums[0..1] += sum mult exp(S / T), the negatives' share of :146-153's means)
+ *   ph_crd_scan_neg with zsum_only = 0: loss_neg[b] = -inv_bnorm sum_r mult (log(m Pn / (x1 + c)) + log(m Pn / (x2 + c))), x = exp(S / T) / Z,
+ *     and S1, S2 overwritten by d loss / d S = inv_bnorm mult (x / (x + c)) / T, so that dv1 += S1 . bank2, dv2 += S2 . bank1 (ph_sgemm_splitk);
+ *   ph_crd_loss_grad_pos: ph_crd_loss_grad over the P positive columns alone with the NCE constant m Pn of m_neg negatives.
+ * params = the memory module's [K T Z_v1 Z_v2 momentum]; loss_neg [B]; zsums [2]. */
+int ph_crd_neg_hist(const int64_t* idx, long row_stride, int col0, int K, int B, int n_data, int* mult, ph_stream_t stream);
+size_t ph_crd_scan_neg_workspace_bytes(int B, int n_data);
+int ph_crd_scan_neg(float* S1, float* S2, const int* mult, const float* params, void* workspace, float* loss_neg, float* zsums,
+                    int B, int n_data, int m_neg, float inv_bnorm, int zsum_only, ph_stream_t stream);
+int ph_crd_loss_grad_pos(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                         const float* posw_s, const float* posw_t, const float* mem1, const float* mem2, const float* params,
+                         float* lossp, float* dv1, float* dv2, int B, int P, int m_neg, int feat_dim, float n_data, float inv_bnorm,
+                         ph_stream_t stream);
 /* MIA-2023 v10 KNN positives (CRD_criterion_v10.py:72-79,110-116): class-masked full-bank cosine top-num_pos of each
  * query's own bank row, for both banks; labels = class of every bank row (int32 [n_data]) */
 size_t ph_crd_bank_topk_workspace_bytes(int B, int n_data);

@@ -119,6 +119,16 @@ class CRDLoss(nn.Module):
         return sample_loss.sum(0) / bn, sample_loss
 
 
+    @staticmethod
+    def scan_negatives(K, n_data):
+        """Bank-scan form of the negatives when every bank row is drawn about once per query or more (K >= n_data); the gathered
+        kernels otherwise.  PH_CRD_SCAN=0 / 1 forces one form (tests, A/B)."""
+        import os
+        e = os.environ.get("PH_CRD_SCAN")
+        if e in ("0", "1"):
+            return e == "1"
+        return K >= n_data
+
     def neighbor_columns(self, B, D, batch_label, contrast_idx):
         """`pos_extra == "neighbors"` (:72-80, :110-117): the num_pos same-class nearest bank rows of every query in either
         bank (ph_crd_bank_topk) in front of the K sampled negatives.  Sets the memory module up for the fused CRD kernels
@@ -133,11 +143,18 @@ class CRDLoss(nn.Module):
         check(lib().ph_crd_bank_topk(ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(mem.all_sample_labels),
                                      ptr(contrast_idx), K + 1, ptr(batch_label), B, mem.nLem, NP, D, ptr(nb1),
                                      ptr(nb2), ptr(sim1), ptr(sim2), ptr(ws), stream()), "ph_crd_bank_topk")
-        # column lists: [num_pos KNN rows of that bank] + [the K sampled negatives]  (:80, :117)
-        idx1 = torch.cat((nb1, contrast_idx[:, 1:]), 1).contiguous()
-        idx2 = torch.cat((nb2, contrast_idx[:, 1:]), 1).contiguous()
         # out_s = out_v1 comes from bank 2 and is weighted by the bank-2 similarities (:226), and vice versa (:227)
         mem.P, mem.P2, mem.K2 = NP, NP, K
+        if self.scan_negatives(K, mem.nLem):
+            # nce_k at or above the number of bank rows (configs[4] read as 65 536 negatives per query): the negatives' terms are
+            # summed over the whole bank weighted by multiplicity (memory_new._crd_core_scan); only the positives are gathered
+            idx1, idx2 = nb1, nb2
+            mem._scan_neg = dict(idx=contrast_idx, col0=1, K=K)
+        else:
+            # column lists: [num_pos KNN rows of that bank] + [the K sampled negatives]  (:80, :117)
+            idx1 = torch.cat((nb1, contrast_idx[:, 1:]), 1).contiguous()
+            idx2 = torch.cat((nb2, contrast_idx[:, 1:]), 1).contiguous()
+            mem._scan_neg = None
         mem._idx_bank2 = idx2
         mem._posw_s = (sim2 / sim2.sum(1, keepdim=True)).contiguous()
         mem._posw_t = (sim1 / sim1.sum(1, keepdim=True)).contiguous()
@@ -160,6 +177,7 @@ class CRDLoss(nn.Module):
         cols = torch.cat(((n + batch_label).view(B, 1), contrast_idx, n + others), 1).contiguous()
         mem.P, mem.P2, mem.K2 = 2, 2, K + C - 1
         mem._idx_bank2 = None
+        mem._scan_neg = None
         mem._posw_s = mem._posw_t = None                                           # ContrastLoss: 1 / P each
         K_saved = mem.K
         mem.K = K + C - 1                                                          # crd_core reads P + K as the list width

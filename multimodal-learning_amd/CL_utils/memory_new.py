@@ -21,6 +21,10 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None, output
     `outputs_only`: the standalone ContrastMemory_v3.forward - instead of the loss, return (out_v1, out_v2, rows1, rows2):
     the selected scores / Z [B, P2+K2] and the gathered pre-update bank rows its backward needs."""
     v1, v2 = ops._f32(v1), ops._f32(v2)
+    if getattr(mem, "_scan_neg", None) is not None:
+        if outputs_only:
+            raise NotImplementedError("the bank-scan form of the negatives has no [B, P+K] score tensor to return")
+        return _crd_core_scan(v1, v2, mem, y, idx, per_sample, loss_out)
     B, D = v1.shape
     P, K, P2, K2 = mem.P, mem.K, mem.P2, mem.K2
     PK, S2 = P + K, P2 + K2
@@ -87,6 +91,86 @@ def crd_core(v1, v2, mem, y, idx, ranks, per_sample=False, loss_out=None, output
         check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
     _crd_update(mem, y, v1, v2, D)
     mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff)
+    return loss, dv1, dv2
+
+
+def _crd_core_scan(v1, v2, mem, y, idx, per_sample, loss_out):
+    """crd_core with the negatives in bank-scan form (`mem._scan_neg` = dict(idx [B, >= col0 + K] int64, col0, K), set by
+    CRD_criterion_v10.CRDLoss.neighbor_columns when nce_k reaches the number of bank rows - BASELINE configs[4] read as 65 536
+    negatives per query, SURVEY 8-e assumption (i)).  `idx` = the P positive columns only.  Same sums as the gathered kernels
+    (reference CRD_criterion_v10.py:106-153, :300-306), taken over every bank row weighted by its multiplicity among the
+    query's negatives: one read of each bank per GEMM instead of B x K gathered rows."""
+    B, D = v1.shape
+    P, n = mem.P, mem.nLem
+    scan = mem._scan_neg
+    K, col0 = int(scan["K"]), int(scan["col0"])
+    neg = require_cuda(scan["idx"])
+    dev = v1.device
+    idx = require_cuda(idx).contiguous()
+    y = require_cuda(y).contiguous()
+    if idx.dtype != torch.int64 or y.dtype != torch.int64 or idx.shape != (B, P):
+        raise RuntimeError("bank-scan form: the positive columns must be int64 [B, nce_p] and idx int64 [B]")
+    if neg.dtype != torch.int64 or neg.dim() != 2 or neg.shape[0] != B or neg.shape[1] < col0 + K or neg.stride(1) != 1:
+        raise RuntimeError("bank-scan form: the sampled negatives must be int64 [B, >= %d] with unit column stride" % (col0 + K))
+    if mem.select_neg_pairs == "True" or getattr(mem, "select_pos_pairs", False) is True:
+        raise NotImplementedError("bank-scan form with a ranked pair selection (it needs the per-column score list)")
+    L, st = lib(), stream()
+    idx2 = getattr(mem, "_idx_bank2", None)
+    posw_s, posw_t = getattr(mem, "_posw_s", None), getattr(mem, "_posw_t", None)
+    xs = torch.empty(B, P, device=dev, dtype=torch.float32); xt = torch.empty_like(xs); diff = torch.empty_like(xs)
+    check(L.ph_crd_score(ptr(v1), ptr(v2), ptr(idx), ptr(idx2), ptr(mem.memory_v1), ptr(mem.memory_v2), ptr(xs), ptr(xt),
+                         ptr(diff), B, P, D, mem.T, st), "ph_crd_score")
+    sel = torch.arange(P, device=dev, dtype=torch.int32).repeat(B, 1).contiguous()
+    mult = torch.empty(B, n, device=dev, dtype=torch.int32)
+    check(L.ph_crd_neg_hist(ptr(neg), neg.stride(0), col0, K, B, n, ptr(mult), st), "ph_crd_neg_hist")
+    S1 = torch.empty(B, n, device=dev, dtype=torch.float32); S2 = torch.empty_like(S1)
+    ops.sgemm(v1, mem.memory_v2, None, S1, B, n, D, D, 1, 1, D)      # S1[b][r] = v1[b] . bank2[r]  (out_v1, Z_v1, feeds dv1)
+    ops.sgemm(v2, mem.memory_v1, None, S2, B, n, D, D, 1, 1, D)
+    ws = torch.empty(L.ph_crd_scan_neg_workspace_bytes(B, n), device=dev, dtype=torch.uint8)
+    if not mem._z_set:
+        sums = torch.empty(2, device=dev, dtype=torch.float32)
+        check(L.ph_crd_zsum(ptr(xs), ptr(xt), ptr(sums), B * P, st), "ph_crd_zsum")
+        check(L.ph_crd_scan_neg(ptr(S1), ptr(S2), ptr(mult), ptr(mem.params), ptr(ws), None, ptr(sums), B, n, K, 1.0, 1, st),
+              "ph_crd_scan_neg (Z)")
+        count = float(B * (P + K))
+        if mem.sync is not None:
+            count = mem.sync.all_reduce_z(sums, count)
+        check(L.ph_crd_setz(ptr(mem.params), ptr(sums), count, float(n), st), "ph_crd_setz")
+        mem._z_set = True
+        if mem.verbose:
+            z = mem.params[2:4].tolist()
+            print("normalization constant Z_v1 is set to {:.1f}".format(z[0]))
+            print("normalization constant Z_v2 is set to {:.1f}".format(z[1]))
+    bnorm = float(mem.batch_norm_size or B)
+    if getattr(mem, "sample_KD", False):
+        bnorm = 1.0
+    lossn = torch.empty(B, device=dev, dtype=torch.float32)
+    check(L.ph_crd_scan_neg(ptr(S1), ptr(S2), ptr(mult), ptr(mem.params), ptr(ws), ptr(lossn), None, B, n, K, 1.0 / bnorm, 0, st),
+          "ph_crd_scan_neg")
+    lossp = torch.empty(B, device=dev, dtype=torch.float32)
+    dv1 = torch.empty(B, D, device=dev, dtype=torch.float32); dv2 = torch.empty_like(dv1)
+    check(L.ph_crd_loss_grad_pos(ptr(xs), ptr(xt), ptr(sel), ptr(idx), ptr(idx2), ptr(posw_s), ptr(posw_t), ptr(mem.memory_v1),
+                                 ptr(mem.memory_v2), ptr(mem.params), ptr(lossp), ptr(dv1), ptr(dv2), B, P, K, D, float(n),
+                                 1.0 / bnorm, st), "ph_crd_loss_grad_pos")
+    # dv1 += coef1 [B, n] x bank2 [n, D] (split over the rows: fixed-order partial sums), likewise dv2
+    nsplit = 128 if n >= 8192 else (32 if n >= 1024 else 1)
+    part = torch.empty(nsplit * B * D, device=dev, dtype=torch.float32)
+    for coef, bank, dv in ((S1, mem.memory_v2, dv1), (S2, mem.memory_v1, dv2)):
+        dn = torch.empty(B, D, device=dev, dtype=torch.float32)
+        if nsplit > 1:
+            check(L.ph_sgemm_splitk(ptr(coef), ptr(bank), None, ptr(dn), ptr(part), nsplit, B, D, n, n, 1, D, 1, D, ops.ACT_NONE, st),
+                  "ph_sgemm_splitk")
+        else:
+            ops.sgemm(coef, bank, None, dn, B, D, n, n, 1, D, 1)
+        dv.add_(dn)
+    lossp.add_(lossn)
+    if per_sample:
+        loss = lossp
+    else:
+        loss = loss_out if loss_out is not None else torch.empty((), device=dev, dtype=torch.float32)
+        check(L.ph_sum(ptr(lossp), ptr(loss), B, 1.0, st), "ph_sum")
+    _crd_update(mem, y, v1, v2, D)
+    mem.last = dict(sel=sel, xs=xs, xt=xt, diff=diff, mult=mult)
     return loss, dv1, dv2
 
 

@@ -90,6 +90,10 @@ SIGNATURES = {
     "ph_crd_setz": (i32, [vp, vp, f32, f32, vp]),
     "ph_crd_loss_grad_workspace_bytes": (sz, [i32]),
     "ph_crd_loss_grad": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, f32, vp, vp]),
+    "ph_crd_neg_hist": (i32, [vp, lng, i32, i32, i32, i32, vp, vp]),
+    "ph_crd_scan_neg_workspace_bytes": (sz, [i32, i32]),
+    "ph_crd_scan_neg": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]),
+    "ph_crd_loss_grad_pos": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "ph_crd_update": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "ph_crd_outputs": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_crd_outputs_bwd": (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, vp]),

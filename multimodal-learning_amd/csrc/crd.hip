@@ -79,6 +79,15 @@ __global__ __launch_bounds__(1024) void crd_select_kernel(const float* __restric
                                                          int P2, int K2, int select_neg, int select_pos) {
   extern __shared__ __attribute__((aligned(16))) float sd[];   // [P+K] discrepancies, then int rank_to_col[P]
   const int b = blockIdx.x, PK = P + K, S2 = P2 + K2;
+  if (!select_pos && !select_neg) {      // every column in order (vanilla / v10 banks): a copy, no LDS - any list length
+    for (int t = threadIdx.x; t < S2; t += blockDim.x) {
+      const int col = t < P2 ? t : P + (t - P2);
+      sel[(size_t)b * S2 + t] = col;
+      xs[(size_t)b * S2 + t] = out1[(size_t)b * PK + col];
+      xt[(size_t)b * S2 + t] = out2[(size_t)b * PK + col];
+    }
+    return;
+  }
   int* r2c = reinterpret_cast<int*>(sd + PK);
   for (int i = threadIdx.x; i < PK; i += blockDim.x) sd[i] = diff[(size_t)b * PK + i];
   __syncthreads();
@@ -171,14 +180,14 @@ __global__ __launch_bounds__(1024) void crd_loss_grad_kernel(const float* __rest
                                                             const float* __restrict__ mem2,
                                                             const float* __restrict__ params,
                                                             float* __restrict__ lossp, float* __restrict__ dv1,
-                                                            float* __restrict__ dv2, int PK, int P2, int K2,
+                                                            float* __restrict__ dv2, int PK, int P2, int K2, int m_neg,
                                                             float n_data, float inv_bnorm, float* __restrict__ part) {
   // gridDim.y > 1 (long column lists, e.g. nce_k = 4096): the columns of a sample are dealt to gridDim.y workgroups whose
   // partial sums go to `part` and are added in a fixed order by crd_loss_grad_reduce_kernel
   const int b = blockIdx.x, S2 = P2 + K2;
   const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
   const float invT = 1.f / params[1], Z1 = params[2], Z2 = params[3];
-  const float mPn = (float)K2 / n_data, c = mPn + 1e-7f;
+  const float mPn = (float)m_neg / n_data, c = mPn + 1e-7f;      // m = the number of negatives of the loss (= K2 unless they are scanned)
   f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
   float ls = 0.f;
   // 32 half-waves per sample: the loop is a chain of dependent gathers (sel -> idx -> bank row), latency-bound; with 8
@@ -740,6 +749,71 @@ __global__ __launch_bounds__(256) void contrast_loss_v2_kernel(const float* __re
   if (threadIdx.x == 0) rows[b] = -(float)(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+
+// ---- bank-scan form of the negatives (SURVEY 8-e assumption (i): nce_k at or above the number of bank rows).  The gathered
+// kernels read B x K bank rows per bank and call (K = 65 536, B = 64: 4.3 GB); every row of a 65 536-row bank is then drawn ~once
+// per query, so the same sums are taken over ALL rows weighted by how often each was drawn: scores S = V x bank^T (one read of the
+// 33.5 MB bank), mult[b][r] = the multiplicity of row r among query b's negatives,
+//   loss_neg[b] = -sum_r mult log(m Pn / (x + c)),  x = exp(S / T) / Z;   d loss / d S = mult (x / (x + c)) / T.
+__global__ __launch_bounds__(256) void crd_neg_hist_kernel(const int64_t* __restrict__ idx, long row_stride, int K, int n_data,
+                                                          int* __restrict__ mult) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+    const int64_t r = idx[(size_t)b * row_stride + k];
+    atomicAdd(mult + (size_t)b * n_data + r, 1);      // integer counts: order-independent
+  }
+}
+
+constexpr int SCAN_CHUNK = 2048;      // bank rows per workgroup
+// grid (chunks, B): S1 = v1 . bank2^T (pairs with Z_v1, feeds dv1), S2 = v2 . bank1^T; both overwritten by the coefficients
+// d loss / d S (x inv_bnorm) unless zsum_only.  part[(b * chunks + chunk) * 4 + {0,1,2,3}] = loss terms of S1 | of S2 | sum mult e1 | sum mult e2
+__global__ __launch_bounds__(256) void crd_scan_neg_kernel(float* __restrict__ S1, float* __restrict__ S2, const int* __restrict__ mult,
+                                                          const float* __restrict__ params, float* __restrict__ part, int n_data,
+                                                          int m_neg, float inv_bnorm, int zsum_only) {
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const float invT = 1.f / params[1], Z1 = params[2], Z2 = params[3];
+  const float mPn = (float)m_neg / (float)n_data, c = mPn + 1e-7f;
+  double l1 = 0.0, l2 = 0.0, z1 = 0.0, z2 = 0.0;
+  const int r0 = chunk * SCAN_CHUNK, r1 = r0 + SCAN_CHUNK < n_data ? r0 + SCAN_CHUNK : n_data;
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+    const size_t o = (size_t)b * n_data + r;
+    const int mu = mult[o];
+    const float e1 = expf(S1[o] * invT), e2 = expf(S2[o] * invT);
+    if (zsum_only) {
+      z1 += (double)mu * (double)e1; z2 += (double)mu * (double)e2;
+    } else {
+      const float x1 = e1 / Z1, x2 = e2 / Z2, fm = (float)mu;
+      if (mu) { l1 += (double)(fm * logf(mPn / (x1 + c))); l2 += (double)(fm * logf(mPn / (x2 + c))); }
+      S1[o] = fm * (x1 / (x1 + c)) * invT * inv_bnorm;
+      S2[o] = fm * (x2 / (x2 + c)) * invT * inv_bnorm;
+    }
+  }
+  __shared__ double sh[4][4];
+  l1 = wave_sum_d(l1); l2 = wave_sum_d(l2); z1 = wave_sum_d(z1); z2 = wave_sum_d(z2);
+  if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[w][0] = l1; sh[w][1] = l2; sh[w][2] = z1; sh[w][3] = z2; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const double t = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    part[((size_t)b * gridDim.x + chunk) * 4 + threadIdx.x] = (float)t;
+  }
+}
+// fixed-order combine: loss_neg[b] = -(sum over chunks) * inv_bnorm, or (zsum_only) zsums[0..1] += the two exp sums over everything
+__global__ __launch_bounds__(64) void crd_scan_neg_finish_kernel(const float* __restrict__ part, int chunks, int B, float inv_bnorm,
+                                                                float* __restrict__ loss_neg, float* __restrict__ zsums, int zsum_only) {
+  if (zsum_only) {
+    if (threadIdx.x < 2 && blockIdx.x == 0) {
+      double t = 0.0;
+      for (int i = 0; i < B * chunks; ++i) t += (double)part[(size_t)i * 4 + 2 + threadIdx.x];
+      zsums[threadIdx.x] += (float)t;
+    }
+    return;
+  }
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  double t = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) t += (double)part[((size_t)b * chunks + ch) * 4] + (double)part[((size_t)b * chunks + ch) * 4 + 1];
+  loss_neg[b] = -(float)t * inv_bnorm;
+}
 }  // namespace
 
 // workspace: list keys [2][B][TOPK_MAX][nlists] u64 | group maxima [2][B][2 * stiles] | thr [2][B]  (B <= 64 per pass)
@@ -824,8 +898,10 @@ int ph_crd_score(const float* v1, const float* v2, const int64_t* idx, const int
 
 int ph_crd_select(const float* diff, const float* out1, const float* out2, const int* ranks, int* sel, float* xs,
                   float* xt, int B, int P, int K, int P2, int K2, int select_neg, int select_pos, hipStream_t st) {
-  if (P2 > P || K2 > K || (!select_pos && P2 != P)) return PH_EINVAL;
-  const size_t lds = (size_t)(P + K) * 4 + (size_t)P * 4;
+  if (P2 > P || K2 > K || (!select_pos && P2 != P) || (!select_neg && K2 != K)) return PH_EINVAL;
+  const bool ranked = select_pos || select_neg;
+  const size_t lds = ranked ? (size_t)(P + K) * 4 + (size_t)P * 4 : 0;
+  if (lds > 160 * 1024) return PH_EINVAL;      // a ranked selection keeps the sample's discrepancy list in LDS
   // 1024 threads per sample: the rank counting is instruction-bound (P^2 + K^2 comparisons), 256 threads left one wave
   // per SIMD on B of the 256 CUs (76 us at B = 64, P + K = 1000)
   hipLaunchKernelGGL(crd_select_kernel, dim3(B), dim3(1024), lds, st, diff, out1, out2, ranks, sel, xs, xt, P, K, P2,
@@ -847,10 +923,30 @@ int ph_crd_setz(float* params, const float* sums, float count, float n_data, hip
 constexpr int LG_SPLIT_MAX = 8;
 size_t ph_crd_loss_grad_workspace_bytes(int B) { return (size_t)B * LG_SPLIT_MAX * (2 * D + 1) * sizeof(float); }
 
+static int crd_loss_grad_impl(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                              const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
+                              const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2, int m_neg,
+                              int feat_dim, float n_data, float inv_bnorm, void* workspace, hipStream_t st);
 int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
                      const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
                      const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2,
                      int feat_dim, float n_data, float inv_bnorm, void* workspace, hipStream_t st) {
+  return crd_loss_grad_impl(xs, xt, sel, idx, idx_bank2, posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, B, PK, P2, K2, K2,
+                            feat_dim, n_data, inv_bnorm, workspace, st);
+}
+// the positive columns alone, with the NCE constant of m_neg negatives that ph_crd_scan_neg accounts for
+int ph_crd_loss_grad_pos(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                         const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
+                         const float* params, float* lossp, float* dv1, float* dv2, int B, int P, int m_neg,
+                         int feat_dim, float n_data, float inv_bnorm, hipStream_t st) {
+  if (m_neg < 1 || P < 1) return PH_EINVAL;
+  return crd_loss_grad_impl(xs, xt, sel, idx, idx_bank2, posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, B, P, P, 0, m_neg,
+                            feat_dim, n_data, inv_bnorm, nullptr, st);
+}
+static int crd_loss_grad_impl(const float* xs, const float* xt, const int* sel, const int64_t* idx, const int64_t* idx_bank2,
+                              const float* posw_s, const float* posw_t, const float* mem1, const float* mem2,
+                              const float* params, float* lossp, float* dv1, float* dv2, int B, int PK, int P2, int K2, int m_neg,
+                              int feat_dim, float n_data, float inv_bnorm, void* workspace, hipStream_t st) {
   if (feat_dim != D) return PH_EINVAL;
   int ns = workspace ? (P2 + K2) / 512 : 1;     // one workgroup per 512 columns of a sample, at most LG_SPLIT_MAX
   ns = ns < 1 ? 1 : (ns > LG_SPLIT_MAX ? LG_SPLIT_MAX : ns);
@@ -858,7 +954,7 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
   if (ph_prof_on())   // algorithmic bytes: the selected rows of both banks + the two gradient rows per sample
     ph_prof_begin(PH_CLS_CRD_LOSSGRAD, 2.0 * B * (P2 + K2) * D * 4 + 2.0 * B * D * 4 + 2.0 * B * (P2 + K2) * 4, st, &tok);
   hipLaunchKernelGGL(crd_loss_grad_kernel, dim3(B, ns), dim3(1024), 0, st, xs, xt, sel, idx, idx_bank2 ? idx_bank2 : idx,
-                     posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, n_data, inv_bnorm,
+                     posw_s, posw_t, mem1, mem2, params, lossp, dv1, dv2, PK, P2, K2, m_neg, n_data, inv_bnorm,
                      reinterpret_cast<float*>(workspace));
   PH_LAUNCH_CHECK();
   if (ns > 1) {
@@ -867,6 +963,29 @@ int ph_crd_loss_grad(const float* xs, const float* xt, const int* sel, const int
     PH_LAUNCH_CHECK();
   }
   ph_prof_end(tok, st);
+  return PH_OK;
+}
+// ---- bank-scan form of the negatives (kernels above).  idx + col0: the K sampled negatives of query b are idx[b * row_stride + col0 ..]
+int ph_crd_neg_hist(const int64_t* idx, long row_stride, int col0, int K, int B, int n_data, int* mult, hipStream_t st) {
+  if (B < 1 || K < 1 || n_data < 1 || !idx || !mult) return PH_EINVAL;
+  if (hipMemsetAsync(mult, 0, (size_t)B * n_data * sizeof(int), st) != hipSuccess) return PH_ELAUNCH;
+  const int gx = cdiv(K, 256) < 64 ? cdiv(K, 256) : 64;
+  hipLaunchKernelGGL(crd_neg_hist_kernel, dim3(gx, B), dim3(256), 0, st, idx + col0, row_stride, K, n_data, mult);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+size_t ph_crd_scan_neg_workspace_bytes(int B, int n_data) { return (size_t)B * cdiv(n_data, SCAN_CHUNK) * 4 * sizeof(float); }
+int ph_crd_scan_neg(float* S1, float* S2, const int* mult, const float* params, void* workspace, float* loss_neg, float* zsums,
+                    int B, int n_data, int m_neg, float inv_bnorm, int zsum_only, hipStream_t st) {
+  if (B < 1 || n_data < 1 || m_neg < 1 || !workspace || (zsum_only ? !zsums : !loss_neg)) return PH_EINVAL;
+  const int chunks = cdiv(n_data, SCAN_CHUNK);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(crd_scan_neg_kernel, dim3(chunks, B), dim3(256), 0, st, S1, S2, mult, params, part, n_data, m_neg, inv_bnorm,
+                     zsum_only);
+  PH_LAUNCH_CHECK();
+  hipLaunchKernelGGL(crd_scan_neg_finish_kernel, dim3(zsum_only ? 1 : cdiv(B, 64)), dim3(64), 0, st, part, chunks, B, inv_bnorm,
+                     loss_neg, zsums, zsum_only);
+  PH_LAUNCH_CHECK();
   return PH_OK;
 }
 int ph_crd_update(float* mem1, float* mem2, const float* v1, const float* v2, const int64_t* y, const float* params,
