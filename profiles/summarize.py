@@ -11,6 +11,11 @@ reads, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
 import collections
 import csv
 import glob
+
+
+def newest(pattern):
+    """files matching `pattern`, newest first (a second collection into one tag leaves the earlier run's files beside it)"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
 import json
 import os
 import sys
@@ -79,7 +84,7 @@ def main():
                              ("stats_trunk_b256", "_trunk_b256", "python3 bench.py --trunk-only --steps 5 (the north-star's literal quantity: the student's ResNet forward + backward alone at batch 256, one captured HIP graph)"),
                              ("stats_fp16x3", "_fp16x3", "python3 bench.py --precision fp16x3/x1 --serial --steps 5 --warmup 3 ... (the tolerance-compliant arithmetic)"),
                              ("stats_mia2023", "_mia2023", "python3 bench.py --variant mia2023 --steps 5 --warmup 3 --eager (BASELINE configs[4] single-GPU leg: the full-bank KNN kernels)")):
-        f = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
+        f = newest(os.path.join(src, sub, "*", "*kernel_stats.csv"))
         if not f:
             continue
         rows = list(csv.DictReader(open(f[0])))
@@ -92,7 +97,7 @@ def main():
                 o.write(f"{short(r['Name'])[:100]:<100s} {r['Calls']:>6s} {int(r['TotalDurationNs'])/1e6:10.3f} "
                         f"{float(r['AverageNs'])/1e3:10.2f} {float(r['Percentage']):6.2f}\n")
     # ---- SQ counters
-    f = glob.glob(os.path.join(src, "sq", "*", "*counter_collection.csv"))
+    f = newest(os.path.join(src, "sq", "*", "*counter_collection.csv"))
     if f:
         agg, cnt = load_pmc(f[0])
         with open(os.path.join(out, f"{tag}_pmc_sq.txt"), "w") as o:
@@ -117,8 +122,8 @@ def main():
             o.write(f"# all kernels of the profiled steps: MFMA busy {tot_m:.4g} SIMD-cycles / ({tot_b:.4g} / 32 x 1024) = "
                     f"{tot_m / max(tot_b, 1) / 32:.3f} of the matrix-pipe cycles while a kernel runs\n")
     # ---- HBM traffic per launch of the MFMA kernel classes
-    ff = glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))
-    fw = glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))
+    ff = newest(os.path.join(src, "fetch", "*", "*counter_collection.csv"))
+    fw = newest(os.path.join(src, "write", "*", "*counter_collection.csv"))
     if ff and fw:
         fa, fc = load_pmc(ff[0])
         wa, wc = load_pmc(fw[0])
@@ -152,8 +157,8 @@ def main():
         open(os.path.join(out, f"{tag}_traffic.txt"), "w").write(
             "# HBM traffic per launch (FETCH_SIZE x2 correction, WRITE_SIZE exact; separate --pmc passes)\n" + "\n".join(lines) + "\n")
     # ---- the same at batch 256 (the north-star's single-GPU point): profiles/<tag>_b256_traffic.json
-    ff = glob.glob(os.path.join(src, "fetch_b256", "*", "*counter_collection.csv"))
-    fw = glob.glob(os.path.join(src, "write_b256", "*", "*counter_collection.csv"))
+    ff = newest(os.path.join(src, "fetch_b256", "*", "*counter_collection.csv"))
+    fw = newest(os.path.join(src, "write_b256", "*", "*counter_collection.csv"))
     if ff and fw:
         fa, fc = load_pmc(ff[0])
         wa, wc = load_pmc(fw[0])
@@ -174,7 +179,7 @@ def main():
                                "bytes_per_launch": round(rd + ww), "launches_sampled": nf}
         json.dump(traffic, open(os.path.join(out, f"{tag}_b256_traffic.json"), "w"), indent=1)
     # ---- L2 (TCC) view per MFMA kernel class: hit rate and fabric read requests
-    ft = glob.glob(os.path.join(src, "tcc", "*", "*counter_collection.csv"))
+    ft = newest(os.path.join(src, "tcc", "*", "*counter_collection.csv"))
     if ft:
         ta, tc = load_pmc(ft[0])
         per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -196,8 +201,8 @@ def main():
     # ---- CRD kernels of the variant steps (bench.py --variant mia2022 / mia2023): counter bytes per CALL of each kernel family
     crd = {}
     for var in ("mia2022", "mia2023"):
-        ff = glob.glob(os.path.join(src, f"fetch_{var}", "*", "*counter_collection.csv"))
-        fw = glob.glob(os.path.join(src, f"write_{var}", "*", "*counter_collection.csv"))
+        ff = newest(os.path.join(src, f"fetch_{var}", "*", "*counter_collection.csv"))
+        fw = newest(os.path.join(src, f"write_{var}", "*", "*counter_collection.csv"))
         if not (ff and fw):
             continue
         fa, fc = load_pmc(ff[0])
