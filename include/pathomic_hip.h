@@ -178,6 +178,12 @@ int ph_counter_inc(uint64_t* counter, ph_stream_t stream);
  * ph_outer. */
 int ph_dropout_bwd_dev(float* g, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_counter,
                        int alpha, ph_stream_t stream);
+/* the same two out of place (dst = f(src); src == dst allowed): one launch per dropout site instead of a copy + an in-place
+ * launch on the latency-bound head chains of the step */
+int ph_dropout_dev_to(const float* src, float* dst, size_t n, float p, uint64_t seed, uint64_t site_offset,
+                      const uint64_t* step_counter, int alpha, ph_stream_t stream);
+int ph_dropout_bwd_dev_to(const float* src, float* dst, size_t n, float p, uint64_t seed, uint64_t site_offset,
+                          const uint64_t* step_counter, int alpha, ph_stream_t stream);
 int ph_gate_bwd(const float* g, const float* z, const float* h, float* dz, float* dh, size_t n, ph_stream_t stream);
 int ph_outer_bwd(const float* g, const float* o1, const float* o2, float* do1, float* do2, int B, int D1, int D2,
                  int append_one, ph_stream_t stream);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "ph_counter_inc": (i32, [vp, vp]),
     "ph_sum": (i32, [vp, vp, i32, f32, vp]),
     "ph_dropout_bwd_dev": (i32, [vp, sz, f32, u64, u64, vp, i32, vp]),
+    "ph_dropout_dev_to": (i32, [vp, vp, sz, f32, u64, u64, vp, i32, vp]),
+    "ph_dropout_bwd_dev_to": (i32, [vp, vp, sz, f32, u64, u64, vp, i32, vp]),
     "ph_gate_bwd": (i32, [vp, vp, vp, vp, vp, sz, vp]),
     "ph_outer_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "ph_contrast_sampler": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, u64, vp, vp, vp]),

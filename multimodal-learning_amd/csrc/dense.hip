@@ -646,18 +646,20 @@ __global__ void dropout_kernel(float* __restrict__ x, size_t n, float p, uint64_
 // graph-replayable variant: the per-step part of the RNG counter lives in device memory
 // backward of the (alpha-)dropout applied by dropout_dev_kernel with the same (seed, site_offset, step counter):
 // g <- g * d(out)/d(in)   (plain: keep / (1-p); alpha: a * keep)
-__global__ void dropout_bwd_dev_kernel(float* __restrict__ g, size_t n, float p, uint64_t seed, uint64_t site_offset,
+// (src may be dst: in place)
+__global__ void dropout_bwd_dev_kernel(const float* src, float* g, size_t n, float p, uint64_t seed, uint64_t site_offset,
                                        const uint64_t* __restrict__ step_ctr, int alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t ctr = (*step_ctr << 34) ^ (site_offset + i);
   const bool keep = u01(seed, ctr) >= p;
+  const float v = src[i];
   if (!alpha) {
-    g[i] = keep ? g[i] / (1.f - p) : 0.f;
+    g[i] = keep ? v / (1.f - p) : 0.f;
   } else {
     const float ap = -1.7580993408473766f;
     const float a = rsqrtf((1.f - p) * (1.f + p * ap * ap));
-    g[i] = keep ? a * g[i] : 0.f;
+    g[i] = keep ? a * v : 0.f;
   }
 }
 
@@ -690,19 +692,21 @@ __global__ __launch_bounds__(256) void outer_bwd_kernel(const float* __restrict_
   }
 }
 
-__global__ void dropout_dev_kernel(float* __restrict__ x, size_t n, float p, uint64_t seed, uint64_t site_offset,
+// (src may be x: in place)
+__global__ void dropout_dev_kernel(const float* src, float* x, size_t n, float p, uint64_t seed, uint64_t site_offset,
                                    const uint64_t* __restrict__ step_ctr, int alpha) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t ctr = (*step_ctr << 34) ^ (site_offset + i);
   const bool keep = u01(seed, ctr) >= p;
+  const float v = src[i];
   if (!alpha) {
-    x[i] = keep ? x[i] / (1.f - p) : 0.f;
+    x[i] = keep ? v / (1.f - p) : 0.f;
   } else {
     const float ap = -1.7580993408473766f;
     const float a = rsqrtf((1.f - p) * (1.f + p * ap * ap));
     const float b = -a * ap * p;
-    x[i] = a * (keep ? x[i] : ap) + b;
+    x[i] = a * (keep ? v : ap) + b;
   }
 }
 __global__ void counter_inc_kernel(uint64_t* c) {
@@ -875,14 +879,31 @@ int ph_dropout(float* x, size_t n, float p, uint64_t seed, uint64_t offset, int 
 int ph_dropout_dev(float* x, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_ctr, int alpha,
                    hipStream_t st) {
   if (p <= 0.f) return PH_OK;
-  hipLaunchKernelGGL(dropout_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, x, n, p, seed, site_offset, step_ctr, alpha);
+  hipLaunchKernelGGL(dropout_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, x, x, n, p, seed, site_offset, step_ctr, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+// out of place (one launch instead of a copy + an in-place launch on the latency-bound head chains); p <= 0 copies
+int ph_dropout_dev_to(const float* src, float* dst, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_ctr,
+                      int alpha, hipStream_t st) {
+  if (!src || !dst) return PH_EINVAL;
+  if (p <= 0.f) return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? PH_OK : PH_ELAUNCH;
+  hipLaunchKernelGGL(dropout_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, src, dst, n, p, seed, site_offset, step_ctr, alpha);
+  PH_LAUNCH_CHECK();
+  return PH_OK;
+}
+int ph_dropout_bwd_dev_to(const float* src, float* dst, size_t n, float p, uint64_t seed, uint64_t site_offset,
+                          const uint64_t* step_ctr, int alpha, hipStream_t st) {
+  if (!src || !dst) return PH_EINVAL;
+  if (p <= 0.f) return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? PH_OK : PH_ELAUNCH;
+  hipLaunchKernelGGL(dropout_bwd_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, src, dst, n, p, seed, site_offset, step_ctr, alpha);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
 int ph_dropout_bwd_dev(float* g, size_t n, float p, uint64_t seed, uint64_t site_offset, const uint64_t* step_ctr,
                        int alpha, hipStream_t st) {
   if (p <= 0.f) return PH_OK;
-  hipLaunchKernelGGL(dropout_bwd_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, g, n, p, seed, site_offset, step_ctr, alpha);
+  hipLaunchKernelGGL(dropout_bwd_dev_kernel, dim3(nblk(n)), dim3(256), 0, st, g, g, n, p, seed, site_offset, step_ctr, alpha);
   PH_LAUNCH_CHECK();
   return PH_OK;
 }

@@ -219,7 +219,7 @@ class PathomicNet(nn.Module):
         if self.fusion_type == "concat":
             raise NotImplementedError("fusion_type concat is not on the hot path (default pofusion)")
         if self.cut_fuse_grad:
-            features = self.fusion(path_vec.clone().detach(), omic_vec.clone().detach())   # :302-306
+            features = self.fusion(path_vec.detach(), omic_vec.detach())   # :302-306 (no copy: the fusion never writes its inputs)
         else:
             features = self.fusion(path_vec, omic_vec)
         hazard = ops.LinearFn.apply(features, self.classifier[0].weight, self.classifier[0].bias)

@@ -189,9 +189,10 @@ class DropoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, p, seed, site_offset, step_counter, alpha):
-        y = _f32(x).clone()
-        check(lib().ph_dropout_dev(ptr(y), y.numel(), p, seed, site_offset, ptr(step_counter), int(alpha), stream()),
-              "ph_dropout_dev")
+        x = _f32(x)
+        y = torch.empty_like(x)
+        check(lib().ph_dropout_dev_to(ptr(x), ptr(y), y.numel(), p, seed, site_offset, ptr(step_counter), int(alpha), stream()),
+              "ph_dropout_dev_to")
         if ctx.needs_input_grad[0]:      # (the frozen teacher's dropouts never run a backward: no 8-byte copy kernel for them)
             ctx.save_for_backward(step_counter.clone())
         ctx.args = (p, seed, site_offset, int(alpha))
@@ -201,9 +202,10 @@ class DropoutFn(torch.autograd.Function):
     def backward(ctx, g):
         (ctr,) = ctx.saved_tensors
         p, seed, site_offset, alpha = ctx.args
-        d = _f32(g).clone()
-        check(lib().ph_dropout_bwd_dev(ptr(d), d.numel(), p, seed, site_offset, ptr(ctr), alpha, stream()),
-              "ph_dropout_bwd_dev")
+        g = _f32(g)
+        d = torch.empty_like(g)
+        check(lib().ph_dropout_bwd_dev_to(ptr(g), ptr(d), d.numel(), p, seed, site_offset, ptr(ctr), alpha, stream()),
+              "ph_dropout_bwd_dev_to")
         return d, None, None, None, None, None
 
 
