@@ -218,7 +218,7 @@ size_t ph_crd_loss_grad_workspace_bytes(int B);
  * the reference gathers them: "MIA 2023/stage2_unimodal_student/CL_utils/CRD_criterion_v10.py":68-70,106-107,140-141 index_select +
  * bmm over [B][K+1][128], and sums their terms in ContrastLoss_v2 :300-306).  With K at or above the number of bank rows the same
  * sums are taken over ALL rows weighted by multiplicity:
- *   ph_crd_neg_hist:  mult[b][r] = #{k : idx[b * row_stride + col0 + k] == r}, k < K  (mult [B][n_data] int32, zeroed inside);
+ *   ph_crd_neg_hist:  mult[b][r] = #{k : idx[b * row_stride + col0 + k] == r}, k < K  (mult [B][n_data] int32, every element written);
  *   scores S1 = v1 . bank2^T, S2 = v2 . bank1^T ([B][n_data], ph_sgemm);
  *   ph_crd_scan_neg with zsum_only = 1 (first call of a bank: zsums[0..1] += sum mult exp(S / T), the negatives' share of :146-153's means)
  *   ph_crd_scan_neg with zsum_only = 0: loss_neg[b] = -inv_bnorm sum_r mult (log(m Pn / (x1 + c)) + log(m Pn / (x2 + c))), x = exp(S / T) / Z,
