@@ -156,3 +156,17 @@ def test_host_logic_under_asan(tmp_path):
     r = subprocess.run([sys.executable, str(script), lib], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ASAN-CHILD-OK" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_crd_v10_picks_the_bank_scan_form_from_the_list_length(monkeypatch):
+    """CRD_criterion_v10.CRDLoss.scan_negatives: bank-scan form of the negatives when nce_k reaches the number of bank rows
+    (BASELINE configs[4] read as 65 536 negatives per query), the gathered kernels below; PH_CRD_SCAN forces either."""
+    from multimodal_learning_amd.CL_utils.CRD_criterion_v10 import CRDLoss
+    monkeypatch.delenv("PH_CRD_SCAN", raising=False)
+    assert CRDLoss.scan_negatives(65536, 65536) and CRDLoss.scan_negatives(70000, 65536)
+    assert not CRDLoss.scan_negatives(4096, 65536)
+    monkeypatch.setenv("PH_CRD_SCAN", "1")
+    assert CRDLoss.scan_negatives(16, 65536)
+    monkeypatch.setenv("PH_CRD_SCAN", "0")
+    assert not CRDLoss.scan_negatives(65536, 1024)
+
