@@ -1,6 +1,6 @@
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-/usr/bin/time -v python bench.py > gpurun_out/final_bench.log 2> gpurun_out/final_bench.err
-grep "Elapsed" gpurun_out/final_bench.err
+T0=$(date +%s); python bench.py > gpurun_out/final_bench.log 2> gpurun_out/final_bench.err; echo "Elapsed $(( $(date +%s) - T0 )) s"
+
 tail -1 gpurun_out/final_bench.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
