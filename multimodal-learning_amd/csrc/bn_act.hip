@@ -3,6 +3,7 @@
 // (resnets.py:150), AdaptiveAvgPool2d (resnets.py:158,234-236).  Activations are NHWC of type T
 // (bf16 in perf mode, float in parity mode); statistics are always fp32 with fp64 combination.
 #include "ph_common.h"
+#include <cstdlib>
 #include "ph_kernels.h"
 
 namespace {
@@ -99,42 +100,75 @@ __global__ void bn_apply_kernel(const TY* __restrict__ y, const float* __restric
                                 const TY* __restrict__ y_r, const float* __restrict__ scale_r,
                                 const float* __restrict__ shift_r, T* __restrict__ out, TY* __restrict__ out32, size_t n8,
                                 int C8, int relu, int res_as_t) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n8) return;
-  const int c = (int)(i % C8) * 8;
-  float v[8], r[8];
-  load8(y + i * 8, v);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = v[k] * scale[c + k] + shift[c + k];
-  if (res) {
-    // res_as_t (PH_PREC_FP16X3, forward-only networks): the shortcut term is read from the half-pair operand image of the
-    // block input (hi + lo 2^-11: 22-23 significant bits) - those networks then keep no fp32 copy of their block outputs
-    if (!std::is_same<T, TY>::value && res_as_t) load8(reinterpret_cast<const T*>(res) + i * 8, r);
-    else load8(res + i * 8, r);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] += r[k];
-  } else if (y_r) {
-    load8(y_r + i * 8, r);
-    if (relu & 2) {
-      // the shortcut is relu(bn(y_r)) (the stem's pooled RAW output feeding layer1.0, forward-only networks): rounded to the
-      // activation type exactly as the separate pass that used to materialise it did, so the sum is bitwise the same
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float t = r[k] * scale_r[c + k] + shift_r[c + k];
-        if constexpr (is_hp<T>::value) v[k] += (t > 0.f ? t : 0.f);
-        else v[k] += (float)(T)(t > 0.f ? t : 0.f);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += r[k] * scale_r[c + k] + shift_r[c + k];
+  // grid-stride loop: the stride (gridDim.x * 256 elements) is a multiple of C8, so a thread keeps its channel group and its
+  // per-channel constants stay in registers (one element per thread spent 4-8 sixteen-byte parameter loads per 16-byte data
+  // load); the next element's operands are requested before the current one is computed (with the constants hoisted but no
+  // prefetch the first data load waited behind the parameter loads: two memory round trips per thread, 25 % slower steps)
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= n8) return;
+  const size_t gstride = (size_t)gridDim.x * blockDim.x;
+  const int c = (int)(i0 % C8) * 8;
+  const bool use_res = res != nullptr, use_yr = !use_res && y_r != nullptr;
+  auto fetch = [&](size_t i, float (&v)[8], float (&r)[8]) {
+    load8(y + i * 8, v);
+    if (use_res) {
+      // res_as_t (PH_PREC_FP16X3, forward-only networks): the shortcut term is read from the half-pair operand image of the
+      // block input (hi + lo 2^-11: 22-23 significant bits) - those networks then keep no fp32 copy of their block outputs
+      if (!std::is_same<T, TY>::value && res_as_t) load8(reinterpret_cast<const T*>(res) + i * 8, r);
+      else load8(res + i * 8, r);
+    } else if (use_yr) {
+      load8(y_r + i * 8, r);
     }
-  }
-  if (relu & 1) {
+  };
+  float v[8], r[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+  for (int k = 0; k < 8; ++k) r[k] = 0.f;
+  fetch(i0, v, r);
+  // (explicit 16-byte loads: written as eight indexed reads the hoisted constants became 32 single-dword loads per thread)
+  float sc8[8], sh8[8], scr8[8], shr8[8];
+  load8(scale + c, sc8);
+  load8(shift + c, sh8);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { scr8[k] = 0.f; shr8[k] = 0.f; }
+  if (use_yr) { load8(scale_r + c, scr8); load8(shift_r + c, shr8); }
+  for (size_t i = i0;;) {
+    const size_t inext = i + gstride;
+    const bool more = inext < n8;
+    float vn[8], rn[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { vn[k] = 0.f; rn[k] = 0.f; }
+    if (more) fetch(inext, vn, rn);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_fmaf(v[k], sc8[k], sh8[k]);      // (explicit: the in-LDS form of the tap-conv kernels must round alike)
+    if (use_res) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    } else if (use_yr) {
+      if (relu & 2) {
+        // the shortcut is relu(bn(y_r)) (the stem's pooled RAW output feeding layer1.0, forward-only networks): rounded to the
+        // activation type exactly as the separate pass that used to materialise it did, so the sum is bitwise the same
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float t = __builtin_fmaf(r[k], scr8[k], shr8[k]);
+          if constexpr (is_hp<T>::value) v[k] += (t > 0.f ? t : 0.f);
+          else v[k] += (float)(T)(t > 0.f ? t : 0.f);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += r[k] * scr8[k] + shr8[k];
+      }
+    }
+    if (relu & 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+    }
+    store8(out + i * 8, v);
+    if constexpr (!std::is_same<T, TY>::value) { if (out32) store8(out32 + i * 8, v); }
+    if (!more) break;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = vn[k]; r[k] = rn[k]; }
+    i = inext;
   }
-  store8(out + i * 8, v);
-  if constexpr (!std::is_same<T, TY>::value) { if (out32) store8(out32 + i * 8, v); }
 }
 
 // stem: relu(bn(y0)) -> maxpool 3x3/2 pad 1; argmax position code (kh*3+kw, first max wins) saved as u8
@@ -246,6 +280,22 @@ struct DzPlain {
   // relu(y * scale + shift)) is a function of y, which the kernels read anyway - the activation tensor `a` is then not
   // read at all (2 of the 6 / 8 bytes per element of the reduce / apply pass)
   const float* mscale; const float* mshift;
+  // the same in two phases for the prefetching apply pass: raw loads now, the mask when the element is consumed
+  __device__ __forceinline__ void fetch(size_t i8, float (&dz)[8], float (&yy)[8], float (&m)[8]) const {
+    load8(g + i8 * 8, dz);
+    load8(y + i8 * 8, yy);
+    if (a) load8(a + i8 * 8, m);
+  }
+  __device__ __forceinline__ void mask(const float (&ms8)[8], const float (&mh8)[8], float (&dz)[8], const float (&yy)[8],
+                                       const float (&m)[8]) const {
+    if (a) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = m[k] > 0.f ? dz[k] : 0.f;
+    } else if (mscale) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dz[k] = __builtin_fmaf(yy[k], ms8[k], mh8[k]) > 0.f ? dz[k] : 0.f;      // (as the forward's a1)
+    }
+  }
   __device__ __forceinline__ void get(size_t i8, int c, float (&dz)[8], float (&yy)[8]) const {
     load8(g + i8 * 8, dz);
     load8(y + i8 * 8, yy);
@@ -256,7 +306,7 @@ struct DzPlain {
       for (int k = 0; k < 8; ++k) dz[k] = m[k] > 0.f ? dz[k] : 0.f;
     } else if (mscale) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dz[k] = (yy[k] * mscale[c + k] + mshift[c + k]) > 0.f ? dz[k] : 0.f;
+      for (int k = 0; k < 8; ++k) dz[k] = __builtin_fmaf(yy[k], mscale[c + k], mshift[c + k]) > 0.f ? dz[k] : 0.f;
     }
   }
 };
@@ -368,19 +418,40 @@ __global__ void bn_bwd_apply_kernel(Src src, const float* __restrict__ mean, con
                                     const float* __restrict__ gamma, const float* __restrict__ c1,
                                     const float* __restrict__ c2, T* __restrict__ dy, size_t n8, int C8,
                                     const float* __restrict__ dzs) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n8) return;
-  const int c = (int)(i % C8) * 8;
-  float dz[8], yy[8];
-  src.get(i, c, dz, yy);
-  const float sc = dzs ? dzs[0] : 1.f;      // power of two (bn_bwd_finalize_kernel): the product is exact
+  // grid-stride loop with the per-channel constants in registers and the next element's operands prefetched (see bn_apply_kernel)
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= n8) return;
+  const size_t gstride = (size_t)gridDim.x * blockDim.x;
+  const int c = (int)(i0 % C8) * 8;
+  float dz[8], yy[8], mm[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float is = invstd[c + k];
-    const float xh = (yy[k] - mean[c + k]) * is;
-    dz[k] = gamma[c + k] * is * (dz[k] - c1[c + k] - xh * c2[c + k]) * sc;
+  for (int k = 0; k < 8; ++k) mm[k] = 0.f;
+  src.fetch(i0, dz, yy, mm);
+  const float sc = dzs ? dzs[0] : 1.f;      // power of two (bn_bwd_finalize_kernel): the product is exact
+  float is8[8], mu8[8], gi8[8], c18[8], c28[8], ms8[8], mh8[8];
+  load8(invstd + c, is8); load8(mean + c, mu8); load8(gamma + c, gi8); load8(c1 + c, c18); load8(c2 + c, c28);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { gi8[k] = gi8[k] * is8[k]; ms8[k] = 0.f; mh8[k] = 0.f; }
+  if (!src.a && src.mscale) { load8(src.mscale + c, ms8); load8(src.mshift + c, mh8); }
+  for (size_t i = i0;;) {
+    const size_t inext = i + gstride;
+    const bool more = inext < n8;
+    float dzn[8], yyn[8], mn[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dzn[k] = 0.f; yyn[k] = 0.f; mn[k] = 0.f; }
+    if (more) src.fetch(inext, dzn, yyn, mn);
+    src.mask(ms8, mh8, dz, yy, mm);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (yy[k] - mu8[k]) * is8[k];
+      dz[k] = gi8[k] * (dz[k] - c18[k] - xh * c28[k]) * sc;
+    }
+    store8(dy + i * 8, dz);
+    if (!more) break;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dz[k] = dzn[k]; yy[k] = yyn[k]; mm[k] = mn[k]; }
+    i = inext;
   }
-  store8(dy + i * 8, dz);
 }
 
 // ---- stem (C = 64): max-pool backward + ReLU mask + BN backward with the image geometry on the grid - a block walks
@@ -595,6 +666,15 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_raw_kernel(const T* __res
 }
 
 inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+// blocks of the grid-stride elementwise passes: ~PH_EW_ITEMS eight-channel vectors per thread once the tensor is large enough to
+// fill the chip anyway (>= 2048 blocks = one wave of 8 blocks per CU); A/B: PH_EW_ITEMS=1 restores one element per thread
+inline unsigned ew_grid(size_t n8) {
+  static const int items = [] { const char* e = getenv("PH_EW_ITEMS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+  const size_t b = (n8 + 255) / 256;
+  if (b <= 2048) return (unsigned)b;
+  const size_t g = (b + items - 1) / items;
+  return (unsigned)(g < 2048 ? 2048 : g);
+}
 
 }  // namespace
 
@@ -644,7 +724,7 @@ int ph_bn_apply_launch2(const void* y, const float* scale, const float* shift, c
   if (ph_prof_on())
     ph_prof_begin(PH_CLS_BN_APPLY, (double)npix * C * (prec == PH_PREC_BF16 ? 2.0 : 4.0) * ((res || y_r) ? 3.0 : 2.0), st, &tok);
 #define PH_CALL(T, TY)                                                                                              \
-  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(nblk(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const TY*)res, \
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(ew_grid(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const TY*)res, \
                      (const TY*)y_r, scale_r, shift_r, (T*)out, (TY*)out32, n8, C / 8, relu, res_as_t)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
@@ -747,7 +827,7 @@ int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const fl
 #define PH_CALL(T, TY)                                                                                                       \
   do {                                                                                                                       \
     DzPlain<T, TY> s{(const TY*)g, (const TY*)a, (const TY*)y, mscale, mshift};                                              \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DzPlain<T, TY>>), dim3(nblk(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DzPlain<T, TY>>), dim3(ew_grid(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, \
                        (T*)dy, n8, C / 8, dzs);                                                                              \
   } while (0)
   PH_DISPATCH(prec, PH_CALL);
