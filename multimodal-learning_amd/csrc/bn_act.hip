@@ -325,17 +325,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(Src src, const float
   const int c = cg * 8;
   float mu[8], is[8], s1[8], s2[8], am = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { mu[k] = mean[c + k]; is[k] = invstd[c + k]; s1[k] = 0.f; s2[k] = 0.f; }
+  for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  load8(mean + c, mu); load8(invstd + c, is);
   const size_t per = (npix + gridDim.x - 1) / gridDim.x;
   const size_t p0 = (size_t)blockIdx.x * per, p1 = min(npix, p0 + per);
-  for (size_t p = p0 + pl; p < p1; p += npl) {
-    float dz[8], yy[8];
-    src.get(p * C8 + cg, c, dz, yy);
+  // the mask's per-channel constants in registers, the next pixel's operands requested before this one is accumulated (as the
+  // apply passes: one dependent memory round trip per iteration otherwise)
+  float ms8[8], mh8[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      s1[k] += dz[k];
-      s2[k] += dz[k] * (yy[k] - mu[k]) * is[k];
-      am = fmaxf(am, fabsf(dz[k]));
+  for (int k = 0; k < 8; ++k) { ms8[k] = 0.f; mh8[k] = 0.f; }
+  if (!src.a && src.mscale) { load8(src.mscale + c, ms8); load8(src.mshift + c, mh8); }
+  size_t p = p0 + pl;
+  if (p < p1) {
+    float dz[8], yy[8], mm[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mm[k] = 0.f;
+    src.fetch(p * C8 + cg, dz, yy, mm);
+    for (;;) {
+      const size_t pn = p + npl;
+      const bool more = pn < p1;
+      float dzn[8], yyn[8], mn[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dzn[k] = 0.f; yyn[k] = 0.f; mn[k] = 0.f; }
+      if (more) src.fetch(pn * C8 + cg, dzn, yyn, mn);
+      src.mask(ms8, mh8, dz, yy, mm);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        s1[k] += dz[k];
+        s2[k] += dz[k] * (yy[k] - mu[k]) * is[k];
+        am = fmaxf(am, fabsf(dz[k]));
+      }
+      if (!more) break;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { dz[k] = dzn[k]; yy[k] = yyn[k]; mm[k] = mn[k]; }
+      p = pn;
     }
   }
   __shared__ float sh[2][256][9];
