@@ -189,8 +189,24 @@ __global__ void bn_relu_maxpool_kernel(const TY* __restrict__ y, const float* __
   const int c = cg * 8;
   float sc[8], sh[8], best[8], braw[8];
   int bi[8];
+  load8(scale + c, sc);
+  load8(shift + c, sh);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { sc[k] = scale[c + k]; sh[k] = shift[c + k]; best[k] = -INFINITY; bi[k] = 0; braw[k] = 0.f; }
+  for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = 0; braw[k] = 0.f; }
+  // all nine window loads are requested unconditionally (coordinates clamped into the image, out-of-image taps skipped when
+  // they are consumed): behind a branch per tap every load was its own memory round trip
+  float win[9][8];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh * 2 - 1 + kh;
+    const int ihc = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow * 2 - 1 + kw;
+      const int iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+      load8(y + ((((size_t)b * H + ihc) * W + iwc) * C8 + cg) * 8, win[kh * 3 + kw]);
+    }
+  }
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int ih = oh * 2 - 1 + kh;
@@ -199,8 +215,7 @@ __global__ void bn_relu_maxpool_kernel(const TY* __restrict__ y, const float* __
     for (int kw = 0; kw < 3; ++kw) {
       const int iw = ow * 2 - 1 + kw;
       if (iw < 0 || iw >= W) continue;
-      float v[8];
-      load8(y + ((((size_t)b * H + ih) * W + iw) * C8 + cg) * 8, v);
+      const float (&v)[8] = win[kh * 3 + kw];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         // (perf mode pools the unrounded activation and rounds the maximum once on store: rounding is monotone, so
