@@ -706,7 +706,8 @@ __global__ __launch_bounds__(256) void stem_bwd_reduce_raw_kernel(const T* __res
 inline unsigned nblk(size_t n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 // blocks of the grid-stride elementwise passes: ~PH_EW_ITEMS eight-channel vectors per thread once the tensor is large enough to
 // fill the chip anyway (>= 2048 blocks = one wave of 8 blocks per CU); A/B: PH_EW_ITEMS=1 restores one element per thread
-inline unsigned ew_grid(size_t n8) {
+inline unsigned ew_grid(size_t n8, int C8) {
+  if (C8 <= 0 || 256 % C8) return (unsigned)((n8 + 255) / 256);      // (a thread keeps its channel group only if C / 8 divides the stride)
   static const int items = [] { const char* e = getenv("PH_EW_ITEMS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
   const size_t b = (n8 + 255) / 256;
   if (b <= 2048) return (unsigned)b;
@@ -762,7 +763,7 @@ int ph_bn_apply_launch2(const void* y, const float* scale, const float* shift, c
   if (ph_prof_on())
     ph_prof_begin(PH_CLS_BN_APPLY, (double)npix * C * (prec == PH_PREC_BF16 ? 2.0 : 4.0) * ((res || y_r) ? 3.0 : 2.0), st, &tok);
 #define PH_CALL(T, TY)                                                                                              \
-  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(ew_grid(n8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const TY*)res, \
+  hipLaunchKernelGGL((bn_apply_kernel<T, TY>), dim3(ew_grid(n8, C / 8)), dim3(256), 0, st, (const TY*)y, scale, shift, (const TY*)res, \
                      (const TY*)y_r, scale_r, shift_r, (T*)out, (TY*)out32, n8, C / 8, relu, res_as_t)
   PH_DISPATCH(prec, PH_CALL);
 #undef PH_CALL
@@ -865,7 +866,7 @@ int ph_bn_bwd_apply_launch(const void* g, const void* a, const void* y, const fl
 #define PH_CALL(T, TY)                                                                                                       \
   do {                                                                                                                       \
     DzPlain<T, TY> s{(const TY*)g, (const TY*)a, (const TY*)y, mscale, mshift};                                              \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DzPlain<T, TY>>), dim3(ew_grid(n8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DzPlain<T, TY>>), dim3(ew_grid(n8, C / 8)), dim3(256), 0, st, s, mean, invstd, gamma, c1, c2, \
                        (T*)dy, n8, C / 8, dzs);                                                                              \
   } while (0)
   PH_DISPATCH(prec, PH_CALL);
