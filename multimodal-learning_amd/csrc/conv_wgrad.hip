@@ -152,6 +152,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
     }
   };
 
+  // ---- the same MFMA stream with the fragment reads issued THREE taps ahead of the MFMA that consumes them (perf mode, 3 x 3
+  // stride 1: the 13 large launches of a step).  compute() above leaves the order to the compiler, which reads a tap's fragments
+  // right in front of its MFMA and relies on a second wave of the SIMD to cover the latency - in the step the kernel runs one
+  // workgroup per CU beside the BatchNorm-backward passes and 60 % of its time was exposed (skip-ablation: -0.86 ms per step).
+  // Every fragment address is one of five per-lane base registers + an immediate: halo pixel h = 18 kk + u + toff (u = 8 khalf +
+  // q4, + 4 for the second row group), swizzle bit = bit 1 of h = (kk & 1) ^ bit1(toff) ^ bit1(u) ^ (bit0(u) & bit0(toff)).
+  constexpr bool PIPE = !SPLIT && !HPM && S == 1 && KS == 3 && (BM / 16 == TH);
+  constexpr int PBUF = C::D_BYTES + C::X_BYTES;
+  const int u_lane = 8 * khalf + q4;
+  const int baseA = u_lane * 128 + ((pieceA ^ (((u_lane >> 1) & 1) << 1)) << 5) + p4 * 8;
+  const int baseB = u_lane * 128 + (pieceB << 5) + p4 * 8;
+  const int bE0 = baseB ^ (((u_lane >> 1) & 1) << 6), bE1 = bE0 ^ 64;                          // taps with an even toff
+  const int bO0 = baseB ^ ((((u_lane >> 1) ^ u_lane) & 1) << 6), bO1 = bO0 ^ 64;               // taps with an odd toff
+  // (the accumulators live in AGPRs from here on: without this the loop-carried values sat in vector registers and were copied
+  // to the accumulation registers and back around every tile - 144 + 144 moves and 190 vector registers)
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+  }
+  auto compute_p = [&](const int boff) __attribute__((always_inline)) {      // boff: byte offset of the LDS buffer pair (ONE body:
+    if constexpr (PIPE) {                                                      // two copies made a 144-register phi of the accumulators)
+      const unsigned char* dD = smem + boff;
+      const unsigned char* dX = dD + C::D_BYTES;
+      constexpr int NI = (BM / 16) * 9, LA = 3;
+      bf16x8 af[2], bfr[4];
+      auto ldA = [&](const int kk) { return tr_pair(dD, baseA + kk * 2048, baseA + 512 + kk * 2048); };
+      auto ldB = [&](const int i) {
+        const int kk = i / 9, t = i % 9;
+        const int toff = (t / 3) * HPW + (t % 3);
+        const int flip = ((kk & 1) ^ ((toff >> 1) & 1)) & 1;
+        const int base = (toff & 1) ? (flip ? bO1 : bO0) : (flip ? bE1 : bE0);
+        const int imm = (kk * HPW + toff) * 128;
+        return tr_pair(dX, base + imm, base + imm + 512);
+      };
+      af[0] = ldA(0);
+#pragma unroll
+      for (int i = 0; i < LA; ++i) bfr[i] = ldB(i);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int kk = i / 9, t = i % 9;
+        if (i + LA < NI) bfr[(i + LA) & 3] = ldB(i + LA);
+        if (t == 4 && kk + 1 < BM / 16) af[(kk + 1) & 1] = ldA(kk + 1);
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(af[kk & 1]), "v"(bfr[i & 3]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
   if constexpr (SPLIT) {
     for (int tt = t_begin; tt < t_end; ++tt) {
       const int b = tt / tiles_img, ti = tt - b * tiles_img;
@@ -242,7 +290,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
             for (int q = 0; q < 16; ++q) acc[t][q] *= PH_HP_LO_INV;
         }
       }
-      compute(smem + buf * BUF, smem + buf * BUF + C::D_BYTES);
+      if constexpr (PIPE) compute_p(buf * PBUF);
+      else compute(smem + buf * BUF, smem + buf * BUF + C::D_BYTES);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next item have landed
       __syncthreads();                                    // ... and everybody's; buffer buf is free again
       buf ^= 1;
@@ -259,8 +308,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
 #ifdef PH_ABL_WG_NOSLAB   // timing ablation only
       asm volatile("" ::"v"(acc[t][q]), "v"(row + col));
 #else
-      slab[((size_t)t * p.Cout + row) * p.Cin + col] = acc[t][q];
+      if constexpr (PIPE) {      // straight from the accumulation register (copied through vector registers the 144 values cost the
+        float* dst = slab + ((size_t)t * p.Cout + row) * p.Cin + col;      // kernel its second wave per SIMD)
+        asm volatile("global_store_dword %0, %1, off" : : "v"(dst), "a"(acc[t][q]) : "memory");
+      } else {
+        slab[((size_t)t * p.Cout + row) * p.Cin + col] = acc[t][q];
+      }
 #endif
+      // (accumulators pinned to AGPRs: one tap's 16 values at a time through the vector registers - hoisted together the 144
+      // reads cost the second workgroup of the CU its registers)
+      if (PIPE && q == 15) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
