@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
   // workgroup per CU beside the BatchNorm-backward passes and 60 % of its time was exposed (skip-ablation: -0.86 ms per step).
   // Every fragment address is one of five per-lane base registers + an immediate: halo pixel h = 18 kk + u + toff (u = 8 khalf +
   // q4, + 4 for the second row group), swizzle bit = bit 1 of h = (kk & 1) ^ bit1(toff) ^ bit1(u) ^ (bit0(u) & bit0(toff)).
-  constexpr bool PIPE = !SPLIT && !HPM && S == 1 && KS == 3 && (BM / 16 == TH);
+  constexpr bool PIPE = !SPLIT && S == 1 && KS == 3 && (BM / 16 == TH);      // (half-pair mode: every pass of its item stream)
   constexpr int PBUF = C::D_BYTES + C::X_BYTES;
   const int u_lane = 8 * khalf + q4;
   const int baseA = u_lane * 128 + ((pieceA ^ (((u_lane >> 1) & 1) << 1)) << 5) + p4 * 8;
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
         const int kk = i / 9, t = i % 9;
         if (i + LA < NI) bfr[(i + LA) & 3] = ldB(i + LA);
         if (t == 4 && kk + 1 < BM / 16) af[(kk + 1) & 1] = ldA(kk + 1);
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(af[kk & 1]), "v"(bfr[i & 3]));
+        if constexpr (HPM) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(af[kk & 1]), "v"(bfr[i & 3]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[t]) : "v"(af[kk & 1]), "v"(bfr[i & 3]));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -287,7 +288,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(PhWgrad p) {
 #pragma unroll
           for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] *= PH_HP_LO_INV;
+            for (int q = 0; q < 16; ++q) {
+              if constexpr (PIPE) {      // one register at a time through ONE vector register (all 144 at once cost the second wave per SIMD)
+                float tmp_;
+                asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 4\n\tv_mul_f32 %1, %2, %1\n\ts_nop 4\n\tv_accvgpr_write_b32 %0, %1\n\ts_nop 4"
+                             : "+a"(acc[t][q]), "=&v"(tmp_) : "v"(PH_HP_LO_INV));
+              } else {
+                acc[t][q] *= PH_HP_LO_INV;
+              }
+            }
         }
       }
       if constexpr (PIPE) compute_p(buf * PBUF);
