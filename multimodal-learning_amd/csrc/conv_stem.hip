@@ -599,10 +599,61 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
       for (int q = 0; q < 16; ++q) { acc[a][j][q] = 0.f; if (HPM) accx[HPM ? a : 0][j][q] = 0.f; }
   const int q4 = (lane & 15) >> 2, p4 = lane & 3, colhalf = (lane >> 4) & 1, khalf = lane >> 5;
 
+  // perf mode: the NEXT tile's operands are requested into registers before this tile's MFMAs and written to LDS after them (a
+  // tile is only 32 MFMAs per wave against 22 KB of operands: staged synchronously - loads, wait, LDS writes, barrier, MFMAs - the
+  // kernel ran at 2.8 TB/s of its 640 MB)
+  constexpr bool PREF = !SPLIT && !HPM;
+  constexpr int DCH = TH * TW * 8 / 256, XCH = (HP + 255) / 256;
+  u32x4 dreg[PREF ? DCH : 1];
+  u32x2 xreg[PREF ? XCH : 1];
+  auto prefetch = [&](int tt) {
+    if constexpr (PREF) {
+      const int b = tt / tiles_img, ti = tt - b * tiles_img;
+      const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
+#pragma unroll
+      for (int e = 0; e < DCH; ++e) {
+        const int i = tid + e * 256, pix = i >> 3, ch = i & 7;
+        const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
+        const bool ok = r < p.OH && c < p.OW;
+        const T* src = ok ? DY + (((size_t)b * p.OH + r) * p.OW + c) * 64 + ch * 8 : reinterpret_cast<const T*>(stem_zero8);
+        dreg[e] = *reinterpret_cast<const u32x4*>(src);
+      }
+      const int iy_base = r0 * 2 - 3, ix_base = c0 * 2 - 3;
+#pragma unroll
+      for (int e = 0; e < XCH; ++e) {
+        const int i = tid + e * 256;
+        const int hr = i / HPW, hc = i - hr * HPW;
+        const int iy = iy_base + hr, ix = ix_base + hc;
+        const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        const T* src = ok ? X + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const T*>(stem_zero8);
+        xreg[e] = *reinterpret_cast<const u32x2*>(src);
+      }
+    }
+  };
+  auto commit = [&]() {
+    if constexpr (PREF) {
+#pragma unroll
+      for (int e = 0; e < DCH; ++e) {
+        const int i = tid + e * 256, pix = i >> 3, ch = i & 7;
+        *reinterpret_cast<u32x4*>(ldsD + pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16) = dreg[e];
+      }
+#pragma unroll
+      for (int e = 0; e < XCH; ++e) {
+        const int i = tid + e * 256;
+        if (i < HP) *reinterpret_cast<u32x2*>(ldsX + i * 8) = xreg[e];
+      }
+    }
+  };
+  if (PREF && t_begin < t_end) prefetch(t_begin);
   for (int tt = t_begin; tt < t_end; ++tt) {
     const int b = tt / tiles_img, ti = tt - b * tiles_img;
     const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
     __syncthreads();
+    if constexpr (PREF) {
+      commit();
+      __syncthreads();
+      if (tt + 1 < t_end) prefetch(tt + 1);
+    } else {
     for (int i = tid; i < TH * TW * 8; i += 256) {
       const int pix = i >> 3, ch = i & 7;
       const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
@@ -634,6 +685,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
     }
     stage_halo<T>(X, b, p.IH, p.IW, r0 * 2 - 3, c0 * 2 - 3, ldsX, tid, p.B);
     __syncthreads();
+    }
 #pragma unroll 2
     for (int kk = 0; kk < TH * TW / 16; ++kk) {
       const int t0 = kk * 16 + 8 * khalf + q4, t1 = t0 + 4;
