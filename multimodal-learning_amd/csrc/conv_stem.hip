@@ -602,21 +602,30 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
   // perf mode: the NEXT tile's operands are requested into registers before this tile's MFMAs and written to LDS after them (a
   // tile is only 32 MFMAs per wave against 22 KB of operands: staged synchronously - loads, wait, LDS writes, barrier, MFMAs - the
   // kernel ran at 2.8 TB/s of its 640 MB)
-  constexpr bool PREF = !SPLIT && !HPM;
+  constexpr bool PREF = !SPLIT;      // (half-pair mode: both fp16 planes of either operand)
+  constexpr int NPL = HPM ? 2 : 1;
   constexpr int DCH = TH * TW * 8 / 256, XCH = (HP + 255) / 256;
-  u32x4 dreg[PREF ? DCH : 1];
-  u32x2 xreg[PREF ? XCH : 1];
+  u32x4 dreg[PREF ? NPL : 1][PREF ? DCH : 1];
+  u32x2 xreg[PREF ? NPL : 1][PREF ? XCH : 1];
   auto prefetch = [&](int tt) {
     if constexpr (PREF) {
       const int b = tt / tiles_img, ti = tt - b * tiles_img;
       const int r0 = (ti / tiles_w) * TH, c0 = (ti % tiles_w) * TW;
+      const unsigned char* zero = reinterpret_cast<const unsigned char*>(stem_zero8);
 #pragma unroll
       for (int e = 0; e < DCH; ++e) {
         const int i = tid + e * 256, pix = i >> 3, ch = i & 7;
         const int r = r0 + (pix >> 4), c = c0 + (pix & 15);
         const bool ok = r < p.OH && c < p.OW;
-        const T* src = ok ? DY + (((size_t)b * p.OH + r) * p.OW + c) * 64 + ch * 8 : reinterpret_cast<const T*>(stem_zero8);
-        dreg[e] = *reinterpret_cast<const u32x4*>(src);
+        const size_t px = ((size_t)b * p.OH + r) * p.OW + c;
+        if constexpr (HPM) {      // a [hi 64 | lo 64] fp16 pixel record
+          const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(reinterpret_cast<const f16*>(p.dy) + px * 128 + ch * 8) : zero;
+          dreg[0][e] = *reinterpret_cast<const u32x4*>(src);
+          dreg[HPM ? 1 : 0][e] = *reinterpret_cast<const u32x4*>(ok ? src + 128 : zero);
+        } else {
+          const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(DY + px * 64 + ch * 8) : zero;
+          dreg[0][e] = *reinterpret_cast<const u32x4*>(src);
+        }
       }
       const int iy_base = r0 * 2 - 3, ix_base = c0 * 2 - 3;
 #pragma unroll
@@ -625,22 +634,31 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
         const int hr = i / HPW, hc = i - hr * HPW;
         const int iy = iy_base + hr, ix = ix_base + hc;
         const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const T* src = ok ? X + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const T*>(stem_zero8);
-        xreg[e] = *reinterpret_cast<const u32x2*>(src);
+        const size_t g = (((size_t)b * p.IH + iy) * p.IW + ix) * 4;
+        if constexpr (HPM) {      // the two fp16 planes [2][B IH IW][4] of ph_pack_input_launch
+          const f16* xp = reinterpret_cast<const f16*>(p.x4);
+          xreg[0][e] = *reinterpret_cast<const u32x2*>(ok ? reinterpret_cast<const unsigned char*>(xp + g) : zero);
+          xreg[HPM ? 1 : 0][e] = *reinterpret_cast<const u32x2*>(ok ? reinterpret_cast<const unsigned char*>(xp + (size_t)p.B * p.IH * p.IW * 4 + g) : zero);
+        } else {
+          xreg[0][e] = *reinterpret_cast<const u32x2*>(ok ? reinterpret_cast<const unsigned char*>(X + g) : zero);
+        }
       }
     }
   };
   auto commit = [&]() {
     if constexpr (PREF) {
 #pragma unroll
-      for (int e = 0; e < DCH; ++e) {
-        const int i = tid + e * 256, pix = i >> 3, ch = i & 7;
-        *reinterpret_cast<u32x4*>(ldsD + pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16) = dreg[e];
-      }
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-      for (int e = 0; e < XCH; ++e) {
-        const int i = tid + e * 256;
-        if (i < HP) *reinterpret_cast<u32x2*>(ldsX + i * 8) = xreg[e];
+        for (int e = 0; e < DCH; ++e) {
+          const int i = tid + e * 256, pix = i >> 3, ch = i & 7;
+          *reinterpret_cast<u32x4*>(ldsD + pl * DB + pix * 128 + sw_piece(pix, ch >> 1) * 32 + (ch & 1) * 16) = dreg[pl][e];
+        }
+#pragma unroll
+        for (int e = 0; e < XCH; ++e) {
+          const int i = tid + e * 256;
+          if (i < HP) *reinterpret_cast<u32x2*>(ldsX + pl * XB + i * 8) = xreg[pl][e];
+        }
       }
     }
   };
