@@ -373,6 +373,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   for (int j = 0; j < FN; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   constexpr int BM = TH * TW;
   constexpr int CROW = BNT * 2;                       // bytes of one pixel row of the bf16 C image in LDS
+  static_assert(!HPM || BM * BNT * 4 <= C::LDS_BYTES, "half-pair mode: the fp32 C image reuses the main loop's LDS");
   unsigned char* ldsC = smem;                          // perf mode: [BM][BNT] bf16 (the main loop's LDS is free)
   float* red = reinterpret_cast<float*>(smem + ((SPLIT || HPM) ? 0 : BM * CROW));   // [WM][2][BNT]
 #pragma unroll
@@ -389,7 +390,11 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         if constexpr (HPM) v *= osc;
         s1[j] += v;
         s2[j] = __builtin_fmaf(v, v, s2[j]);      // (explicit: the compiler's contraction choice must not move the statistics)
-        if constexpr (SPLIT || HPM) {
+        if constexpr (HPM) {
+          // fp32 C image in LDS (the main loop's LDS is free), stored below as 16-byte chunks like the bf16 image of the perf
+          // mode: one 4-byte store per value was 64 store instructions per wave and tile (+ 128 residual loads in a dgrad)
+          *reinterpret_cast<float*>(ldsC + (rl * TW + q) * (BNT * 4) + nrow[j] * 4) = v;
+        } else if constexpr (SPLIT) {
           if (valid) {
             if (resg) {
               float g = ldf(resg + o + nrow[j]);
@@ -427,6 +432,28 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
         }
       }
       *reinterpret_cast<bf16x8*>(out + o) = v;
+    }
+  }
+  if constexpr (HPM) {
+    __syncthreads();
+    constexpr int CPRF = BNT / 4;                      // 16-byte chunks (4 floats) per pixel row
+    for (int id = tid; id < BM * CPRF; id += NTH) {
+      const int m = id / CPRF, ch = id - m * CPRF;
+      const int r = r0 + (m >> 4), c = c0 + (m & 15);
+      if (!(full || (r < p.OHt && c < p.OWt))) continue;
+      const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + ch * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ldsC + m * (BNT * 4) + ch * 16);
+      if (resg) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(resg + o);
+        if (resa) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(resa + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] += a[k] > 0.f ? g[k] : 0.f;
+        } else {
+          v += g;
+        }
+      }
+      *reinterpret_cast<f32x4*>(out + o) = v;
     }
   }
   PH_TRACE(4);
