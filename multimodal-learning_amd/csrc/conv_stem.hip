@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       // fp32 outputs, one 4-byte store per value (a wave-instruction writes two 128-byte runs).  Half-pair mode: the next tile's
       // halo planes (requested before the MFMAs) go to the other buffer first, one barrier per tile as in perf mode
       if constexpr (HPM) { if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * NPA * XB); }
+      // half-pair mode: the fp32 tile goes through an LDS image [128 pixels][64 channels] behind the operand buffers and leaves as
+      // 16-byte chunks (one 4-byte store per value: 32 store instructions per wave and tile for 1.07 GB of output)
+      float* cimg = reinterpret_cast<float*>(smem + XB * XBUFS + WB * NP);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
@@ -248,10 +251,20 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         for (int j = 0; j < 2; ++j) {
           const float v = valid ? (HPM ? acc[j][q] * PH_HP_LO_INV : acc[j][q]) : 0.f;
           s1[j] += v; s2[j] = __builtin_fmaf(v, v, s2[j]);
-          if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
+          if constexpr (HPM) cimg[mm * 64 + j * 32 + (lane & 31)] = v;
+          else if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
         }
       }
-      if constexpr (HPM) __syncthreads();
+      if constexpr (HPM) {
+        __syncthreads();
+        for (int id = tid; id < TH * TW * 16; id += 256) {
+          const int mm = id >> 4, ch = id & 15;
+          const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+          if (r < p.OH && c < p.OW)
+            *reinterpret_cast<f32x4*>(out + ((size_t)r * p.OW + c) * 64 + ch * 4) = *reinterpret_cast<const f32x4*>(cimg + mm * 64 + ch * 4);
+        }
+        __syncthreads();
+      }
     }
   }
   if (p.stats) {   // one partial row per workgroup
@@ -834,7 +847,7 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, q);
   } else if (prec == PH_PREC_FP16X3) {
     static bool done = false;
-    const int lds = 4 * XB + PH_NPLANES * WB;      // two halo buffers of two planes + the three weight planes
+    const int lds = 4 * XB + PH_NPLANES * WB + TH * TW * 64 * 4;      // two halo buffers of two planes + the three weight planes + the fp32 output image
     if (set_lds(stem_fwd_kernel<hp16>, lds, done)) return PH_ELAUNCH;
     hipLaunchKernelGGL(stem_fwd_kernel<hp16>, grid, dim3(256), lds, st, *p);
   } else {
