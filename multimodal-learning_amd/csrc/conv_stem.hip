@@ -163,6 +163,41 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+    if constexpr (HPM) {
+      // half-pair mode runs ONE workgroup per CU (143 KB of LDS: two halo buffers of two planes, three weight planes, the fp32
+      // output image), so nothing hides a fragment read issued in front of its MFMA - the compiler-scheduled loop below waited
+      // for lgkmcnt(0) 41 times per tile (25 % of the fp16 MFMA rate).  Here the 8 fragments of step st + 1 (of the 14 (kh, s)
+      // steps) are read before the 6 MFMAs of step st; MFMAs as asm behind sched_barriers, accumulators pinned to AGPRs.
+      asm volatile("" : "+a"(acc[0]));
+      asm volatile("" : "+a"(acc[1]));
+      bf16x8 fa[2][2], fb[2][3][2];
+      auto ldstep = [&](const int st, const int buf) {
+        const int kh = st >> 1, s_ = st & 1;
+        const int chunk = s_ * 2 + khalf;
+        const int aoff = (pbase + kh * HPW + 4 * s_ + 2 * khalf) * 8;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) fa[buf][pl] = *reinterpret_cast<const bf16x8*>(ldsXc + pl * XB + aoff);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int row = kh * 64 + j * 32 + (lane & 31);
+            fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(ldsW + pl * WB + row * 64 + (wsw(row, chunk) << 4));
+          }
+      };
+#define PH_STEM_MMA(J, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[J]) : "v"(A), "v"(B)); __builtin_amdgcn_sched_barrier(0)
+      ldstep(0, 0);
+#pragma unroll
+      for (int st = 0; st < 14; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < 14) ldstep(st + 1, cur ^ 1);
+        // (the product order of the loop below: (x lo, w hi), (x hi, w lo), (x hi, w hi 2^11))
+        PH_STEM_MMA(0, fa[cur][1], fb[cur][2][0]); PH_STEM_MMA(1, fa[cur][1], fb[cur][2][1]);
+        PH_STEM_MMA(0, fa[cur][0], fb[cur][1][0]); PH_STEM_MMA(1, fa[cur][0], fb[cur][1][1]);
+        PH_STEM_MMA(0, fa[cur][0], fb[cur][0][0]); PH_STEM_MMA(1, fa[cur][0], fb[cur][0][1]);
+      }
+#undef PH_STEM_MMA
+    } else {
 #pragma unroll
     for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
@@ -197,6 +232,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
           for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0][j], acc[j], 0, 0, 0);
         }
       }
+    }
     }
     // ---- per-tile epilogue: mask, accumulate statistics in registers, store.  bf16 outputs leave as 4-byte words:
     // lanes l, l^1 hold neighbouring channels of the same pixels, so they swap one value of each column pair by DPP and
