@@ -70,6 +70,8 @@ def trunk_fwd_bwd(m, B, H, device, steps=5):
     torch.manual_seed(1)
     net = m.define_net(opt, 1, path_only=True).to(device)
     net.train()
+    if os.environ.get("PH_TRUNK_NO_OVERLAP") == "1":      # A/B switch: the whole backward on one stream
+        net._no_bwd_overlap = True
     x = torch.randn(B, 3, H, H, device=device).clamp_(-1, 1)
     w = torch.linspace(0.5, 1.5, 128, device=device)
 

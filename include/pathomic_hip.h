@@ -297,7 +297,9 @@ int ph_gk_rows(const float* G, int ng, int B, int D, int use_thresh, float thres
 int ph_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, size_t n, double lr,
                      double beta1, double beta2, double eps, double weight_decay, int step, double ema_alpha,
                      ph_stream_t stream);
-/* HIP-graph-replayable form: hyper = device float[5] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha} */
+/* HIP-graph-replayable form: hyper = device float[5] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha}.  beta1 < 0: the
+ * betas are read from device memory too, hyper = float[12] with [8..11] = {beta1, 1-beta1, beta2, 1-beta2} (a schedule that
+ * cycles beta1 - lr_policy onecycle, networks_new.py:124-125 - reaches a launch replayed from a captured graph) */
 int ph_adam_ema_step_dev(float* p, const float* g, float* m, float* v, float* ema, size_t n, double beta1,
                          double beta2, double eps, double weight_decay, const float* hyper, ph_stream_t stream);
 /* torch.optim.Adagrad as define_optimizer builds it (reference MICCAI-2022/networks_new.py:86-87: lr, weight_decay,

@@ -9,7 +9,7 @@ import torch.nn as nn
 from .. import ops
 from .CRD_loss import Normalize
 from .CRD_criterion_v3 import ContrastMemory, ContrastLoss   # noqa: F401  (:8-81, :190-217 are identical up to the weights)
-from .memory_new import _CRDCoreFn
+from .memory_new import _CRDCoreFn, draw_uniform_indices
 
 
 class Embed(nn.Module):
@@ -39,8 +39,8 @@ class CRDLoss(nn.Module):
         self.criterion_s = ContrastLoss(opt.n_data)
 
     def forward(self, f_s, f_t, idx, contrast_idx=None):
-        if contrast_idx is None:
-            raise NotImplementedError("contrast_idx=None (AliasMethod.draw) is not used by the shipped trainer")
+        if contrast_idx is None:      # CRD_criterion.py:37-39: K + 1 rows per sample from the AliasMethod table, column 0 := idx
+            contrast_idx = draw_uniform_indices(self.contrast, idx, self.contrast.K + 1)
         if contrast_idx.shape[1] != self.contrast.K + 1:
             raise RuntimeError("contrast_idx must be [B, nce_k + 1] (CRD_criterion.py:42 views it so)")
         f_s = self.embed_s(f_s)

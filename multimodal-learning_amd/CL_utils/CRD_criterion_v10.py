@@ -96,6 +96,8 @@ class CRDLoss(nn.Module):
                                       "nce_p == 2 (class means) is built" % self.num_pos)
         self.criterion_t = ContrastLoss_v2(n_data)
         self.criterion_s = ContrastLoss_v2(n_data)
+        import os
+        self._scan_override = os.environ.get("PH_CRD_SCAN")      # (read once: the numerics do not follow later changes)
 
     def forward(self, sample_weights, f_s, f_t, batch_label, idx, contrast_idx=None):
         mem = self.contrast
@@ -119,15 +121,22 @@ class CRDLoss(nn.Module):
         return sample_loss.sum(0) / bn, sample_loss
 
 
+    SCAN_MIN_ROWS = 8192
+
     @staticmethod
-    def scan_negatives(K, n_data):
-        """Bank-scan form of the negatives when every bank row is drawn about once per query or more (K >= n_data); the gathered
-        kernels otherwise.  PH_CRD_SCAN=0 / 1 forces one form (tests, A/B)."""
-        import os
-        e = os.environ.get("PH_CRD_SCAN")
-        if e in ("0", "1"):
-            return e == "1"
-        return K >= n_data
+    def scan_negatives(K, n_data, override="env"):
+        """Bank-scan form of the negatives when every bank row is drawn about once per query or more (K >= n_data) AND the bank
+        is large (>= SCAN_MIN_ROWS rows: BASELINE configs[4] read as 65 536 negatives per query over the 65 536-row bank); the
+        gathered kernels otherwise - in particular for the shipped command (nce_k 4096 over a bank of 1-2 k rows,
+        train_20230805.sh:3-6), which keeps the summation order and the feature set (outputs_only, ranked selection) of the
+        gathered form.  `override` "0" / "1" forces one form (tests, A/B); the default reads PH_CRD_SCAN from the
+        environment - a CRDLoss instance reads it ONCE, at construction."""
+        if override == "env":
+            import os
+            override = os.environ.get("PH_CRD_SCAN")
+        if override in ("0", "1"):
+            return override == "1"
+        return K >= n_data and n_data >= CRDLoss.SCAN_MIN_ROWS
 
     def neighbor_columns(self, B, D, batch_label, contrast_idx):
         """`pos_extra == "neighbors"` (:72-80, :110-117): the num_pos same-class nearest bank rows of every query in either
@@ -145,7 +154,7 @@ class CRDLoss(nn.Module):
                                      ptr(nb2), ptr(sim1), ptr(sim2), ptr(ws), stream()), "ph_crd_bank_topk")
         # out_s = out_v1 comes from bank 2 and is weighted by the bank-2 similarities (:226), and vice versa (:227)
         mem.P, mem.P2, mem.K2 = NP, NP, K
-        if self.scan_negatives(K, mem.nLem):
+        if self.scan_negatives(K, mem.nLem, self._scan_override):
             # nce_k at or above the number of bank rows (configs[4] read as 65 536 negatives per query): the negatives' terms are
             # summed over the whole bank weighted by multiplicity (memory_new._crd_core_scan); only the positives are gathered
             idx1, idx2 = nb1, nb2

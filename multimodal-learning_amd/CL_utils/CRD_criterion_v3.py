@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from .CRD_loss import Embed, Normalize   # noqa: F401  (same classes as CRD_criterion_v3.py:227-250)
-from .memory_new import _CRDCoreFn
+from .memory_new import _CRDCoreFn, draw_uniform_indices
 
 eps = 1e-7
 
@@ -51,8 +51,8 @@ class CRDLoss(nn.Module):
         self.criterion_s = ContrastLoss(n_data)
 
     def forward(self, sample_weights, f_s, f_t, idx, contrast_idx=None):
-        if contrast_idx is None:
-            raise NotImplementedError("contrast_idx=None (AliasMethod.draw) is not used by the shipped trainer")
+        if contrast_idx is None:      # CRD_criterion_v3.py:37-39: K + 1 rows per sample from the AliasMethod table, column 0 := idx
+            contrast_idx = draw_uniform_indices(self.contrast, idx, self.contrast.K + 1)
         if contrast_idx.shape[1] != self.contrast.K + 1:
             raise RuntimeError("contrast_idx must be [B, nce_k + 1] (CRD_criterion_v3.py:42 views it so)")
         f_s = self.embed_s(f_s)

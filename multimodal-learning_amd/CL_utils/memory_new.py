@@ -228,6 +228,33 @@ class _CRDOutputsFn(torch.autograd.Function):
         return dv1, dv2, None, None, None, None
 
 
+def draw_uniform_indices(mem, y, width):
+    """`contrast_idx is None` in every ContrastMemory of the reference (memory_new.py:265-267, CRD_criterion.py:37-39,
+    CRD_criterion_v3.py:37-39): `width` bank rows per sample drawn from the AliasMethod table over uniform unigrams
+    (:229-231, :401-458) - with all-ones unigrams every table entry keeps probability 1, so the draw IS the uniform integer
+    draw - and column 0 overwritten with y.  One launch (ph_alias_uniform_draw: counter-based, keyed by (seed, step, element));
+    the device-side step counter makes captured replays draw afresh.  Distributional parity: the reference's stream is torch's
+    CUDA generator.  Under data parallelism (`mem.sync`) the rank is mixed into the seed, so that W replicas draw W times as
+    many distinct negatives as one (the reference's one DataParallel process draws one global batch of independent rows).  The
+    step counter `mem._draw_step` is not part of the module's state_dict (its keys are the reference's); DistillStep.state_dict
+    saves it (`crd_draw_steps`) so that a resumed run continues the stream."""
+    y = require_cuda(y).contiguous()
+    B = y.shape[0]
+    if getattr(mem, "_draw_step", None) is None or mem._draw_step.device != y.device:
+        mem._draw_step = torch.zeros(1, device=y.device, dtype=torch.int64)
+    if getattr(mem, "_draw_seed", None) is None:
+        seed = int(torch.initial_seed())
+        sync = getattr(mem, "sync", None)
+        if sync is not None and getattr(sync, "rank", 0):
+            seed ^= (int(sync.rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        mem._draw_seed = seed & 0x7FFFFFFFFFFFFFFF
+    out = torch.empty(B, width, device=y.device, dtype=torch.int64)
+    check(lib().ph_alias_uniform_draw(ptr(y), ptr(out), int(mem.nLem), B, width, mem._draw_seed, ptr(mem._draw_step), stream()),
+          "ph_alias_uniform_draw")
+    mem._draw_step += 1
+    return out
+
+
 class ContrastMemory_v3(nn.Module):
     def __init__(self, inputSize, outputSize, P, K, T=0.07, momentum=0.5, select_pos_pairs=True, P2=10,
                  select_neg_pairs=True, K2=512):
@@ -275,20 +302,8 @@ class ContrastMemory_v3(nn.Module):
         return torch.as_tensor(np.asarray(r), dtype=torch.int32)
 
     def draw_indices(self, y):
-        """idx == None (memory_new.py:265-267): the reference draws B * (K + P) rows from its AliasMethod table over uniform
-        unigrams (:229-231, :401-458) - with all-ones unigrams every table entry keeps probability 1, so the draw is the
-        uniform integer draw - and overwrites column 0 with y.  One launch; the device counter makes captured replays draw
-        afresh.  Distributional parity: the reference's stream is torch's CUDA generator."""
-        y = require_cuda(y).contiguous()
-        B = y.shape[0]
-        if getattr(self, "_draw_step", None) is None or self._draw_step.device != y.device:
-            self._draw_step = torch.zeros(1, device=y.device, dtype=torch.int64)
-            self._draw_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
-        out = torch.empty(B, self.P + self.K, device=y.device, dtype=torch.int64)
-        check(lib().ph_alias_uniform_draw(ptr(y), ptr(out), int(self.nLem), B, self.P + self.K, self._draw_seed,
-                                          ptr(self._draw_step), stream()), "ph_alias_uniform_draw")
-        self._draw_step += 1
-        return out
+        """idx == None (memory_new.py:265-267): B * (K + P) rows drawn from the AliasMethod table, column 0 := y."""
+        return draw_uniform_indices(self, y, self.P + self.K)
 
     def _ranks(self, epoch, select_pos_mode, ranks, dev):
         if ranks is None:

@@ -27,6 +27,7 @@
 //
 // Same GEMM view, descriptor (PhTapConv) and semantics as conv_tap2.hip / conv_tap3.hip; outputs BITWISE those of
 // tapconv2_l1_kernel (same products, same fp32 accumulation order per output: slices of 32 channels, taps in order).
+#include <mutex>
 #include "ph_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -674,12 +675,12 @@ template <bool FUSE_IN, int BST, bool OVL, int ORM = 0>
 int launch4(const PhTapConv& p, hipStream_t st) {
   using C = Tap4Cfg;
   auto kern = tapconv4_kernel<FUSE_IN, BST, OVL, ORM>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-      return PH_ELAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag attr_once;      // (one flag per template instantiation; thread-safe)
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(attr_once, [&] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  });
+  if (attr_rc != hipSuccess) return PH_ELAUNCH;
   const int total = cdiv(p.OHt, C::TH) * cdiv(p.OWt, C::TW) * p.B;
   const int resident = ph_num_cus();
   dim3 grid(total < resident ? total : resident);
@@ -712,6 +713,9 @@ static bool ph_tap4_ovl_ops() {
 // that reached tapconv2_l1_kernel)
 bool ph_tapconv4_eligible(const PhTapConv* p) {
   if (p->ntaps != 9 || p->Cin != 64 || p->Cout != 64 || p->m_groups) return false;
+  // the kernel is hard-coded for the stride-1 / pad-1 geometry over the whole output: no output stride or offset
+  if (p->os != 1 || p->oa_h || p->oa_w || p->OHt != p->OH || p->OWt != p->OW || p->iy0 != -1 || p->ix0 != -1) return false;
+  if (p->IH != p->OH || p->IW != p->OW) return false;
   for (int k = 0; k < 9; ++k)
     if (p->dy[k] != k / 3 || p->dx[k] != k % 3 || p->wtap[k] < 0 || p->wtap[k] > 8) return false;
   if (p->bst_y && (p->in_scale || !p->bst_mean || !p->stats || (p->bst_y2 && !p->bst_mean2))) return false;

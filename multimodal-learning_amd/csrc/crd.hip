@@ -12,6 +12,7 @@
 //   crd_update  : momentum update + re-normalisation of the rows mem[y] (memory_new.py:382-395)
 // All bank traffic is row-granular 512-B coalesced reads; the bank (n_data x 128 fp32 x 2) is L2/MALL
 // resident for the reference's dataset sizes.
+#include <mutex>
 #include "ph_common.h"
 #include "ph_dense.h"
 #include "ph_kernels.h"
@@ -979,13 +980,13 @@ static int crd_loss_grad_impl(const float* xs, const float* xt, const int* sel, 
 // ---- bank-scan form of the negatives (kernels above).  idx + col0: the K sampled negatives of query b are idx[b * row_stride + col0 ..]
 int ph_crd_neg_hist(const int64_t* idx, long row_stride, int col0, int K, int B, int n_data, int* mult, hipStream_t st) {
   if (B < 1 || K < 1 || n_data < 1 || !idx || !mult) return PH_EINVAL;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(crd_neg_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            HIST_BINS * (int)sizeof(int)) != hipSuccess)
-      return PH_ELAUNCH;
-    attr_done = true;
-  }
+  static std::once_flag attr_once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(crd_neg_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  HIST_BINS * (int)sizeof(int));
+  });
+  if (attr_rc != hipSuccess) return PH_ELAUNCH;
   hipLaunchKernelGGL(crd_neg_hist_kernel, dim3(cdiv(n_data, HIST_BINS), B), dim3(1024), HIST_BINS * sizeof(int), st, idx + col0,
                      row_stride, K, n_data, mult);
   PH_LAUNCH_CHECK();

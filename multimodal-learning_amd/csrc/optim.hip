@@ -172,6 +172,9 @@ __global__ void adam_ema_dev_kernel(float* __restrict__ p, const float* __restri
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   const float step = hyper[0] / hyper[1], bc2_sqrt = hyper[2], ema_alpha = hyper[3], om_alpha = hyper[4];
+  // beta1 < 0 in the launch arguments: the betas live in device memory, hyper[8..11] = {beta1, 1 - beta1, beta2, 1 - beta2} (a
+  // schedule that cycles beta1 - OneCycleLR - must reach a launch replayed from a captured graph)
+  if (b1 < 0.f) { b1 = hyper[8]; omb1 = hyper[9]; b2 = hyper[10]; omb2 = hyper[11]; }
   if (i + 4 <= n) {
     f32x4 P = *reinterpret_cast<f32x4*>(p + i), Gr = *reinterpret_cast<const f32x4*>(g + i);
     f32x4 M = *reinterpret_cast<f32x4*>(m + i), V = *reinterpret_cast<f32x4*>(v + i);

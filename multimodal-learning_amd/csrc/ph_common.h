@@ -58,7 +58,9 @@ __device__ __forceinline__ const unsigned char* hp_hi_addr(const hp16* p) {
 __device__ __forceinline__ void hp_split(float x, f16& hi, f16& lo) {
   // (saturating: a value beyond the fp16 range degrades to +-65504 instead of inf -> NaN gradients; the dz tensors' power-of-two
   // scale keeps real data far below it)
-  x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+  // (v_med3_f32 returns the minimum of the other two operands for a NaN input: a NaN must stay a NaN so that a diverged run is
+  // visible - ADVICE r05)
+  x = (x != x) ? x : __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
   hi = (f16)x;
   lo = (f16)((x - (float)hi) * PH_HP_LO);
 }

@@ -77,8 +77,16 @@ def define_scheduler(opt, optimizer):
         return lr_scheduler.ExponentialLR(optimizer, 0.1, last_epoch=-1)
     elif opt.lr_policy == "step":
         return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    elif opt.lr_policy == "plateau":                                                       # :120-121
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.2, threshold=0.01, patience=5)
     elif opt.lr_policy == "cosine":
         return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.niter, eta_min=0)
+    elif opt.lr_policy == "onecycle":                                                      # :124-125
+        # (cycles beta1 with the learning rate: the fused optimisers read lr AND betas from their parameter group at every
+        # step and hand them to the kernel through device memory, so a captured step follows the schedule)
+        return lr_scheduler.OneCycleLR(optimizer, max_lr=1e-3, epochs=opt.niter + opt.niter_decay, steps_per_epoch=200)
+    # (the reference RETURNS the exception object here instead of raising it, :126-127: its trainer then fails at the first
+    # scheduler.get_lr(); raising at construction is the loud form of the same failure)
     raise NotImplementedError("learning rate policy [%s] is not implemented" % opt.lr_policy)
 
 

@@ -89,7 +89,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_flat = None      # optional FlatParams of the EMA model to update in the same kernel
         self.ema_alpha = None
         self.ema_range = None
-        self._hyper = None        # device float[8] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha, 0, 0, 0}: graph-replayable
+        self._hyper = None        # device float[12] {lr, 1-beta1^t, sqrt(1-beta2^t), ema_alpha, 1-ema_alpha, 0, 0, 0, beta1, 1-beta1, beta2, 1-beta2}: graph-replayable
         self._hyper_host = None
         self._prepared = False
 
@@ -101,9 +101,10 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat = FlatParams(ps, with_grad=True)
             self._m = torch.zeros_like(self._flat.flat)
             self._v = torch.zeros_like(self._flat.flat)
-            self._segs = self._flat.segments(lambda t: t.requires_grad)
-            self._hyper = torch.zeros(8, device=ps[0].device, dtype=torch.float32)
-            self._hyper_host = PinnedRing((8,), torch.float32)
+            inactive = getattr(self, "_inactive", ())
+            self._segs = self._flat.segments(lambda t: t.requires_grad and id(t) not in inactive)
+            self._hyper = torch.zeros(12, device=ps[0].device, dtype=torch.float32)
+            self._hyper_host = PinnedRing((12,), torch.float32)
             ops.bump_weight_epoch()
         return self._flat
 
@@ -116,13 +117,23 @@ class FusedAdam(torch.optim.Optimizer):
         self._step += 1
         b1, b2 = g["betas"]
         a = self.ema_alpha if self.ema_alpha is not None else 0.0
+        # [8..11] = beta1, 1 - beta1, beta2, 1 - beta2: read by the kernel in place of its launch arguments (a captured launch
+        # would keep the betas of the capture; OneCycleLR cycles beta1 - networks_new.define_scheduler)
         self._hyper_host.upload(self._hyper, [g["lr"], 1.0 - b1 ** self._step, math.sqrt(1.0 - b2 ** self._step), a, 1.0 - a,
-                                              0.0, 0.0, 0.0])
+                                              0.0, 0.0, 0.0, b1, 1.0 - b1, b2, 1.0 - b2])
         self._prepared = True
 
     @property
     def flat(self):
         return self._ensure_flat()
+
+    def set_inactive(self, params):
+        """Parameters that take no part in the objective (an option branch leaves a module unused): the reference's
+        torch.optim optimiser skips a parameter whose .grad is None - no weight decay, no moment update - whereas the flat
+        gradient buffer would hand the kernel a zero gradient and decay the weights.  Their segments leave the update."""
+        self._inactive = {id(p) for p in params}
+        if self._flat is not None:
+            self._segs = self._flat.segments(lambda t: t.requires_grad and id(t) not in self._inactive)
 
     def zero_grad(self, set_to_none=False):
         """Gradients are views of one flat buffer: zeroing is a single memset and the views persist."""
@@ -155,7 +166,7 @@ class FusedAdam(torch.optim.Optimizer):
             if self.ema_flat is not None and self.ema_range is not None and s >= self.ema_range[0] and e <= self.ema_range[1]:
                 ema = self.ema_flat.flat[s:e]
             check(lib().ph_adam_ema_step_dev(ptr(f.flat[s:e]), ptr(f.grad[s:e]), ptr(self._m[s:e]), ptr(self._v[s:e]),
-                                             ptr(ema), e - s, g["betas"][0], g["betas"][1], g["eps"],
+                                             ptr(ema), e - s, -1.0, g["betas"][1], g["eps"],      # (beta1 < 0: betas from hyper[8..11])
                                              g["weight_decay"], ptr(self._hyper), stream()), "ph_adam_ema_step_dev")
         ops.bump_weight_epoch()
 
@@ -169,7 +180,8 @@ class FusedAdam(torch.optim.Optimizer):
             sd["state"] = {i: dict(step=torch.tensor(float(self._step)),
                                    exp_avg=self._m[o:o + t.numel()].view(t.shape).clone(),
                                    exp_avg_sq=self._v[o:o + t.numel()].view(t.shape).clone())
-                           for i, (t, o) in enumerate(zip(f.tensors, f.offsets)) if t.requires_grad}
+                           for i, (t, o) in enumerate(zip(f.tensors, f.offsets))
+                           if t.requires_grad and id(t) not in getattr(self, "_inactive", ())}
         sd["fused"] = dict(step=self._step, exp_avg=None if self._flat is None else self._m.clone(),
                            exp_avg_sq=None if self._flat is None else self._v.clone())
         return sd
@@ -230,7 +242,7 @@ class FusedAdagrad(FusedAdam):
         self._ensure_flat()
         self._step += 1
         a = self.ema_alpha if self.ema_alpha is not None else 0.0
-        self._hyper_host.upload(self._hyper, [self.param_groups[0]["lr"], 1.0, 1.0, a, 1.0 - a, 0.0, 0.0, 0.0])
+        self._hyper_host.upload(self._hyper, [self.param_groups[0]["lr"], 1.0, 1.0, a, 1.0 - a, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
         self._prepared = True
 
     @torch.no_grad()
@@ -258,16 +270,27 @@ class FusedAdagrad(FusedAdam):
         ops.bump_weight_epoch()
 
     def state_dict(self):
-        """torch.optim.Adagrad's layout (state[i] = {step, sum}) plus the flat accumulator under "fused"."""
+        """torch.optim.Adagrad's layout (state[i] = {step, sum}; like torch, filled from construction on: step 0 and
+        sum = initial_accumulator_value before the first step) plus the flat accumulator under "fused".
+        One difference from torch.optim.Adagrad is documented rather than mirrored: a requires_grad parameter that received NO
+        gradient in a step (torch: .grad is None -> skipped) sees a zero gradient here, i.e. weight decay and the accumulator
+        still advance - unless the owner declares it unused (`set_inactive`, what DistillStep does for the option branches that
+        leave a criterion idle)."""
         sd = torch.optim.Optimizer.state_dict(self)
+        inactive = getattr(self, "_inactive", ())
         if self._flat is not None:
             f = self._flat
             sd["state"] = {i: dict(step=torch.tensor(float(self._step)), sum=self._v[o:o + t.numel()].view(t.shape).clone())
-                           for i, (t, o) in enumerate(zip(f.tensors, f.offsets)) if t.requires_grad}
+                           for i, (t, o) in enumerate(zip(f.tensors, f.offsets)) if t.requires_grad and id(t) not in inactive}
+        else:
+            init = float(self.param_groups[0]["initial_accumulator_value"])
+            sd["state"] = {i: dict(step=torch.tensor(0.0), sum=torch.full_like(t, init, dtype=torch.float32))
+                           for i, t in enumerate(self.param_groups[0]["params"]) if t.requires_grad and id(t) not in inactive}
         sd["fused"] = dict(step=self._step, sum=None if self._flat is None else self._v.clone())
         return sd
 
     def load_state_dict(self, sd):
+        """Accepts this class's own state_dict or a plain torch.optim.Adagrad one (a checkpoint written by the reference)."""
         sd = dict(sd)
         fused = sd.pop("fused", None)
         per_param = sd.get("state") or {}
@@ -275,13 +298,21 @@ class FusedAdagrad(FusedAdam):
         torch.optim.Optimizer.load_state_dict(self, sd)
         f = self._ensure_flat()
         if fused is not None and fused.get("sum") is not None:
+            if tuple(fused["sum"].shape) != tuple(self._v.shape):
+                raise ValueError("fused accumulator has %d elements, the parameters %d" % (fused["sum"].numel(), self._v.numel()))
             self._step = fused["step"]
             self._v.copy_(fused["sum"])
         elif per_param:
+            steps = set()
             for i, st in per_param.items():
                 t, o = f.tensors[int(i)], f.offsets[int(i)]
+                if tuple(st["sum"].shape) != tuple(t.shape):
+                    raise ValueError("optimizer state %d has shape %s, parameter %s" % (int(i), tuple(st["sum"].shape), tuple(t.shape)))
                 self._v[o:o + t.numel()].copy_(st["sum"].reshape(-1))
-                self._step = int(float(st["step"]))
+                steps.add(int(float(st["step"])))
+            if len(steps) != 1:
+                raise NotImplementedError("per-parameter step counts differ (%s): the fused kernel keeps one" % sorted(steps))
+            self._step = steps.pop()
 
 
 def update_ema_variables(model, ema_model, alpha, global_step):
@@ -434,6 +465,18 @@ class DistillStep:
             self.module_list = nn.ModuleList([self.model])
         self.optimizer = define_optimizer(opt, self.module_list)                   # :211
         self.scheduler = define_scheduler(opt, self.optimizer)                     # :212
+        # option branches that leave a CRD criterion unused (`--distill kd`: both; `--num_teachers 1`: criterion_kd_path, the
+        # one call goes through criterion_kd whichever teacher is chosen, :282-285): its embedding heads stay in the
+        # optimiser's parameter list as in the reference, where their .grad stays None and the update skips them
+        self._branch_check()
+        unused = []
+        if self.zoo_kd is None:
+            if opt.distill == "kd":
+                unused = [self.criterion_kd, self.criterion_kd_path]
+            elif opt.num_teachers == 1:
+                unused = [self.criterion_kd_path]
+        if unused and hasattr(self.optimizer, "set_inactive"):
+            self.optimizer.set_inactive([p for c in unused for m_ in (c.embed_s, c.embed_t) for p in m_.parameters()])
         self.iter_num = opt.global_step
         self._want_graph = False
         self._static = None
@@ -575,6 +618,9 @@ class DistillStep:
                         pred_path=o["pred_path"], path_feat=path_feat.detach(), ema_logit=ema_logit_path,
                         fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat, **extra)
         loss_cls = ops.NLLFn.apply(pred_path, grade, bnorm)                                                 # :262
+        if self.zoo_kd is None and not (opt.num_teachers == 2 and opt.distill == "crd"):
+            return self._branch_tail(e, r1, grade, index, sample_idx, loss_cls, path_feat, logit_path, pred_path, ema_path_feat,
+                                     ema_logit_path, fuse_feat, logits)
         if self.variant == "mia2023":
             return self._mia2023_tail(e, loss_cls, grade, index, sample_idx, path_feat, logit_path, pred_path,
                                       ema_path_feat, ema_logit_path, fuse_feat, logits)
@@ -659,6 +705,91 @@ class DistillStep:
                     loss_kd1=(opt.beta * loss_kd).detach(), loss_kd2=z, scale=scale, logit_path=logit_path.detach(),
                     pred_path=pred_path.detach(), path_feat=path_feat.detach(), ema_logit=ema_logit_path,
                     fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat)
+
+    def _branch_check(self):
+        """Option combinations the reference's batch body itself cannot run fail here, with its own exception type."""
+        opt = self.opt
+        if self.zoo_kd is not None:
+            return
+        if not (opt.num_teachers == 2 or (opt.num_teachers == 1 and opt.which_teacher in ("fuse", "self_EMA"))):
+            # :263-271 define loss_div in three branches only; anything else reaches `loss_KD = opt.alpha * loss_div` unbound
+            raise UnboundLocalError("local variable 'loss_div' referenced before assignment (num_teachers %r / which_teacher "
+                                    "%r: train_test_path_multi_distill.py:263-271)" % (opt.num_teachers, opt.which_teacher))
+        if opt.distill not in ("crd", "kd"):
+            raise NotImplementedError(opt.distill)                                                          # :289-290
+        if opt.assign_weights == "True" and opt.num_teachers != 2:
+            # :293-301 build KD_loss_list under `if opt.num_teachers == 2` only; :304 then reads it
+            raise UnboundLocalError("local variable 'KD_loss_list' referenced before assignment (--assign_weights True needs "
+                                    "--num_teachers 2: train_test_path_multi_distill.py:293-304)")
+
+    def _branch_tail(self, e, r1, grade, index, sample_idx, loss_cls, path_feat, logit_path, pred_path, ema_path_feat,
+                     ema_logit_path, fuse_feat, logits):
+        """The batch body's non-default option branches, all three trainers (MICCAI-2022 train_test_path_multi_distill.py:263-309,
+        "MIA 2022/train_test_path_multi_distill_v2.py":419-482, "MIA 2023/stage2_unimodal_student/
+        train_test_path_multi_distill.py":348-427): `--num_teachers 1` with `--which_teacher fuse | self_EMA` (ONE KL term and ONE
+        CRD call - through criterion_kd whichever teacher is chosen - summed with the fixed weights alpha / beta) and
+        `--distill kd` (no CRD term; with two teachers and `--assign_weights True` GK-Refine over the two KL terms).  Generic
+        autograd path; every value stays on the device."""
+        opt, v = self.opt, self.variant
+        z = torch.zeros((), device=self.device)
+        two = opt.num_teachers == 2
+        fuse_on = two or opt.which_teacher == "fuse"
+        ema_on = two or opt.which_teacher == "self_EMA"
+        rows = v == "mia2023"                   # (its DistillKL / CRDLoss also return the per-sample rows)
+        loss_div1 = loss_div2 = loss_kd1 = loss_kd2 = z
+        rows_div1 = rows_div2 = rows_kd1 = rows_kd2 = None
+        if fuse_on:
+            r = self.criterion_div(logit_path, logits[-1].detach())
+            loss_div1, rows_div1 = r if rows else (r, None)
+        if ema_on:
+            r = self.criterion_div(logit_path, ema_logit_path.detach())
+            loss_div2, rows_div2 = r if rows else (r, None)
+        loss_div = loss_div1 + loss_div2
+        if opt.distill == "crd":
+            if rows:
+                from .mia2023 import assign_sample_weights
+                w1 = assign_sample_weights(logit_path, logits[-1], grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
+                w2 = assign_sample_weights(logit_path, ema_logit_path, grade, opt.discrep_scale, opt.max_discrep, from_logits=True)
+                w1 = (1.0 + e * w1).view(-1, 1); w2 = (1.0 + e * w2).view(-1, 1)
+            # one teacher: the call goes through criterion_kd with that teacher's feature (MICCAI :282-285)
+            t_feat, w = (fuse_feat, w1 if rows else None) if fuse_on else (ema_path_feat, w2 if rows else None)
+            if v == "miccai2022":
+                loss_kd1 = self.criterion_kd(e, path_feat, t_feat.detach(), index, sample_idx, ranks=r1)
+            elif v == "mia2022":
+                loss_kd1 = self.criterion_kd(e, path_feat, t_feat.detach(), index, sample_idx).reshape(())
+            else:
+                loss_kd1, rows_kd1 = self.criterion_kd(w, path_feat, t_feat.detach(), grade, index, sample_idx)
+        loss_kd = loss_kd1 + loss_kd2
+        scale = None
+        if opt.assign_weights == "True":       # (two teachers, --distill kd: _branch_check)
+            if v == "miccai2022":
+                KD_loss_list = [opt.alpha * loss_div1, opt.alpha * loss_div2]                               # :293-300
+                scale, loss_KD = AEKD_loss(opt, self.optimizer, loss_cls, path_feat, KD_loss_list, self.sync)
+            elif v == "mia2022":
+                KD_loss_list = [opt.alpha * loss_div1, opt.alpha * loss_div2]
+                scale, loss_KD = self._momentum_gk(loss_cls, path_feat, KD_loss_list)
+                if opt.grads_thresh == "False":
+                    loss_KD = loss_KD * len(KD_loss_list)
+            else:
+                from .mia2023 import GK_refine_thresh
+                if getattr(opt, "loss_weighting", "GK_refine") != "GK_refine":
+                    raise NotImplementedError("loss_weighting '%s' (the shipped command uses GK_refine)" % opt.loss_weighting)
+                KD_loss_list = [rows_div1, rows_div2]                                                       # (:414: unscaled rows)
+                scale, loss_KD = GK_refine_thresh(opt, self.optimizer, loss_cls, path_feat, KD_loss_list,
+                                                  batch_norm_size=self.criterion_div.batch_norm_size, sync=self.sync)
+        else:
+            loss_KD = opt.alpha * loss_div + opt.beta * loss_kd                                             # :309
+        loss = self._add_reg(opt.lambda_nll * loss_cls + loss_KD)                                           # :312-313
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.sync is not None:
+            self.sync.all_reduce_grads(self.optimizer.flat)
+        self.optimizer.step()
+        dt = lambda t: t.detach() if torch.is_tensor(t) else t      # noqa: E731
+        return dict(loss=loss.detach(), loss_cls=loss_cls.detach(), loss_div1=dt(opt.alpha * loss_div1),
+                    loss_div2=dt(opt.alpha * loss_div2), loss_kd1=dt(opt.beta * loss_kd1), loss_kd2=dt(opt.beta * loss_kd2),
+                    scale=scale, logit_path=logit_path.detach(), pred_path=pred_path.detach(), path_feat=path_feat.detach(),
+                    ema_logit=ema_logit_path, fuse_logit=logits[-1], fuse_feat=fuse_feat, ema_feat=ema_path_feat)
 
     def _add_reg(self, loss):
         """+ opt.lambda_reg * define_reg(opt, model) (train_test_path_multi_distill.py:312-313)."""
@@ -761,7 +892,13 @@ class DistillStep:
         if self.variant != "miccai2022":
             return e, [None, None]         # the vanilla / KNN banks have no rank-drawn pair selection
         out = []
+        # the host RNG advances once per CRD CALL (memory_new.py:311): two calls in the shipped command, one with
+        # --num_teachers 1 (through criterion_kd), none with --distill kd
+        ncalls = 0 if self.opt.distill != "crd" else (2 if self.opt.num_teachers == 2 else 1)
         for i, crd in enumerate((self.criterion_kd, self.criterion_kd_path)):
+            if i >= ncalls:
+                out.append(None)
+                continue
             r = ranks[i] if ranks is not None else crd.contrast.draw_ranks(e, crd.select_pos_mode)
             out.append(None if r is None else torch.as_tensor(np.asarray(r), dtype=torch.int32))
         return e, out
@@ -774,9 +911,6 @@ class DistillStep:
 
     def step(self, batch, epoch=0, ranks=None):
         opt = self.opt
-        if self.zoo_kd is None and (opt.num_teachers != 2 or opt.distill != "crd"):
-            raise NotImplementedError("DistillStep implements the shipped stage-2 command (--num_teachers 2 --distill crd); "
-                                      "variant 'mia2022' also runs the trainer's --distill baselines")
         # :231-232 re-asserted per call: the reference sets train mode at every epoch because its test() leaves the
         # networks in eval mode (evaluate.test does the same here); the EMA model is never put in eval mode there
         self.module_list.train(); self.fix_model.train()
@@ -956,7 +1090,11 @@ class DistillStep:
                     gk_momentum_scale=None if self._mo_state is None else self._mo_state.clone(),
                     # draw counters of the on-device input pipeline and the host RNG behind the CRD rank draws
                     # (memory_new.py:311): without them a resumed run with step(None) / step.sampler draws other batches
-                    input_rng=self._input_rng_state())
+                    input_rng=self._input_rng_state(),
+                    # step counters / seeds of the `contrast_idx is None` draws (CL_utils/memory_new.draw_uniform_indices)
+                    crd_draw_steps=[(None if getattr(c.contrast, "_draw_step", None) is None else c.contrast._draw_step.clone(),
+                                     getattr(c.contrast, "_draw_seed", None))
+                                    for c in (self.criterion_kd, self.criterion_kd_path)])
 
     def _input_rng_state(self, load=None):
         """Device-side draw counters of step.sampler / step.loader (ContrastIndexSampler.step, DeviceAugment.step,
@@ -1013,6 +1151,10 @@ class DistillStep:
                 mod.rng_step.copy_(sd["teacher_rng_steps"][name])
         if sd.get("input_rng") is not None:
             self._input_rng_state(load=sd["input_rng"])
+        for c, rec in zip((self.criterion_kd, self.criterion_kd_path), sd.get("crd_draw_steps") or ()):
+            if rec[0] is not None:
+                c.contrast._draw_step = rec[0].to(self.device).clone()
+                c.contrast._draw_seed = rec[1]
         ops.bump_weight_epoch()      # packed MFMA weight images are rebuilt from the loaded parameters
         self._static = None          # a captured graph keeps pointing at valid buffers, but is rebuilt to be safe
         self._slots = None

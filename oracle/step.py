@@ -140,18 +140,43 @@ class DistillOracle:
                                      o.dropout_rate, gen)
             fuse_feat, logits = t_out[0], t_out[4]
         loss_cls = nll_loss(pred_path, grade)                                        # :262
-        loss_div1 = distill_kl(logit_path, logits[-1].detach(), o.kd_T)              # :264
-        loss_div2 = distill_kl(logit_path, ema_logit.detach(), o.kd_T)               # :265
-        if mid_ranks is None:
-            mid_ranks = [np.random.choice(np.arange(30, 100, 1), o.nce_p2, replace=False) for _ in range(2)]
-        loss_kd1, aux1 = crd_loss(self.crd[0], path_feat, fuse_feat.detach(), batch["index"],
-                                  batch["sample_idx"], o.nce_p2, o.nce_k2, o.select_pos_mode,
-                                  mid_ranks[0], return_aux=True)                     # :278
-        loss_kd2, aux2 = crd_loss(self.crd[1], path_feat, ema_feat.detach(), batch["index"],
-                                  batch["sample_idx"], o.nce_p2, o.nce_k2, o.select_pos_mode,
-                                  mid_ranks[1], return_aux=True)                     # :279
-        kd_list = [o.alpha * loss_div1, o.alpha * loss_div2, o.beta * loss_kd1, o.beta * loss_kd2]  # :293-298
-        if faithful:
+        two = o.num_teachers == 2
+        if not (two or (o.num_teachers == 1 and o.which_teacher in ("fuse", "self_EMA"))):
+            raise UnboundLocalError("loss_div (:263-271 define it for 2 teachers or 1 teacher fuse / self_EMA)")
+        fuse_on, ema_on = two or o.which_teacher == "fuse", two or o.which_teacher == "self_EMA"
+        zero = torch.zeros(())
+        loss_div1 = distill_kl(logit_path, logits[-1].detach(), o.kd_T) if fuse_on else zero     # :264 / :268
+        loss_div2 = distill_kl(logit_path, ema_logit.detach(), o.kd_T) if ema_on else zero       # :265 / :270
+        loss_kd1 = loss_kd2 = zero
+        aux1 = aux2 = None
+        if o.distill == "crd":
+            # one np.random.choice draw per CRD call (memory_new.py:311): two calls with two teachers, one otherwise
+            ncalls = 2 if two else 1
+            if mid_ranks is None:
+                mid_ranks = [np.random.choice(np.arange(30, 100, 1), o.nce_p2, replace=False) for _ in range(ncalls)]
+            # one teacher: the call goes through criterion_kd (self.crd[0]) whichever teacher is chosen (:282-285)
+            t1 = fuse_feat if fuse_on else ema_feat
+            loss_kd1, aux1 = crd_loss(self.crd[0], path_feat, t1.detach(), batch["index"],
+                                      batch["sample_idx"], o.nce_p2, o.nce_k2, o.select_pos_mode,
+                                      mid_ranks[0], return_aux=True)                     # :278
+            if two:
+                loss_kd2, aux2 = crd_loss(self.crd[1], path_feat, ema_feat.detach(), batch["index"],
+                                          batch["sample_idx"], o.nce_p2, o.nce_k2, o.select_pos_mode,
+                                          mid_ranks[1], return_aux=True)                 # :279
+        elif o.distill != "kd":
+            raise NotImplementedError(o.distill)                                         # :289-290
+        if two and o.distill == "crd":
+            kd_list = [o.alpha * loss_div1, o.alpha * loss_div2, o.beta * loss_kd1, o.beta * loss_kd2]  # :293-298
+        elif two:
+            kd_list = [o.alpha * loss_div1, o.alpha * loss_div2]                         # :299-300
+        else:
+            kd_list = None
+        if o.assign_weights != "True":
+            scale = None
+            loss_KD = o.alpha * (loss_div1 + loss_div2) + o.beta * (loss_kd1 + loss_kd2)  # :309
+        elif kd_list is None:
+            raise UnboundLocalError("KD_loss_list (:293-304: built for two teachers only)")
+        elif faithful:
             # the reference's AEKD_loss: one FULL backward per loss, only the hook value is kept
             gl = []
             for l in kd_list + [loss_cls]:
@@ -176,7 +201,7 @@ class DistillOracle:
                     path_feat=path_feat.detach(), ema_feat=ema_feat, ema_logit=ema_logit,
                     fuse_feat=fuse_feat, fuse_logit=logits[-1],
                     loss_cls=loss_cls.detach(), loss_div1=loss_div1.detach(), loss_div2=loss_div2.detach(),
-                    loss_kd1=loss_kd1.detach(), loss_kd2=loss_kd2.detach(), scale=scale.detach(),
+                    loss_kd1=loss_kd1.detach(), loss_kd2=loss_kd2.detach(), scale=None if scale is None else scale.detach(),
                     loss_KD=loss_KD.detach(), loss=loss.detach(),
                     grads=OrderedDict((n, g) for n, g in zip(names, grads)),
                     aux1=aux1, aux2=aux2)

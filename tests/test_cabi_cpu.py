@@ -165,8 +165,38 @@ def test_crd_v10_picks_the_bank_scan_form_from_the_list_length(monkeypatch):
     monkeypatch.delenv("PH_CRD_SCAN", raising=False)
     assert CRDLoss.scan_negatives(65536, 65536) and CRDLoss.scan_negatives(70000, 65536)
     assert not CRDLoss.scan_negatives(4096, 65536)
+    # the shipped MIA-2023 command (nce_k 4096 over a bank of 1-2 k rows) keeps the gathered kernels
+    assert not CRDLoss.scan_negatives(4096, 1024) and not CRDLoss.scan_negatives(4096, 2048)
     monkeypatch.setenv("PH_CRD_SCAN", "1")
     assert CRDLoss.scan_negatives(16, 65536)
     monkeypatch.setenv("PH_CRD_SCAN", "0")
     assert not CRDLoss.scan_negatives(65536, 1024)
 
+
+
+@pytest.mark.parametrize("policy", ["linear", "exp", "step", "plateau", "cosine", "onecycle"])
+def test_define_scheduler_policies_match_the_reference(golden_dir, policy):
+    """define_scheduler (networks_new.py:111-129): every `--lr_policy` the reference builds - incl. `plateau` and `onecycle`
+    (VERDICT r05 missing 2) - gives the learning rates (and, for onecycle, the cycled beta1) of the reference's own scheduler
+    over 12 epochs (tests/golden/make_golden_branches.py ran the reference's define_scheduler on torch.optim.Adam)."""
+    import numpy as np
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt
+    g = np.load(os.path.join(golden_dir, "lr_policies.npz"))
+    opt = default_opt(lr_policy=policy, niter=int(g["niter"]), niter_decay=int(g["niter_decay"]), lr_decay_iters=int(g["lr_decay_iters"]),
+                      epoch_count=int(g["epoch_count"]), lr=float(g["lr"]))
+    lin = torch.nn.Linear(2, 2)
+    o = torch.optim.Adam(lin.parameters(), lr=opt.lr, betas=(float(g["beta1"]), float(g["beta2"])), weight_decay=4e-4)
+    sch = m.networks_new.define_scheduler(opt, o)
+    lrs, b1 = [], []
+    for ep in range(12):
+        lrs.append(o.param_groups[0]["lr"]); b1.append(o.param_groups[0]["betas"][0])
+        o.step()
+        if policy == "plateau":
+            sch.step(1.0 if ep < 3 else 2.0)
+        else:
+            sch.step()
+    np.testing.assert_allclose(lrs, g[policy + ".lr"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(b1, g[policy + ".beta1"], rtol=1e-12, atol=0)
+    with pytest.raises(NotImplementedError):
+        m.networks_new.define_scheduler(default_opt(lr_policy="nope"), o)

@@ -803,3 +803,63 @@ def test_relational_losses_and_masks_on_degenerate_batches():
     assert float(mask.min()) == 1.0
     mask, mean = m.superpixel.superpixel_topk_mask(grad, sp * 2, 2, num_superpixels=8, return_mean=True)   # odd labels unused
     assert torch.isfinite(mean).all() and float(mean[:, 1::2].abs().max()) == 0.0 and set(mask.unique().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["stage1", "v3"])
+def test_vanilla_crd_criteria_draw_their_own_negatives(which):
+    """`contrast_idx=None` in the stage-1 criterion (CRD_criterion.py:37-39) and in CRD_criterion_v3 (:37-39): the K + 1 bank rows
+    per sample come from the AliasMethod table over uniform unigrams - the uniform draw (ph_alias_uniform_draw), column 0 := idx
+    (VERDICT r05 missing 3).  The reference's stream is torch's CUDA generator, so the check is distributional + exact
+    self-consistency: the loss and gradients equal those of a twin criterion fed the drawn rows explicitly; draws lie in the
+    bank, differ from call to call and are uniform."""
+    import copy
+    from types import SimpleNamespace
+    import multimodal_learning_amd as m
+    from multimodal_learning_amd.CL_utils import memory_new as MN
+    n_data, K, B = 4096, 512, 16
+    torch.manual_seed(11)
+    if which == "stage1":
+        from multimodal_learning_amd.CL_utils import CRD_criterion as C
+        crd = C.CRDLoss(SimpleNamespace(s_dim=128, t_dim=128, feat_dim=128, nce_k=K, nce_t=0.07, nce_m=0.5, n_data=n_data)).cuda()
+        call = lambda c, fs, ft, idx, ci: c(fs, ft, idx, ci)            # noqa: E731
+    else:
+        from multimodal_learning_amd.CL_utils import CRD_criterion_v3 as C
+        crd = C.CRDLoss(m.stage2_opt(nce_k=K), n_data).cuda()
+        call = lambda c, fs, ft, idx, ci: c(0.7, fs, ft, idx, ci)       # noqa: E731
+    crd.contrast.verbose = False
+    twin = copy.deepcopy(crd)
+    drawn = []
+    orig = MN.draw_uniform_indices
+
+    def spy(mem, y, width):
+        out = orig(mem, y, width)
+        drawn.append(out.clone())
+        return out
+    C.draw_uniform_indices = spy
+    try:
+        g = torch.Generator().manual_seed(5)
+        for it in range(3):
+            f_s = torch.randn(B, 128, generator=g).cuda().requires_grad_(True)
+            f_t = torch.randn(B, 128, generator=g).cuda()
+            idx = torch.randperm(n_data, generator=g)[:B].cuda()
+            loss = call(crd, f_s, f_t, idx, None)
+            ci = drawn[-1]
+            assert tuple(ci.shape) == (B, K + 1) and ci.dtype == torch.int64
+            assert torch.equal(ci[:, 0], idx) and int(ci.min()) >= 0 and int(ci.max()) < n_data
+            f_s2 = f_s.detach().clone().requires_grad_(True)
+            loss2 = call(twin, f_s2, f_t, idx, ci)
+            assert torch.equal(loss, loss2) and torch.isfinite(loss).all()
+            g1, = torch.autograd.grad(loss.sum(), f_s); g2, = torch.autograd.grad(loss2.sum(), f_s2)
+            assert torch.equal(g1, g2) and float(g1.abs().max()) > 0
+            assert torch.equal(crd.contrast.memory_v1, twin.contrast.memory_v1)
+    finally:
+        C.draw_uniform_indices = orig
+    assert not torch.equal(drawn[0][:, 1:], drawn[1][:, 1:]) and not torch.equal(drawn[1][:, 1:], drawn[2][:, 1:])
+    allv = torch.cat([d[:, 1:].reshape(-1) for d in drawn]).double()
+    n = allv.numel()                                                   # 3 x 16 x 512 = 24 576 draws over 4096 rows
+    assert abs(float(allv.mean()) - (n_data - 1) / 2) < 5 * n_data / (12 ** 0.5) / n ** 0.5
+    counts = torch.bincount(allv.long(), minlength=n_data).double()
+    chi2 = float(((counts - n / n_data) ** 2 / (n / n_data)).sum())
+    assert abs(chi2 - (n_data - 1)) < 6 * (2 * (n_data - 1)) ** 0.5      # chi-square with n_data - 1 degrees of freedom
+    assert int(crd.contrast._draw_step) == 3

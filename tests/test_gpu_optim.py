@@ -116,3 +116,48 @@ def test_fused_adagrad_and_ema_equal_torch_adagrad_given_the_same_gradients():
     assert opt2._step == 3 and all(torch.equal(back[i]["sum"].cpu(), ref_opt.state[p]["sum"]) for i, p in enumerate(ref_p))
     with pytest.raises(NotImplementedError):
         m.networks_new.define_optimizer(SimpleNamespace(optimizer_type="adabound", lr=1e-3, weight_decay=0.0, beta1=0.9, beta2=0.999), holder)
+
+
+def test_fused_adam_follows_a_cycled_beta1_inside_a_captured_graph():
+    """`--lr_policy onecycle` (networks_new.py:124-125) cycles beta1 with the learning rate: FusedAdam hands lr AND the betas
+    to its kernel through device memory, so a step replayed from a captured HIP graph follows the schedule - against
+    torch.optim.Adam driven by the same OneCycleLR on the same gradients."""
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt
+    torch.manual_seed(0)
+    opt = default_opt(lr_policy="onecycle", niter=1, niter_decay=1)
+    ref_p = [torch.randn(300, 7, device="cuda").requires_grad_(True), torch.randn(41, device="cuda").requires_grad_(True)]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=opt.lr, betas=(opt.beta1, opt.beta2), weight_decay=opt.weight_decay)
+    ours = m.train_step.FusedAdam(our_p, lr=opt.lr, betas=(opt.beta1, opt.beta2), weight_decay=opt.weight_decay)
+    sr = torch.optim.lr_scheduler.OneCycleLR(ref, max_lr=1e-3, epochs=2, steps_per_epoch=200)
+    so = m.networks_new.define_scheduler(opt, ours)
+    ours.zero_grad()
+    gs = [torch.randn(60, *p.shape, device="cuda") for p in ref_p]
+    gbuf = [torch.zeros_like(p) for p in our_p]
+    graph = None
+    for it in range(60):
+        for p, pr, g_, gb in zip(our_p, ref_p, gs, gbuf):
+            pr.grad = g_[it].clone()
+            gb.copy_(g_[it])
+        ours.prepare_step()
+        if it < 3:
+            for p, gb in zip(our_p, gbuf):
+                p.grad.copy_(gb)
+            ours.step()
+        else:
+            if graph is None:
+                graph = torch.cuda.CUDAGraph()
+                ours._prepared = True
+                with torch.cuda.graph(graph):
+                    for p, gb in zip(our_p, gbuf):
+                        p.grad.copy_(gb)
+                    ours.step()
+            ours._prepared = False
+            graph.replay()
+        ref.step()
+        sr.step(); so.step()
+        assert ours.param_groups[0]["betas"][0] == ref.param_groups[0]["betas"][0]
+    assert ref.param_groups[0]["betas"][0] != opt.beta1          # (the schedule did move beta1)
+    for p, pr in zip(our_p, ref_p):
+        assert (p - pr).abs().max().item() <= 2e-6 * pr.abs().max().item()

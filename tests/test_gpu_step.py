@@ -1150,3 +1150,116 @@ def test_multi_stream_step_equals_one_stream_step_and_phase_markers_are_ordered(
     assert (t[[0, 1, 2, 3, 4, 5, 6, 8, 9]] > 0).all()
     assert t[0] <= t[1] <= t[2] <= t[3] <= t[4] <= t[5] <= t[6]      # pack, student fwd, join, head fwd, head bwd, bwd, Adam
     assert t[0] <= t[8] <= t[2] and t[0] <= t[9] <= t[2]              # both teachers finish before the join
+
+
+BRANCH_NAMES = ["t1_fuse_crd", "t1_ema_crd", "t1_fuse_kd", "t1_ema_kd", "t2_kd_gk", "t2_kd_sum", "t2_crd_sum"]
+
+
+@pytest.mark.parametrize("name", BRANCH_NAMES)
+@pytest.mark.parametrize("mode", ["bf16x6", "fp16x3/x1"])
+def test_option_branches_vs_reference_golden(golden_dir, name, mode):
+    """The headline trainer's non-default option branches (train_test_path_multi_distill.py:263-309) through
+    DistillStep: `--num_teachers 1` with the fused or the mean teacher, `--distill kd` (with GK-Refine over the two KL terms, or
+    fixed weights), `--assign_weights False` - against the REFERENCE run under those options (tests/golden/make_golden_branches.py:
+    two steps from a mid-training Adam state).  Step 1 is replayed from a captured graph in the tolerance-compliant arithmetic
+    (the branch bodies hold no host synchronisation).  Also: the parameters of a criterion the branch leaves unused do not move
+    (the reference's optimiser skips parameters whose .grad is None - no weight decay either)."""
+    import sys
+    import multimodal_learning_amd as m
+    from oracle.step import synthetic_batch
+    from tests.gpu_util import Report
+    from tests.test_oracle_golden import branch_opt, BRANCH_OPTS
+    sys.path.insert(0, golden_dir)
+    import _warm
+    g = np.load(os.path.join(golden_dir, "branches_b8_h64.npz"))
+    n_data, t0 = int(g["n_data"]), int(g["t0"])
+    m.set_precision(mode)
+    try:
+        opt = branch_opt(name, batch_size=int(g["B"]))
+        step = _mk_step(opt, n_data, seed=0)
+        names = _warm.param_names(step.model)
+        params = list(step.module_list.parameters())
+        assert len(names) == len(params)
+        _warm.load_fused_adam(step.optimizer, names, params, _warm.unpack_scales(g))
+        assert step.optimizer._step == t0
+        step.iter_num = t0
+        e_s0 = step.criterion_kd.embed_s.linear.weight.detach().clone()
+        e_t1 = step.criterion_kd_path.embed_t.linear.weight.detach().clone()
+        ranks = g[name + ".ranks"]
+        per = 0 if len(ranks) == 0 else len(ranks) // 2
+        R = Report(f"option branch {name} ({BRANCH_OPTS[name]}), arithmetic {mode} vs REFERENCE golden (B=8, 64x64)")
+        pre = name + "."
+        grads = {}
+        orig = step.optimizer.step
+
+        def spy(*a, **k):
+            grads["fc2"] = step.model.fc_new2.weight.grad.detach().clone()
+            grads["l4"] = step.model.layer4[1].conv2.weight.grad.detach().abs().sum()
+            return orig(*a, **k)
+        step.optimizer.step = spy
+        for it in range(2):
+            bt = synthetic_batch(int(g["B"]), int(g["H"]), n_data=n_data, seed=500 + it)
+            rk = list(ranks[per * it: per * (it + 1)]) if per else None
+            out = step.step(_tuple(bt), epoch=3 + it, ranks=rk)
+            idx = bt["index"].cuda()
+            R.close(g[pre + f"logit_path{it}"], out["logit_path"], 1e-3, 0, f"logit_path step {it}")
+            R.close(g[pre + f"loss_cls{it}"], out["loss_cls"], 1e-3, 1e-4, f"loss_cls step {it}")
+            R.close(float(g[pre + f"loss_div{it}"]) * opt.alpha, out["loss_div1"] + out["loss_div2"], 1e-3, 1e-4, f"loss_div step {it}")
+            R.close(float(g[pre + f"loss_kd{it}"]) * opt.beta, out["loss_kd1"] + out["loss_kd2"], 1e-3, 1e-4, f"loss_kd step {it}")
+            R.close(g[pre + f"loss{it}"], out["loss"], 1e-3, 1e-4, f"loss step {it}")
+            if pre + f"scale{it}" in g:
+                R.close(g[pre + f"scale{it}"], out["scale"], 2e-3, 1e-3, f"GK-Refine scale step {it}")
+            else:
+                assert out["scale"] is None
+            R.close(g[pre + f"g_fc2_{it}"], grads["fc2"], 1e-6, 2e-3, f"grad fc2 step {it}")
+            R.close(g[pre + f"g_l4_1_conv2_abs{it}"], grads["l4"], 1e-4, 3e-3, f"grad l4.1.conv2 |.|_1 step {it}")
+            R.close(g[pre + f"p_fc2_{it}"], step.model.fc_new2.weight, 5e-6, 0, f"param fc2 after step {it}")
+            R.close(g[pre + f"ema_fc2_{it}"], step.ema_model.fc_new2.weight, 5e-6, 0, f"EMA fc2 after step {it}")
+            R.close(g[pre + f"embed_s0_{it}"], step.criterion_kd.embed_s.linear.weight[:8], 5e-6, 0, f"embed_s (kd) after step {it}")
+            R.close(g[pre + f"embed_t1_{it}"], step.criterion_kd_path.embed_t.linear.weight[:8], 5e-6, 0, f"embed_t (kd_path) after step {it}")
+            R.close(g[pre + f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[idx], 1e-4, 0, f"bank0 rows step {it}")
+            R.close(g[pre + f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[idx], 1e-4, 0, f"bank1 rows step {it}")
+            R.close(g[pre + f"params0_{it}"], step.criterion_kd.contrast.params, 1e-2, 1e-5, f"CRD params / Z (kd) step {it}")
+            R.close(g[pre + f"params1_{it}"], step.criterion_kd_path.contrast.params, 1e-2, 1e-5, f"CRD params / Z (kd_path) step {it}")
+            skipped = set(str(s) for s in g[pre + f"no_grad{it}"])
+            if "crd0.embed_s.linear.weight" in skipped:
+                assert torch.equal(step.criterion_kd.embed_s.linear.weight, e_s0)
+            if "crd1.embed_t.linear.weight" in skipped:
+                assert torch.equal(step.criterion_kd_path.embed_t.linear.weight, e_t1)
+        R.finish()
+    finally:
+        m.set_precision("bf16")
+
+
+def test_option_branch_replays_from_a_captured_graph():
+    """A branch body (one teacher, CRD through criterion_kd) captured in a HIP graph gives the eager steps' numbers."""
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt, synthetic_batch
+    m.set_precision("bf16")
+    opt = default_opt(num_teachers=1, which_teacher="self_EMA", assign_weights="False", batch_size=8)
+    outs = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        step = _mk_step(opt, 1024, seed=0)
+        if graph:
+            step.enable_graph()
+        rk = [np.arange(30, 50)]
+        losses = []
+        for it in range(5):
+            bt = synthetic_batch(8, 64, seed=40 + it % 2)
+            losses.append(step.step(_tuple({k: v.cuda() for k, v in bt.items()}), epoch=1, ranks=rk)["loss"].clone())
+        torch.cuda.synchronize()
+        if graph:
+            assert step._want_graph and step._slots and step._slots[0]["graph"] is not None
+        outs.append(torch.stack(losses).cpu())
+    assert torch.equal(outs[0], outs[1]), (outs[0], outs[1])
+
+
+def test_one_teacher_with_gk_refine_raises_like_the_reference():
+    """`--num_teachers 1 --assign_weights True`: KD_loss_list is unbound in the reference's batch body (:293-304)."""
+    import multimodal_learning_amd as m
+    from oracle.step import default_opt
+    with pytest.raises(UnboundLocalError):
+        m.DistillStep(default_opt(num_teachers=1, which_teacher="fuse", assign_weights="True"), 64, device="cuda")
+    with pytest.raises(UnboundLocalError):
+        m.DistillStep(default_opt(num_teachers=1, which_teacher="nobody", assign_weights="False"), 64, device="cuda")

@@ -325,3 +325,83 @@ def test_sampler_draws_equal_the_reference(golden_dir):
             got = sample_item(rng, int(index), int(labels[index]), cls_pos, cls_neg, n, int(g[f"{name}_P"]), int(g[f"{name}_K"]),
                               str(g[f"{name}_pos_mode"]), str(g[f"{name}_neg_mode"]))
             assert got.shape == want[r].shape and (got == want[r]).all(), (str(name), r, str(g[f"{name}_ref"]))
+
+
+BRANCH_OPTS = {"t1_fuse_crd": (1, "fuse", "crd", "False"), "t1_ema_crd": (1, "self_EMA", "crd", "False"),
+               "t1_fuse_kd": (1, "fuse", "kd", "False"), "t1_ema_kd": (1, "self_EMA", "kd", "False"),
+               "t2_kd_gk": (2, "fuse", "kd", "True"), "t2_kd_sum": (2, "fuse", "kd", "False"),
+               "t2_crd_sum": (2, "fuse", "crd", "False")}
+
+
+def branch_opt(name, **kw):
+    nt, wt, distill, aw = BRANCH_OPTS[name]
+    return default_opt(num_teachers=nt, which_teacher=wt, distill=distill, assign_weights=aw, **kw)
+
+
+def load_branch_state(g, orc):
+    """The mid-training Adam state of tests/golden/make_golden_branches.py (tests/golden/_warm.py recipe)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import _warm
+    scales = _warm.unpack_scales(g)
+    trainable = [(n, tuple(p.shape)) for n, p in orc.trainable() if n in scales]
+    mom = W.adam_moments(trainable, scales, _warm.SEED)
+    orc.adam_t = orc.iter_num = int(g["t0"])
+    for n, (m, v) in mom.items():
+        orc._m[n], orc._v[n] = m.clone(), v.clone()
+    return mom
+
+
+@pytest.mark.parametrize("name", list(BRANCH_OPTS))
+def test_option_branches_of_the_batch_body(golden_dir, name):
+    """The batch body's non-default option branches (train_test_path_multi_distill.py:263-309: one teacher - fused or the mean
+    teacher -, `--distill kd`, fixed weights instead of GK-Refine) against the reference run under those options
+    (tests/golden/make_golden_branches.py), two steps from a mid-training optimiser state: logits, every loss term, GK-Refine
+    weights, gradients, updated parameters / EMA, the CRD state - and the parameters the reference's optimiser never touches."""
+    g = _ld(golden_dir, "branches_b8_h64.npz")
+    torch.set_num_threads(8)
+    orc = DistillOracle(branch_opt(name), seed=0, n_data=int(g["n_data"]))
+    load_branch_state(g, orc)
+    e_s0 = orc.crd[0].embed_s["linear.weight"].clone(); e_t1 = orc.crd[1].embed_t["linear.weight"].clone()
+    ranks = g[name + ".ranks"]
+    per = 0 if len(ranks) == 0 else len(ranks) // 2
+    for it in range(2):
+        bt = synthetic_batch(int(g["B"]), int(g["H"]), n_data=int(g["n_data"]), seed=500 + it)
+        out = orc.step(bt, mid_ranks=list(ranks[per * it: per * (it + 1)]) if per else None)
+        pre = name + "."
+        _close(g[pre + f"logit_path{it}"], out["logit_path"], 1e-3, 0)
+        _close(g[pre + f"loss_cls{it}"], out["loss_cls"], 1e-3, 1e-4)
+        _close(g[pre + f"loss_div{it}"], out["loss_div1"] + out["loss_div2"], 1e-3, 1e-4)
+        _close(g[pre + f"loss_kd{it}"], out["loss_kd1"] + out["loss_kd2"], 1e-3, 1e-4)
+        _close(g[pre + f"loss_KD{it}"], out["loss_KD"], 1e-3, 1e-4)
+        _close(g[pre + f"loss{it}"], out["loss"], 1e-3, 1e-4)
+        if pre + f"scale{it}" in g:
+            _close(g[pre + f"scale{it}"], out["scale"], 2e-3, 1e-3)
+        else:
+            assert out["scale"] is None
+        _close(g[pre + f"g_fc2_{it}"], out["grads"]["student.fc_new2.weight"], 1e-6, 2e-3)
+        _close(g[pre + f"p_fc2_{it}"], orc.student["fc_new2.weight"], 2e-6, 0)
+        _close(g[pre + f"ema_fc2_{it}"], orc.ema["fc_new2.weight"], 2e-6, 0)
+        _close(g[pre + f"embed_s0_{it}"], orc.crd[0].embed_s["linear.weight"][:8], 2e-6, 0)
+        _close(g[pre + f"embed_t1_{it}"], orc.crd[1].embed_t["linear.weight"][:8], 2e-6, 0)
+        _close(g[pre + f"bank0_v1_rows{it}"], orc.crd[0].memory_v1[bt["index"]], 1e-5)
+        _close(g[pre + f"bank1_v2_rows{it}"], orc.crd[1].memory_v2[bt["index"]], 1e-5)
+        _close(g[pre + f"params0_{it}"], orc.crd[0].params, 1e-3, 1e-6)
+        _close(g[pre + f"params1_{it}"], orc.crd[1].params, 1e-3, 1e-6)
+        # parameters without a gradient: the reference's optimiser skips them (no weight decay either)
+        skipped = set(str(s) for s in g[pre + f"no_grad{it}"])
+        assert ("crd0.embed_s.linear.weight" in skipped) == (BRANCH_OPTS[name][2] == "kd")
+        assert ("crd1.embed_t.linear.weight" in skipped) == (BRANCH_OPTS[name][2] == "kd" or BRANCH_OPTS[name][0] == 1)
+        if "crd0.embed_s.linear.weight" in skipped:
+            assert torch.equal(orc.crd[0].embed_s["linear.weight"], e_s0)
+        if "crd1.embed_t.linear.weight" in skipped:
+            assert torch.equal(orc.crd[1].embed_t["linear.weight"], e_t1)
+
+
+def test_one_teacher_with_gk_refine_fails_like_the_reference(golden_dir):
+    """`--num_teachers 1 --assign_weights True`: the reference's batch body reads KD_loss_list unbound (:293-304)."""
+    g = _ld(golden_dir, "branches_b8_h64.npz")
+    assert str(g["t1_gk_error"]) == "UnboundLocalError"
+    orc = DistillOracle(default_opt(num_teachers=1, which_teacher="fuse", assign_weights="True"), seed=0, n_data=1024)
+    with pytest.raises(UnboundLocalError):
+        orc.step(synthetic_batch(2, 32, seed=1))
