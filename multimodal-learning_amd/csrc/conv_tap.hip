@@ -63,11 +63,20 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tiles_w = (p.OWt + TW - 1) / TW;
+  // output-parity classes of a stride-2 dgrad in one launch (PhTapConv::ncls): class = blockIdx.z / B, every per-class value a
+  // wave-uniform scalar read from the descriptor
+  int cls = 0, b = blockIdx.z;
+  int L_ntaps = p.ntaps, L_oa_h = p.oa_h, L_oa_w = p.oa_w, L_OHt = p.OHt, L_OWt = p.OWt;
+  if (p.ncls) {
+    cls = (b >= p.B) + (b >= 2 * p.B) + (b >= 3 * p.B);
+    b -= cls * p.B;
+    L_ntaps = p.c_ntaps[cls]; L_oa_h = p.c_oa_h[cls]; L_oa_w = p.c_oa_w[cls]; L_OHt = p.c_OHt[cls]; L_OWt = p.c_OWt[cls];
+  }
+  const int tiles_w = (L_OWt + TW - 1) / TW;
   const int tile = blockIdx.x;
+  if (p.ncls && tile >= tiles_w * ((L_OHt + TH - 1) / TH)) return;      // (a smaller class in a grid sized for the largest)
   const int r0 = (tile / tiles_w) * TH, c0 = (tile % tiles_w) * TW;
   const int n0 = blockIdx.y * BNT;
-  const int b = blockIdx.z;
   const long pix_st = (p.in_pix_stride ? p.in_pix_stride : p.Cin) * EW;
   const long row_st = (p.in_row_stride ? p.in_row_stride : (long)p.IW * p.Cin) * EW;
   const long img_st = (p.in_img_stride ? p.in_img_stride : (long)p.IH * p.IW * p.Cin) * EW;
@@ -106,12 +115,14 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   const int khalf = lane >> 5;
 
   const int nslices = (p.Cin >> 6) * ((HPM && !p.hp_hi_only) ? 3 : 1);
-  const int ngroups = (p.ntaps + TG - 1) / TG;
+  const int ngroups = (L_ntaps + TG - 1) / TG;
   const int nstages = nslices * ngroups;
   // tap table in a VGPR (lane t holds tap t): the per-tap weight slab and halo offset are fetched with
   // v_readlane instead of kernarg loads, so no memory round trip (and no s_waitcnt) sits on the stage path
   int tap_tab = 0;
-  if (lane < p.ntaps) tap_tab = (p.wtap[lane] << 16) | (p.dy[lane] * HPW + p.dx[lane]);
+  if (lane < L_ntaps)
+    tap_tab = p.ncls ? ((p.c_wtap[cls][lane & 3] << 16) | (p.c_dy[cls][lane & 3] * HPW + p.c_dx[cls][lane & 3]))
+                     : ((p.wtap[lane] << 16) | (p.dy[lane] * HPW + p.dx[lane]));
   auto tap_slab = [&](int t) { return __builtin_amdgcn_readlane(tap_tab, t) >> 16; };
   auto tap_off = [&](int t) { return __builtin_amdgcn_readlane(tap_tab, t) & 0xffff; };
   // per-lane constant parts of the weight staging addresses: chunk e of a tap is row (tid + e*NTH) >> 3, 16-B piece & 7
@@ -257,8 +268,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
       const int k0 = sl << 6;      // (split-plane modes: A and W blocks coincide)
       __syncthreads();
       stage_halo_sync(k0);
-      for (int tg0 = 0; tg0 < p.ntaps; tg0 += TG) {
-        const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
+      for (int tg0 = 0; tg0 < L_ntaps; tg0 += TG) {
+        const int gcount = (L_ntaps - tg0) < TG ? (L_ntaps - tg0) : TG;
         if (tg0 > 0) __syncthreads();
         stage_w_sync(k0, tg0, gcount);
         __syncthreads();
@@ -272,9 +283,9 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     // the single A buffer) still needs the write phase between two barriers.
     auto advance = [&](int& sl_, int& tg_) {
       tg_ += TG;
-      if (tg_ >= p.ntaps) { tg_ = 0; ++sl_; }
+      if (tg_ >= L_ntaps) { tg_ = 0; ++sl_; }
     };
-    auto gc = [&](int tg_) { return (p.ntaps - tg_) < TG ? (p.ntaps - tg_) : TG; };
+    auto gc = [&](int tg_) { return (L_ntaps - tg_) < TG ? (L_ntaps - tg_) : TG; };
     int sl = 0, tg0 = 0, sl1 = 0, tg1 = 0;
     advance(sl1, tg1);
     load_halo_regs(slice_a(0));
@@ -319,9 +330,9 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     // s+1 (weights, and the next slice's halo when the slice changes) are in flight into registers; they
     // are written to LDS after the barrier that ends stage s.
     load_halo_regs(slice_a(0));
-    load_w_regs(slice_w(0), 0, p.ntaps < TG ? p.ntaps : TG);
+    load_w_regs(slice_w(0), 0, L_ntaps < TG ? L_ntaps : TG);
     store_halo_regs();
-    store_w_regs(p.ntaps < TG ? p.ntaps : TG, ldsB);
+    store_w_regs(L_ntaps < TG ? L_ntaps : TG, ldsB);
     __syncthreads();
     PH_TRACE(1);
     unsigned long long cyc_compute = 0, cyc_bar1 = 0, cyc_write = 0;
@@ -329,11 +340,11 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     (void)kl0_;
     int sl = 0, tg0 = 0;
     for (int st = 0; st < nstages; ++st) {
-      const int gcount = (p.ntaps - tg0) < TG ? (p.ntaps - tg0) : TG;
+      const int gcount = (L_ntaps - tg0) < TG ? (L_ntaps - tg0) : TG;
       int nsl = sl, ntg0 = tg0 + TG;
-      if (ntg0 >= p.ntaps) { ntg0 = 0; nsl = sl + 1; }
+      if (ntg0 >= L_ntaps) { ntg0 = 0; nsl = sl + 1; }
       const bool has_next = st + 1 < nstages;
-      const int ngcount = (p.ntaps - ntg0) < TG ? (p.ntaps - ntg0) : TG;
+      const int ngcount = (L_ntaps - ntg0) < TG ? (L_ntaps - ntg0) : TG;
       if (has_next) {
         load_w_regs(slice_w(nsl), ntg0, ngcount);
         if (nsl != sl) load_halo_regs(slice_a(nsl));
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
   // ---------------- epilogue: mask, BN partial statistics, (residual), store
   // accumulator register q of fragment (i,j) holds MFMA row (q&3) + 8*(q>>2) + 4*khalf, i.e. (see
   // frag_row_to_pixel) tile row 2*(wm*FM+i) + ((popc(q>>2) + khalf) & 1), column q; channel n0 + nrow[j].
-  const bool full = (r0 + TH <= p.OHt) && (c0 + TW <= p.OWt);
+  const bool full = (r0 + TH <= L_OHt) && (c0 + TW <= L_OWt);
   TO* out = reinterpret_cast<TO*>(p.out) + (size_t)b * p.OH * p.OW * p.Cout;
   const TO* resg = p.res_g ? reinterpret_cast<const TO*>(p.res_g) + (size_t)b * p.OH * p.OW * p.Cout : nullptr;
   // (res_a: a block output as the elementwise passes read it - the fp32 copy in the half-pair mode)
@@ -382,8 +393,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     for (int q = 0; q < 16; ++q) {
       const int rl = (wm * FM + i) * 2 + ((__popc(q >> 2) + khalf) & 1);
       const int r = r0 + rl, c = c0 + q;
-      const bool valid = full || (r < p.OHt && c < p.OWt);
-      const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0;
+      const bool valid = full || (r < L_OHt && c < L_OWt);
+      const size_t o = ((size_t)(r * p.os + L_oa_h) * p.OW + (c * p.os + L_oa_w)) * p.Cout + n0;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         float v = valid ? acc[i][j][q] : 0.f;
@@ -417,8 +428,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     for (int id = tid; id < BM * CPR; id += NTH) {
       const int m = id / CPR, ch = id - m * CPR;
       const int r = r0 + (m >> 4), c = c0 + (m & 15);
-      if (!(full || (r < p.OHt && c < p.OWt))) continue;
-      const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + ch * 8;
+      if (!(full || (r < L_OHt && c < L_OWt))) continue;
+      const size_t o = ((size_t)(r * p.os + L_oa_h) * p.OW + (c * p.os + L_oa_w)) * p.Cout + n0 + ch * 8;
       bf16x8 v = *reinterpret_cast<const bf16x8*>(ldsC + m * CROW + ch * 16);
       if (resg) {
         const bf16x8 g = *reinterpret_cast<const bf16x8*>(resg + o);
@@ -440,8 +451,8 @@ __global__ __launch_bounds__(WM * WN * 64) void tapconv_kernel(PhTapConv p) {
     for (int id = tid; id < BM * CPRF; id += NTH) {
       const int m = id / CPRF, ch = id - m * CPRF;
       const int r = r0 + (m >> 4), c = c0 + (m & 15);
-      if (!(full || (r < p.OHt && c < p.OWt))) continue;
-      const size_t o = ((size_t)(r * p.os + p.oa_h) * p.OW + (c * p.os + p.oa_w)) * p.Cout + n0 + ch * 4;
+      if (!(full || (r < L_OHt && c < L_OWt))) continue;
+      const size_t o = ((size_t)(r * p.os + L_oa_h) * p.OW + (c * p.os + L_oa_w)) * p.Cout + n0 + ch * 4;
       f32x4 v = *reinterpret_cast<const f32x4*>(ldsC + m * (BNT * 4) + ch * 16);
       if (resg) {
         const f32x4 g = *reinterpret_cast<const f32x4*>(resg + o);
@@ -493,11 +504,18 @@ int launch_cfg(const PhTapConv& p, hipStream_t st) {
       return PH_ELAUNCH;
     attr_done = true;
   }
-  dim3 grid(cdiv(p.OHt, TH) * cdiv(p.OWt, 16), p.Cout / BNT, p.B);
+  if (p.ncls && (S != 1 || p.ncls < 2 || p.ncls > 4 || p.stats)) return PH_EINVAL;
+  dim3 grid(cdiv(p.OHt, TH) * cdiv(p.OWt, 16), p.Cout / BNT, p.B * (p.ncls ? p.ncls : 1));
   void* tok = nullptr;
-  if (ph_prof_on())   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin
+  if (ph_prof_on()) {   // algorithmic FLOPs: 2 * positions * Cout * ntaps * Cin (merged classes: summed)
+    double work = 2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin;
+    if (p.ncls) {
+      work = 0;
+      for (int k = 0; k < p.ncls; ++k) work += 2.0 * p.B * p.c_OHt[k] * p.c_OWt[k] * (double)p.Cout * p.c_ntaps[k] * p.Cin;
+    }
     ph_prof_begin2(S == 2 ? PH_CLS_TAPCONV_S2 : (BNT == 64 ? PH_CLS_TAPCONV_N64 : PH_CLS_TAPCONV_N128),
-                   2.0 * p.B * p.OHt * p.OWt * (double)p.Cout * p.ntaps * p.Cin, ph_tapconv_bytes(p, S, sizeof(T)), st, &tok);
+                   work, ph_tapconv_bytes(p, S, sizeof(T)), st, &tok);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(C::NTH), C::LDS_BYTES, st, p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
@@ -512,8 +530,13 @@ double ph_tapconv_bytes(const PhTapConv& p, int S, int es) {
   const double in_pix = (double)p.B * ((double)p.OHt * S + 2) * ((double)p.OWt * S + 2);
   const double in_full = (double)p.B * p.IH * p.IW;
   const double in = (in_pix < in_full ? in_pix : in_full) * p.Cin * es * (p.m_groups ? p.m_groups : 1);
-  const double out = (double)p.B * p.OHt * p.OWt * p.Cout * es * (p.res_g ? (p.res_a ? 3.0 : 2.0) : 1.0);
-  return in + out + (double)p.ntaps * p.Cin * p.Cout * 2.0;
+  double pos = (double)p.OHt * p.OWt, taps = p.ntaps;
+  if (p.ncls) {      // merged output-parity classes: every class's positions and weight slabs
+    pos = 0; taps = 0;
+    for (int k = 0; k < p.ncls; ++k) { pos += (double)p.c_OHt[k] * p.c_OWt[k]; taps += p.c_ntaps[k]; }
+  }
+  const double out = (double)p.B * pos * p.Cout * es * (p.res_g ? (p.res_a ? 3.0 : 2.0) : 1.0);
+  return in + out + taps * p.Cin * p.Cout * 2.0;
 }
 namespace {
 

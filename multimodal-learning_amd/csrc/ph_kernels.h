@@ -79,6 +79,14 @@ struct PhTapConv {
   // branch's raw output, whose BatchNorm backward reduces the same dz.  ph_bn_bwd_finalize_launch combines the rows.
   const void* bst_y; const void* bst_a; const void* bst_y2;
   const float* bst_scale; const float* bst_shift; const float* bst_mean; const float* bst_mean2;
+  // optional (first-generation kernel, stride-1 configurations): ONE launch for the output-parity classes of a stride-2 dgrad
+  // (round 6).  ncls in 2..4 (0 = off): class k = blockIdx.z / B covers the positions (r * os + c_oa_h[k], c * os + c_oa_w[k]),
+  // r < c_OHt[k], c < c_OWt[k], with c_ntaps[k] <= 4 taps (c_dy / c_dx / c_wtap).  The classes write disjoint pixels of `out`
+  // and read the same `in`: as separate launches (1 / 2 / 2 / 4 taps each) layers 3.0 / 4.0 filled 256 / 128 of the 256 CUs
+  // four times in a row.  OHt / OWt / ntaps / oa_* / dy / dx / wtap above are then the largest class's (grid, profiler).
+  int ncls;
+  int c_ntaps[4], c_oa_h[4], c_oa_w[4], c_OHt[4], c_OWt[4];
+  int c_dy[4][4], c_dx[4][4], c_wtap[4][4];
 };
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st);
 double ph_tapconv_bytes(const PhTapConv& p, int S, int es);

@@ -336,7 +336,13 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
     }
     return ph_tapconv_launch(&t, 1, c.bprec(), c.st);
   }
-  // stride 2: one launch per output parity class (a,b); x row 2i+a receives kh with (a + pad - kh) even
+  // stride 2: output parity classes (a,b); x row 2i+a receives kh with (a + pad - kh) even.  One launch per class, or - the
+  // 3x3 convolutions (1 / 2 / 2 / 4 taps over the same dz, disjoint output pixels) - ONE launch for all four (PhTapConv::ncls,
+  // round 6: as four launches in a row layers 3.0 / 4.0 put 256 / 128 workgroups on the 256 CUs each time; PH_S2_MERGE=0
+  // keeps them apart, A/B and test switch)
+  static const bool merge = [] { const char* e = getenv("PH_S2_MERGE"); return !(e && e[0] == '0'); }();
+  PhTapConv mt = t;
+  mt.ncls = 0;
   for (int a = 0; a < 2; ++a)
     for (int b = 0; b < 2; ++b) {
       int nk = 0, khs[3], dhs[3], nw = 0, kws[3], dws[3];
@@ -359,9 +365,31 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
           if (dhs[i] < 0 || dws[j] < 0 || dhs[i] > 2 || dws[j] > 2) return PH_EINVAL;
           t.dy[q] = dhs[i]; t.dx[q] = dws[j]; t.wtap[q] = khs[i] * u.KS + kws[j]; ++q;
         }
+      if (merge && u.KS == 3 && t.ntaps <= 4 && mt.ncls < 4) {
+        const int k = mt.ncls++;
+        mt.c_ntaps[k] = t.ntaps; mt.c_oa_h[k] = a; mt.c_oa_w[k] = b; mt.c_OHt[k] = t.OHt; mt.c_OWt[k] = t.OWt;
+        for (int e = 0; e < t.ntaps; ++e) { mt.c_dy[k][e] = t.dy[e]; mt.c_dx[k][e] = t.dx[e]; mt.c_wtap[k][e] = t.wtap[e]; }
+        for (int e = t.ntaps; e < 4; ++e) { mt.c_dy[k][e] = 0; mt.c_dx[k][e] = 0; mt.c_wtap[k][e] = 0; }
+        // the descriptor's own fields: the largest class (grid extent; profiler)
+        if (k == 0 || t.OHt * t.OWt > mt.OHt * mt.OWt) { mt.OHt = t.OHt; mt.OWt = t.OWt; }
+        if (k == 0 || t.ntaps > mt.ntaps) {
+          mt.ntaps = t.ntaps;
+          for (int e = 0; e < t.ntaps; ++e) { mt.dy[e] = t.dy[e]; mt.dx[e] = t.dx[e]; mt.wtap[e] = t.wtap[e]; }
+        }
+        mt.os = 2; mt.oa_h = 0; mt.oa_w = 0; mt.iy0 = 0; mt.ix0 = 0;
+        continue;
+      }
       int rc = ph_tapconv_launch(&t, 1, c.bprec(), c.st);
       if (rc) return rc;
     }
+  if (mt.ncls >= 2) return ph_tapconv_launch(&mt, 1, c.bprec(), c.st);
+  if (mt.ncls == 1) {      // (a single class that qualified: an ordinary launch)
+    PhTapConv one = mt;
+    one.ncls = 0;
+    one.ntaps = mt.c_ntaps[0]; one.oa_h = mt.c_oa_h[0]; one.oa_w = mt.c_oa_w[0]; one.OHt = mt.c_OHt[0]; one.OWt = mt.c_OWt[0];
+    for (int e = 0; e < one.ntaps; ++e) { one.dy[e] = mt.c_dy[0][e]; one.dx[e] = mt.c_dx[0][e]; one.wtap[e] = mt.c_wtap[0][e]; }
+    return ph_tapconv_launch(&one, 1, c.bprec(), c.st);
+  }
   return PH_OK;
 }
 

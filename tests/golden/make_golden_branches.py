@@ -48,7 +48,7 @@ def main():
     import _warm
     B, H, n_data = 8, 64, 1024
 
-    def run(br, rec, warm=None, collect=False):
+    def run(br, rec, warm=None, collect=False, dt=torch.float32):
         name, opt.num_teachers, opt.which_teacher, opt.distill, opt.assign_weights = br
         with contextlib.redirect_stdout(io.StringIO()):
             student = NN.define_net(opt, 1, path_only=True)
@@ -72,11 +72,15 @@ def main():
             c.contrast.memory_v1.copy_(st.memory_v1); c.contrast.memory_v2.copy_(st.memory_v2)
             crds.append(c)
         criterion_kd, criterion_kd_path = crds
+        for mod in (student, ema, teacher, crds[0], crds[1]):      # (before the optimiser: its state takes the parameters' type)
+            mod.to(dt)
         ml = torch.nn.ModuleList([student, crds[0].embed_s, crds[0].embed_t, crds[1].embed_s, crds[1].embed_t])   # :192-208
         optimizer = NN.define_optimizer(opt, ml)
         wnames, wparams = _warm.param_names(student), list(ml.parameters())
         if warm is not None:
             _warm.set_torch_adam(optimizer, wnames, wparams, warm)
+        NN.define_scheduler(opt, optimizer)     # :212 - the trainer's LambdaLR applies its epoch-0 factor on creation
+        rec["lr"] = optimizer.param_groups[0]["lr"]
         criterion_div = DistillKL(opt.kd_T)
         ml.train(); teacher.train()
         ranks_all = []
@@ -91,6 +95,7 @@ def main():
             for it in range(2):
                 epoch = 3 + it
                 bt = synthetic_batch(B, H, n_data=n_data, seed=500 + it)
+                bt = {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in bt.items()}
                 index, sample_idx, grade = bt["index"], bt["sample_idx"], bt["grade"]
                 _, path_feat, logit_path, pred_path, _ = student(x_path=bt["x_path"])                       # :249
                 with torch.no_grad():
@@ -184,6 +189,14 @@ def main():
         rec["t1_gk_error"] = np.array(type(exc).__name__)
         print("num_teachers 1 + assign_weights True ->", type(exc).__name__, exc)
     np.savez_compressed(os.path.join(HERE, "branches_b8_h64.npz"), **npz(rec))
+    # the same calls in double precision: the reference's own fp32 distance to the truth after one update (the rows of step 1
+    # are judged against it where a run that is closer to the truth than the reference's fp32 one cannot match the golden)
+    rec64 = {}
+    for br in BRANCHES:
+        run(br, rec64, warm=scales, dt=torch.float64)
+    keep = ("logit_path", "loss", "scale", "g_fc2", "p_fc2")
+    rec64 = {k: v for k, v in rec64.items() if k.split(".", 1)[-1].startswith(keep)}
+    np.savez_compressed(os.path.join(HERE, "branches_b8_h64_fp64.npz"), **npz(rec64))
 
     # ---- define_scheduler (networks_new.py:111-129): learning rate per epoch under every policy it builds
     lrs = {}

@@ -1182,6 +1182,7 @@ def test_option_branches_vs_reference_golden(golden_dir, name, mode):
         assert len(names) == len(params)
         _warm.load_fused_adam(step.optimizer, names, params, _warm.unpack_scales(g))
         assert step.optimizer._step == t0
+        assert abs(step.optimizer.param_groups[0]["lr"] - float(g["lr"])) < 1e-12      # LambdaLR's epoch-0 factor on both sides
         step.iter_num = t0
         e_s0 = step.criterion_kd.embed_s.linear.weight.detach().clone()
         e_t1 = step.criterion_kd_path.embed_t.linear.weight.detach().clone()
@@ -1213,10 +1214,12 @@ def test_option_branches_vs_reference_golden(golden_dir, name, mode):
                 assert out["scale"] is None
             R.close(g[pre + f"g_fc2_{it}"], grads["fc2"], 1e-6, 2e-3, f"grad fc2 step {it}")
             R.close(g[pre + f"g_l4_1_conv2_abs{it}"], grads["l4"], 1e-4, 3e-3, f"grad l4.1.conv2 |.|_1 step {it}")
-            R.close(g[pre + f"p_fc2_{it}"], step.model.fc_new2.weight, 5e-6, 0, f"param fc2 after step {it}")
-            R.close(g[pre + f"ema_fc2_{it}"], step.ema_model.fc_new2.weight, 5e-6, 0, f"EMA fc2 after step {it}")
-            R.close(g[pre + f"embed_s0_{it}"], step.criterion_kd.embed_s.linear.weight[:8], 5e-6, 0, f"embed_s (kd) after step {it}")
-            R.close(g[pre + f"embed_t1_{it}"], step.criterion_kd_path.embed_t.linear.weight[:8], 5e-6, 0, f"embed_t (kd_path) after step {it}")
+            # (lr = 5e-4: a wrong update is ~1e-4; step 1's update inherits step 1's 6e-4 logit distance)
+            ptol = 5e-6 if it == 0 else 2e-5
+            R.close(g[pre + f"p_fc2_{it}"], step.model.fc_new2.weight, ptol, 0, f"param fc2 after step {it}")
+            R.close(g[pre + f"ema_fc2_{it}"], step.ema_model.fc_new2.weight, ptol, 0, f"EMA fc2 after step {it}")
+            R.close(g[pre + f"embed_s0_{it}"], step.criterion_kd.embed_s.linear.weight[:8], ptol, 0, f"embed_s (kd) after step {it}")
+            R.close(g[pre + f"embed_t1_{it}"], step.criterion_kd_path.embed_t.linear.weight[:8], ptol, 0, f"embed_t (kd_path) after step {it}")
             R.close(g[pre + f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[idx], 1e-4, 0, f"bank0 rows step {it}")
             R.close(g[pre + f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[idx], 1e-4, 0, f"bank1 rows step {it}")
             R.close(g[pre + f"params0_{it}"], step.criterion_kd.contrast.params, 1e-2, 1e-5, f"CRD params / Z (kd) step {it}")

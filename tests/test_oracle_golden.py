@@ -347,6 +347,7 @@ def load_branch_state(g, orc):
     trainable = [(n, tuple(p.shape)) for n, p in orc.trainable() if n in scales]
     mom = W.adam_moments(trainable, scales, _warm.SEED)
     orc.adam_t = orc.iter_num = int(g["t0"])
+    orc.lr = float(g["lr"])            # the trainer's LambdaLR has applied its epoch-0 factor (define_scheduler, :212)
     for n, (m, v) in mom.items():
         orc._m[n], orc._v[n] = m.clone(), v.clone()
     return mom
@@ -372,7 +373,9 @@ def test_option_branches_of_the_batch_body(golden_dir, name):
         _close(g[pre + f"logit_path{it}"], out["logit_path"], 1e-3, 0)
         _close(g[pre + f"loss_cls{it}"], out["loss_cls"], 1e-3, 1e-4)
         _close(g[pre + f"loss_div{it}"], out["loss_div1"] + out["loss_div2"], 1e-3, 1e-4)
-        _close(g[pre + f"loss_kd{it}"], out["loss_kd1"] + out["loss_kd2"], 1e-3, 1e-4)
+        # (the UNSCALED CRD loss, ~16 per criterion: what enters the objective is beta = 0.02 times it; the reference's own fp32
+        # value sits 5e-4 relative from its float64 run at step 1, tests/golden/branches_b8_h64_fp64.npz)
+        _close(g[pre + f"loss_kd{it}"], out["loss_kd1"] + out["loss_kd2"], 1e-3, 1e-3)
         _close(g[pre + f"loss_KD{it}"], out["loss_KD"], 1e-3, 1e-4)
         _close(g[pre + f"loss{it}"], out["loss"], 1e-3, 1e-4)
         if pre + f"scale{it}" in g:
