@@ -7,9 +7,14 @@
 // wgrad: M = cout, N = (kw,ch) 32 per kh, K = pixels, both operands through ds_read_b64_tr_b16.
 // There is no dgrad (the image needs no gradient on the hot path; dx is produced only on request by a
 // separate small kernel for the parity tests).
+#include <cstdlib>
 #include "ph_common.h"
 #include <type_traits>
 #include "ph_kernels.h"
+
+#ifndef PH_STEM_HP_ABL      // timing ablations of the half-pair stem (make trace TRACE_TAG=_x EXTRA=-DPH_STEM_HP_ABL=n): 1 no output
+#define PH_STEM_HP_ABL 0    // stores, 2 no MFMAs
+#endif
 
 namespace {
 
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   const T* x4 = reinterpret_cast<const T*>(p.x4);
 
   // the 28 KB (x planes) weight image is staged ONCE per workgroup and reused for STEM_TPW consecutive tiles
+  if constexpr (!HPM) {
   for (int i = tid; i < 7 * 64 * 4; i += 256) {   // 16-B chunks of the weight plane(s)
     const int ch = i & 3, row = i >> 2;           // row = kh*64 + cout
     const int off = row * 64 + (wsw(row, ch) << 4);
@@ -87,10 +93,42 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       *reinterpret_cast<u32x4*>(ldsW + pl * WB + off) =
           reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16*>(p.w) + (size_t)pl * p.wplane)[i];
   }
+  }
   const int m = wave * 32 + (lane & 31), khalf = lane >> 5;
+  // Half-pair mode (round 6): ALL weight fragments of the lane - 14 (kh, s) steps x 3 planes x 2 cout halves = 84 fragments of
+  // 16 bytes = 336 registers - live in REGISTERS for the whole workgroup (one wave per SIMD: 512 registers; the bf16 pooled
+  // kernel does the same with one plane).  With the three weight planes in LDS a (kh, s) step read 6 weight + 2 input fragments
+  // for its 6 MFMAs - 170 B / clk per CU against the array's 256 - and the kernel ran at a quarter of the fp16 MFMA rate.
+  // Planes 0 / 1 (w hi 2^11, w lo) are pinned to the accumulation registers (an MFMA takes its B operand from either file),
+  // plane 2 and everything else stays in the vector registers: 224 + 32 (accumulators) AGPRs, ~190 VGPRs.
+  bf16x8 wr[HPM ? 14 : 1][HPM ? 3 : 1][2];
+  if constexpr (HPM) {
+#pragma unroll
+    for (int st = 0; st < 14; ++st)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = (st >> 1) * 64 + j * 32 + (lane & 31), chunk = (st & 1) * 2 + khalf;
+          wr[st][pl][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.w) + (size_t)pl * p.wplane + row * 32 + chunk * 8);
+        }
+#pragma unroll
+    for (int st = 0; st < 14; ++st)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+a"(wr[st][0][j]));
+        asm volatile("" : "+a"(wr[st][1][j]));
+        asm volatile("" : "+v"(wr[st][2][j]));
+      }
+  }
   const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-  const int t_begin = blockIdx.x * STEM_TPW, t_end = min(ntiles, t_begin + STEM_TPW);
+  // blocks of STEM_TPW tiles: one per workgroup, or (PhStem::vblocks, half-pair mode) several per workgroup - the 336 weight
+  // registers are loaded once per workgroup, every block still leaves its own statistics row
+  const int nvb = p.vblocks > 0 ? p.vblocks : (int)gridDim.x;
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  if (vb != (int)blockIdx.x) { __syncthreads(); s1[0] = s1[1] = s2[0] = s2[1] = 0.f; }      // (the row reduction below reads the halo buffers' LDS)
+  const int t_begin = vb * STEM_TPW, t_end = min(ntiles, t_begin + STEM_TPW);
   // perf mode: the halo of tile t+1 is loaded into registers before the MFMAs of tile t (unconditional loads - an
   // out-of-image pixel reads a zero page - and, for interior tiles, unconditional stores in the epilogue, so the
   // compiler can count the s_waitcnt instead of draining the queue) and written to the other LDS buffer after them.
@@ -109,8 +147,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         const int iy = iy_base + hr, ix = ix_base + hc;
         const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         const f16* src = ok ? xp + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const f16*>(stem_zero8);
-        hreg[e] = *reinterpret_cast<const u32x2*>(src);
-        hregl[e] = *reinterpret_cast<const u32x2*>(ok ? src + lo_plane : src);
+        hreg[e] = ld_global<u32x2>(src);
+        hregl[e] = ld_global<u32x2>(ok ? src + lo_plane : src);
       }
     } else if constexpr (!SPLIT) {
       const int b = t / tiles_img, tile = t - b * tiles_img;
@@ -122,7 +160,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         const int iy = iy_base + hr, ix = ix_base + hc;
         const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         const T* src = ok ? x4 + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const T*>(stem_zero8);
-        hreg[e] = *reinterpret_cast<const u32x2*>(src);
+        hreg[e] = ld_global<u32x2>(src);
       }
     }
   };
@@ -170,32 +208,31 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       // steps) are read before the 6 MFMAs of step st; MFMAs as asm behind sched_barriers, accumulators pinned to AGPRs.
       asm volatile("" : "+a"(acc[0]));
       asm volatile("" : "+a"(acc[1]));
-      bf16x8 fa[2][2], fb[2][3][2];
+      bf16x8 fa[2][2];
       auto ldstep = [&](const int st, const int buf) {
         const int kh = st >> 1, s_ = st & 1;
-        const int chunk = s_ * 2 + khalf;
         const int aoff = (pbase + kh * HPW + 4 * s_ + 2 * khalf) * 8;
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) fa[buf][pl] = *reinterpret_cast<const bf16x8*>(ldsXc + pl * XB + aoff);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int row = kh * 64 + j * 32 + (lane & 31);
-            fb[buf][pl][j] = *reinterpret_cast<const bf16x8*>(ldsW + pl * WB + row * 64 + (wsw(row, chunk) << 4));
-          }
       };
+#if PH_STEM_HP_ABL & 2      // timing ablation: no MFMAs (the operands stay live)
+#define PH_STEM_MMA(J, A, B) asm volatile("" : "+a"(acc[J]) : "v"(A), "v"(B)); __builtin_amdgcn_sched_barrier(0)
+#define PH_STEM_MMA_A(J, A, B) asm volatile("" : "+a"(acc[J]) : "v"(A), "a"(B)); __builtin_amdgcn_sched_barrier(0)
+#else
 #define PH_STEM_MMA(J, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[J]) : "v"(A), "v"(B)); __builtin_amdgcn_sched_barrier(0)
+#define PH_STEM_MMA_A(J, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[J]) : "v"(A), "a"(B)); __builtin_amdgcn_sched_barrier(0)
+#endif
       ldstep(0, 0);
 #pragma unroll
       for (int st = 0; st < 14; ++st) {
         const int cur = st & 1;
         if (st + 1 < 14) ldstep(st + 1, cur ^ 1);
         // (the product order of the loop below: (x lo, w hi), (x hi, w lo), (x hi, w hi 2^11))
-        PH_STEM_MMA(0, fa[cur][1], fb[cur][2][0]); PH_STEM_MMA(1, fa[cur][1], fb[cur][2][1]);
-        PH_STEM_MMA(0, fa[cur][0], fb[cur][1][0]); PH_STEM_MMA(1, fa[cur][0], fb[cur][1][1]);
-        PH_STEM_MMA(0, fa[cur][0], fb[cur][0][0]); PH_STEM_MMA(1, fa[cur][0], fb[cur][0][1]);
+        PH_STEM_MMA(0, fa[cur][1], wr[st][2][0]); PH_STEM_MMA(1, fa[cur][1], wr[st][2][1]);
+        PH_STEM_MMA_A(0, fa[cur][0], wr[st][1][0]); PH_STEM_MMA_A(1, fa[cur][0], wr[st][1][1]);
+        PH_STEM_MMA_A(0, fa[cur][0], wr[st][0][0]); PH_STEM_MMA_A(1, fa[cur][0], wr[st][0][1]);
       }
+#undef PH_STEM_MMA_A
 #undef PH_STEM_MMA
     } else {
 #pragma unroll
@@ -270,14 +307,16 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * NPA * XB);
       if (r0 + TH <= p.OH && c0 + TW <= p.OW) store_tile(std::true_type{});
       else store_tile(std::false_type{});
-      __syncthreads();
+      // LDS-only barrier (round 6): it publishes the next tile's halo; __syncthreads() would also wait for this tile's 16 KB of
+      // output stores (vmcnt(0)) in every wave before the next tile's MFMAs may start - the stores drain behind them instead
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     } else {
       // fp32 outputs, one 4-byte store per value (a wave-instruction writes two 128-byte runs).  Half-pair mode: the next tile's
       // halo planes (requested before the MFMAs) go to the other buffer first, one barrier per tile as in perf mode
       if constexpr (HPM) { if (tt + 1 < t_end) store_halo_regs(ldsX + (((tt - t_begin) & 1) ^ 1) * NPA * XB); }
       // half-pair mode: the fp32 tile goes through an LDS image [128 pixels][64 channels] behind the operand buffers and leaves as
       // 16-byte chunks (one 4-byte store per value: 32 store instructions per wave and tile for 1.07 GB of output)
-      float* cimg = reinterpret_cast<float*>(smem + XB * XBUFS + WB * NP);
+      float* cimg = reinterpret_cast<float*>(smem + XB * XBUFS + (HPM ? 0 : WB * NP));      // (half-pair mode keeps no weight image)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
@@ -292,14 +331,20 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
         }
       }
       if constexpr (HPM) {
-        __syncthreads();
+        // (LDS-only barriers: the 32 KB of output stores of a tile drain behind the next tile's MFMAs; the image is free again
+        // once every wave has READ its chunks - lgkmcnt - not once the stores have completed)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         for (int id = tid; id < TH * TW * 16; id += 256) {
           const int mm = id >> 4, ch = id & 15;
           const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
+#if PH_STEM_HP_ABL & 1      // timing ablation: no output stores
+          if (r < p.OH && c < p.OW) { f32x4 v_ = *reinterpret_cast<const f32x4*>(cimg + mm * 64 + ch * 4); asm volatile("" ::"v"(v_)); }
+#else
           if (r < p.OH && c < p.OW)
             *reinterpret_cast<f32x4*>(out + ((size_t)r * p.OW + c) * 64 + ch * 4) = *reinterpret_cast<const f32x4*>(cimg + mm * 64 + ch * 4);
+#endif
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
   }
@@ -321,9 +366,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) v += red[(w * 2 + which) * 64 + n];
-      p.stats[((size_t)blockIdx.x * 2 + which) * 64 + n] = v;
+      p.stats[((size_t)vb * 2 + which) * 64 + n] = v;
     }
   }
+  }      // blocks of this workgroup
 }
 
 
@@ -426,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     for (int e = 0; e < HCH; ++e) {
       const unsigned iy = (unsigned)(iy_base + hrow[e]);      // (invalid elements: a huge row)
       const bf16* src = iy < (unsigned)p.IH ? rowbase + hoff[e] : reinterpret_cast<const bf16*>(stem_zero8);
-      hreg[e] = *reinterpret_cast<const u32x2*>(src);
+      hreg[e] = ld_global<u32x2>(src);
     }
   };
   auto store_halo_regs = [&](unsigned char* dst) {
@@ -669,11 +715,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
         const size_t px = ((size_t)b * p.OH + r) * p.OW + c;
         if constexpr (HPM) {      // a [hi 64 | lo 64] fp16 pixel record
           const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(reinterpret_cast<const f16*>(p.dy) + px * 128 + ch * 8) : zero;
-          dreg[0][e] = *reinterpret_cast<const u32x4*>(src);
-          dreg[HPM ? 1 : 0][e] = *reinterpret_cast<const u32x4*>(ok ? src + 128 : zero);
+          dreg[0][e] = ld_global<u32x4>(src);
+          dreg[HPM ? 1 : 0][e] = ld_global<u32x4>(ok ? src + 128 : zero);
         } else {
           const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(DY + px * 64 + ch * 8) : zero;
-          dreg[0][e] = *reinterpret_cast<const u32x4*>(src);
+          dreg[0][e] = ld_global<u32x4>(src);
         }
       }
       const int iy_base = r0 * 2 - 3, ix_base = c0 * 2 - 3;
@@ -686,10 +732,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(PhStemWgrad p) {
         const size_t g = (((size_t)b * p.IH + iy) * p.IW + ix) * 4;
         if constexpr (HPM) {      // the two fp16 planes [2][B IH IW][4] of ph_pack_input_launch
           const f16* xp = reinterpret_cast<const f16*>(p.x4);
-          xreg[0][e] = *reinterpret_cast<const u32x2*>(ok ? reinterpret_cast<const unsigned char*>(xp + g) : zero);
-          xreg[HPM ? 1 : 0][e] = *reinterpret_cast<const u32x2*>(ok ? reinterpret_cast<const unsigned char*>(xp + (size_t)p.B * p.IH * p.IW * 4 + g) : zero);
+          xreg[0][e] = ld_global<u32x2>(ok ? reinterpret_cast<const unsigned char*>(xp + g) : zero);
+          xreg[HPM ? 1 : 0][e] = ld_global<u32x2>(ok ? reinterpret_cast<const unsigned char*>(xp + (size_t)p.B * p.IH * p.IW * 4 + g) : zero);
         } else {
-          xreg[0][e] = *reinterpret_cast<const u32x2*>(ok ? reinterpret_cast<const unsigned char*>(X + g) : zero);
+          xreg[0][e] = ld_global<u32x2>(ok ? reinterpret_cast<const unsigned char*>(X + g) : zero);
         }
       }
     }
@@ -873,7 +919,11 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     static bool done = false;
     const int lds = 2 * XB + WB;
     if (set_lds(stem_fwd_kernel<bf16>, lds, done)) return PH_ELAUNCH;
-    hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, *p);
+    // (PH_STEM_VB16=n: n x CUs workgroups walk the blocks - the 28 KB weight image is staged once per workgroup; 0 = one block each)
+    static const int vb16 = [] { const char* e = getenv("PH_STEM_VB16"); return e ? atoi(e) : 0; }();
+    PhStem q = *p;
+    if (vb16 > 0 && (int)grid.x > vb16 * ph_num_cus()) { q.vblocks = (int)grid.x; grid.x = vb16 * ph_num_cus(); }
+    hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, q);
   } else if (PH_IS_SPLIT_PREC(prec)) {
     static bool done = false;
     const int lds = PH_NPLANES * (XB + WB);
@@ -883,9 +933,15 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     hipLaunchKernelGGL(stem_fwd_kernel<float>, grid, dim3(256), lds, st, q);
   } else if (prec == PH_PREC_FP16X3) {
     static bool done = false;
-    const int lds = 4 * XB + PH_NPLANES * WB + TH * TW * 64 * 4;      // two halo buffers of two planes + the three weight planes + the fp32 output image
+    const int lds = 4 * XB + TH * TW * 64 * 4;      // two halo buffers of two planes + the fp32 output image (the weights live in registers)
     if (set_lds(stem_fwd_kernel<hp16>, lds, done)) return PH_ELAUNCH;
-    hipLaunchKernelGGL(stem_fwd_kernel<hp16>, grid, dim3(256), lds, st, *p);
+    // one wave per SIMD (the weights hold 336 of the 512 registers): two workgroups per CU can never be resident, so at most
+    // 2 x CUs workgroups walk the blocks (PH_STEM_VB=0: one block per workgroup, A/B switch)
+    static const int vb_mul = [] { const char* e = getenv("PH_STEM_VB"); return e ? atoi(e) : 1; }();
+    PhStem q = *p;
+    const int cap = vb_mul * ph_num_cus();
+    if (vb_mul > 0 && (int)grid.x > cap) { q.vblocks = (int)grid.x; grid.x = cap; }
+    hipLaunchKernelGGL(stem_fwd_kernel<hp16>, grid, dim3(256), lds, st, q);
   } else {
     return PH_EINVAL;
   }

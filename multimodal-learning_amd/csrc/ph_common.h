@@ -65,6 +65,21 @@ __device__ __forceinline__ void hp_split(float x, f16& hi, f16& lo) {
   lo = (f16)((x - (float)hi) * PH_HP_LO);
 }
 
+// A load through a pointer the compiler cannot prove to be global - `in_image ? tensor + offset : zero_page` selects between a
+// kernel argument and a __device__ variable and degrades to FLAT instructions: those count in vmcnt AND lgkmcnt and return out of
+// order, so every wait on them is a full drain (vmcnt(0) + lgkmcnt(0)) of the wave's memory queue - outstanding output stores
+// and LDS traffic included (round 6: all stem kernels prefetched their halos this way).  ld_global states the address space.
+template <typename V>
+__device__ __forceinline__ V ld_global(const void* p) {
+  typedef __attribute__((address_space(1))) const V GV;
+  return *reinterpret_cast<GV*>(reinterpret_cast<unsigned long long>(p));
+}
+template <typename V>
+__device__ __forceinline__ void st_global(void* p, const V& v) {
+  typedef __attribute__((address_space(1))) V GV;
+  *reinterpret_cast<GV*>(reinterpret_cast<unsigned long long>(p)) = v;
+}
+
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 
@@ -72,15 +87,16 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16* p, float v) { *p = (bf16)v; }
+// (hp_hi_addr goes through an integer: the accesses state the global address space themselves - ld_global / st_global above)
 __device__ __forceinline__ float ldf(const hp16* p) {
-  const f16* h = reinterpret_cast<const f16*>(hp_hi_addr(p));
-  return (float)h[0] + (float)h[64] * PH_HP_LO_INV;
+  const unsigned char* h = hp_hi_addr(p);
+  return (float)ld_global<f16>(h) + (float)ld_global<f16>(h + 128) * PH_HP_LO_INV;
 }
 __device__ __forceinline__ void stf(hp16* p, float v) {
-  f16* h = reinterpret_cast<f16*>(const_cast<unsigned char*>(hp_hi_addr(p)));
+  unsigned char* h = const_cast<unsigned char*>(hp_hi_addr(p));
   f16 a, b;
   hp_split(v, a, b);
-  h[0] = a; h[64] = b;
+  st_global<f16>(h, a); st_global<f16>(h + 128, b);
 }
 
 // 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32); pointers must be 16-B aligned
@@ -112,8 +128,8 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 // 8 consecutive channels (p 32-B aligned in the fp32 view): one 16-B hi chunk + one 16-B lo chunk, 128 B apart
 __device__ __forceinline__ void load8(const hp16* p, float (&v)[8]) {
   const unsigned char* a = hp_hi_addr(p);
-  const f16x8 h = *reinterpret_cast<const f16x8*>(a);
-  const f16x8 l = *reinterpret_cast<const f16x8*>(a + 128);
+  const f16x8 h = ld_global<f16x8>(a);
+  const f16x8 l = ld_global<f16x8>(a + 128);
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (float)h[i] + (float)l[i] * PH_HP_LO_INV;
 }
@@ -122,8 +138,8 @@ __device__ __forceinline__ void store8(hp16* p, const float (&v)[8]) {
   f16x8 h, l;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { f16 x, y; hp_split(v[i], x, y); h[i] = x; l[i] = y; }
-  *reinterpret_cast<f16x8*>(a) = h;
-  *reinterpret_cast<f16x8*>(a + 128) = l;
+  st_global<f16x8>(a, h);
+  st_global<f16x8>(a + 128, l);
 }
 
 // 3-way bf16 split of an fp32 value (parity mode "bf16x6"): x = p0 + p1 + p2 exactly (3 x 8 significant

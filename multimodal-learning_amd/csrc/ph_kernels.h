@@ -135,6 +135,8 @@ struct PhStem {
   float* stats;          // [B*tiles][2][64]
   int B, IH, IW, OH, OW;
   int prod6;             // split-plane modes: six products or the three leading ones (set by the launcher)
+  int vblocks;           // > 0: the grid is smaller than the `vblocks` blocks of STEM_TPW tiles - workgroup b walks blocks b, b + grid, ..
+                         // (one statistics row per BLOCK either way: rows and summation order do not depend on the grid)
 };
 int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st);
 int ph_stem_stat_parts(int B, int OH, int OW);
