@@ -396,8 +396,20 @@ constexpr int PCOLS = 14;
 #define PH_STEM_ABL 0    // 1 no halo loads after the first, 2 no pooling phase, 4 no MFMAs, 8 no staging writes
 #endif
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+// (inline asm: through __builtin_elementwise_max the compiler first canonicalises every operand it has not produced itself - a
+// v_pk_max_f16 x, x, x per loaded word, 34 of the 70 packed maxima of a tile; the staged values are finite bf16 patterns or the
+// -inf identity, for which the plain instruction is exact)
+#ifndef PH_POOL_VARIANT
+#define PH_POOL_VARIANT 1      // 1 = inline-asm packed maximum; 2 = negated weight rows (OFF: not bitwise - see below)
+#endif
 __device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+#if PH_POOL_VARIANT & 1
+  unsigned r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+#else
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)));
+#endif
 }
 constexpr unsigned POOL_IDENT = 0xFC00FC00u;
 // scalar fp32 add / fused multiply-add the SLP vectoriser cannot pair: hipcc -O3 turned the BatchNorm sums of the epilogue
@@ -445,6 +457,26 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
       for (int j = 0; j < 2; ++j)
         wfrag[kh][s2][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.w) +
                                                             ((size_t)(kh * 64 + j * 32 + (lane & 31)) * 32 + (s2 * 2 + khalf) * 8));
+  // (PH_POOL_VARIANT & 2, measured and OFF, round 6) Channels with gamma < 0 need the window's MINIMUM: with their weight rows
+  // NEGATED once per strip the accumulators would hold -y and the staged word would need no exclusive-or (16 of a tile's vector
+  // instructions).  But the matrix pipe's fp32 accumulation is NOT sign-symmetric: A (-B) + C differs from -(A B + C) in the last
+  // bit for rare operands - at B = 64 / 512 x 512 a handful of the 67 M pooled values moved by one bf16 step and the eval-mode
+  // comparison with the separate passes (bitwise) failed.  Kept as a documented dead end.
+  float wsgn[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bool neg = (PH_POOL_VARIANT & 2) && p.gamma[j * 32 + (lane & 31)] < 0.f;
+    wsgn[j] = neg ? -1.f : 1.f;
+    const unsigned fx = neg ? 0x80008000u : 0u;
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 w_ = __builtin_bit_cast(u32x4, wfrag[kh][s2][j]);
+        w_[0] ^= fx; w_[1] ^= fx; w_[2] ^= fx; w_[3] ^= fx;
+        wfrag[kh][s2][j] = __builtin_bit_cast(bf16x8, w_);
+      }
+  }
   const int pbase = ((m >> 4) * 2) * HPW + (m & 15) * 2;
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   // ---- halo: the thread's (up to) four pixels of the 21 x 38 halo keep their offsets for the whole strip; only the row
@@ -490,12 +522,6 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     pflip[k] = (p.gamma[cg * 8 + 2 * k] < 0.f ? 0x8000u : 0u) | (p.gamma[cg * 8 + 2 * k + 1] < 0.f ? 0x80000000u : 0u);
   const int poff = (2 * pcl * 64 + cg * 8) * 2;               // byte offset of the window's first column in a staged row
   // ---- epilogue role: the lane's channel pair (lane & 30, + 1) of each 32-channel half j; its staging byte offset
-  unsigned eflip[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c0 = j * 32 + ((lane & 31) & ~1);
-    eflip[j] = (p.gamma[c0] < 0.f ? 0x8000u : 0u) | (p.gamma[c0 + 1] < 0.f ? 0x80000000u : 0u);
-  }
   const int eoff = ((4 * khalf + (lane & 1)) * 64 + ((lane & 31) & ~1)) * 2;
   // local columns 0 and 15 of a tile belong to the neighbouring strips: registers (khalf 0: q = 0, 8), (khalf 1: q = 7, 15)
   const float own_lo = khalf == 0 ? 0.f : 1.f, own_hi = khalf == 1 ? 0.f : 1.f;
@@ -513,11 +539,17 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     const unsigned char* ldsXc = ldsX + (tpar & 1) * XB;
     if (!(PH_STEM_ABL & 1) && tr + 1 < tr_end) load_halo_regs(tr + 1);
     f32x16 acc[2];
+    // all fourteen input fragments of the tile are requested before the first MFMA (the accumulators and the pooling window
+    // are dead here: 56 registers are free): as `read, wait, two MFMAs` per step every step exposed an LDS round trip
+    bf16x8 afr[14];
+#pragma unroll
+    for (int st = 0; st < 14; ++st)
+      afr[st] = *reinterpret_cast<const bf16x8*>(ldsXc + (pbase + (st >> 1) * HPW + 4 * (st & 1) + 2 * khalf) * 8);
 #pragma unroll
     for (int kh = 0; kh < 7; ++kh) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ldsXc + (pbase + kh * HPW + 4 * s + 2 * khalf) * 8);
+        const bf16x8 a = afr[kh * 2 + s];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (kh == 0 && s == 0) {
@@ -575,7 +607,12 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
           own[1] = (bf16)v1;
           const unsigned x = __builtin_bit_cast(unsigned, own);
           const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-          const unsigned word = __builtin_amdgcn_perm(y, x, psel) ^ eflip[j];                    // [even channel, odd channel]
+#if PH_POOL_VARIANT & 2
+          const unsigned word = __builtin_amdgcn_perm(y, x, psel);                               // [even channel, odd channel], signs as staged
+#else
+          const int c0_ = j * 32 + ((lane & 31) & ~1);
+          const unsigned word = __builtin_amdgcn_perm(y, x, psel) ^ ((p.gamma[c0_] < 0.f ? 0x8000u : 0u) | (p.gamma[c0_ + 1] < 0.f ? 0x80000000u : 0u));
+#endif
           if (PH_STEM_ABL & 8) asm volatile("" ::"v"(word));
           else *reinterpret_cast<unsigned*>(dst + j * 64) = word;
         }
@@ -636,6 +673,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     float* red = reinterpret_cast<float*>(smem);   // [4 waves][2][64] (the halo buffers are dead)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      s1[j] *= wsgn[j];      // (the negated channels accumulated -y: exact)
       const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
       const float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
       if (khalf == 0) {
