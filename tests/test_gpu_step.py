@@ -1266,3 +1266,99 @@ def test_one_teacher_with_gk_refine_raises_like_the_reference():
         m.DistillStep(default_opt(num_teachers=1, which_teacher="fuse", assign_weights="True"), 64, device="cuda")
     with pytest.raises(UnboundLocalError):
         m.DistillStep(default_opt(num_teachers=1, which_teacher="nobody", assign_weights="False"), 64, device="cuda")
+
+
+MIA_BRANCHES = [("mia2022", "t1_fuse_crd"), ("mia2022", "t1_ema_crd"), ("mia2023", "t1_fuse_crd"), ("mia2023", "t1_ema_crd"),
+                ("mia2023", "t1_fuse_kd"), ("mia2023", "t2_kd_gk")]
+MIA_BRANCH_OPTS = {"t1_fuse_crd": (1, "fuse", "crd", "False"), "t1_ema_crd": (1, "self_EMA", "crd", "False"),
+                   "t1_fuse_kd": (1, "fuse", "kd", "False"), "t2_kd_gk": (2, "fuse", "kd", "True")}
+
+
+@pytest.mark.parametrize("variant,name", MIA_BRANCHES)
+def test_mia_option_branches_vs_reference_golden(golden_dir, variant, name):
+    """The one-teacher and `--distill kd` branches of the MIA-2022 / MIA-2023 batch bodies ("MIA 2022/
+    train_test_path_multi_distill_v2.py":419-482, "MIA 2023/stage2_unimodal_student/train_test_path_multi_distill.py":348-427)
+    through DistillStep(variant=...) against each REFERENCE run under those options (tests/golden/make_golden_branches_mia.py:
+    two steps from a mid-training Adam state): logits, loss terms, per-sample GK-Refine weights (MIA-2023 kd), gradients, updated
+    parameters, EMA, bank rows - and the unused criterion's heads stay untouched."""
+    import sys
+    import multimodal_learning_amd as m
+    from oracle import weights as W
+    from oracle.step import default_opt, synthetic_batch
+    from oracle.variants import CRDv3State, CRDv10State
+    from tests.gpu_util import Report
+    sys.path.insert(0, golden_dir)
+    import _warm
+    g = np.load(os.path.join(golden_dir, "branches_%s.npz" % variant))
+    B, H, n_data, K, t0 = int(g["B"]), int(g["H"]), int(g["n_data"]), int(g["K"]), int(g["t0"])
+    nt, wt, distill, aw = MIA_BRANCH_OPTS[name]
+    kw = dict(num_teachers=nt, which_teacher=wt, distill=distill, assign_weights=aw, nce_k=K, batch_size=B)
+    if variant == "mia2022":
+        opt = default_opt(grads_m=float(g["grads_m"]), grads_thresh="False", thresh=0.1, niter_decay=int(g["niter_decay"]), **kw)
+        extra = {}
+    else:
+        labels = torch.as_tensor(g["labels"])
+        class_idx = [np.nonzero((labels == c).numpy())[0] for c in range(3)]
+        opt = default_opt(nce_p=int(g["num_pos"]), pos_extra="neighbors", neg_mode="all_others",
+                          start_reweight=int(g["start_reweight"]), discrep_scale=1, max_discrep=float(g["max_discrep"]),
+                          use_grads_thresh="True", grads_thresh=float(g["grads_thresh"]), loss_weighting="GK_refine", **kw)
+        extra = dict(train_class_idx=class_idx)
+    m.set_precision("bf16x6")
+    try:
+        step = m.DistillStep(opt, n_data, device="cuda", variant=variant, **extra)
+        step.model.load_state_dict(W.make_state_dict(W.student_shapes(), 1))
+        step.ema_model.load_state_dict(W.make_state_dict(W.student_shapes(), 2))
+        step.fix_model.load_state_dict(W.make_state_dict(W.teacher_shapes(320), 3))
+        for i, crd in enumerate((step.criterion_kd, step.criterion_kd_path)):
+            crd.embed_s.load_state_dict(W.make_state_dict(W.embed_shapes(), 10 + 2 * i))
+            crd.embed_t.load_state_dict(W.make_state_dict(W.embed_shapes(), 11 + 2 * i))
+            st = CRDv3State(n_data, K=K, seed=20 + i) if variant == "mia2022" else CRDv10State(n_data, labels, K=K, seed=20 + i)
+            crd.contrast.memory_v1.copy_(st.memory_v1); crd.contrast.memory_v2.copy_(st.memory_v2)
+            crd.contrast.verbose = False
+        names = _warm.param_names(step.model)
+        params = list(step.module_list.parameters())
+        assert len(names) == len(params)
+        _warm.load_fused_adam(step.optimizer, names, params, _warm.unpack_scales(g))
+        assert step.optimizer._step == t0 and abs(step.optimizer.param_groups[0]["lr"] - float(g["lr"])) < 1e-12
+        step.iter_num = t0
+        e_t1 = step.criterion_kd_path.embed_t.linear.weight.detach().clone()
+        R = Report(f"{variant} option branch {name} vs REFERENCE golden (B=8, 64x64)")
+        pre = name + "."
+        grads = {}
+        orig = step.optimizer.step
+
+        def spy(*a, **k):
+            grads["fc2"] = step.model.fc_new2.weight.grad.detach().clone()
+            grads["l4"] = step.model.layer4[1].conv2.weight.grad.detach().abs().sum()
+            return orig(*a, **k)
+        step.optimizer.step = spy
+        for it in range(2):
+            bt = synthetic_batch(B, H, n_data=n_data, P=1, K=K, seed=(600 if variant == "mia2022" else 700) + it)
+            if variant == "mia2023":
+                bt["grade"] = labels[bt["index"]]
+            out = step.step(_tuple(bt), epoch=int(g[pre + f"epoch{it}"]))
+            idx = bt["index"].cuda()
+            R.close(g[pre + f"logit_path{it}"], out["logit_path"], 1e-3, 0, f"logit_path step {it}")
+            R.close(g[pre + f"loss_cls{it}"], out["loss_cls"], 1e-3, 1e-4, f"loss_cls step {it}")
+            R.close(float(g[pre + f"loss_div{it}"]) * opt.alpha, out["loss_div1"] + out["loss_div2"], 1e-3, 1e-4, f"loss_div step {it}")
+            R.close(float(g[pre + f"loss_kd{it}"]) * opt.beta, out["loss_kd1"] + out["loss_kd2"], 1e-3, 1e-4, f"loss_kd step {it}")
+            R.close(g[pre + f"loss{it}"], out["loss"], 1e-3, 1e-4, f"loss step {it}")
+            if pre + f"scale{it}" in g:
+                R.close(g[pre + f"scale{it}"], out["scale"], 2e-3, 1e-3, f"GK-Refine scale step {it}")
+            else:
+                assert out["scale"] is None
+            ptol = 5e-6 if it == 0 else 2e-5
+            R.close(g[pre + f"g_fc2_{it}"], grads["fc2"], 1e-6, 2e-3, f"grad fc2 step {it}")
+            R.close(g[pre + f"g_l4_1_conv2_abs{it}"], grads["l4"], 1e-4, 3e-3, f"grad l4.1.conv2 |.|_1 step {it}")
+            R.close(g[pre + f"p_fc2_{it}"], step.model.fc_new2.weight, ptol, 0, f"param fc2 after step {it}")
+            R.close(g[pre + f"ema_fc2_{it}"], step.ema_model.fc_new2.weight, ptol, 0, f"EMA fc2 after step {it}")
+            R.close(g[pre + f"embed_s0_{it}"], step.criterion_kd.embed_s.linear.weight[:8], ptol, 0, f"embed_s (kd) after step {it}")
+            R.close(g[pre + f"embed_t1_{it}"], step.criterion_kd_path.embed_t.linear.weight[:8], ptol, 0, f"embed_t (kd_path) after step {it}")
+            R.close(g[pre + f"bank0_v1_rows{it}"], step.criterion_kd.contrast.memory_v1[idx], 1e-4, 0, f"bank0 rows step {it}")
+            R.close(g[pre + f"bank1_v2_rows{it}"], step.criterion_kd_path.contrast.memory_v2[idx], 1e-4, 0, f"bank1 rows step {it}")
+            R.close(g[pre + f"params0_{it}"], step.criterion_kd.contrast.params, 1e-2, 1e-5, f"CRD params / Z (kd) step {it}")
+            skipped = set(str(s) for s in g[pre + f"no_grad{it}"])
+            assert "crd1.embed_t.linear.weight" in skipped and torch.equal(step.criterion_kd_path.embed_t.linear.weight, e_t1)
+        R.finish()
+    finally:
+        m.set_precision("bf16")
