@@ -28,6 +28,21 @@ constexpr int STEM_TPW = 8;           // output tiles per forward workgroup (wei
 
 __device__ __forceinline__ int wsw(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 
+// scalar fp32 add / fused multiply-add the SLP vectoriser cannot pair: hipcc -O3 turned the BatchNorm sums of the epilogue
+// into v_pk_add_f32 / v_pk_mul_f32, which cost ~16 cycles each beside an MFMA stream (the staging phase: 2200 cycles for
+// ~200 instructions, interval tracer) - MI355X_MICROARCH.md, "price of one filler beside MFMAs"
+__device__ __forceinline__ float fadd_s(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float ffma_s(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+
 // (T = hp16: x4 = the two fp16 planes [2][B IH IW][4] of ph_pack_input_launch, staged as they lie; `nb` = batch size)
 template <typename T>
 __device__ __forceinline__ void stage_halo(const T* x4, int b, int IH, int IW, int iy_base, int ix_base,
@@ -86,7 +101,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   // the 28 KB (x planes) weight image is staged ONCE per workgroup and reused for STEM_TPW consecutive tiles
   if constexpr (!HPM) {
   for (int i = tid; i < 7 * 64 * 4; i += 256) {   // 16-B chunks of the weight plane(s)
-    const int ch = i & 3, row = i >> 2;           // row = kh*64 + cout
+    const int ch = i & 3, srow = i >> 2;          // source row = kh*64 + cout
+    // perf mode (round 6): LDS row kh*64 + j*32 + l holds cout 2 l + j, so that lane l of the MFMA owns the channel PAIR
+    // (2 l, 2 l + 1) in its two accumulator sets: a pixel's [even, odd] bf16 word is one v_cvt_pk of the lane's own values - the
+    // lane-pair DPP exchange + byte permute per word (32 of a tile's ~590 instructions) are gone; values, statistics and their
+    // summation order are unchanged (an MFMA column's result does not depend on which column it is)
+    const int co = srow & 63;
+    const int row = (!SPLIT) ? ((srow & ~63) | ((co & 1) << 5) | (co >> 1)) : srow;
     const int off = row * 64 + (wsw(row, ch) << 4);
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
@@ -134,33 +155,35 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
   // compiler can count the s_waitcnt instead of draining the queue) and written to the other LDS buffer after them.
   constexpr int HCH = (HP + 255) / 256;
   u32x2 hreg[SPLIT ? 1 : HCH], hregl[HPM ? HCH : 1];
+  // (round 6) per-thread constants of the halo prefetch: element e of the thread is halo pixel (hrow, hcol), `hoff` elements
+  // past the tile's first halo pixel; a tile only contributes a wave-uniform base and the two range checks.  Recomputing row /
+  // column / 64-bit address per element and tile was ~180 of a tile's ~590 instructions (device assembly, bf16 kernel).
+  int hrow_[SPLIT ? 1 : HCH], hcol_[SPLIT ? 1 : HCH];
+  long hoff_[SPLIT ? 1 : HCH];
+  if constexpr (!SPLIT) {
+#pragma unroll
+    for (int e = 0; e < HCH; ++e) {
+      const int i = tid + e * 256;
+      const int hr = i / HPW, hc = i - hr * HPW;
+      hrow_[e] = i < HP ? hr : (1 << 28);      // (an element past the halo: a row that is never inside)
+      hcol_[e] = hc;
+      hoff_[e] = ((long)hr * p.IW + hc) * 4;
+    }
+  }
   auto load_halo_regs = [&](int t) {
-    if constexpr (HPM) {
+    if constexpr (!SPLIT) {
       const int b = t / tiles_img, tile = t - b * tiles_img;
       const int iy_base = (tile / tiles_w) * TH * 2 - 3, ix_base = (tile % tiles_w) * TW * 2 - 3;
+      // (T = hp16: two fp16 planes [2][B IH IW][4]; 4 fp16 = 8 bytes per pixel and plane, like the bf16 image)
       const f16* xp = reinterpret_cast<const f16*>(p.x4);
-      const size_t lo_plane = (size_t)p.B * p.IH * p.IW * 4;
+      const f16* base = xp + (((long)b * p.IH + iy_base) * p.IW + ix_base) * 4;
+      const long lo_plane = (long)p.B * p.IH * p.IW * 4;
 #pragma unroll
       for (int e = 0; e < HCH; ++e) {
-        const int i = tid + e * 256;
-        const int hr = i / HPW, hc = i - hr * HPW;
-        const int iy = iy_base + hr, ix = ix_base + hc;
-        const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const f16* src = ok ? xp + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const f16*>(stem_zero8);
+        const bool ok = (unsigned)(iy_base + hrow_[e]) < (unsigned)p.IH && (unsigned)(ix_base + hcol_[e]) < (unsigned)p.IW;
+        const f16* src = ok ? base + hoff_[e] : reinterpret_cast<const f16*>(stem_zero8);
         hreg[e] = ld_global<u32x2>(src);
-        hregl[e] = ld_global<u32x2>(ok ? src + lo_plane : src);
-      }
-    } else if constexpr (!SPLIT) {
-      const int b = t / tiles_img, tile = t - b * tiles_img;
-      const int iy_base = (tile / tiles_w) * TH * 2 - 3, ix_base = (tile % tiles_w) * TW * 2 - 3;
-#pragma unroll
-      for (int e = 0; e < HCH; ++e) {
-        const int i = tid + e * 256;
-        const int hr = i / HPW, hc = i - hr * HPW;
-        const int iy = iy_base + hr, ix = ix_base + hc;
-        const bool ok = i < HP && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        const T* src = ok ? x4 + (((size_t)b * p.IH + iy) * p.IW + ix) * 4 : reinterpret_cast<const T*>(stem_zero8);
-        hreg[e] = ld_global<u32x2>(src);
+        if constexpr (HPM) hregl[e] = ld_global<u32x2>(ok ? src + lo_plane : src);
       }
     }
   };
@@ -278,7 +301,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
     TO* out = reinterpret_cast<TO*>(p.out) + (size_t)b * p.OH * p.OW * 64;
     if constexpr (!SPLIT && !HPM) {
       typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-      const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
       auto store_tile = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
@@ -286,19 +308,23 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
           const int mm = wave * 32 + ((2 * q2) & 3) + 8 * ((2 * q2) >> 2) + 4 * khalf;   // pixel of column 2*q2 (even)
           const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
           const bool v0ok = FULL || (r < p.OH && c < p.OW), v1ok = FULL || (r < p.OH && c + 1 < p.OW);
-          const bool mine = (lane & 1) ? v1ok : v0ok;
-          bf16* dst = reinterpret_cast<bf16*>(out) + ((size_t)r * p.OW + c + (lane & 1)) * 64 + ((lane & 31) & ~1);
+          // the lane's channel pair (2 l, 2 l + 1) of pixels (r, c) and (r, c + 1): 32 lanes write one pixel's 128 bytes
+          bf16* dst = reinterpret_cast<bf16*>(out) + ((size_t)r * p.OW + c) * 64 + 2 * (lane & 31);
+          float v[2][2];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const float v0 = v0ok ? acc[j][2 * q2] : 0.f, v1 = v1ok ? acc[j][2 * q2 + 1] : 0.f;
-            s1[j] += v0 + v1;
-            s2[j] = __builtin_fmaf(v1, v1, __builtin_fmaf(v0, v0, s2[j]));
-            bf16x2 own;
-            own[0] = (bf16)v0;
-            own[1] = (bf16)v1;
-            const unsigned x = __builtin_bit_cast(unsigned, own);
-            const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-            if (FULL || mine) *reinterpret_cast<unsigned*>(dst + j * 32) = __builtin_amdgcn_perm(y, x, psel);
+            v[j][0] = v0ok ? acc[j][2 * q2] : 0.f; v[j][1] = v1ok ? acc[j][2 * q2 + 1] : 0.f;
+            // (scalar ops in asm: left to the compiler the sums of the two accumulator sets became v_pk_add_f32 / v_pk_fma_f32,
+            // which issue far slower than two plain ops on a SIMD that other waves keep busy with MFMAs; same values, same order)
+            s1[j] = fadd_s(s1[j], fadd_s(v[j][0], v[j][1]));
+            s2[j] = ffma_s(v[j][1], v[j][1], ffma_s(v[j][0], v[j][0], s2[j]));
+          }
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            bf16x2 w;
+            w[0] = (bf16)v[0][px];
+            w[1] = (bf16)v[1][px];
+            if (FULL || (px ? v1ok : v0ok)) *reinterpret_cast<unsigned*>(dst + px * 64) = __builtin_bit_cast(unsigned, w);
           }
         }
       };
@@ -356,8 +382,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
       const float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
       if (khalf == 0) {
-        red[(wave * 2 + 0) * 64 + j * 32 + (lane & 31)] = a1;
-        red[(wave * 2 + 1) * 64 + j * 32 + (lane & 31)] = a2;
+        const int chn = (!SPLIT && !HPM) ? 2 * (lane & 31) + j : j * 32 + (lane & 31);      // (perf mode: channel pairs per lane)
+        red[(wave * 2 + 0) * 64 + chn] = a1;
+        red[(wave * 2 + 1) * 64 + chn] = a2;
       }
     }
     __syncthreads();
@@ -412,19 +439,6 @@ __device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
 #endif
 }
 constexpr unsigned POOL_IDENT = 0xFC00FC00u;
-// scalar fp32 add / fused multiply-add the SLP vectoriser cannot pair: hipcc -O3 turned the BatchNorm sums of the epilogue
-// into v_pk_add_f32 / v_pk_mul_f32, which cost ~16 cycles each beside an MFMA stream (the staging phase: 2200 cycles for
-// ~200 instructions, interval tracer) - MI355X_MICROARCH.md, "price of one filler beside MFMAs"
-__device__ __forceinline__ float fadd_s(float a, float b) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float ffma_s(float a, float b, float c) {
-  float r;
-  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 constexpr int PROWB = TW * 64;   // bf16 elements of one staged conv row
 
 __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
@@ -455,8 +469,9 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
+        // (round 6: accumulator set j of lane l = channel 2 l + j - the lane owns a channel PAIR, see stem_fwd_kernel)
         wfrag[kh][s2][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.w) +
-                                                            ((size_t)(kh * 64 + j * 32 + (lane & 31)) * 32 + (s2 * 2 + khalf) * 8));
+                                                            ((size_t)(kh * 64 + 2 * (lane & 31) + j) * 32 + (s2 * 2 + khalf) * 8));
   // (PH_POOL_VARIANT & 2, measured and OFF, round 6) Channels with gamma < 0 need the window's MINIMUM: with their weight rows
   // NEGATED once per strip the accumulators would hold -y and the staged word would need no exclusive-or (16 of a tile's vector
   // instructions).  But the matrix pipe's fp32 accumulation is NOT sign-symmetric: A (-B) + C differs from -(A B + C) in the last
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
   float wsgn[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const bool neg = (PH_POOL_VARIANT & 2) && p.gamma[j * 32 + (lane & 31)] < 0.f;
+    const bool neg = (PH_POOL_VARIANT & 2) && p.gamma[2 * (lane & 31) + j] < 0.f;
     wsgn[j] = neg ? -1.f : 1.f;
     const unsigned fx = neg ? 0x80008000u : 0u;
 #pragma unroll
@@ -522,7 +537,10 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     pflip[k] = (p.gamma[cg * 8 + 2 * k] < 0.f ? 0x8000u : 0u) | (p.gamma[cg * 8 + 2 * k + 1] < 0.f ? 0x80000000u : 0u);
   const int poff = (2 * pcl * 64 + cg * 8) * 2;               // byte offset of the window's first column in a staged row
   // ---- epilogue role: the lane's channel pair (lane & 30, + 1) of each 32-channel half j; its staging byte offset
-  const int eoff = ((4 * khalf + (lane & 1)) * 64 + ((lane & 31) & ~1)) * 2;
+  // ---- epilogue role: the lane's channel pair (2 l, 2 l + 1); staging byte offset of its word in pixel column 4 khalf
+  const int eoff = ((4 * khalf) * 64 + 2 * (lane & 31)) * 2;
+  const unsigned eflipw = (PH_POOL_VARIANT & 2) ? 0u : ((p.gamma[2 * (lane & 31)] < 0.f ? 0x8000u : 0u) |
+                                                        (p.gamma[2 * (lane & 31) + 1] < 0.f ? 0x80000000u : 0u));
   // local columns 0 and 15 of a tile belong to the neighbouring strips: registers (khalf 0: q = 0, 8), (khalf 1: q = 7, 15)
   const float own_lo = khalf == 0 ? 0.f : 1.f, own_hi = khalf == 1 ? 0.f : 1.f;
   // a strip that starts at the top of the image reads a "row above" that does not exist
@@ -570,7 +588,6 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
     unsigned char* erow0 = midb + (2 * wave) * PROWB * 2 + eoff;
     unsigned char* erow1 = (wave < 3 ? midb + (2 * wave + 1) * PROWB * 2 : lastb) + eoff;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
     // (out-of-image pixels are staged like any other: the pooling pass skips them by coordinate)
     // (`OWN` - does the tile count for the statistics - is a template argument, not a branch around each of the 16 updates:
     // the inline-asm statistics ops cannot be hoisted, so hipcc had emitted one s_cbranch per register pair, and ~30 scalar
@@ -601,20 +618,17 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
             s1[j] = fadd_s(fadd_s(s1[j], w0), w1);
             s2[j] = ffma_s(w1, w1, ffma_s(w0, w0, s2[j]));
           }
-          if (PH_STEM_ABL & 64) { asm volatile("" ::"v"(v0), "v"(v1)); continue; }
-          bf16x2 own;
-          own[0] = (bf16)v0;
-          own[1] = (bf16)v1;
-          const unsigned x = __builtin_bit_cast(unsigned, own);
-          const unsigned y = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-#if PH_POOL_VARIANT & 2
-          const unsigned word = __builtin_amdgcn_perm(y, x, psel);                               // [even channel, odd channel], signs as staged
-#else
-          const int c0_ = j * 32 + ((lane & 31) & ~1);
-          const unsigned word = __builtin_amdgcn_perm(y, x, psel) ^ ((p.gamma[c0_] < 0.f ? 0x8000u : 0u) | (p.gamma[c0_ + 1] < 0.f ? 0x80000000u : 0u));
-#endif
+        }
+        if (PH_STEM_ABL & 64) { asm volatile("" ::"v"(acc[0][2 * q2]), "v"(acc[1][2 * q2])); continue; }
+        // the lane's channel pair of the two pixels (local columns clc, clc + 1): one conversion and one LDS word each
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          bf16x2 w;
+          w[0] = (bf16)acc[0][2 * q2 + px];
+          w[1] = (bf16)acc[1][2 * q2 + px];
+          const unsigned word = __builtin_bit_cast(unsigned, w) ^ eflipw;      // [even channel, odd channel], gamma < 0: sign flipped
           if (PH_STEM_ABL & 8) asm volatile("" ::"v"(word));
-          else *reinterpret_cast<unsigned*>(dst + j * 64) = word;
+          else *reinterpret_cast<unsigned*>(dst + px * 128) = word;
         }
       }
     };
@@ -677,8 +691,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
       const float a1 = s1[j] + __shfl_xor(s1[j], 32, 64);
       const float a2 = s2[j] + __shfl_xor(s2[j], 32, 64);
       if (khalf == 0) {
-        red[(wave * 2 + 0) * 64 + j * 32 + (lane & 31)] = a1;
-        red[(wave * 2 + 1) * 64 + j * 32 + (lane & 31)] = a2;
+        red[(wave * 2 + 0) * 64 + 2 * (lane & 31) + j] = a1;
+        red[(wave * 2 + 1) * 64 + 2 * (lane & 31) + j] = a2;
       }
     }
     __syncthreads();
