@@ -115,7 +115,7 @@ def trunk_fwd_bwd(m, B, H, device, steps=5):
             "steps": steps, "ms": round(1000.0 * dt, 3), "tiles_per_s": round(B / dt, 1),
             "algorithmic_tflop": round(tfl, 3), "achieved": round(tfl / dt, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tfl / dt / MFMA_BF16_PEAK_TFLOPS, 4), "target_frac": 0.70,
-            "profile": "profiles/r05_kernel_stats_trunk_b256.txt (rocprofv3 --kernel-trace --stats -- python3 bench.py --trunk-only)"}
+            "profile": "profiles/r06_kernel_stats_trunk_b256.txt (rocprofv3 --kernel-trace --stats -- python3 bench.py --trunk-only)"}
 
 
 def hbm_ledger(B, H, es=2):
@@ -185,7 +185,7 @@ def hbm_ledger(B, H, es=2):
 
 def _counter_step_gb():
     """HBM bytes of one whole step from the PMC counters (profiles/summarize.py writes `step_total_bytes` into the traffic file)."""
-    for tname in ("r05_traffic.json", "r04_traffic.json"):
+    for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):
         tf = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tf):
             try:
@@ -372,14 +372,14 @@ def run_variant(name, B, H, device, L, steps=5, nce_k=None):
         buf = (ctypes.c_double * (4 * NALL))()
         L.ph_prof_summary4(buf, NALL)
         traffic = {}
-        for tname in ("r05_crd_traffic.json", "r04_crd_traffic.json", "r03_crd_traffic.json"):      # (the newest committed counter pass)
+        for tname in ("r06_crd_traffic.json", "r05_crd_traffic.json", "r04_crd_traffic.json", "r03_crd_traffic.json"):      # (the newest committed counter pass)
             tf = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get(name, {})
                 break
         rows = []
         for cls, key, nm in ((8, "crd_score", "crd_score_kernel: 2 banks x B x (P+K) rows of 512 B"),
-                             (TOPK_CLS, "crd_bank_topk", "ph_crd_bank_topk = 4 launches (sample pass, threshold, full pass, merge) under ONE event pair in eager steps, launch gaps included; kernel durations alone: profiles/r05_kernel_stats_mia2023.txt (11 + 6 + 35 + 11 us); 2 banks x n_data rows of 512 B, each once (+ 1/16 in the sample pass)"),
+                             (TOPK_CLS, "crd_bank_topk", "ph_crd_bank_topk = 4 launches (sample pass, threshold, full pass, merge) under ONE event pair in eager steps, launch gaps included; kernel durations alone: profiles/r06_kernel_stats_mia2023.txt; 2 banks x n_data rows of 512 B, each once (+ 1/16 in the sample pass)"),
                              (9, "crd_loss_grad", "crd_loss_grad_kernel (+ reduce): 2 banks x B x (P2+K2) rows of 512 B")):
             n, ms, by = buf[4 * cls], buf[4 * cls + 1], buf[4 * cls + 2]
             if n == 0:
@@ -857,7 +857,7 @@ def main():
         n_, ms_, fl_ = pr[4 * domc], pr[4 * domc + 1], pr[4 * domc + 2]
         ach_ = fl_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
         tr_ = None
-        tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_b256_traffic.json", "r04_b256_traffic.json"))
+        tf = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_b256_traffic.json", "r05_b256_traffic.json", "r04_b256_traffic.json"))
                    if os.path.exists(f)), "")
         if os.path.exists(tf):
             try:
@@ -971,7 +971,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             traffic = None
             tname = None
-            for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
                 tf = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tf):
                     try:
@@ -1018,7 +1018,7 @@ def main():
                                                          "note": "per-tensor algorithmic HBM bytes of one step (bench.py: hbm_ledger) / ms_per_step / 8 TB/s - "
                                                                  "the step's real bound: train-mode BatchNorm makes every conv output travel "
                                                                  "to HBM and back; counter_gb_per_step: FETCH_SIZE x 2 + WRITE_SIZE over all "
-                                                                 "kernels of one step (profiles/r05_traffic.json, null until collected)"})(
+                                                                 "kernels of one step (profiles/r06_traffic.json, null until collected)"})(
                                    hbm_ledger(args.batch, args.size)) if args.precision == "bf16" else None,
                                "step_note": "whole step: %.2f GFLOP per tile (3 ResNet-18 forwards + 1 backward, SURVEY 8-d) x tiles / "
                                             "ms_per_step / 2500 TFLOP/s; the reference executes 276.8 GFLOP per tile for the same "

@@ -343,11 +343,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
       // half-pair mode: the fp32 tile goes through an LDS image [128 pixels][64 channels] behind the operand buffers and leaves as
       // 16-byte chunks (one 4-byte store per value: 32 store instructions per wave and tile for 1.07 GB of output)
       float* cimg = reinterpret_cast<float*>(smem + XB * XBUFS + (HPM ? 0 : WB * NP));      // (half-pair mode keeps no weight image)
+      const bool full_tile = r0 + TH <= p.OH && c0 + TW <= p.OW;
+      auto stats_and_image = [&](auto fullc) {      // (interior tiles: no per-value range selects - half-pair mode, round 6)
+        constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int mm = wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * khalf;
         const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
-        const bool valid = r < p.OH && c < p.OW;
+        const bool valid = FULL || (r < p.OH && c < p.OW);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float v = valid ? (HPM ? acc[j][q] * PH_HP_LO_INV : acc[j][q]) : 0.f;
@@ -356,10 +359,31 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(PhStem p) {
           else if (valid) stf(out + ((size_t)r * p.OW + c) * 64 + j * 32 + (lane & 31), v);
         }
       }
+      };
+      if (HPM && full_tile) stats_and_image(std::true_type{});
+      else stats_and_image(std::false_type{});
       if constexpr (HPM) {
         // (LDS-only barriers: the 32 KB of output stores of a tile drain behind the next tile's MFMAs; the image is free again
         // once every wave has READ its chunks - lgkmcnt - not once the stores have completed)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (full_tile) {
+          // all eight 16-byte chunks of the thread are read before the first store (as a loop each iteration waited for its own read)
+          f32x4 cv[TH * TW * 16 / 256];
+#pragma unroll
+          for (int e = 0; e < TH * TW * 16 / 256; ++e) {
+            const int id = tid + e * 256;
+            cv[e] = *reinterpret_cast<const f32x4*>(cimg + (id >> 4) * 64 + (id & 15) * 4);
+          }
+#pragma unroll
+          for (int e = 0; e < TH * TW * 16 / 256; ++e) {
+            const int id = tid + e * 256, mm = id >> 4, ch = id & 15;
+#if PH_STEM_HP_ABL & 1
+            asm volatile("" ::"v"(cv[e]));
+#else
+            *reinterpret_cast<f32x4*>(out + ((size_t)(r0 + (mm >> 4)) * p.OW + c0 + (mm & 15)) * 64 + ch * 4) = cv[e];
+#endif
+          }
+        } else
         for (int id = tid; id < TH * TW * 16; id += 256) {
           const int mm = id >> 4, ch = id & 15;
           const int r = r0 + (mm >> 4), c = c0 + (mm & 15);
@@ -437,6 +461,11 @@ __device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
 #else
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)));
 #endif
+}
+__device__ __forceinline__ unsigned pkmax3(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
 }
 constexpr unsigned POOL_IDENT = 0xFC00FC00u;
 constexpr int PROWB = TW * 64;   // bf16 elements of one staged conv row
@@ -661,18 +690,21 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_pool_kernel(PhStemPool p) {
             for (int kw = 0; kw < 3; ++kw) v[kh][kw] = *reinterpret_cast<const u32x4*>(rowp + kw * 128);
           }
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (EDGE) {
 #pragma unroll
-          for (int kh = 0; kh < 3; ++kh)
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-              if constexpr (EDGE) {
+              for (int kw = 0; kw < 3; ++kw) {
                 const bool skip = (kw == 0 && cut_l) || (kw == 2 && cut_r) || (kh == 2 && cut_b);
 #pragma unroll
                 for (int kq = 0; kq < 4; ++kq) v[kh][kw][kq] = skip ? POOL_IDENT : v[kh][kw][kq];
               }
+          }
+          // the nine taps as a tree of three-input packed maxima (v_pk_maximum3_f16, gfx950): 4 instructions per word instead of 9
 #pragma unroll
-              for (int kq = 0; kq < 4; ++kq) best[kq] = pkmax(best[kq], v[kh][kw][kq]);
-            }
+          for (int kq = 0; kq < 4; ++kq)
+            best[kq] = pkmax3(pkmax3(v[0][0][kq], v[0][1][kq], v[0][2][kq]), pkmax3(v[1][0][kq], v[1][1][kq], v[1][2][kq]),
+                              pkmax3(v[2][0][kq], v[2][1][kq], v[2][2][kq]));
         };
         if (cut_l || cut_r || cut_b) pool(std::true_type{});
         else pool(std::false_type{});
