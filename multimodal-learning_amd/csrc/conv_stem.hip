@@ -1003,8 +1003,9 @@ int ph_stem_fwd_launch(const PhStem* p, int prec, hipStream_t st) {
     static bool done = false;
     const int lds = 2 * XB + WB;
     if (set_lds(stem_fwd_kernel<bf16>, lds, done)) return PH_ELAUNCH;
-    // (PH_STEM_VB16=n: n x CUs workgroups walk the blocks - the 28 KB weight image is staged once per workgroup; 0 = one block each)
-    static const int vb16 = [] { const char* e = getenv("PH_STEM_VB16"); return e ? atoi(e) : 0; }();
+    // 3 x CUs workgroups (what the registers admit: 3 waves per SIMD) walk the blocks - the 28 KB weight image is staged once per
+    // workgroup: 173 -> 165 us per launch, two alternations on one box; 2 x: 185, 4 x: 209.  PH_STEM_VB16=n overrides, 0 = one block each
+    static const int vb16 = [] { const char* e = getenv("PH_STEM_VB16"); return e ? atoi(e) : 3; }();
     PhStem q = *p;
     if (vb16 > 0 && (int)grid.x > vb16 * ph_num_cus()) { q.vblocks = (int)grid.x; grid.x = vb16 * ph_num_cus(); }
     hipLaunchKernelGGL(stem_fwd_kernel<bf16>, grid, dim3(256), lds, st, q);
