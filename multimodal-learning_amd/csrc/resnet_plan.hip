@@ -676,7 +676,9 @@ int backward_impl(const PhResnetPlan* P, const void* const* params, const void* 
   const bool ov = sr != nullptr;
   const hipStream_t side = ov ? sr->side : st;
   Ctx cs = c;                       // the weight-gradient launches' context
-  if (ov) { cs.st = side; cs.wg_want = WG_WANT_BESIDE; }
+  // (PH_WG_BESIDE=n: A/B override of the side-stream weight gradients' workgroup target)
+  static const int wg_beside = [] { const char* e = getenv("PH_WG_BESIDE"); const int v = e ? atoi(e) : 0; return v > 0 ? v : WG_WANT_BESIDE; }();
+  if (ov) { cs.st = side; cs.wg_want = wg_beside; }
   // this call's block of events (see SideRes): eager calls take one of 15 blocks (waiting for the oldest call in flight when
   // all are held), captured calls the 16th
   size_t ev_base = 0;
