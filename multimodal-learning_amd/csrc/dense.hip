@@ -20,6 +20,9 @@ __global__ void bn1d_eval_bwd_kernel(const float* __restrict__ g, const float* _
 // ------------------------------------------------------------------ generic strided SGEMM
 // C[m][n] (ldc) = act( sum_k A(m,k) * B(k,n) + bias[n] ) (+ C if accumulate)
 //   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn]
+#ifndef PH_BN1D_NC
+#define PH_BN1D_NC 16      // channels per workgroup of the BatchNorm1d kernels (256 / PH_BN1D_NC row lanes)
+#endif
 constexpr int GT = 64, GK = 32;   // all global loads of a K step are issued before any is consumed
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                     const float* __restrict__ bias, float* __restrict__ Cm, int M,
@@ -256,18 +259,22 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
                                                        float* mean, float* invstd, float* running_mean,
                                                        float* running_var, int64_t* nbt, int B, int C, float eps,
                                                        float momentum, int relu) {
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  __shared__ double sh1[4][64], sh2[4][64];
-  __shared__ float shsc[64], shsh[64];
+  // (round 6) 16 channels x 16 row lanes per workgroup (was 64 x 4): C / 16 workgroups instead of C / 64 = 2 for the heads'
+  // 128-wide BatchNorms, a quarter of the rows per thread - these launches sit on the latency-bound head chains
+  constexpr int NC = PH_BN1D_NC, NR = 256 / PH_BN1D_NC;
+  const int cl = threadIdx.x % NC, rl = threadIdx.x / NC;
+  const int c = blockIdx.x * NC + cl;
+  __shared__ double sh1[NR][NC], sh2[NR][NC];
+  __shared__ float shsc[NC], shsh[NC];
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int b = rl; b < B; b += 4) { const double v = x[(size_t)b * C + c]; s1 += v; s2 += v * v; }
+    for (int b = rl; b < B; b += NR) { const double v = x[(size_t)b * C + c]; s1 += v; s2 += v * v; }
   sh1[rl][cl] = s1; sh2[rl][cl] = s2;
   __syncthreads();
   if (rl == 0 && c < C) {
-    s1 = (sh1[0][cl] + sh1[1][cl]) + (sh1[2][cl] + sh1[3][cl]);
-    s2 = (sh2[0][cl] + sh2[1][cl]) + (sh2[2][cl] + sh2[3][cl]);
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { s1 += sh1[r][cl]; s2 += sh2[r][cl]; }      // fixed order
     const double m = s1 / B;
     double var = s2 / B - m * m;
     if (var < 0.0) var = 0.0;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const float* __restrict__
   __syncthreads();
   if (c < C) {
     const float sc = shsc[cl], shf = shsh[cl];
-    for (int b = rl; b < B; b += 4) {
+    for (int b = rl; b < B; b += NR) {
       float v = x[(size_t)b * C + c] * sc + shf;
       if (relu) v = v > 0.f ? v : 0.f;
       y[(size_t)b * C + c] = v;
@@ -313,13 +320,14 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                        float* __restrict__ dx, float* dgamma, float* dbeta, int B, int C,
                                                        int relu) {
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  __shared__ double sh1[4][64], sh2[4][64];
+  constexpr int NC = PH_BN1D_NC, NR = 256 / PH_BN1D_NC;      // (16 channels x 16 row lanes, as in the forward)
+  const int cl = threadIdx.x % NC, rl = threadIdx.x / NC;
+  const int c = blockIdx.x * NC + cl;
+  __shared__ double sh1[NR][NC], sh2[NR][NC];
   const float mu = c < C ? mean[c] : 0.f, is = c < C ? invstd[c] : 0.f;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int b = rl; b < B; b += 4) {
+    for (int b = rl; b < B; b += NR) {
       float dz = g[(size_t)b * C + c];
       if (relu && !(y[(size_t)b * C + c] > 0.f)) dz = 0.f;
       s1 += dz;
@@ -328,14 +336,15 @@ __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const float* __restrict__
   sh1[rl][cl] = s1; sh2[rl][cl] = s2;
   __syncthreads();
   if (c >= C) return;
-  s1 = (sh1[0][cl] + sh1[1][cl]) + (sh1[2][cl] + sh1[3][cl]);
-  s2 = (sh2[0][cl] + sh2[1][cl]) + (sh2[2][cl] + sh2[3][cl]);
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) { s1 += sh1[r][cl]; s2 += sh2[r][cl]; }      // fixed order, every lane the same value
   if (rl == 0) {
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
   }
   const float c1 = (float)(s1 / B), c2 = (float)(s2 / B), sc = gamma[c] * is;
-  for (int b = rl; b < B; b += 4) {
+  for (int b = rl; b < B; b += NR) {
     float dz = g[(size_t)b * C + c];
     if (relu && !(y[(size_t)b * C + c] > 0.f)) dz = 0.f;
     const float xh = (x[(size_t)b * C + c] - mu) * is;
@@ -755,7 +764,7 @@ int ph_sgemm_splitk(const float* A, const float* B, const float* bias, float* C,
 int ph_bn1d_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* invstd,
                 float* running_mean, float* running_var, int64_t* nbt, int B, int C, float eps, float momentum,
                 int relu, hipStream_t st) {
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, x, gamma, beta, y, mean, invstd,
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3(cdiv(C, PH_BN1D_NC)), dim3(256), 0, st, x, gamma, beta, y, mean, invstd,
                      running_mean, running_var, nbt, B, C, eps, momentum, relu);
   PH_LAUNCH_CHECK();
   return PH_OK;
@@ -779,7 +788,7 @@ int ph_bn1d_eval(const float* x, const float* gamma, const float* beta, const fl
 }
 int ph_bn1d_bwd(const float* g, const float* y, const float* x, const float* mean, const float* invstd,
                 const float* gamma, float* dx, float* dgamma, float* dbeta, int B, int C, int relu, hipStream_t st) {
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, g, y, x, mean, invstd, gamma, dx, dgamma,
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3(cdiv(C, PH_BN1D_NC)), dim3(256), 0, st, g, y, x, mean, invstd, gamma, dx, dgamma,
                      dbeta, B, C, relu);
   PH_LAUNCH_CHECK();
   return PH_OK;
