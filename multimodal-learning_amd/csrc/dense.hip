@@ -175,11 +175,14 @@ __global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
-  for (int k0 = kb; k0 < ke; k0 += GK) {
-    constexpr int PER = GT * GK / 256;
-    float ra[PER], rb[PER];
+  // (round 6) the loads of K step s + 1 are in flight while step s is multiplied: a workgroup has only ~5 steps (K / nsplit / GK),
+  // and as load -> LDS -> multiply one after the other every step exposed a full memory round trip (16-18 us for the fusion
+  // head's three 8.5 MB weight matrices on the fused teacher's tail)
+  constexpr int PER = GT * GK / 256;
+  float ra[PER], rb[PER];
+  auto load_step = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {          // phase 1: every load in flight together
+    for (int q = 0; q < PER; ++q) {          // every load in flight together
       const int e = tid + q * 256;
       int m, k;
       if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
@@ -190,8 +193,11 @@ __global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restri
       const int gn = n0 + n, gk2 = k0 + kk;
       rb[q] = (gn < N && gk2 < ke) ? Bm[gk2 * sbk + gn * sbn] : 0.f;
     }
+  };
+  if (kb < ke) load_step(kb);
+  for (int k0 = kb; k0 < ke; k0 += GK) {
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {          // phase 2: LDS
+    for (int q = 0; q < PER; ++q) {          // LDS
       const int e = tid + q * 256;
       int m, k;
       if (a_kfast) { k = e % GK; m = e / GK; } else { m = e % GT; k = e / GT; }
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restri
       Bs[kk][n] = rb[q];
     }
     __syncthreads();
+    if (k0 + GK < ke) load_step(k0 + GK);      // next step's operands travel while this one is multiplied
 #pragma unroll
     for (int k = 0; k < GK; ++k) {
       float a[4], b[4];
@@ -228,23 +235,23 @@ __global__ __launch_bounds__(256) void sgemm_splitk_kernel(const float* __restri
   }
 }
 
+// four lanes per output element (each sums every fourth slab in a fixed order, then a fixed-order combine): with one thread per
+// element the 64 x 128 outputs of the heads made 32 workgroups walk 128 slabs each (9.7 us)
 __global__ void splitk_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                      float* __restrict__ Cm, int M, int N, long ldc, int nsplit, int act) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * N) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 2, q = t & 3;
+  const bool live = i < M * N;
+  float p = 0.f;
+  if (live)
+    for (int s = q; s < nsplit; s += 4) p += part[(size_t)s * M * N + i];
+  // lanes 4 i .. 4 i + 3 hold the four interleaved partial sums p0..p3 of the one-thread form: (p0 + p1) + (p2 + p3), bitwise as before
+  const float p1 = __shfl_xor(p, 1, 64);
+  const float s01 = (q & 1) ? p1 + p : p + p1;      // lanes 0,1: p0 + p1; lanes 2,3: p2 + p3 (operand order fixed)
+  const float s23 = __shfl_xor(s01, 2, 64);
+  if (!live || q != 0) return;
   const int m = i / N, n = i % N;
-  float v = bias ? bias[n] : 0.f;
-  // four interleaved partial sums (fixed order): the loads of a group of four are independent of each other
-  float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-  int s = 0;
-  for (; s + 4 <= nsplit; s += 4) {
-    p0 += part[(size_t)(s + 0) * M * N + i];
-    p1 += part[(size_t)(s + 1) * M * N + i];
-    p2 += part[(size_t)(s + 2) * M * N + i];
-    p3 += part[(size_t)(s + 3) * M * N + i];
-  }
-  for (; s < nsplit; ++s) p0 += part[(size_t)s * M * N + i];
-  v += (p0 + p1) + (p2 + p3);
+  float v = (bias ? bias[n] : 0.f) + (s01 + s23);
   if (act == PH_ACT_RELU) v = v > 0.f ? v : 0.f;
   else if (act == PH_ACT_ELU) v = v > 0.f ? v : expm1f(v);
   else if (act == PH_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
@@ -755,7 +762,7 @@ int ph_sgemm_splitk(const float* A, const float* B, const float* bias, float* C,
   nsplit = cdiv(K, kchunk);
   dim3 grid(cdiv(N, GT), cdiv(M, GT), nsplit);
   hipLaunchKernelGGL(sgemm_splitk_kernel, grid, dim3(256), 0, st, A, B, part, M, N, K, sam, sak, sbk, sbn, kchunk);
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk((size_t)M * N)), dim3(256), 0, st, part, bias, C, M, N, ldc,
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3(nblk((size_t)M * N * 4)), dim3(256), 0, st, part, bias, C, M, N, ldc,
                      nsplit, act);
   PH_LAUNCH_CHECK();
   return PH_OK;
