@@ -101,7 +101,7 @@ int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* re
   if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64 || (stride != 1 && stride != 2)) return PH_EINVAL;
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws_);
-  int rc = prec == PH_PREC_FP16X3 ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
+  int rc = (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
@@ -196,7 +196,7 @@ int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, in
   if ((KS != 1 && KS != 3) || Cin % 64 || Cout % 64) return PH_EINVAL;
   const size_t plane = (size_t)KS * KS * Cin * Cout;
   bf16* hi = reinterpret_cast<bf16*>(ws_);
-  int rc = prec == PH_PREC_FP16X3 ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
+  int rc = (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};

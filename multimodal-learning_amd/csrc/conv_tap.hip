@@ -566,6 +566,7 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_stat_parts(p);
   // (half-pair mode on the third-generation kernel: one partial row per persistent workgroup, like the second generation)
   if (prec == PH_PREC_FP16X3 && S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv2_stat_parts(p);
+  if ((prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) && S == 1 && ph_tap5_switch(-1) && ph_tapconv5_eligible(p)) return ph_tapconv5_stat_parts(p);
   const bool perf_cfg = prec == PH_PREC_BF16 || prec == PH_PREC_FP16X3;
   const int TH = (S == 1) ? ((p->Cout % 128 == 0 && !perf_cfg) ? 8 : 16) : (perf_cfg ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
@@ -581,6 +582,8 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
     q.hp_hi_only = prec == PH_PREC_FP16X1;
     // dense 3x3 stride-1, Cout % 128 == 0: the third-generation kernel's half-pair form (conv_tap3.hip)
     if (S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(&q)) return ph_tapconv3_launch_hp(&q, st);
+    // dense 3x3 stride-1, Cin = Cout = 64 (layer 1): conv_tap5.hip
+    if (S == 1 && ph_tap5_switch(-1) && ph_tapconv5_eligible(&q)) return ph_tapconv5_launch(&q, st);
     return launch_T<hp16>(q, S, st);
   }
   if (PH_IS_SPLIT_PREC(prec)) {

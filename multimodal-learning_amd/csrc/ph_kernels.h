@@ -106,6 +106,15 @@ int ph_tapconv3_launch_hp(const PhTapConv* p, hipStream_t st);      // PH_PREC_F
 int ph_tap4_switch(int set);
 bool ph_tapconv4_eligible(const PhTapConv* p);
 int ph_tapconv4_launch(const PhTapConv* p, hipStream_t st);
+// half-pair kernel for Cin = Cout = 64 (conv_tap5.hip: both halo planes of a 32 x 16 tile resident in LDS, weight fragments from
+// global memory into a rotating register window, two barriers per tile); p->hp_hi_only selects the hi-only form; PH_TAP5=0 keeps
+// the first-generation kernel (same-box A/B)
+int ph_tap5_switch(int set);
+bool ph_tapconv5_eligible(const PhTapConv* p);
+int ph_tapconv5_launch(const PhTapConv* p, hipStream_t st);
+int ph_tapconv5_stat_parts(const PhTapConv* p);
+// (its 64 x 64 x 9 weight slabs are packed fragment-major while the switch is on: pack_all_tiled_hp_kernel, conv_wgrad.hip - do not
+// change the switch between a pack and the launches that read it)
 // stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
 bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 

@@ -196,6 +196,65 @@ def test_tapconv3_half_pair_multitile_stream(case):
     assert_close(dx_ref, nchw_cpu(dx), 1e-6, 3e-6, "multi-tile half-pair conv dgrad")
 
 
+@pytest.mark.parametrize("case", [(64, 24), (40, 40), (128, 5), (16, 3), (33, 7), (72, 9)])
+def test_tapconv5_half_pair_layer1_stream(case):
+    """The half-pair kernel of the 64 -> 64 convolutions (conv_tap5.hip: 32 x 16 tiles with both halo planes in LDS, weight
+    fragments from global memory through a register window, hand-counted vmcnt, two barriers per tile): persistent workgroups
+    walking several tiles, ragged maps (40 = 32 + 8 rows, 2.5 column tiles; 33; 72), fewer tiles than compute units, forward
+    (+ BatchNorm partial sums) and dgrad (+ fused residual / mask) against fp64 F.conv2d on the same fp32 operands, the hi-only
+    backward form (PH_PREC_FP16X1) at its 11-bit operand tolerance, repeated launches bitwise, and the first-generation kernel
+    (PH_TAP5 off) as the second opinion."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close, hp_pack
+    m, L, ptr, stream, check = _setup()
+    H, B = case
+    Cin = Cout = 64
+    g = torch.Generator().manual_seed(H * 100 + B)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    dy = torch.randn(B, Cout, H, H, generator=g)
+    res_g = torch.randn(B, H, H, Cin, generator=g)
+    res_a = torch.randn(B, H, H, Cin, generator=g)
+    torch.set_num_threads(8)
+    y_ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    dx_ref = F.conv_transpose2d(dy.double(), w.double(), None, 1, 1)
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 1, 1), device="cuda", dtype=torch.uint8)
+    xd = hp_pack(nhwc(x, torch.float32)); wd = w.cuda(); dyd = hp_pack(nhwc(dy, torch.float32))
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    outs = []
+    for rep in range(4):
+        y = torch.full((B, H, H, Cout), float("nan"), device="cuda")
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 1, 1, 3, ptr(ws), stream()), "fwd")
+        outs.append((y.clone(), s1.clone(), s2.clone()))
+    assert_close(y_ref, nchw_cpu(outs[0][0]), 1e-6, 3e-6, "layer-1 half-pair conv fwd")
+    assert_close(y_ref.sum(dim=(0, 2, 3)), outs[0][1].cpu(), 1e-2, 1e-4, "channel sum")
+    assert_close((y_ref ** 2).sum(dim=(0, 2, 3)), outs[0][2].cpu(), 1e-2, 1e-4, "channel sumsq")
+    for rep in range(1, 4):
+        assert torch.equal(outs[0][0], outs[rep][0]), "fwd differs between launches"
+        assert torch.equal(outs[0][1], outs[rep][1]) and torch.equal(outs[0][2], outs[rep][2])
+    L.ph_debug_set_tap5(0)
+    try:
+        y1 = torch.full((B, H, H, Cout), float("nan"), device="cuda")
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y1), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 1, 1, 3, ptr(ws), stream()), "fwd gen1")
+    finally:
+        L.ph_debug_set_tap5(1)
+    assert (y1 - outs[0][0]).abs().max().item() <= 4e-6 * y_ref.abs().max().item()
+    # dgrad: plain, + residual, + masked residual; 3 products and the hi-only form
+    rg = res_g.cuda(); ra = res_a.cuda()
+    for prec, rtol in ((3, 3e-6), (4, 3e-3)):
+        dx = torch.full((B, H, H, Cin), float("nan"), device="cuda")
+        check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx), B, Cin, H, H, Cout, 3, 1, 1, prec, ptr(ws), stream()), "dgrad")
+        assert_close(dx_ref, nchw_cpu(dx), 1e-6, rtol, "layer-1 half-pair conv dgrad prec %d" % prec)
+        dx1 = torch.full((B, H, H, Cin), float("nan"), device="cuda")
+        check(L.ph_conv2d_dgrad_res(ptr(dyd), ptr(wd), ptr(dx1), ptr(rg), None, B, Cin, H, H, Cout, 3, 1, 1, prec, ptr(ws), stream()), "dgrad+res")
+        assert (dx1 - (dx + rg)).abs().max().item() <= 1e-6 * dx_ref.abs().max().item() + 1e-6
+        dx2 = torch.full((B, H, H, Cin), float("nan"), device="cuda")
+        check(L.ph_conv2d_dgrad_res(ptr(dyd), ptr(wd), ptr(dx2), ptr(rg), ptr(ra), B, Cin, H, H, Cout, 3, 1, 1, prec, ptr(ws), stream()), "dgrad+masked res")
+        assert (dx2 - (dx + rg * (ra > 0))).abs().max().item() <= 1e-6 * dx_ref.abs().max().item() + 1e-6
+        dx3 = torch.full((B, H, H, Cin), float("nan"), device="cuda")
+        check(L.ph_conv2d_dgrad(ptr(dyd), ptr(wd), ptr(dx3), B, Cin, H, H, Cout, 3, 1, 1, prec, ptr(ws), stream()), "dgrad again")
+        assert torch.equal(dx, dx3), "dgrad differs between launches"
+
+
 MASKED_S2 = [  # Cin, Cout, H (input), B
     (64, 128, 64, 40),      # 1 slice per plane, 32 x 32 maps: 160 tiles ... x 1 Cout block
     (64, 128, 128, 12),     # 64 x 64 maps: 192 tiles (the 512^2 layer-2 shape)
