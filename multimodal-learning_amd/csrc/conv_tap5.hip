@@ -69,10 +69,10 @@ __device__ __forceinline__ int a5_off(int hr, int hc, int c) {
 // kinds 2, 3, 4 fetch x hi of the NEXT tile into the buffer the barrier of the slice before released - all issued by tap 5: a piece of
 // tap t is complete at the wait that ends tap t + 2, the hand-over barrier sits in tap 8.
 __host__ __device__ constexpr int ph5_ndma(int kind, int t) {
-  return kind == 0 ? 2 : kind == 1 ? (t == 0 ? 2 : 0) : (t < 2 ? 4 : (t < 6 ? 3 : 0));
+  return kind == 0 ? 0 : (t < 2 ? 4 : (t < 6 ? 3 : 0));
 }
 __host__ __device__ constexpr int ph5_dma0(int kind, int t) {
-  return kind == 0 ? 2 * t : kind == 1 ? 18 : (t < 2 ? 4 * t : 8 + 3 * (t - 2));
+  return t < 2 ? 4 * t : 8 + 3 * (t - 2);
 }
 __host__ __device__ constexpr int ph5_next_kind(int kind) { return kind == 0 ? 1 : kind == 1 ? 2 : kind == 2 ? 0 : kind == 3 ? 4 : 3; }
 __host__ __device__ constexpr int ph5_abuf(int kind) { return (kind == 2 || kind == 4) ? 1 : 0; }
@@ -238,10 +238,22 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
       const unsigned orow = o00 + (unsigned)m * rowstep;
+      int off[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) off[q] = (int)((FULL || (m < rlim && q < clim)) ? orow + (unsigned)q * 256u : OOB);
+      // the residual operands of the whole tile row first: 8 loads in flight per wave (one pixel at a time the round trips of a
+      // tile were 32 in a row - 8 KiB in flight per compute unit, a quarter of what the HBM-bound masked-residual dgrad needs)
+      f32x4 g[4], a[4];
+      if constexpr (RM > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_g, off[q], 0, 0));
+          if constexpr (RM > 1) a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_a, off[q], 0, 0));
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bool mine = FULL || (m < rlim && q < clim);
-        const int off = (int)(mine ? orow + (unsigned)q * 256u : OOB);
         f32x4 v;
 #pragma unroll
         for (int n = 0; n < NN; ++n) {
@@ -255,19 +267,13 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
           s1[n] += v[n];
           s2[n] = __builtin_fmaf(v[n], v[n], s2[n]);
         }
-        if constexpr (RM > 0) {
-          const f32x4 g = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_g, off, 0, 0));
-          if constexpr (RM > 1) {
-            const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_a, off, 0, 0));
+        if constexpr (RM > 1) {
 #pragma unroll
-            for (int n = 0; n < NN; ++n) v[n] += a[n] > 0.f ? g[n] : 0.f;
-          } else {
-            v += g;
-          }
+          for (int n = 0; n < NN; ++n) v[n] += a[q][n] > 0.f ? g[q][n] : 0.f;
+        } else if constexpr (RM > 0) {
+          v += g[q];
         }
-#if !(PH5_DBG & 1)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, off, 0, 0);
-#endif
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out, off[q], 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);      // one tile row at a time
     }
@@ -339,7 +345,9 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
 
   constexpr int KIND0 = HI1 ? 3 : 0;
   unsigned mask_cur = 0, mask_next = 0;      // piece masks of tcur / of tnext
+#ifndef PH5_TRACE_KIND
   PH_TRACE(0);
+#endif
   {  // prologue: x hi of the first tile, the weights of the first two taps
 #pragma unroll
     for (int e = 0; e < C::NHE; ++e) mask_cur |= piece_bit(e, tcur.iy_base, tcur.ix_base);
@@ -357,18 +365,21 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifndef PH5_TRACE_KIND
   PH_TRACE(1);
+#endif
   fa[0] = PH5_LDA(ab0[0][0], 0, 0);
   fa[1] = PH5_LDA(ab0[0][0], 0, 1);
   fa[2] = PH5_LDA(ab0[0][0], 0, 2);
 
   // One slice = 9 taps x 2 k-steps x 8 groups.  KIND is a literal at every call site: after inlining + unrolling every register
   // array index, immediate offset and wait count below is a constant.
+  int trace_k = 0;      // (debug builds: tile counter for the tracer)
   auto slice_body = [&](const int KIND) __attribute__((always_inline)) {
     const int NEXT = ph5_next_kind(KIND);
     const int BUFC = ph5_abuf(KIND), BUFN = ph5_abuf(NEXT);
     // what this slice's DMAs fetch: kind 0 / 1 the lo plane of the current tile (buffer 1), kinds 2.. the hi plane of the next tile
-    const bool lo_cur = KIND < 2;
+    const bool lo_cur = KIND == 1;
     // (scalars, not a reference chosen between the two contexts: a select of their addresses keeps every captured array in memory)
     const bool dnext = !lo_cur && nvalid;
     const unsigned char* d_in = dnext ? tnext.in : tcur.in;
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
       // weights of stream tap g + 2
       const unsigned long long wb = (t + 2 < NTAPS) ? w_base(ph5_wblk(KIND), t + 2) : w_base(ph5_wblk(NEXT), t + 2 - NTAPS);
       const int nd = ph5_ndma(KIND, t), e0 = ph5_dma0(KIND, t);
-      const int ndp = t > 0 ? ph5_ndma(KIND, t - 1) : (KIND == 1 ? ph5_ndma(0, NTAPS - 1) : 0);
+      const int ndp = t > 0 ? ph5_ndma(KIND, t - 1) : 0;      // (no kind issues pieces in its last taps)
 #if PH5_DBG & 2
 #define PH5_DMA(I) ((void)0)
 #else
@@ -408,8 +419,8 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
       PH5_GROUP(2, set, 1, fa[1] = PH5_LDA(ab1[BUFC][dx], aoff, 5), PH5_NOP, PH5_DMA(2));
       PH5_GROUP(3, set, 1, fa[2] = PH5_LDA(ab1[BUFC][dx], aoff, 6), PH5_NOP, PH5_DMA(3));
       PH5_GROUP(4, set, 1, fa[3] = PH5_LDA(ab1[BUFC][dx], aoff, 7), PH5_NOP, PH5_NOP);
-      // (kind 1 has no DMA after its first tap: its issue slots take the piece mask of the NEXT tile, two pieces per tap + the last two)
-      if (KIND == 1) {
+      // (kind 0 has no DMA: its issue slots take the piece mask of the NEXT tile, two pieces per tap + the last two)
+      if (KIND == 0) {
         if (t == 0) mask_next = 0;
         mask_next |= piece_bit(2 * t, tnext.iy_base, tnext.ix_base) | piece_bit(2 * t + 1, tnext.iy_base, tnext.ix_base);
         if (t + 1 == NTAPS) mask_next |= piece_bit(18, tnext.iy_base, tnext.ix_base) | piece_bit(19, tnext.iy_base, tnext.ix_base);
@@ -426,7 +437,12 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
       PH5_GROUP(7, set, 1, fa[2] = PH5_LDA(ab0[bufn][dxn], aoffn, 2), PH5_NOP, PH5_NOP);
       // ---- tap end: the weights of tap g + 1 (loaded during tap g - 1) must be in their registers.  Younger than them: the previous
       // tap's pieces, this tap's 8 weight fragments, this tap's pieces.
-      ph5_wait_vmcnt(ndp + 8 + nd);
+      // (first tap of a tile: the wait in front of the epilogue already covered the weights of tap g + 1, and nothing this tap could wait
+      // for is older than the epilogue's 32 stores - a counted wait here would stall until they have drained)
+      if (!first) ph5_wait_vmcnt(ndp + 8 + nd);
+#if defined(PH_TAP_TRACE) && defined(PH5_TRACE_KIND)
+      if (KIND == PH5_TRACE_KIND && trace_k == 1) PH_TRACE_ACC(t + 1, wall_clock64());      // per-tap stamps of one slice of the second tile
+#endif
 #undef PH5_DMA
     }
   };
@@ -444,32 +460,49 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
     }
   };
   for (int k = 0;;) {
+    trace_k = k;
     if constexpr (!HI1) {
+#ifdef PH5_TRACE_KIND      // (debug: per-tap stamps of one slice of the second tile, slot 0 = its start)
+      if (k == 1 && PH5_TRACE_KIND == 0) PH_TRACE(0);
+      slice_body(0);
+      if (k == 1 && PH5_TRACE_KIND == 1) PH_TRACE(0);
+      slice_body(1);
+      if (k == 1 && PH5_TRACE_KIND == 2) PH_TRACE(0);
+      slice_body(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      epilogue_any(tcur);
+#else
       slice_body(0);
       if (k == 0) PH_TRACE(2); else if (k == 1) PH_TRACE(6);
       slice_body(1);
       if (k == 0) PH_TRACE(3); else if (k == 1) PH_TRACE(7);
       slice_body(2);
       if (k == 0) PH_TRACE(4); else if (k == 1) PH_TRACE(8);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights of the next tile's first two taps (see the first tap's end)
       epilogue_any(tcur);
       if (k == 0) PH_TRACE(5); else if (k == 1) PH_TRACE(9);
+#endif
       if (!nvalid) break;
       advance(k);
       ++k;
     } else {
       slice_body(3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights of the next tile's first two taps (see the first tap's end)
       epilogue_any(tcur);
       if (!nvalid) break;
       advance(k);
       ++k;
       slice_body(4);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights of the next tile's first two taps (see the first tap's end)
       epilogue_any(tcur);
       if (!nvalid) break;
       advance(k);
       ++k;
     }
   }
+#ifndef PH5_TRACE_KIND
   PH_TRACE(10);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // refills issued past the end of the stream must not outlive the workgroup's LDS
   if (p.stats) {
     float* red = reinterpret_cast<float*>(smem + C::RED_OFF);      // [NW][2][BNT]

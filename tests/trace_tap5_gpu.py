@@ -21,6 +21,11 @@ nwg = 256
 buf = np.zeros((nwg, 12), dtype=np.uint64)
 L.ph_debug_tap5_trace.argtypes = [C.c_void_p, C.c_int]
 assert L.ph_debug_tap5_trace(buf.ctypes.data_as(C.c_void_p), nwg) == 0
+if len(sys.argv) > 1 and sys.argv[1] == "taps":      # build with -DPH5_TRACE_KIND=k: slot 0 = slice start, 1..9 = end of tap 0..8
+    t = buf[:, :10].astype(np.int64)
+    d = np.diff(t, axis=1) * 0.01
+    print("per-tap medians (us):", " ".join("%.2f" % np.median(d[:, i]) for i in range(9)), " slice %.2f" % np.median((t[:, 9] - t[:, 0]) * 0.01))
+    sys.exit(0)
 t = buf[:, :11].astype(np.int64)
 d = np.diff(t, axis=1) * 0.01
 names = ["prologue", "tile0 S0 (hi.hi')", "tile0 S1 (hi.lo)", "tile0 S2 (lo.hi)", "tile0 epilogue", "tile1 S0", "tile1 S1", "tile1 S2",
