@@ -61,7 +61,9 @@ size_t ph_conv2d_workspace_bytes(int B, int Cin, int IH, int IW, int Cout, int K
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   const size_t wbytes = up((size_t)PH_NPLANES * KS * KS * Cin * Cout * sizeof(bf16));
   PhTapConv t{}; t.B = B; t.Cout = Cout; t.OHt = OH; t.OWt = OW;
-  const size_t parts = up((size_t)ph_tapconv_stat_parts(&t, stride, PH_PREC_BF16X6) * 2 * Cout * sizeof(float));
+  // (the largest row count of any arithmetic: the split modes' small tiles, or two rows per persistent workgroup of conv_tap6.hip)
+  const int nparts = ph_tapconv_stat_parts(&t, stride, PH_PREC_BF16X6), nparts_hp = ph_tapconv_stat_parts(&t, stride, PH_PREC_FP16X3);
+  const size_t parts = up((size_t)(nparts > nparts_hp ? nparts : nparts_hp) * 2 * Cout * sizeof(float));
   int tpc; const int nc = chunks_for(B, OH, OW, stride, Cout, Cin, &tpc);
   const size_t slab = up((size_t)nc * KS * KS * Cin * Cout * sizeof(float));
   return wbytes + (parts > slab ? parts : slab) + 256;

@@ -13,6 +13,7 @@
 // Precision: T = bf16 -> perf mode (1 MFMA / k-step).  T = float -> parity mode "bf16x6": fp32 activations are
 //   split into 3 bf16 planes while staging, weights come as 3 planes, 6 MFMAs / k-step reproduce the fp32
 //   products to ~2^-24 (fp32 accumulate as in the reference).
+#include <algorithm>
 #include "ph_common.h"
 #include "ph_kernels.h"
 #include "tap_common.h"
@@ -567,6 +568,12 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
   // (half-pair mode on the third-generation kernel: one partial row per persistent workgroup, like the second generation)
   if (prec == PH_PREC_FP16X3 && S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv2_stat_parts(p);
   if ((prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) && S == 1 && ph_tap5_switch(-1) && ph_tapconv5_eligible(p)) return ph_tapconv5_stat_parts(p);
+  if (prec == PH_PREC_FP16X3 && S == 2 && ph_tap6_switch(-1)) {
+    // (ntaps == 0: a sizing query with B / OHt / OWt / Cout only - resnet_plan.hip - take the larger of the two kernels' counts)
+    const int first_gen = p->B * cdiv(p->OHt, 8) * cdiv(p->OWt, 16);
+    if (p->ntaps == 0) return std::max(first_gen, p->Cout % 128 == 0 ? ph_tapconv6_stat_parts(p) : 0);
+    if (ph_tapconv6_eligible(p)) return ph_tapconv6_stat_parts(p);
+  }
   const bool perf_cfg = prec == PH_PREC_BF16 || prec == PH_PREC_FP16X3;
   const int TH = (S == 1) ? ((p->Cout % 128 == 0 && !perf_cfg) ? 8 : 16) : (perf_cfg ? 8 : 2);
   return p->B * cdiv(p->OHt, TH) * cdiv(p->OWt, 16);
@@ -584,6 +591,8 @@ int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
     if (S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(&q)) return ph_tapconv3_launch_hp(&q, st);
     // dense 3x3 stride-1, Cin = Cout = 64 (layer 1): conv_tap5.hip
     if (S == 1 && ph_tap5_switch(-1) && ph_tapconv5_eligible(&q)) return ph_tapconv5_launch(&q, st);
+    // 3x3 / stride 2 forward (layers 2-4 conv1): conv_tap6.hip
+    if (S == 2 && prec == PH_PREC_FP16X3 && ph_tap6_switch(-1) && ph_tapconv6_eligible(&q)) return ph_tapconv6_launch(&q, st);
     return launch_T<hp16>(q, S, st);
   }
   if (PH_IS_SPLIT_PREC(prec)) {

@@ -497,7 +497,8 @@ __device__ __forceinline__ void hp_w3(float v, f16& b0, f16& b1, f16& b2) {
   b0 = (f16)((float)b2 * PH_HP_LO);
 }
 // conv_tap5.hip's layout of a 64 x 64 x 9 slab set: per tap [block 3][k-step 2][N tile 4][lane 64][8]: row r = 4 li + n, k = 32 ks + 8 lg + j,
-// lane = 16 lg + li -> element index inside the tap (block 0); blocks are 4096 elements apart
+// lane = 16 lg + li -> element index inside the tap (block 0); blocks are 4096 elements apart.  frag5: bit 0 = conv_tap5.hip's
+// switch, bit 1 = conv_tap6.hip's (host: ph_tap5_switch / ph_tap6_switch at pack time)
 __device__ __forceinline__ size_t ph5_frag_index(int r, int k) {
   return (size_t)(((k >> 5) * 4 + (r & 3)) * 512 + ((((k >> 3) & 3) << 4) + (r >> 2)) * 8 + (k & 7));
 }
@@ -522,8 +523,13 @@ __global__ __launch_bounds__(256) void pack_all_tiled_hp_kernel(PhPackAll t, Pac
     f16 b0, b1, b2;
     if (!ONE || dgrad_only == 0) {   // forward layout [tap][O][3 I]: x = input channel (fastest), y = output channel
       hp_w3(sh[y][x * NT + tp], b0, b1, b2);
-      if (frag5 && O == 64 && I == 64 && NT == 9) {
+      if ((frag5 & 1) && O == 64 && I == 64 && NT == 9) {
         f16* d = packed + t.dst_fwd[u] + (size_t)tp * 12288 + ph5_frag_index(o0 + y, i0 + x);
+        d[0] = b0; d[4096] = b1; d[8192] = b2;
+      } else if ((frag5 & 2) && O == 2 * I && NT == 9) {
+        // conv_tap6.hip (the stride-2 convolutions, forward orientation only): [tap][O / 64][I / 64][block 3] x 4096 elements
+        const int o = o0 + y, i = i0 + x;
+        f16* d = packed + t.dst_fwd[u] + (size_t)tp * O * 3 * I + (size_t)(((o >> 6) * (I >> 6) + (i >> 6)) * 3) * 4096 + ph5_frag_index(o & 63, i & 63);
         d[0] = b0; d[4096] = b1; d[8192] = b2;
       } else {
         f16* d = packed + t.dst_fwd[u] + ((size_t)tp * O + o0 + y) * (3 * (size_t)I) + hp_k(i0 + x);
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(256) void pack_all_tiled_hp_kernel(PhPackAll t, Pac
     }
     if (!ONE || dgrad_only == 1) {   // dgrad layout [tap][I][3 O]: x = output channel (fastest), y = input channel
       hp_w3(sh[x][y * NT + tp], b0, b1, b2);
-      if (frag5 && O == 64 && I == 64 && NT == 9) {
+      if ((frag5 & 1) && O == 64 && I == 64 && NT == 9) {
         f16* d = packed + t.dst_dg[u] + (size_t)tp * 12288 + ph5_frag_index(i0 + y, o0 + x);
         d[0] = b0; d[4096] = b1; d[8192] = b2;
       } else {
@@ -573,7 +579,7 @@ int ph_pack_w_hp_launch(const float* w, void* packed, int O, int I, int KS, int 
   t.start[0] = 0; t.start[1] = t.total = (size_t)KS * KS * O * I;
   PackTiles pt;
   pt.tstart[0] = 0; pt.tstart[1] = (O >> 5) * (I >> 5);
-  hipLaunchKernelGGL(pack_all_tiled_hp_kernel<true>, dim3(pt.tstart[1]), dim3(256), 0, st, t, pt, (f16*)packed, dgrad ? 1 : 0, ph_tap5_switch(-1));
+  hipLaunchKernelGGL(pack_all_tiled_hp_kernel<true>, dim3(pt.tstart[1]), dim3(256), 0, st, t, pt, (f16*)packed, dgrad ? 1 : 0, ph_tap5_switch(-1) | (ph_tap6_switch(-1) << 1));
   PH_LAUNCH_CHECK();
   return PH_OK;
 }
@@ -588,7 +594,7 @@ int ph_pack_all_launch(const PhPackAll* t, void* packed, int nplanes, hipStream_
   }
   if (nplanes == -3) {
     if (!tiled) return PH_EINVAL;
-    hipLaunchKernelGGL(pack_all_tiled_hp_kernel<false>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (f16*)packed, 0, ph_tap5_switch(-1));
+    hipLaunchKernelGGL(pack_all_tiled_hp_kernel<false>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (f16*)packed, 0, ph_tap5_switch(-1) | (ph_tap6_switch(-1) << 1));
   } else if (tiled && nplanes == 1)
     hipLaunchKernelGGL(pack_all_tiled_kernel<1>, dim3(pt.tstart[t->n]), dim3(256), 0, st, *t, pt, (bf16*)packed);
   else if (tiled && nplanes == 3)

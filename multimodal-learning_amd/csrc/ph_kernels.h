@@ -115,6 +115,13 @@ int ph_tapconv5_launch(const PhTapConv* p, hipStream_t st);
 int ph_tapconv5_stat_parts(const PhTapConv* p);
 // (its 64 x 64 x 9 weight slabs are packed fragment-major while the switch is on: pack_all_tiled_hp_kernel, conv_wgrad.hip - do not
 // change the switch between a pack and the launches that read it)
+// half-pair kernel of the 3x3 / stride-2 forward convolutions (conv_tap6.hip: parity-plane images through four LDS buffers on a
+// compile-time DMA schedule, conv_tap5.hip's weight window); PH_TAP6=0 keeps the first-generation kernel; its weights are packed
+// fragment-major while the switch is on (same caveat as PH_TAP5)
+int ph_tap6_switch(int set);
+bool ph_tapconv6_eligible(const PhTapConv* p);
+int ph_tapconv6_launch(const PhTapConv* p, hipStream_t st);
+int ph_tapconv6_stat_parts(const PhTapConv* p);
 // stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
 bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 

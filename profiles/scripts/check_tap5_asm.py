@@ -1,17 +1,18 @@
-"""Static check of conv_tap5.hip's device assembly: the weight fragments are loaded by inline-asm global_load_dwordx4 whose data
-lands asynchronously; between such a load and the second end-of-tap `s_waitcnt vmcnt(N >= 8)` after it nothing but the load itself
-may touch the destination registers (a register-allocator copy / spill of them would move garbage).
+"""Static check of the device assembly of conv_tap5.hip / conv_tap6.hip: the weight fragments are loaded by inline-asm
+global_load_dwordx4 (recognisable by the s_mov_b64 of the base in front) whose data lands asynchronously, long after the compiler
+considers the destination defined.  Between such a load and the FIRST MFMA that reads the registers (by then the schedule's waits
+have covered it) nothing may touch them: a register-allocator copy / spill of a set in flight would move garbage.  Also reports scratch traffic (a
+scratch load is a full drain of the hand-counted vmcnt queue).
 usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include --cuda-device-only -S conv_tap5.hip -o t5.s; python check_tap5_asm.py t5.s"""
 import re
 import sys
 
 lines = open(sys.argv[1]).read().split("\n")
-reg = re.compile(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b")
 
 
-def regs_of(text):
+def regs(text, kind):
     out = set()
-    for m in reg.finditer(text):
+    for m in re.finditer(r"\b%s\[(\d+):(\d+)\]|\b%s(\d+)\b" % (kind, kind), text):
         if m.group(1):
             out.update(range(int(m.group(1)), int(m.group(2)) + 1))
         else:
@@ -19,35 +20,40 @@ def regs_of(text):
     return out
 
 
+def is_inline_load(i):
+    t = lines[i].strip()
+    if not re.match(r"global_load_dwordx4 [av]\[", t):
+        return False
+    k = i - 1
+    while k > 0 and (not lines[k].strip() or lines[k].strip().startswith(";")):
+        k -= 1
+    return lines[k].strip().startswith("s_mov_b64") or lines[k].strip().startswith("s_nop")
+
+
 bad = 0
-nload = 0
+n = 0
 for i, ln in enumerate(lines):
-    s = ln.strip()
-    if not s.startswith("global_load_dwordx4 a["):
+    if not is_inline_load(i):
         continue
-    nload += 1
-    dst = regs_of(s.split(",")[0])
-    waits = 0
-    for j in range(i + 1, min(i + 6000, len(lines))):
-        t = lines[j].strip()
-        if not t or t.startswith(";") or t.startswith("."):
+    t = ln.strip()
+    m = re.match(r"global_load_dwordx4 ([av])\[(\d+):(\d+)\]", t)
+    kind = m.group(1)
+    dst = set(range(int(m.group(2)), int(m.group(3)) + 1))
+    n += 1
+    for j in range(i + 1, min(i + 40000, len(lines))):
+        u = lines[j].strip()
+        if not u or u.startswith(";") or u.startswith("."):
             continue
-        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
-        if m:
-            if int(m.group(1)) == 0:
-                break
-            if int(m.group(1)) >= 8:
-                waits += 1
-                if waits == 2:
-                    break
-            continue
-        if t.startswith("s_endpgm"):
+        if u.startswith("s_endpgm"):
             break
-        if t.startswith("v_mfma") and waits >= 1:
-            continue   # (a use after the FIRST wait would be a bug of the schedule, not of the allocator: the set is read two taps later)
-        if regs_of(t) & dst:
-            bad += 1
-            if bad <= 20:
-                print("line %d: load %s touched by line %d: %s (waits passed %d)" % (i + 1, s, j + 1, t, waits))
-print("weight loads: %d, violations: %d" % (nload, bad))
-sys.exit(1 if bad else 0)
+        if not (regs(u, kind) & dst):
+            continue
+        if u.startswith("v_mfma"):
+            break                       # first use: the in-flight window is over
+        bad += 1
+        if bad <= 20:
+            print("line %d: %s touched by line %d: %s" % (i + 1, t, j + 1, u))
+        break
+scratch = sum(1 for l in lines if l.strip().startswith("scratch_"))
+print("inline weight loads: %d, violations: %d, scratch instructions: %d" % (n, bad, scratch))
+sys.exit(1 if (bad or scratch) else 0)

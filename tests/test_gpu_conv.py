@@ -255,6 +255,45 @@ def test_tapconv5_half_pair_layer1_stream(case):
         assert torch.equal(dx, dx3), "dgrad differs between launches"
 
 
+@pytest.mark.parametrize("case", [(64, 128, 64, 20), (64, 128, 128, 20), (128, 256, 48, 8), (256, 512, 30, 5), (128, 256, 64, 40), (256, 512, 32, 64), (64, 128, 9, 3)])
+def test_tapconv6_half_pair_stride2_stream(case):
+    """The half-pair kernel of the 3x3 / stride-2 forward convolutions (conv_tap6.hip: eight parity-plane images per 64-channel group
+    through four LDS buffers on a compile-time DMA schedule, fragment-major weights through a register window): persistent workgroups
+    walking several tiles, ragged / odd maps (24 = 16 + 8, 15, 5), 1 / 2 / 4 channel groups and Cout blocks, fewer tiles than compute
+    units, against fp64 F.conv2d on the same fp32 operands (+ BatchNorm partial sums), repeated launches bitwise, and the
+    first-generation kernel (PH_TAP6 off) as the second opinion."""
+    from tests.gpu_util import nhwc, nchw_cpu, assert_close, hp_pack
+    m, L, ptr, stream, check = _setup()
+    Cin, Cout, H, B = case
+    g = torch.Generator().manual_seed(Cin + Cout + H * 7 + B)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    torch.set_num_threads(8)
+    y_ref = F.conv2d(x.double(), w.double(), None, 2, 1)
+    OH = y_ref.shape[-1]
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cin, H, H, Cout, 3, 2, 1), device="cuda", dtype=torch.uint8)
+    xd = hp_pack(nhwc(x, torch.float32)); wd = w.cuda()
+    s1 = torch.empty(Cout, device="cuda"); s2 = torch.empty(Cout, device="cuda")
+    outs = []
+    for rep in range(4):
+        y = torch.full((B, OH, OH, Cout), float("nan"), device="cuda")
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 2, 1, 3, ptr(ws), stream()), "fwd")
+        outs.append((y.clone(), s1.clone(), s2.clone()))
+    assert_close(y_ref, nchw_cpu(outs[0][0]), 1e-6, 3e-6, "stride-2 half-pair conv fwd")
+    assert_close(y_ref.sum(dim=(0, 2, 3)), outs[0][1].cpu(), 1e-2, 1e-4, "channel sum")
+    assert_close((y_ref ** 2).sum(dim=(0, 2, 3)), outs[0][2].cpu(), 1e-2, 1e-4, "channel sumsq")
+    for rep in range(1, 4):
+        assert torch.equal(outs[0][0], outs[rep][0]), "fwd differs between launches"
+        assert torch.equal(outs[0][1], outs[rep][1]) and torch.equal(outs[0][2], outs[rep][2])
+    L.ph_debug_set_tap6(0)
+    try:
+        y1 = torch.full((B, OH, OH, Cout), float("nan"), device="cuda")
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y1), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 2, 1, 3, ptr(ws), stream()), "fwd gen1")
+    finally:
+        L.ph_debug_set_tap6(1)
+    assert (y1 - outs[0][0]).abs().max().item() <= 4e-6 * y_ref.abs().max().item()
+
+
 MASKED_S2 = [  # Cin, Cout, H (input), B
     (64, 128, 64, 40),      # 1 slice per plane, 32 x 32 maps: 160 tiles ... x 1 Cout block
     (64, 128, 128, 12),     # 64 x 64 maps: 192 tiles (the 512^2 layer-2 shape)
