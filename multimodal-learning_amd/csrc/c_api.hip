@@ -77,6 +77,8 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
   bf16* hi = reinterpret_cast<bf16*>(ws);
   int rc = prec == PH_PREC_FP16X3 ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 0, st) : ph_pack_w_fwd_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
+  // perf mode, what conv_tap7.hip takes: the fragment-major copy in plane 1 (a split plane this mode does not read)
+  if (prec == PH_PREC_BF16 && KS == 3 && Cin == Cout && Cin >= 128 && (rc = ph_frag7_repack_launch(hi, Cout, Cin, 9, st))) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
   t.in = x; t.w = hi; t.wplane = plane; t.out = y;
@@ -105,6 +107,7 @@ int ph_conv2d_dgrad_res(const void* dy, const float* w, void* dx, const void* re
   bf16* hi = reinterpret_cast<bf16*>(ws_);
   int rc = (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
+  if (prec == PH_PREC_BF16 && KS == 3 && Cin == Cout && Cin >= 128 && (rc = ph_frag7_repack_launch(hi, Cin, Cout, 9, st))) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
   t.in = dy; t.w = hi; t.wplane = plane; t.out = dx; t.res_g = res_g; t.res_a = res_a;
@@ -200,6 +203,7 @@ int ph_conv2d_dgrad(const void* dy, const float* w, void* dx, int B, int Cin, in
   bf16* hi = reinterpret_cast<bf16*>(ws_);
   int rc = (prec == PH_PREC_FP16X3 || prec == PH_PREC_FP16X1) ? ph_pack_w_hp_launch(w, hi, Cout, Cin, KS, 1, st) : ph_pack_w_dgrad_launch(w, hi, Cout, Cin, KS, st);
   if (rc) return rc;
+  if (prec == PH_PREC_BF16 && KS == 3 && Cin == Cout && Cin >= 128 && (rc = ph_frag7_repack_launch(hi, Cin, Cout, 9, st))) return rc;
   const int OH = (IH + 2 * pad - KS) / stride + 1, OW = (IW + 2 * pad - KS) / stride + 1;
   PhTapConv t{};
   t.in = dy; t.w = hi; t.wplane = plane; t.out = dx;

@@ -1295,7 +1295,11 @@ int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
   if (p->in_scale && (!p->in_shift || p->Cin > 512)) return PH_EINVAL;
   if (p->m_groups) return (p->Cout % 128 == 0 && !p->in_scale) ? launch2<2, 2, 4, false, true>(*p, st) : PH_EINVAL;
   if (p->Cout % 128 == 0) {
-    if (ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv3_launch(p, st);
+    if (ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) {
+      // the plain form (no in-LDS BatchNorm, no fused BatchNorm-backward sums) of Cin = Cout: conv_tap7.hip, same outputs
+      if (ph_tap7_switch(-1) && ph_tapconv7_eligible(p)) return ph_tapconv7_launch(p, st);
+      return ph_tapconv3_launch(p, st);
+    }
     if (p->bst_y) return PH_EINVAL;      // (the fused BatchNorm-backward sums exist in conv_tap3.hip / conv_tap4.hip only)
     return launch2<2, 2, 4, false>(*p, st);
   }

@@ -450,6 +450,11 @@ __global__ void pack_all_kernel(PhPackAll t, bf16* __restrict__ packed, int npla
 // elements (110 us for the 11 M weights of a ResNet-18, twice per step); here the OIHW rows are read as contiguous
 // runs of 32*NT floats and both layouts leave as 64-byte runs.
 struct PackTiles { int tstart[21]; };
+// fragment-major order of a 64 x 64 (row, k) block for the register-window kernels (conv_tap5/6/7.hip): [k-step 2][N tile 4][lane 64][8]:
+// row r = 4 li + n, k = 32 ks + 8 lg + j, lane = 16 lg + li
+__device__ __forceinline__ size_t frag64_index(int r, int k) {
+  return (size_t)(((k >> 5) * 4 + (r & 3)) * 512 + ((((k >> 3) & 3) << 4) + (r >> 2)) * 8 + (k & 7));
+}
 template <int NP>
 __global__ __launch_bounds__(256) void pack_all_tiled_kernel(PhPackAll t, PackTiles pt, bf16* __restrict__ packed) {
   __shared__ bf16 sh[NP][32][32 * 9 + 2];
@@ -485,6 +490,16 @@ __global__ __launch_bounds__(256) void pack_all_tiled_kernel(PhPackAll t, PackTi
       packed[fdst + pl * n] = sh[pl][y][x * NT + tp];
       packed[ddst + pl * n] = sh[pl][x][y * NT + tp];
     }
+    // perf mode, dense 3x3 stride-1 units with Cin = Cout >= 128 (ResNet layers 2-4: what conv_tap7.hip takes): a fragment-major
+    // copy of both orientations in plane 1 of the unit's region (unused in this mode): [tap][rows / 64][K / 64] x 4096 elements
+    if constexpr (NP == 1) {
+      if (NT == 9 && O == I && I >= 128) {
+        const int o = o0 + y, i = i0 + x;      // forward: row o, k i
+        packed[t.dst_fwd[u] + n + (size_t)tp * O * I + (size_t)((o >> 6) * (I >> 6) + (i >> 6)) * 4096 + frag64_index(o & 63, i & 63)] = sh[0][y][x * NT + tp];
+        const int r = i0 + y, k = o0 + x;      // dgrad: row = input channel, k = output channel
+        packed[t.dst_dg[u] + n + (size_t)tp * I * O + (size_t)((r >> 6) * (O >> 6) + (k >> 6)) * 4096 + frag64_index(r & 63, k & 63)] = sh[0][x][y * NT + tp];
+      }
+    }
   }
 }
 
@@ -499,9 +514,7 @@ __device__ __forceinline__ void hp_w3(float v, f16& b0, f16& b1, f16& b2) {
 // conv_tap5.hip's layout of a 64 x 64 x 9 slab set: per tap [block 3][k-step 2][N tile 4][lane 64][8]: row r = 4 li + n, k = 32 ks + 8 lg + j,
 // lane = 16 lg + li -> element index inside the tap (block 0); blocks are 4096 elements apart.  frag5: bit 0 = conv_tap5.hip's
 // switch, bit 1 = conv_tap6.hip's (host: ph_tap5_switch / ph_tap6_switch at pack time)
-__device__ __forceinline__ size_t ph5_frag_index(int r, int k) {
-  return (size_t)(((k >> 5) * 4 + (r & 3)) * 512 + ((((k >> 3) & 3) << 4) + (r >> 2)) * 8 + (k & 7));
-}
+__device__ __forceinline__ size_t ph5_frag_index(int r, int k) { return frag64_index(r, k); }
 template <bool ONE>
 __global__ __launch_bounds__(256) void pack_all_tiled_hp_kernel(PhPackAll t, PackTiles pt, f16* __restrict__ packed, int dgrad_only, int frag5) {
   __shared__ float sh[32][32 * 9 + 1];

@@ -115,6 +115,13 @@ int ph_tapconv5_launch(const PhTapConv* p, hipStream_t st);
 int ph_tapconv5_stat_parts(const PhTapConv* p);
 // (its 64 x 64 x 9 weight slabs are packed fragment-major while the switch is on: pack_all_tiled_hp_kernel, conv_wgrad.hip - do not
 // change the switch between a pack and the launches that read it)
+// perf-mode kernel of the dense 3x3 stride-1 convolutions with Cin = Cout >= 128 (conv_tap7.hip: conv_tap3.hip's plain form on the
+// register-window machinery, bitwise the same outputs); reads the fragment-major copy of the weights in plane 1 of the unit's packed
+// region (p->w + p->wplane elements; pack_all_tiled_kernel<1> writes it, ph_frag7_repack_launch for a single convolution)
+int ph_tap7_switch(int set);
+bool ph_tapconv7_eligible(const PhTapConv* p);
+int ph_tapconv7_launch(const PhTapConv* p, hipStream_t st);
+int ph_frag7_repack_launch(void* packed, int R, int K, int ntaps, hipStream_t st);
 // half-pair kernel of the 3x3 / stride-2 forward convolutions (conv_tap6.hip: parity-plane images through four LDS buffers on a
 // compile-time DMA schedule, conv_tap5.hip's weight window); PH_TAP6=0 keeps the first-generation kernel; its weights are packed
 // fragment-major while the switch is on (same caveat as PH_TAP5)

@@ -27,7 +27,9 @@ def is_inline_load(i):
     k = i - 1
     while k > 0 and (not lines[k].strip() or lines[k].strip().startswith(";")):
         k -= 1
-    return lines[k].strip().startswith("s_mov_b64") or lines[k].strip().startswith("s_nop")
+    # conv_tap5/6: s_mov_b64 of the scalar base in front; conv_tap7: vector address, `off` - the only dwordx4 loads with a register
+    # destination in these kernels (the compiler's own are buffer loads)
+    return lines[k].strip().startswith("s_mov_b64") or lines[k].strip().startswith("s_nop") or (", off" in t and "offset:" in t)
 
 
 bad = 0

@@ -255,6 +255,52 @@ def test_tapconv5_half_pair_layer1_stream(case):
         assert torch.equal(dx, dx3), "dgrad differs between launches"
 
 
+@pytest.mark.parametrize("case", [(128, 64, 20), (256, 24, 40), (512, 16, 80), (128, 40, 9), (256, 32, 64), (128, 9, 3)])
+def test_tapconv7_bitwise_equals_the_ring_kernel(case):
+    """conv_tap7.hip (the plain perf-mode form of the dense 3x3 convolutions with Cin = Cout >= 128 on the register-window machinery:
+    fragment-major weights four taps ahead, one barrier per slice) against conv_tap3.hip (PH_TAP7 off) - the same GEMM in the same
+    summation order: forward outputs, BatchNorm sums, dgrad outputs with no / plain / masked residual BITWISE equal; persistent workgroups walking several tiles and Cout blocks, ragged maps (24, 40, 9), repeated
+    launches bitwise."""
+    from tests.gpu_util import nhwc
+    m, L, ptr, stream, check = _setup()
+    Cn, H, B = case
+    g = torch.Generator().manual_seed(Cn + H + B)
+    x = nhwc(torch.randn(B, Cn, H, H, generator=g), torch.bfloat16)
+    dy = nhwc(torch.randn(B, Cn, H, H, generator=g), torch.bfloat16)
+    rg = nhwc(torch.randn(B, Cn, H, H, generator=g), torch.bfloat16)
+    ra = nhwc(torch.randn(B, Cn, H, H, generator=g).relu_(), torch.bfloat16)
+    wd = (torch.randn(Cn, Cn, 3, 3, generator=g) * (2.0 / (Cn * 9)) ** 0.5).cuda()
+    ws = torch.empty(L.ph_conv2d_workspace_bytes(B, Cn, H, H, Cn, 3, 1, 1), device="cuda", dtype=torch.uint8)
+
+    def run_all():
+        out = []
+        y = torch.full((B, H, H, Cn), float("nan"), device="cuda", dtype=torch.bfloat16)
+        s1 = torch.empty(Cn, device="cuda"); s2 = torch.empty(Cn, device="cuda")
+        check(L.ph_conv2d_fwd(ptr(x), ptr(wd), ptr(y), ptr(s1), ptr(s2), B, Cn, H, H, Cn, 3, 1, 1, 0, ptr(ws), stream()), "fwd")
+        out += [y, s1, s2]
+        for g_, a_ in ((None, None), (rg, None), (rg, ra)):
+            dx = torch.full((B, H, H, Cn), float("nan"), device="cuda", dtype=torch.bfloat16)
+            check(L.ph_conv2d_dgrad_res(ptr(dy), ptr(wd), ptr(dx), ptr(g_) if g_ is not None else None, ptr(a_) if a_ is not None else None,
+                                        B, Cn, H, H, Cn, 3, 1, 1, 0, ptr(ws), stream()), "dgrad")
+            out.append(dx)
+        torch.cuda.synchronize()
+        return out
+
+    new = run_all()
+    again = run_all()
+    L.ph_debug_set_tap7(0)
+    try:
+        old = run_all()
+    finally:
+        L.ph_debug_set_tap7(1)
+    assert not torch.isnan(new[0].float()).any()
+    for i in (0, 3, 4, 5):
+        assert torch.equal(new[i].view(torch.int16), old[i].view(torch.int16)), "output %d differs from conv_tap3.hip" % i
+        assert torch.equal(new[i].view(torch.int16), again[i].view(torch.int16)), "output %d differs between launches" % i
+    for i in (1, 2):
+        assert torch.equal(new[i], again[i]) and torch.equal(new[i], old[i]), "BatchNorm sums differ"
+
+
 @pytest.mark.parametrize("case", [(64, 128, 64, 20), (64, 128, 128, 20), (128, 256, 48, 8), (256, 512, 30, 5), (128, 256, 64, 40), (256, 512, 32, 64), (64, 128, 9, 3)])
 def test_tapconv6_half_pair_stride2_stream(case):
     """The half-pair kernel of the 3x3 / stride-2 forward convolutions (conv_tap6.hip: eight parity-plane images per 64-channel group
