@@ -155,9 +155,8 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
   const unsigned char* w0 = reinterpret_cast<const unsigned char*>(p.w) + (long)p.wtap[0] * slab_bytes + 4096;
   const long wtap_step = (long)(p.wtap[1] - p.wtap[0]) * slab_bytes;
   const int voffB = lane * 16;
-  auto w_base = [&](int blk, int tap) -> unsigned long long {      // wave-uniform; + 4 KiB: the 8 fragments are immediates -4096 .. 3072
-    const unsigned long long a = reinterpret_cast<unsigned long long>(w0 + (long)tap * wtap_step + blk * 8192);
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+  auto w_base = [&](int blk, int tap) -> const unsigned char* {      // per-lane; + 4 KiB: the 8 fragments are immediates -4096 .. 3072
+    return w0 + (long)tap * wtap_step + blk * 8192 + voffB;
   };
 
   // ---- per-lane halo DMA sources: piece h = wave + 4 e of a plane covers row pairs 4 h .. 4 h + 3; lane l fills slot l & 15 of
@@ -314,15 +313,12 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
 #define PH5_SB() __builtin_amdgcn_sched_barrier(0)
 #define PH5_LDA(AB, AOFF, MT) PH5_LD(AB, (AOFF) + (MT) * C::ROW_BYTES)
   // weight fragment (KS, N) of the tap at wave-uniform base WB -> register set SET (literal byte offset (4 KS + N) KiB - 4 KiB)
-  // (the base may have just been restored from a spill lane by v_readlane: a VALU write of an SGPR needs 5 wait states before a
-  // VMEM instruction reads it and the hazard recognizer does not look inside inline assembly - the first run loaded through a
-  // stale high word.  The copy below makes the VMEM operand a SALU result, which the hardware interlocks.)
-#define PH5_BLD(SET, KS, N, WB, OFF)                                                                     \
-  do {                                                                                                   \
-    unsigned long long wb_;                                                                              \
-    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1 offset:" #OFF                       \
-                 : "=a"(fb[SET][KS][N]), "=&s"(wb_) : "v"(voffB), "s"(WB) : "memory");                  \
-  } while (0)
+  // (WB is a per-lane 64-bit address - the lane's 16 bytes of fragment (0, 0) - made by ONE vector add per tap; the loads carry nothing
+  // but an immediate.  The first version passed a scalar base: a base restored from a spill lane by v_readlane right in front of the
+  // inline assembly needs 5 wait states before a VMEM instruction reads it, the hazard recognizer does not look inside inline
+  // assembly, and the first run loaded through a stale high word.)
+#define PH5_BLD(SET, KS, N, WB, OFF) \
+  asm volatile("global_load_dwordx4 %0, %1, off offset:" #OFF : "=a"(fb[SET][KS][N]) : "v"(WB) : "memory")
 #define PH5_BLD_I(SET, I, WB)                                        \
   do {                                                               \
     if (PH5_DBG & 4) break;                                          \
@@ -353,7 +349,7 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
     for (int e = 0; e < C::NHE; ++e) mask_cur |= piece_bit(e, tcur.iy_base, tcur.ix_base);
 #pragma unroll
     for (int e = 0; e < C::NHE; ++e) dma_piece(e, tcur.in, mask_cur, 0, 0);
-    const unsigned long long wb0 = w_base(ph5_wblk(KIND0), 0), wb1 = w_base(ph5_wblk(KIND0), 1);
+    const unsigned char *wb0 = w_base(ph5_wblk(KIND0), 0), *wb1 = w_base(ph5_wblk(KIND0), 1);
     PH5_BLD(0, 0, 0, wb0, -4096); PH5_BLD(0, 0, 1, wb0, -3072); PH5_BLD(0, 0, 2, wb0, -2048); PH5_BLD(0, 0, 3, wb0, -1024);
     PH5_BLD(0, 1, 0, wb0, 0); PH5_BLD(0, 1, 1, wb0, 1024); PH5_BLD(0, 1, 2, wb0, 2048); PH5_BLD(0, 1, 3, wb0, 3072);
     PH5_BLD(1, 0, 0, wb1, -4096); PH5_BLD(1, 0, 1, wb1, -3072); PH5_BLD(1, 0, 2, wb1, -2048); PH5_BLD(1, 0, 3, wb1, -1024);
@@ -395,7 +391,7 @@ __global__ __launch_bounds__(256) void tapconv5_kernel(PhTapConv p) {
       const int set = t % 3, setl = (t + 2) % 3;
       const bool first = t == 0 && (KIND == 0 || KIND >= 3);      // first tap of a tile
       // weights of stream tap g + 2
-      const unsigned long long wb = (t + 2 < NTAPS) ? w_base(ph5_wblk(KIND), t + 2) : w_base(ph5_wblk(NEXT), t + 2 - NTAPS);
+      const unsigned char* wb = (t + 2 < NTAPS) ? w_base(ph5_wblk(KIND), t + 2) : w_base(ph5_wblk(NEXT), t + 2 - NTAPS);
       const int nd = ph5_ndma(KIND, t), e0 = ph5_dma0(KIND, t);
       const int ndp = t > 0 ? ph5_ndma(KIND, t - 1) : 0;      // (no kind issues pieces in its last taps)
 #if PH5_DBG & 2
