@@ -41,7 +41,7 @@ CLS_NAMES = ["tapconv_kernel<bf16,S=1,BNT=64> (first generation: Cout=64 dgrad p
              "tapconv_kernel<bf16,S=1,BNT=128> (first generation: 1x1 and dgrad parity classes, Cout>=128)",
              "tapconv_kernel<bf16,S=2> (stride-2 fwd)", "wgrad_kernel<bf16>", "stem_fwd_kernel<bf16>",
              "stem_wgrad_kernel<bf16>",
-             "tapconv3_kernel (conv_tap3.hip: 3x3 stride-1 fwd+dgrad, Cout>=128, 16x16x32 fragments; PH_TAP3=0: tapconv2_kernel<2,2,4,false>)",
+             "tapconv7_kernel (conv_tap7.hip, round 6: 3x3 stride-1 fwd+dgrad, Cin=Cout>=128, weights through a register window; PH_TAP7=0: tapconv3_kernel, conv_tap3.hip - bitwise the same outputs)",
              "tapconv4_kernel (conv_tap4.hip: 3x3 stride-1 fwd+dgrad, Cin=Cout=64: layer 1; one wave per SIMD, 16x16x32 fragments, resident weights, epilogue inside the next tile; PH_TAP4=0: tapconv2_l1_kernel)"]
 NCLS = len(CLS_NAMES)
 # ... + class 12 of ph_kernels.h (behind the four HBM-bound classes 8-11)

@@ -30,8 +30,12 @@ def short(k):
 def cls_of(name):
     """kernel name -> class index of ph_prof_summary / bench.py CLS_NAMES"""
     n = name
-    if "tapconv3_kernel" in n:      # third-generation dense 3x3 kernel (conv_tap3.hip): the same launches as class 6
+    if "tapconv3_kernel" in n or "tapconv7_kernel" in n:      # dense 3x3 kernels (conv_tap3.hip; round 6: conv_tap7.hip for its plain perf-mode form): class 6
         return 6
+    if "tapconv5_kernel" in n:      # half-pair layer-1 kernel (conv_tap5.hip, round 6): the layer-1 class
+        return 7
+    if "tapconv6_kernel" in n:      # half-pair stride-2 forward kernel (conv_tap6.hip, round 6): the stride-2 class
+        return 2
     if "tapconv2_l1_kernel" in n or "tapconv4_kernel" in n:   # layer 1 (Cin = Cout = 64): conv_tap4.hip (round 5), before it the two-group kernel
         return 7
     if "tapconv2_kernel" in n:   # second-generation 3x3 stride-1 kernel, Cout >= 128; <..., true>: masked stride-2 grid
