@@ -181,6 +181,7 @@ int ph_conv2d_dgrad_bnstat(const void* dy, const float* w, void* dx, const void*
   bf16* hi = reinterpret_cast<bf16*>(ws);
   int rc = ph_pack_w_dgrad_launch(w, hi, Cout, Cin, 3, st);
   if (rc) return rc;
+  if (Cin == Cout && Cin >= 128 && (rc = ph_frag7_repack_launch(hi, Cin, Cout, 9, st))) return rc;
   PhTapConv t{};
   t.in = dy; t.w = hi; t.wplane = plane; t.out = dx; t.res_g = res_g; t.res_a = res_a;
   t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cout; t.Cout = Cin; t.OH = IH; t.OW = IW;

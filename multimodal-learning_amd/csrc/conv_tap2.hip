@@ -1296,7 +1296,7 @@ int ph_tapconv2_launch(const PhTapConv* p, hipStream_t st) {
   if (p->m_groups) return (p->Cout % 128 == 0 && !p->in_scale) ? launch2<2, 2, 4, false, true>(*p, st) : PH_EINVAL;
   if (p->Cout % 128 == 0) {
     if (ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) {
-      // the plain form (no in-LDS BatchNorm, no fused BatchNorm-backward sums) of Cin = Cout: conv_tap7.hip, same outputs
+      // every form but the in-LDS input BatchNorm, Cin = Cout: conv_tap7.hip, same outputs
       if (ph_tap7_switch(-1) && ph_tapconv7_eligible(p)) return ph_tapconv7_launch(p, st);
       return ph_tapconv3_launch(p, st);
     }

@@ -70,6 +70,11 @@ __device__ __forceinline__ void ph7_wait_vmcnt(int n) {
   }
 }
 
+// BST: fused BatchNorm-backward sums over the tensor this (dgrad) launch writes (PhTapConv::bst_y, conv_tap3.hip's semantics and row
+// layout): 0 = none (rows [2][Cout]: sum y | sum y^2 of a forward launch), 1 = mask from the BatchNorm's own ReLU
+// (bst_y * bst_scale + bst_shift > 0), 2 = mask (bst_a > 0), 3 = 2 + a second BatchNorm (bst_y2) over the same dz; rows [3][Cout]:
+// sum dz | sum dz (y - mean) | sum dz (y2 - mean2), taken over the STORED (bf16) gradient.
+template <int BST>
 __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
   using C = Tap7Cfg;
   constexpr int NM = C::NM, NN = C::NN, TH = C::TH, TW = C::TW, HPW = C::HPW, NTAPS = C::NTAPS, BNT = C::BNT;
@@ -184,40 +189,44 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
     }
 
   f32x4 acc[NM][NN];
-  float s1[NN], s2[NN];
+  constexpr bool Y2 = BST == 3;
+  constexpr int NSR = BST ? 3 : 2;      // rows per workgroup
+  float s1[NN], s2[NN], s3[Y2 ? NN : 1];
 #pragma unroll
-  for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; }
+  for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; s3[Y2 ? n : 0] = 0.f; }
   // BatchNorm partial row [blockIdx][2][Cout] (conv_tap3.hip's: one per persistent workgroup, the same fp32 additions in the same
   // order - the two pixel-row halves of a block combined first, then added to what earlier visits of the block left): zeroed here
   if (p.stats) {
-    float* rows = p.stats + (size_t)blockIdx.x * 2 * p.Cout;
-    for (int i = tid; i < 2 * p.Cout; i += C::NTH) rows[i] = 0.f;
+    float* rows = p.stats + (size_t)blockIdx.x * NSR * p.Cout;
+    for (int i = tid; i < NSR * p.Cout; i += C::NTH) rows[i] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
   // (called between two tiles: buffer 1 - the image of the tile's last slice - is free until the next tile's first pieces)
   auto flush_stats = [&](const int nb) __attribute__((always_inline)) {
     if (!p.stats) return;
-    float* red = reinterpret_cast<float*>(smem + C::A_BYTES);      // [WM][2][BNT]
+    float* red = reinterpret_cast<float*>(smem + C::A_BYTES);      // [WM][NSR][BNT]
 #pragma unroll
     for (int n = 0; n < NN; ++n) {
-      float x1 = s1[n], x2 = s2[n];
+      float x1 = s1[n], x2 = s2[n], x3 = s3[Y2 ? n : 0];
       x1 += __shfl_xor(x1, 16, 64); x2 += __shfl_xor(x2, 16, 64);
       x1 += __shfl_xor(x1, 32, 64); x2 += __shfl_xor(x2, 32, 64);
+      if (Y2) { x3 += __shfl_xor(x3, 16, 64); x3 += __shfl_xor(x3, 32, 64); } else x3 = 0.f;
       if (lg == 0) {
-        red[(wm * 2 + 0) * BNT + wn * 64 + 4 * li + n] = x1;
-        red[(wm * 2 + 1) * BNT + wn * 64 + 4 * li + n] = x2;
+        red[(wm * NSR + 0) * BNT + wn * 64 + 4 * li + n] = x1;
+        red[(wm * NSR + 1) * BNT + wn * 64 + 4 * li + n] = x2;
+        if (NSR == 3) red[(wm * NSR + 2) * BNT + wn * 64 + 4 * li + n] = x3;
       }
-      s1[n] = 0.f; s2[n] = 0.f;
+      s1[n] = 0.f; s2[n] = 0.f; s3[Y2 ? n : 0] = 0.f;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // an earlier flush of this row has landed before it is read back
     __syncthreads();
-    {
-      const int which = tid / BNT, n = tid % BNT;           // 256 threads = 2 x 128 entries
+    for (int i = tid; i < NSR * BNT; i += C::NTH) {
+      const int which = i / BNT, n = i % BNT;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < C::WM; ++w) v += red[(w * 2 + which) * BNT + n];
-      volatile float* row = p.stats + ((size_t)blockIdx.x * 2 + which) * p.Cout + nb * BNT + n;
+      for (int w = 0; w < C::WM; ++w) v += red[(w * NSR + which) * BNT + n];
+      volatile float* row = p.stats + ((size_t)blockIdx.x * NSR + which) * p.Cout + nb * BNT + n;
       *row = *row + v;
     }
     __syncthreads();
@@ -238,6 +247,20 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
         const_cast<bf16*>(reinterpret_cast<const bf16*>(p.res_g)) + img, 0, RM > 0 ? img_bytes : 0, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(reinterpret_cast<const bf16*>(p.res_a)) + img, 0, RM > 1 ? img_bytes : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_y)) + img, 0, BST != 0 ? img_bytes : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_a)) + img, 0, BST >= 2 ? img_bytes : 0, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t r_y2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_y2)) + img, 0, Y2 ? img_bytes : 0, RSRC_FLAGS);
+    // per-channel constants of this lane's four channels: mask scale / shift (BST 1), mean, second mean
+    f32x4 cms = {0.f, 0.f, 0.f, 0.f}, cmh = cms, cmu = cms, cmu2 = cms;
+    if constexpr (BST != 0) {
+      const int chan = tc.nb * BNT + wn * 64 + 4 * li;
+      if constexpr (BST == 1) { cms = *reinterpret_cast<const f32x4*>(p.bst_scale + chan); cmh = *reinterpret_cast<const f32x4*>(p.bst_shift + chan); }
+      cmu = *reinterpret_cast<const f32x4*>(p.bst_mean + chan);
+      if constexpr (Y2) cmu2 = *reinterpret_cast<const f32x4*>(p.bst_mean2 + chan);
+    }
     const unsigned o00 = 2u * ((unsigned)((tc.r0 + wm * NM) * p.OW + tc.c0 + 4 * lg) * (unsigned)p.Cout + (unsigned)(tc.nb * BNT + wn * 64 + 4 * li));
     const unsigned rowstep = 2u * (unsigned)(p.OW * p.Cout), colstep = 2u * (unsigned)p.Cout;
     const int rlim = p.OH - (tc.r0 + wm * NM), clim = p.OW - (tc.c0 + 4 * lg);
@@ -247,12 +270,20 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
       int off[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) off[q] = (int)((FULL || (m < rlim && q < clim)) ? orow + (unsigned)q * colstep : OOB);
-      u32x2 rg[4], ra[4];
+      u32x2 rg[4], ra[4], ry[4], rb[4], ry2[4];
       if constexpr (RM > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           rg[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_g, off[q], 0, 0));
           if constexpr (RM > 1) ra[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_a, off[q], 0, 0));
+        }
+      }
+      if constexpr (BST != 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ry[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_y, off[q], 0, 0));
+          if constexpr (BST >= 2) rb[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_b, off[q], 0, 0));
+          if constexpr (Y2) ry2[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_y2, off[q], 0, 0));
         }
       }
 #pragma unroll
@@ -265,8 +296,10 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
           asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[m][n][q]));
           v[n] = x;
           if constexpr (!FULL) v[n] = mine ? v[n] : 0.f;
-          s1[n] += v[n];
-          s2[n] = __builtin_fmaf(v[n], v[n], s2[n]);
+          if constexpr (BST == 0) {
+            s1[n] += v[n];
+            s2[n] = __builtin_fmaf(v[n], v[n], s2[n]);
+          }
         }
         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
         u32x2 w;
@@ -283,8 +316,27 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
             b[1] = (bf16)((float)b[1] + ((RM < 2 || a1 > 0.f) ? g1 : 0.f));
           }
           w[h] = __builtin_bit_cast(unsigned, b);
+          if constexpr (BST != 0) {
+            // the sums are taken over the STORED gradient (bf16), exactly what the separate reduction pass reads back
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int n = 2 * h + e;
+              const float y = __builtin_bit_cast(float, e ? (ry[q][h] & 0xffff0000u) : (ry[q][h] << 16));
+              bool on;
+              if constexpr (BST == 1) on = __builtin_fmaf(y, cms[n], cmh[n]) > 0.f;
+              else on = __builtin_bit_cast(float, e ? (rb[q][h] & 0xffff0000u) : (rb[q][h] << 16)) > 0.f;
+              float dz = (float)b[e];
+              dz = (on && mine) ? dz : 0.f;
+              s1[n] += dz;
+              s2[n] = __builtin_fmaf(dz, y - cmu[n], s2[n]);
+              if constexpr (Y2) {
+                const float y2 = __builtin_bit_cast(float, e ? (ry2[q][h] & 0xffff0000u) : (ry2[q][h] << 16));
+                s3[Y2 ? n : 0] = __builtin_fmaf(dz, y2 - cmu2[n], s3[Y2 ? n : 0]);
+              }
+            }
+          }
         }
-        if (!(PH7_DBG & 8)) __builtin_amdgcn_raw_buffer_store_b64(w, r_out, off[q], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(w, r_out, off[q], 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);      // one tile row at a time
     }
@@ -476,22 +528,23 @@ int ph_tap7_switch(int set) {
 }
 extern "C" int ph_debug_set_tap7(int on) { return ph_tap7_switch(on ? 1 : 0); }
 
-// eligible: conv_tap3.hip's plain perf-mode configuration (dense 3x3 stride-1 over the whole map, Cin = Cout in 128 .. 512) on a dense
-// NHWC tensor; the caller has checked ph_tapconv3_eligible
+// eligible: conv_tap3.hip's perf-mode configuration without the in-LDS input BatchNorm (dense 3x3 stride-1 over the whole map,
+// Cin = Cout in 128 .. 512) on a dense NHWC tensor
 bool ph_tapconv7_eligible(const PhTapConv* p) {
-  return ph_tapconv3_eligible(p) && !p->in_scale && !p->bst_y && !p->m_groups && !p->ncls && p->Cin == p->Cout && p->os == 1 && p->oa_h == 0 &&
+  return ph_tapconv3_eligible(p) && !p->in_scale && !p->m_groups && !p->ncls && p->Cin == p->Cout && p->os == 1 && p->oa_h == 0 &&
          p->oa_w == 0 && p->OHt == p->OH && p->OWt == p->OW && p->IH == p->OH && p->IW == p->OW && p->iy0 == -1 && p->ix0 == -1 &&
          !p->in_pix_stride && !p->in_row_stride && !p->in_img_stride && p->wplane == (size_t)9 * p->Cin * p->Cout &&
          (long)p->OH * p->OW * p->Cout * 2 < 0x7ffffff0L;
 }
 
-int ph_tapconv7_launch(const PhTapConv* p, hipStream_t st) {
+namespace {
+template <int BST>
+int launch7(const PhTapConv* p, hipStream_t st) {
   using C = Tap7Cfg;
-  if (!ph_tapconv7_eligible(p)) return PH_EINVAL;
   static std::once_flag once;
   static hipError_t attr_rc = hipSuccess;
   std::call_once(once, [&] {
-    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(tapconv7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(tapconv7_kernel<BST>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
   });
   if (attr_rc != hipSuccess) return PH_ELAUNCH;
   const int total = cdiv(p->OH, C::TH) * cdiv(p->OW, C::TW) * (p->Cout / C::BNT) * p->B;
@@ -500,10 +553,21 @@ int ph_tapconv7_launch(const PhTapConv* p, hipStream_t st) {
   void* tok = nullptr;
   if (ph_prof_on())
     ph_prof_begin2(PH_CLS_TAPCONV2, 2.0 * p->B * p->OH * p->OW * (double)p->Cout * 9 * p->Cin, ph_tapconv_bytes(*p, 1, 2), st, &tok);
-  hipLaunchKernelGGL(tapconv7_kernel, grid, dim3(C::NTH), C::LDS_BYTES, st, *p);
+  hipLaunchKernelGGL(tapconv7_kernel<BST>, grid, dim3(C::NTH), C::LDS_BYTES, st, *p);
   ph_prof_end(tok, st);
   PH_LAUNCH_CHECK();
   return PH_OK;
+}
+}  // namespace
+
+int ph_tapconv7_launch(const PhTapConv* p, hipStream_t st) {
+  if (!ph_tapconv7_eligible(p)) return PH_EINVAL;
+  if (p->bst_y) {      // fused BatchNorm-backward sums (dgrad launches): conv_tap3.hip's argument rules
+    if (!p->stats || !p->bst_mean || (p->bst_y2 && !p->bst_mean2) || (!p->bst_a && (!p->bst_scale || !p->bst_shift))) return PH_EINVAL;
+    if (!p->bst_a) return p->bst_y2 ? PH_EINVAL : launch7<1>(p, st);
+    return p->bst_y2 ? launch7<3>(p, st) : launch7<2>(p, st);
+  }
+  return launch7<0>(p, st);
 }
 
 // the fragment-major copy of ONE convolution's packed perf-mode weights (test hooks, c_api.hip): plane 0 -> plane 1

@@ -323,11 +323,20 @@ int conv_dgrad(const Ctx& c, int ui, const void* dy, void* dx, const void* res_g
       // y: one extra 8-byte load per piece; 114 us against 76 + a 65 us reduction pass).  Built, tested and OFF by default:
       // the mask-tensor form behind conv1's dgrad + residual (four epilogue operands per piece: PH_BST2=1) and the dense
       // kernel of layers 2-4 (conv_tap3.hip at 512 registers: 93 against 64 us per launch, more than the pass it replaces: PH_BST3=1)
-      static const bool bst3 = [] { const char* e = getenv("PH_BST3"); return e && e[0] == '1'; }();
-      static const bool bst2 = [] { const char* e = getenv("PH_BST2"); return e && e[0] == '1'; }();
-      const bool ok = bu.Cout == t.Cout && bu.OH == t.OH && bu.OW == t.OW && (bst2 || !bst->a) &&
-                      ((ph_tap4_switch(-1) && ph_tapconv4_eligible(&f)) ||
-                       (bst3 && ph_tap3_switch(-1) && ph_tapconv2_tile_h(&f, 1, P->prec) && ph_tapconv3_eligible(&f)));
+      // Round 6: conv_tap7.hip has the registers conv_tap3.hip lacked (178 - 237 vector registers with the sums, no scratch), so layers
+      // 2-4 CAN take the sums in the dgrad epilogue - measured same-box (profiles/EXPERIMENTS.md): B = 64: 10.16 ms without, 10.27 with
+      // (the launches get slower by more than the 30 us pass they replace, which ran beside a weight gradient anyway); B = 256: trunk
+      // 23.82 -> 23.60 ms, step 36.6 -> 36.3 ms.  Default: on from B = 128 where conv_tap7.hip takes the launch (PH_BST3 / PH_BST2 = 0 / 1
+      // force it off / on, 1 also on conv_tap3.hip)
+      static const int bst3 = [] { const char* e = getenv("PH_BST3"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+      static const int bst2 = [] { const char* e = getenv("PH_BST2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+      const bool dense = ph_tap3_switch(-1) && ph_tapconv2_tile_h(&f, 1, P->prec) && ph_tapconv3_eligible(&f);
+      const bool on7 = dense && ph_tap7_switch(-1) && ph_tapconv7_eligible(&f);
+      const bool l1 = ph_tap4_switch(-1) && ph_tapconv4_eligible(&f);
+      const bool big = P->B >= 128;
+      const bool mask_ok = !bst->a || bst2 == 1 || (bst2 == -1 && on7 && big);      // the mask-tensor forms (bn2 / downsample behind conv1's dgrad)
+      const bool ok = bu.Cout == t.Cout && bu.OH == t.OH && bu.OW == t.OW && mask_ok &&
+                      (l1 || (dense && (bst3 == 1 || (bst3 == -1 && on7 && big))));
       if (ok) {
         const int rc = ph_tapconv_launch(&f, 1, c.bprec(), c.st);
         if (rc == PH_OK) *fused_parts = ph_tapconv2_stat_parts(&f);

@@ -29,7 +29,7 @@ def is_inline_load(i):
         k -= 1
     # conv_tap5/6: s_mov_b64 of the scalar base in front; conv_tap7: vector address, `off` - the only dwordx4 loads with a register
     # destination in these kernels (the compiler's own are buffer loads)
-    return lines[k].strip().startswith("s_mov_b64") or lines[k].strip().startswith("s_nop") or (", off" in t and "offset:" in t)
+    return ((lines[k].strip().startswith("s_mov_b64") or lines[k].strip().startswith("s_nop")) and ", off" not in t) or (", off" in t and "offset:" in t)
 
 
 bad = 0
@@ -46,8 +46,8 @@ for i, ln in enumerate(lines):
         u = lines[j].strip()
         if not u or u.startswith(";") or u.startswith("."):
             continue
-        if u.startswith("s_endpgm"):
-            break
+        if u.startswith("s_endpgm") or u.startswith("s_waitcnt vmcnt(0)"):
+            break                       # (a full drain: whatever touches the registers afterwards sees landed data)
         if not (regs(u, kind) & dst):
             continue
         if u.startswith("v_mfma"):
