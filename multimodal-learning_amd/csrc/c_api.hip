@@ -86,7 +86,9 @@ int ph_conv2d_fwd(const void* x, const float* w, void* y, float* ch_sum, float* 
   t.B = B; t.IH = IH; t.IW = IW; t.Cin = Cin; t.Cout = Cout; t.OHt = OH; t.OWt = OW; t.OH = OH; t.OW = OW;
   t.os = 1; t.iy0 = -pad; t.ix0 = -pad; t.ntaps = KS * KS;
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / KS; t.dx[k] = k % KS; t.wtap[k] = k; }
-  if (KS == 3 && stride == 2 && pad == 1 && ph_tapconv2_setup_s2_fwd(&t, Cin, Cout, IH, IW, prec)) stride = 1;
+  const bool tap6b = prec == PH_PREC_BF16 && KS == 3 && stride == 2 && pad == 1 && ph_tap6b_switch(-1) && ph_tapconv6b_eligible(&t);
+  if (tap6b && (rc = ph_frag7_repack_launch(hi, Cout, Cin, 9, st))) return rc;      // the fragment-major copy in plane 1
+  if (!tap6b && KS == 3 && stride == 2 && pad == 1 && ph_tapconv2_setup_s2_fwd(&t, Cin, Cout, IH, IW, prec)) stride = 1;
   if (KS == 1 && stride == 2) {   // strided view (see resnet_plan.hip conv_fwd)
     t.in_pix_stride = 2L * Cin; t.in_row_stride = 2L * IW * Cin; t.in_img_stride = (long)IH * IW * Cin;
     t.IH = OH; t.IW = OW; stride = 1;

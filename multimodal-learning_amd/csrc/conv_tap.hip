@@ -564,6 +564,11 @@ int launch_T(const PhTapConv& p, int S, hipStream_t st) {
 
 // number of statistic partial rows a launch writes: B * tiles
 int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
+  if (prec == PH_PREC_BF16 && S == 2 && ph_tap6b_switch(-1)) {
+    // (ntaps == 0: a sizing query with B / OHt / OWt / Cout only - the larger of the candidates' counts)
+    if (p->ntaps == 0 && p->Cout % 128 == 0) return std::max(p->B * cdiv(p->OHt, 8) * cdiv(p->OWt, 16), ph_tapconv6b_stat_parts(p));
+    if (p->ntaps != 0 && ph_tapconv6b_eligible(p)) return ph_tapconv6b_stat_parts(p);
+  }
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_stat_parts(p);
   // (half-pair mode on the third-generation kernel: one partial row per persistent workgroup, like the second generation)
   if (prec == PH_PREC_FP16X3 && S == 1 && ph_tap3_switch(-1) && ph_tapconv3_eligible(p)) return ph_tapconv2_stat_parts(p);
@@ -581,6 +586,8 @@ int ph_tapconv_stat_parts(const PhTapConv* p, int S, int prec) {
 
 int ph_tapconv_launch(const PhTapConv* p, int S, int prec, hipStream_t st) {
   if (p->Cin % 64 || p->Cout % 64 || p->ntaps < 1 || p->ntaps > 9 || (S != 1 && S != 2)) return PH_EINVAL;
+  // perf mode, 3x3 / stride 2 forward over the un-masked descriptor (the callers skip ph_tapconv2_setup_s2_fwd for it): conv_tap6b.hip
+  if (S == 2 && prec == PH_PREC_BF16 && ph_tap6b_switch(-1) && ph_tapconv6b_eligible(p)) return ph_tapconv6b_launch(p, st);
   if (ph_tapconv2_tile_h(p, S, prec)) return ph_tapconv2_launch(p, st);
   if (p->in_scale || p->m_groups) return PH_EINVAL;   // in-LDS BatchNorm + ReLU / masked tap grids: second-generation kernels only
   if (prec == PH_PREC_BF16) return launch_T<bf16>(*p, S, st);

@@ -493,6 +493,10 @@ __global__ __launch_bounds__(256) void pack_all_tiled_kernel(PhPackAll t, PackTi
     // perf mode, dense 3x3 stride-1 units with Cin = Cout >= 128 (ResNet layers 2-4: what conv_tap7.hip takes): a fragment-major
     // copy of both orientations in plane 1 of the unit's region (unused in this mode): [tap][rows / 64][K / 64] x 4096 elements
     if constexpr (NP == 1) {
+      if (NT == 9 && O == 2 * I) {      // the stride-2 units, forward orientation (conv_tap6b.hip)
+        const int o = o0 + y, i = i0 + x;
+        packed[t.dst_fwd[u] + n + (size_t)tp * O * I + (size_t)((o >> 6) * (I >> 6) + (i >> 6)) * 4096 + frag64_index(o & 63, i & 63)] = sh[0][y][x * NT + tp];
+      }
       if (NT == 9 && O == I && I >= 128) {
         const int o = o0 + y, i = i0 + x;      // forward: row o, k i
         packed[t.dst_fwd[u] + n + (size_t)tp * O * I + (size_t)((o >> 6) * (I >> 6) + (i >> 6)) * 4096 + frag64_index(o & 63, i & 63)] = sh[0][y][x * NT + tp];

@@ -129,6 +129,12 @@ int ph_tap6_switch(int set);
 bool ph_tapconv6_eligible(const PhTapConv* p);
 int ph_tapconv6_launch(const PhTapConv* p, hipStream_t st);
 int ph_tapconv6_stat_parts(const PhTapConv* p);
+// ... and its perf-mode (bf16) form (conv_tap6b.hip); reads the fragment-major copy in plane 1 of the unit's packed region; PH_TAP6B=0
+// keeps conv_tap2.hip's masked grid
+int ph_tap6b_switch(int set);
+bool ph_tapconv6b_eligible(const PhTapConv* p);
+int ph_tapconv6b_launch(const PhTapConv* p, hipStream_t st);
+int ph_tapconv6b_stat_parts(const PhTapConv* p);
 // stride-2 3x3 convolutions as masked stride-1 tap grids (conv_tap2.hip); false = not eligible, descriptor untouched
 bool ph_tapconv2_setup_s2_fwd(PhTapConv* t, int Cin, int Cout, int IH, int IW, int prec);
 

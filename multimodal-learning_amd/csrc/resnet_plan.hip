@@ -265,7 +265,9 @@ int conv_fwd(const Ctx& c, int ui, const void* in, const float* in_scale = nullp
   for (int k = 0; k < t.ntaps; ++k) { t.dy[k] = k / u.KS; t.dx[k] = k % u.KS; t.wtap[k] = k; }
   int S = u.S;
   // 3x3 / stride 2 in perf mode: a stride-1 MASKED tap grid over the four pixel-parity planes of the input (conv_tap2.hip)
-  if (u.KS == 3 && u.S == 2 && u.pad == 1 && !c.no_masked && ph_tapconv2_setup_s2_fwd(&t, u.Cin, u.Cout, u.IH, u.IW, P->prec)) S = 1;
+  // (round 6: conv_tap6b.hip takes the un-masked stride-2 descriptor itself)
+  const bool tap6b = P->prec == PH_PREC_BF16 && u.KS == 3 && u.S == 2 && !c.no_masked && ph_tap6b_switch(-1) && ph_tapconv6b_eligible(&t);
+  if (!tap6b && u.KS == 3 && u.S == 2 && u.pad == 1 && !c.no_masked && ph_tapconv2_setup_s2_fwd(&t, u.Cin, u.Cout, u.IH, u.IW, P->prec)) S = 1;
   if (u.KS == 1 && u.S == 2) {   // 1x1 / stride 2 == 1x1 / stride 1 over the even-pixel view of the input
     t.in_pix_stride = 2L * u.Cin; t.in_row_stride = 2L * u.IW * u.Cin; t.in_img_stride = (long)u.IH * u.IW * u.Cin;
     t.IH = u.OH; t.IW = u.OW; S = 1;

@@ -46,8 +46,9 @@ for i, ln in enumerate(lines):
         u = lines[j].strip()
         if not u or u.startswith(";") or u.startswith("."):
             continue
-        if u.startswith("s_endpgm") or u.startswith("s_waitcnt vmcnt(0)"):
-            break                       # (a full drain: whatever touches the registers afterwards sees landed data)
+        if u.startswith("s_endpgm") or u.startswith("s_waitcnt vmcnt(0)") or u.startswith("s_branch") or u.startswith("s_setpc"):
+            break                       # (a full drain: whatever touches the registers afterwards sees landed data; an unconditional
+                                        # branch: the text that follows is not this path - the scan is linear)
         if not (regs(u, kind) & dst):
             continue
         if u.startswith("v_mfma"):

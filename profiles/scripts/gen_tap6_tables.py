@@ -142,3 +142,96 @@ for i in range(8):
     n = 4 * (2 * T - 2 * tl) + sum(nd[t % 27] for t in range(tl + 1, T + 1))
     hw[start[i + 1] - 1] = min(n, 63)
 arr("HWAIT", hw)
+
+
+# ---- perf-mode (bf16) form: one image per parity plane and 64-channel slice (no hi / lo), 9 taps per slice, plane p in buffer p
+def gen_bf16():
+    import itertools as it
+    planes = {"P11": (1, 1, T4), "P01": (0, 1, [(1, 0), (1, 2)]), "P10": (1, 0, [(0, 1), (2, 1)]), "P00": (0, 0, [(1, 1)])}
+    SL = 5                                    # pieces per tap (second k-step, groups 0..4)
+    best = None
+    for order in it.permutations(list(planes)):
+        dd = [len(planes[n][2]) for n in order]
+        st = [0]
+        for x in dd:
+            st.append(st[-1] + x)
+        # image i of the NEXT slice may be issued from the tap after image i of this slice ends (its buffer = its plane)
+        left = [NP] * 4
+        sched = [[] for _ in range(9)]
+        ok = True
+        for t in range(9):
+            cap = SL
+            for i in range(4):
+                if cap == 0:
+                    break
+                if left[i] == 0 or t < st[i + 1]:
+                    continue
+                n = min(cap, left[i])
+                for k in range(n):
+                    sched[t].append((i, NP - left[i] + k))
+                left[i] -= n
+                cap -= n
+        if any(left):
+            # the rest spills into the next slice's first taps (before the image's own first tap - 4)
+            spill = [[] for _ in range(9)]
+            for t in range(9):
+                cap = SL - len(sched[t])
+                for i in range(4):
+                    if cap <= 0 or left[i] == 0:
+                        continue
+                    if t > st[i] - 4:
+                        continue
+                    n = min(cap, left[i])
+                    for k in range(n):
+                        spill[t].append((i + 4, NP - left[i] + k))      # + 4: image of THIS slice issued inside it
+                    left[i] -= n
+                    cap -= n
+            if any(left):
+                continue
+            for t in range(9):
+                sched[t] = spill[t] + sched[t]
+        key = -sum(len(x) for x in sched[:2])
+        if best is None or key > best[0]:
+            best = (key, order, sched, dd, st)
+    if best is None:
+        print("// perf mode: no schedule"); return
+    _, order, sched, dd, st = best
+    print("// perf-mode order:", " ".join(order), "durations", dd)
+    img, ky, kx = [], [], []
+    for i, n in enumerate(order):
+        for (y, x) in planes[n][2]:
+            img.append(i); ky.append(y); kx.append(x)
+    arr("B_IMG", img); arr("B_KY", ky); arr("B_KX", kx)
+    arr("B_IM_PY", [planes[n][0] for n in order]); arr("B_IM_PX", [planes[n][1] for n in order])
+    ndb = [len(sched[t]) for t in range(9)]
+    arr("B_ND", ndb)
+    fi, fe = [], []
+    for t in range(9):
+        row = sched[t] + [(-1, 0)] * (SL - len(sched[t]))
+        for (j, e) in row:
+            fi.append(j); fe.append(e)
+    arr("B_DMA_IMG", fi)      # 0..3: image of the NEXT slice; 4..7: image (index - 4) of THIS slice; -1 none
+    arr("B_DMA_E", fe)
+    w0b, w1b = [], []
+    for t in range(9):
+        p3 = ndb[(t - 3) % 9] + ndb[(t - 2) % 9] + ndb[(t - 1) % 9]
+        w0b.append(28 + p3); w1b.append(28 + p3 + ndb[t])
+    arr("B_WAIT0", w0b); arr("B_WAIT1", w1b)
+    # hand-over wait in the last tap of image i: pieces of image i + 1 (of this slice, or image 0 of the next) landed
+    lastp = {}
+    for grp in range(3):
+        for t in range(9):
+            for (j, e) in sched[t]:
+                inst = 4 * (grp + 1) + j if j < 4 else 4 * grp + (j - 4)
+                lastp[inst] = max(lastp.get(inst, -1), 9 * grp + t)
+    hwb = [63] * 9
+    for i in range(4):
+        T = 9 + st[i + 1] - 1
+        tl = lastp[4 + i + 1]
+        assert tl < T, (i, tl, T)
+        n = 4 * (2 * T - 2 * tl) + sum(ndb[t % 9] for t in range(tl + 1, T + 1))
+        hwb[st[i + 1] - 1] = min(n, 63)
+    arr("B_HWAIT", hwb)
+
+
+gen_bf16()

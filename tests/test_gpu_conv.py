@@ -381,6 +381,17 @@ def test_tapconv2_masked_stride2_stream(case):
     for rep in range(1, 4):
         assert torch.equal(outs[0][0].view(torch.int16), outs[rep][0].view(torch.int16)), "fwd differs between launches"
         assert torch.equal(outs[0][1], outs[rep][1]) and torch.equal(outs[0][2], outs[rep][2])
+    # round 6: the launch above went to conv_tap6b.hip (parity-plane images, register-window weights); conv_tap2.hip's masked grid
+    # (PH_TAP6B off) as the second opinion: the same products summed in another order and rounded once to bf16
+    L.ph_debug_set_tap6b(0)
+    try:
+        y1 = torch.full((B, OH, OH, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+        check(L.ph_conv2d_fwd(ptr(xd), ptr(wd), ptr(y1), ptr(s1), ptr(s2), B, Cin, H, H, Cout, 3, 2, 1, 0, ptr(ws), stream()), "fwd masked grid")
+    finally:
+        L.ph_debug_set_tap6b(1)
+    d = (y1.float() - outs[0][0].float()).abs()
+    assert d.max().item() <= 2.0 ** -7 * y_ref.abs().max().item() and d.mean().item() <= 2e-3 * y_ref.abs().mean().item(), (d.max().item(), d.mean().item())
+    assert (s1 - outs[0][1]).abs().max().item() <= 1e-5 * outs[0][1].abs().max().item() + 1e-3
 
 
 RES_CASES = [  # Cin (= dgrad output channels), Cout, H, B
