@@ -65,9 +65,10 @@ __device__ __forceinline__ int a5_off(int hr, int hc, int c) {
 
 // DMA pieces a slice kind issues in tap t (k-step 1, groups 0..3) and the first piece index.  Kinds: 0 / 1 / 2 = the three slices
 // of a tile of the 3-product form (x hi . w hi 2^11 | x hi . w lo | x lo . w hi), 3 / 4 = the single slice of a tile of the hi-only
-// form on buffer 0 / 1.  Kind 0 and tap 0 of kind 1 fetch x lo of THIS tile (buffer 1, free since the previous tile's lo slice);
-// kinds 2, 3, 4 fetch x hi of the NEXT tile into the buffer the barrier of the slice before released - all issued by tap 5: a piece of
-// tap t is complete at the wait that ends tap t + 2, the hand-over barrier sits in tap 8.
+// form on buffer 0 / 1.  Kind 1 fetches x lo of THIS tile (buffer 1, free since the previous tile's lo slice), kinds 2, 3, 4 fetch
+// x hi of the NEXT tile into the buffer the barrier of the slice before released - 4, 4, 3, 3, 3, 3 pieces in taps 0..5: a piece of
+// tap t has landed at the wait that ends tap t + 2, the hand-over barrier sits in tap 8.  Kind 0 issues none (its issue slots take
+// the piece mask of the next tile); with the lo plane's pieces in kind 0 instead, that slice ran 1.4 us longer.
 __host__ __device__ constexpr int ph5_ndma(int kind, int t) {
   return kind == 0 ? 0 : (t < 2 ? 4 : (t < 6 ? 3 : 0));
 }
