@@ -25,7 +25,7 @@
 #include "ph_kernels.h"
 #include "tap_common.h"
 #ifndef PH5_DBG
-#define PH5_DBG 0
+#define PH5_DBG 0      // ablation builds (timing only): 2 = no halo pieces inside the slices, 4 = no weight loads inside the slices
 #endif
 
 namespace {
@@ -48,7 +48,7 @@ struct Tap5Cfg {
   static constexpr int ROW_BYTES = (HPW / 2) * 256;                             // one halo row: 9 pixel pairs of 2 x 128 B
   static constexpr int A_BYTES = (HPH * ROW_BYTES + 1023) / 1024 * 1024;        // whole 1-KiB DMA pieces
   static constexpr int NHD = A_BYTES / 1024, NHE = (NHD + NW - 1) / NW;         // pieces per plane / per wave
-  static constexpr int STAT_OFF = 2 * A_BYTES, RED_OFF = STAT_OFF + 512, DUMMY_OFF = RED_OFF + NW * 2 * BNT * 4;
+  static constexpr int RED_OFF = 2 * A_BYTES + 512, DUMMY_OFF = RED_OFF + NW * 2 * BNT * 4;      // cross-wave sum scratch, dummy piece
   static constexpr int LDS_BYTES = DUMMY_OFF + 1024;
   static constexpr int NTH = NW * 64;
   static constexpr int WK = 192;                                                // packed weight row: [hi 2^11 | lo | hi] x 64
