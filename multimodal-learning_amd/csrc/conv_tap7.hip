@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
 
   f32x4 acc[NM][NN];
   constexpr bool Y2 = BST == 3;
-  constexpr int NSR = BST ? 3 : 2;      // rows per workgroup
+  constexpr int NSR = BST > 0 ? 3 : 2;      // rows per workgroup (BST = -1: a launch without sums - plain dgrad - skips the arithmetic too)
   float s1[NN], s2[NN], s3[Y2 ? NN : 1];
 #pragma unroll
   for (int n = 0; n < NN; ++n) { s1[n] = 0.f; s2[n] = 0.f; s3[Y2 ? n : 0] = 0.f; }
@@ -248,14 +248,14 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
     const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(reinterpret_cast<const bf16*>(p.res_a)) + img, 0, RM > 1 ? img_bytes : 0, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_y = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_y)) + img, 0, BST != 0 ? img_bytes : 0, RSRC_FLAGS);
+        const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_y)) + img, 0, BST > 0 ? img_bytes : 0, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_a)) + img, 0, BST >= 2 ? img_bytes : 0, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t r_y2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(reinterpret_cast<const bf16*>(p.bst_y2)) + img, 0, Y2 ? img_bytes : 0, RSRC_FLAGS);
     // per-channel constants of this lane's four channels: mask scale / shift (BST 1), mean, second mean
     f32x4 cms = {0.f, 0.f, 0.f, 0.f}, cmh = cms, cmu = cms, cmu2 = cms;
-    if constexpr (BST != 0) {
+    if constexpr (BST > 0) {
       const int chan = tc.nb * BNT + wn * 64 + 4 * li;
       if constexpr (BST == 1) { cms = *reinterpret_cast<const f32x4*>(p.bst_scale + chan); cmh = *reinterpret_cast<const f32x4*>(p.bst_shift + chan); }
       cmu = *reinterpret_cast<const f32x4*>(p.bst_mean + chan);
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
           if constexpr (RM > 1) ra[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_a, off[q], 0, 0));
         }
       }
-      if constexpr (BST != 0) {
+      if constexpr (BST > 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           ry[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_y, off[q], 0, 0));
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void tapconv7_kernel(PhTapConv p) {
             b[1] = (bf16)((float)b[1] + ((RM < 2 || a1 > 0.f) ? g1 : 0.f));
           }
           w[h] = __builtin_bit_cast(unsigned, b);
-          if constexpr (BST != 0) {
+          if constexpr (BST > 0) {
             // the sums are taken over the STORED gradient (bf16), exactly what the separate reduction pass reads back
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -567,7 +567,7 @@ int ph_tapconv7_launch(const PhTapConv* p, hipStream_t st) {
     if (!p->bst_a) return p->bst_y2 ? PH_EINVAL : launch7<1>(p, st);
     return p->bst_y2 ? launch7<3>(p, st) : launch7<2>(p, st);
   }
-  return launch7<0>(p, st);
+  return p->stats ? launch7<0>(p, st) : launch7<-1>(p, st);
 }
 
 // the fragment-major copy of ONE convolution's packed perf-mode weights (test hooks, c_api.hip): plane 0 -> plane 1
