@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak check of the multi-stream step at the benchmark size (not a test; ~1 minute on the GPU box):
-    python tests/soak_determinism_gpu.py [steps] [miccai2022 | mia2022 | mia2023 | tsvd]
+    python tests/soak_determinism_gpu.py [steps] [miccai2022 | mia2022 | mia2023 | tsvd] [precision, e.g. fp16x3/x1]
 Two fresh runs of `steps` graph-replayed distillation steps (B = 64, 512 x 512, same seeds) must produce bitwise the same loss
 trajectory, parameters and bank rows: a missing dependency between the streams of the step (three forward streams, the
 trunk backward's side stream, the loss head's) would show up as run-to-run noise sooner or later."""
@@ -16,6 +16,8 @@ import multimodal_learning_amd as m  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 variant = sys.argv[2] if len(sys.argv) > 2 else "miccai2022"
+if len(sys.argv) > 3:
+    m.set_precision(sys.argv[3])      # (round 6: the half-pair kernels conv_tap5 / conv_tap6.hip count their own vmcnt - soak them too)
 dev = torch.device("cuda:0")
 
 
